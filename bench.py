@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py -- slides/sec of the MADELEINE cross-stain pretrain step on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W           (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" = zero_grad + encoder fwd + losses + bwd + AdamW step, train mode (dropout on), on DEVICE-RESIDENT
+synthetic bags: per rank B=32 slides x M stains x N=4096 patches x D=512 fp32
+(weak scaling: per-GPU work fixed).  N=1 workload = BASELINE.json configs[1] ("c2": 2 stains, ABMIL pool +
+global InfoNCE), the configuration the metric is quoted on.  Rank 0 prints ONE JSON line.
+
+Extra objects on that line:
+  roofline      -- A3 softmax-pool forward kernel (the HBM-bound kernel north_star targets at >= 60 %):
+                   algorithmic bytes (8,208 B/token + 8 KiB/bag) / HIP-event duration inside the timed region.
+  roofline_mfma -- A2 gate kernels (fwd + dX + dW), the time-dominant fp32-MFMA contractions: algorithmic
+                   FLOP / HIP-event duration vs the 157.3 TFLOP/s fp32 matrix peak.
+  cpu_baseline  -- the CPU oracle (oracle/restatement.py, kind "port") timed on this box's host cores on a
+                   bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MODS5 = ["HE", "HER2", "PGR", "KI67", "ER"]
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+F32_MFMA_PEAK_TF = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+CONFIGS = {
+    # name: (B per rank, M, N, D, use_got, stain_encoding)
+    "c1": (4, 2, 256, 512, False, False),
+    "c2": (32, 2, 4096, 512, False, False),
+    "c3": (32, 5, 4096, 512, True, False),
+}
+
+
+def make_cfg(M, D):
+    return SimpleNamespace(MODALITIES=MODS5[:M], wsi_encoder="abmil", patch_embedding_dim=D,
+                           wsi_encoder_hidden_dim=512, activation="softmax", n_heads=4)
+
+
+def cpu_baseline(B_sample, M, N, D, use_got, steps=2):
+    """Times the CPU oracle's full step (fwd + losses + bwd + AdamW, train-mode dropout) on B_sample slides."""
+    from oracle import restatement as R
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    mods = MODS5[:M]
+    sd = R.make_params(M, D, 4, False, seed=42)
+    params = [v.requires_grad_() for v in sd.values()]
+    opt = torch.optim.AdamW(params, lr=1e-4)
+    g = torch.Generator().manual_seed(1234)
+    feats = torch.randn(B_sample, M, N, D, generator=g)
+    labels = torch.ones(B_sample, M)
+    times = []
+    for it in range(steps + 1):
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        pre, gate = R.random_keep_masks(B_sample * M, N, 4, g)
+        loss, flag, _ = R.pretrain_step_loss(feats, labels, sd, mods, 0.001, True, use_got=use_got, pre_keep=pre,
+                                             gate_keep=gate)
+        loss.backward()
+        opt.step()
+        dt = time.perf_counter() - t0
+        if it > 0:
+            times.append(dt)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": round(B_sample / med, 4), "unit": "slides/s", "cores": threads, "kind": "port",
+            "sample": f"{B_sample} of the step's slides x {M} stains x {N} x {D}, full step (fwd+loss+bwd+AdamW), "
+                      f"train-mode dropout, median of {steps} after 1 warm-up; {med:.2f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--eval-mode", action="store_true", help="dropout off (parity-mode timing; not the headline)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=4, help="slides in the bounded CPU-oracle sample")
+    a = ap.parse_args()
+
+    from madeleine_amd import InfoNCE, MADELEINE, calculate_losses
+    from madeleine_amd import distributed as D
+    from madeleine_amd import functional as MF
+
+    rank, world, local_rank = D.init_from_env()
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU: the HIP kernels are the only backend"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    B, M, N, Dm, use_got, stain_enc = CONFIGS[a.config]
+    mods = MODS5[:M]
+    torch.manual_seed(42)
+    model = MADELEINE(make_cfg(M, Dm), stain_encoding=stain_enc).to(dev)
+    model.eval() if a.eval_mode else model.train()
+    net = model
+    if world > 1:
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank])
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
+    crit = InfoNCE(temperature=0.001)
+    got = None
+    if use_got:
+        from madeleine_amd import GOT as got  # noqa: N811
+    largs = SimpleNamespace(global_loss="info-nce", symmetric_cl=True, local_loss_weight=1.0)
+
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    feats = torch.randn(B, M, N, Dm, device=dev, generator=gen)
+    labels = torch.ones(B, M)
+    if M > 2:  # ACROBAT stain presence rates; absent stain -> all-zero bag (wsi_dataset.py:66)
+        rates = torch.tensor([1.0, 0.46, 0.73, 0.73, 0.73][:M])
+        labels = (torch.rand(B, M, generator=torch.Generator().manual_seed(77 + rank)) < rates).float()
+        labels[:, 0] = 1
+        feats = feats * labels.to(dev)[:, :, None, None]
+    data = {"feats": feats, "modality_labels": labels}
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        embs, toks = net(data, device=dev)
+        lab = labels
+        if world > 1:
+            lab = D.all_gather_labels(labels, dev)
+            embs = D.gather_slide_embeddings(embs, mods)
+        loss, flag = calculate_losses(mods[1:], crit, got, None, embs, toks, lab[:, 1:], largs)
+        loss.backward()
+        opt.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    MF.TIMER = MF.KernelTimer()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof = MF.TIMER.report()
+    MF.TIMER = None
+    final_loss = float(loss)
+
+    tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    elapsed = float(tmax)
+    ms_per_step = 1e3 * elapsed / a.steps
+    value = B * world * a.steps / elapsed
+
+    if rank == 0:
+        tokens = B * M * N
+        H = 4
+        out = {
+            "metric": "slides/sec (pretrain step) at B=32 N=4096 d=512; 1/2/4/8 GPU",
+            "value": round(value, 3), "unit": "slides/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic (device-resident randn bags, random-init weights, manual_seed 42)",
+            "config": {"workload": f"{a.config}: {B} slides/GPU x {M} stains x {N} patches x {Dm}-d, "
+                                   f"ABMIL pool + global InfoNCE{' + local GOT' if use_got else ''}, "
+                                   f"{'eval (dropout off)' if a.eval_mode else 'train mode (dropout on)'}, AdamW",
+                       "global_batch": B * world, "bags_per_sec": round(value * M, 2), "parallelism": f"dp{world}",
+                       "final_loss": final_loss},
+        }
+        if "pool_fwd" in prof:
+            ms, n = prof["pool_fwd"]
+            alg = tokens * (H * 512 * 4 + H * 4) + B * M * H * 512 * 4
+            ach = alg / (ms * 1e-3) / 1e9
+            out["roofline"] = {"kernel": "abmil_pool_fwd (pool_partial + pool_combine)", "bound": "hbm",
+                               "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                               "algorithmic_bytes_per_launch": alg, "avg_ms": round(ms, 4), "launches": n}
+        if "gate_fwd" in prof and "gate_bwd" in prof:
+            msf, _ = prof["gate_fwd"]
+            msb, _ = prof["gate_bwd"]
+            flop_f = tokens * H * 2 * 512 * 1024
+            tf_f = flop_f / (msf * 1e-3) / 1e12
+            tf_b = 2 * flop_f / (msb * 1e-3) / 1e12
+            tf = 3 * flop_f / ((msf + msb) * 1e-3) / 1e12
+            out["roofline_mfma"] = {"kernel": "abmil_gate fwd + bwd(dX, dW) on v_mfma_f32_32x32x2_f32", "bound": "mfma",
+                                    "achieved": round(tf, 2), "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                                    "frac": round(tf / F32_MFMA_PEAK_TF, 4), "fwd_tflops": round(tf_f, 2),
+                                    "bwd_tflops": round(tf_b, 2), "fwd_ms": round(msf, 3), "bwd_ms": round(msb, 3)}
+        out["kernel_ms"] = {k: round(v[0], 4) for k, v in prof.items()}
+        if world == 1 and not a.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(min(a.cpu_sample, B), M, N, Dm, use_got)
+            except Exception as e:  # never lose the GPU line because the host box is short on RAM
+                out["cpu_baseline"] = {"value": None, "unit": "slides/s", "cores": os.cpu_count(), "kind": "port",
+                                       "sample": f"failed: {type(e).__name__}: {e}"}
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,160 @@
+/*
+ * madeleine_amd.h -- C ABI of libmadeleine_amd.so (gfx950 / MI355X).
+ *
+ * The reference (mahmoodlab/MADELEINE) has no FFI / operator registry: its hot path is plain
+ * PyTorch modules.  This header is therefore the boundary the reference's *call sites* would bind
+ * if the path were native; every entry point names the reference code it replaces (file:line are
+ * relative to the reference checkout).  The Python mirror of the reference classes
+ * (madeleine_amd/{model,abmil,loss,trainer}.py) calls these through ctypes with raw device pointers
+ * (see INTEGRATION.md for the binding stub).
+ *
+ * Conventions (all entry points):
+ *   - extern "C", plain pointers and sizes, no torch / C++ types.
+ *   - every pointer is a DEVICE pointer unless the name ends in _host; the CALLER allocates all
+ *     inputs, outputs and workspaces.  Kernels never allocate, free or keep global state; they are
+ *     re-entrant.
+ *   - launches are asynchronous on the caller-provided hipStream_t (passed as void*); no internal
+ *     synchronisation.
+ *   - return value: 0 on success; a positive hipError_t if a launch failed; a negative MDL_E_* code
+ *     for argument validation.  Nothing throws across the boundary.
+ *   - fp32 everywhere ("f32" compute; MFMA contractions use v_mfma_f32_32x32x2_f32, exact fp32).
+ *
+ * Internal activation layout ("head-major"): the reference interleaves heads as channel j = e*H + c
+ * (rearrange 'b t (e c) -> b t e c', Model.py:396).  Our encoder emits the same numbers with the
+ * channel axis permuted to j' = c*512 + e by permuting the rows of pre_attn.8 / LayerNorm 9 and the
+ * columns of token_projector / projector on the host (madeleine_amd/model.py) -- zero-cost, and every
+ * kernel below then reads contiguous 2 KiB head rows.  H (heads) <= 8, hidden = 512 fixed
+ * (Model.py:71).
+ */
+#ifndef MADELEINE_AMD_H
+#define MADELEINE_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDL_HIDDEN 512
+#define MDL_MAX_HEADS 8
+
+#define MDL_OK 0
+#define MDL_E_ARG (-1)      /* bad size / null pointer */
+#define MDL_E_ALIGN (-2)    /* pointer not 16-byte aligned */
+#define MDL_E_UNSUPPORTED (-3)
+
+/* library / build info: returns a static string "madeleine_amd <ver> gfx950" */
+const char* mdl_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * A2 -- gated attention scores.  Replaces BatchedABMIL.forward (madeleine/models/abmil.py:41-68)
+ * for all H heads at once (the reference loops H module instances, Model.py:406-409).
+ *
+ *   s[t,c] = bc[c] + sum_j wc[c,j] * drop(tanh(E[t,c,:].Wa[c,j,:] + ba[c,j])) * drop(sigmoid(E[t,c,:].Wb[c,j,:] + bb[c,j]))
+ *
+ * E      [T, H*512]  head-major token embeddings (row stride ldE floats, >= H*512)
+ * Wa,Wb  [H,512,512] torch Linear layout [out,in];  ba,bb [H,512];  wc [H,512];  bc [H]
+ * scores [T,H]       raw (pre-softmax) attention, == raw_attention of Model.py:406-411
+ * act_a, act_b [T,H,512]  tanh / sigmoid activations BEFORE dropout, saved for backward (may be NULL
+ *                    when no backward is needed: inference)
+ * dropout: p_drop in [0,1). keep_a/keep_b (uint8 [T,H,512], 1 = keep) inject explicit masks (parity
+ *          tests); when NULL and p_drop > 0 a counter-based hash of (seed, element index) decides.
+ *          p_drop == 0 (module.eval()) => identity.
+ * ws     workspace of mdl_abmil_gate_fwd_ws_bytes(T,H) bytes (score partials per 128-wide j tile).
+ */
+int64_t mdl_abmil_gate_fwd_ws_bytes(int64_t T, int H);
+int mdl_abmil_gate_fwd(const float* E, int64_t ldE, const float* Wa, const float* ba, const float* Wb,
+                       const float* bb, const float* wc, const float* bc, float* scores, float* act_a,
+                       float* act_b, int64_t T, int H, float p_drop, uint64_t seed,
+                       const uint8_t* keep_a, const uint8_t* keep_b, void* ws, void* stream);
+
+/* Backward of the above.  d_scores [T,H] incoming gradient.
+ * dE [T,H*512] (row stride ldE): gradient wrt the token embeddings through the gates; written when
+ *    accumulate == 0, added to the existing contents when accumulate != 0.
+ * dWa,dWb [H,512,512]; dba,dbb,dwc [H,512]  (overwritten).  dbc = sum_t d_scores is left to the caller.
+ * ws: mdl_abmil_gate_bwd_ws_bytes(T,H) bytes (split-K slabs). */
+int64_t mdl_abmil_gate_bwd_ws_bytes(int64_t T, int H);
+int mdl_abmil_gate_bwd(const float* E, int64_t ldE, const float* Wa, const float* Wb, const float* wc,
+                       const float* act_a, const float* act_b, const float* d_scores, float* dE,
+                       int accumulate, float* dWa, float* dWb, float* dba, float* dbb, float* dwc,
+                       int64_t T, int H, float p_drop, uint64_t seed, const uint8_t* keep_a,
+                       const uint8_t* keep_b, void* ws, void* stream);
+
+/* Materialises the keep-mask the two calls above derive from (seed, p_drop) when keep_a/keep_b are NULL:
+ * keep uint8 [T,H,512], which = 0 (tanh branch) or 1 (sigmoid branch).  For reproducibility / tests. */
+int mdl_abmil_gate_dropout_mask(uint8_t* keep, int64_t T, int H, int which, float p_drop, uint64_t seed,
+                                void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * A3 -- softmax over patches + weighted pooling.  Replaces F.softmax(A, dim=1) (abmil.py:55) and
+ * `(embeddings * attention).sum(dim=1)` (Model.py:416-417) without materialising E*attention.
+ *
+ *   pooled[b,c,e] = sum_t softmax_t(scores[b,:,c])[t] * E[b,t,c,e]
+ *
+ * Bags: dense (cu_seqlens == NULL: bag b = tokens [b*N, (b+1)*N)) or ragged (cu_seqlens int64
+ * [n_bags+1] device array of token offsets into the packed E / scores; max_len = longest bag).
+ * An empty bag pools to 0.
+ * E [T,H*512] (stride ldE), scores [T,H], pooled [n_bags,H*512],
+ * stat_m, stat_l [n_bags,H]: softmax max / sum-of-exp per bag and head (saved for backward).
+ * ws: mdl_abmil_pool_ws_bytes(n_bags,max_len,H).
+ */
+int64_t mdl_abmil_pool_ws_bytes(int64_t n_bags, int64_t max_len, int H);
+int mdl_abmil_pool_fwd(const float* E, int64_t ldE, const float* scores, float* pooled, float* stat_m,
+                       float* stat_l, int64_t n_bags, int64_t N, const int64_t* cu_seqlens,
+                       int64_t max_len, int H, void* ws, void* stream);
+
+/* Backward.  d_pooled [n_bags,H*512].  Outputs: dE [T,H*512] (stride ldE; written or accumulated as
+ * above) and d_scores [T,H] (gradient wrt the RAW scores through the softmax; written, or added to
+ * existing contents when accumulate_scores != 0 -- used when raw attention also feeds a loss). */
+int mdl_abmil_pool_bwd(const float* E, int64_t ldE, const float* scores, const float* pooled,
+                       const float* stat_m, const float* stat_l, const float* d_pooled, float* dE,
+                       int accumulate, float* d_scores, int accumulate_scores, int64_t n_bags, int64_t N,
+                       const int64_t* cu_seqlens, int64_t max_len, int H, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * L1 -- InfoNCE with in-batch negatives.  Replaces InfoNCE.info_nce, negative_keys=None branch
+ * (madeleine/utils/loss.py:92,111-127) for S independent problems in one launch (the reference
+ * calls it once per stain from trainer.py:33).
+ *
+ * Q,P [S,Kmax,D] padded row blocks (problem s uses rows [0,cnt[s])); cnt int32 [S] device array.
+ * loss [S]: mean-reduced cross entropy of Q_hat P_hat^T / temperature against the diagonal
+ *           (symmetric != 0: 0.5*rows + 0.5*columns, loss.py:120-123).  cnt[s] == 0 => loss 0.
+ * ws: mdl_infonce_ws_bytes(S,Kmax,D): normalised rows, inverse norms, logits, LSEs (kept for bwd).
+ */
+int64_t mdl_infonce_ws_bytes(int S, int Kmax, int D);
+int mdl_infonce_fwd(const float* Q, const float* P, const int32_t* cnt, float* loss, int S, int Kmax,
+                    int D, float temperature, int symmetric, void* ws, void* stream);
+/* d_loss [S] incoming; dQ,dP [S,Kmax,D] (rows >= cnt[s] are zeroed).  ws must be the forward's. */
+int mdl_infonce_bwd(const float* d_loss, const int32_t* cnt, float* dQ, float* dP, int S, int Kmax, int D,
+                    float temperature, int symmetric, void* ws, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * G0-G3 -- Graph Optimal Transport.  Replaces GOT (madeleine/utils/loss.py:278-302) =
+ * cost_matrix_batch_torch (:162-176) + global-threshold ReLU (:288-292) + IPOT Wasserstein
+ * (:179-207, 30 iterations, beta .5) + Gromov-Wasserstein (:236-275, 5 x 20 IPOT iterations,
+ * beta .1) with cos_batch_torch intra costs (:210-233).
+ *
+ * V,Q [k,n,d] the (already sub-sampled) token sets of k cases; d <= 128.
+ * Thresholds: the reference takes min/max over the WHOLE [k,n,n] cost tensor.  When `minmax_in`
+ * (float[6] = cross min,max, Cs min,max, Ct min,max) is non-NULL those values are used instead of
+ * the local ones -- the data-parallel driver all-gathers per-rank extrema to keep the global-batch
+ * semantics of nn.DataParallel.  minmax_out float[6] receives the local extrema
+ * plus, in [6..11], the flat argmin/argmax positions as floats are NOT stored -- backward recomputes.
+ * out [2]: out[0] = sum_b WD_b, out[1] = sum_b GWD_b  (GOT returns out[0] + out[1]).
+ * ws: mdl_got_ws_bytes(k,n,d): cost matrices and the per-iteration transport-plan history that the
+ * reverse sweep replays (the reference's autograd tape holds the same tensors).
+ */
+int64_t mdl_got_ws_bytes(int k, int n, int d);
+int mdl_got_fwd(const float* V, const float* Q, float* out, float* minmax_out, const float* minmax_in,
+                int k, int n, int d, void* ws, void* stream);
+/* d_out [2] incoming gradients of (WD sum, GWD sum); dV,dQ [k,n,d] written.  ws = forward's.
+ * d_minmax [6] (optional, may be NULL): gradient wrt the six threshold extrema, needed only when
+ * minmax_in was supplied (the driver routes it back to the owning rank); when minmax_in was NULL the
+ * extrema are local and their gradient is folded into dV,dQ like autograd does. */
+int mdl_got_bwd(const float* V, const float* Q, const float* d_out, float* dV, float* dQ, float* d_minmax,
+                const float* minmax_in, int k, int n, int d, void* ws, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MADELEINE_AMD_H */

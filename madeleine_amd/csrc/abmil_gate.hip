@@ -1,0 +1,627 @@
+// abmil_gate.hip -- A2: gated attention scores of all heads (forward, backward).
+//
+// Replaces BatchedABMIL.forward (reference madeleine/models/abmil.py:41-68) called once per head from
+// ABMILEmbedder.forward (reference madeleine/models/Model.py:406-409):
+//     a = Dropout(.25)(tanh(x Wa^T + ba));  b = Dropout(.25)(sigmoid(x Wb^T + bb));  s = (a*b) wc^T + bc
+// Three fp32 contractions per head dominate the path (4.19 MFLOP/token fwd); they run
+// on v_mfma_f32_32x32x2_f32 (exact fp32 = an fmaf chain, 157 TFLOP/s peak) with the activation, dropout
+// and the wc-reduction fused into the epilogue (forward) / the operand staging (backward), so za, zb,
+// a*b and d(za), d(zb) never touch HBM.
+//
+//   forward : S_part[t, jt] = sum_{j in tile jt} a'_j b'_j wc_j          GEMM [T,512] x [512, 128a|128b]
+//   dX      : dE[t,c,:]     = dza[t,:] Wa + dzb[t,:] Wb                   GEMM [T, 512a|512b] x [1024,512]
+//   dW      : dWa = dza^T X, dWb = dzb^T X  (+ dba, dbb, dwc column sums) GEMM [512, T] x [T, 128a|128b], split over T
+//
+// One block tile shape for all three: 128 x 256 outputs, BK = 16, 256 threads = 4 waves (2 x 2), each
+// wave 64 x 128 = 2 x 4 MFMA 32x32 accumulators (128 acc registers).  LDS tiles are K-major
+// ([k][row]) so every MFMA fragment read is 32 consecutive floats per half-wave (conflict-free
+// ds_read_b32); global->register staging of chunk i+1 overlaps the MFMAs of chunk i, two LDS stages,
+// one barrier per chunk.  fp32 MFMA issues once per 64 cycles per SIMD, so LDS/global traffic is far
+// from limiting; 2 workgroups per CU keep the matrix pipe busy across barriers.
+#include "common.hpp"
+
+namespace mdl {
+
+constexpr int GBM = 128, GBN = 256, GBK = 16;
+constexpr int LDA_S = GBM + 4;  // 132 floats: 16-B aligned rows, 2-way max on transposed stores
+constexpr int LDB_S = GBN + 4;  // 260
+constexpr int GATE_JT = HID / 128;  // 4 j-tiles of 128 gate columns per head
+
+struct GateSmem {
+    float A[2][GBK][LDA_S];
+    float B[2][GBK][LDB_S];
+};  // 50,176 bytes
+
+struct DropCfg {
+    float p, inv;
+    uint32_t thr;
+    uint64_t seed;
+    const uint8_t* ka;
+    const uint8_t* kb;
+    int on;
+};
+
+__device__ __forceinline__ bool drop_keep(const DropCfg& d, int which, int64_t idx) {
+    if (!d.on) return true;
+    const uint8_t* k = which ? d.kb : d.ka;
+    if (k) return k[idx] != 0;
+    return rng_u32(d.seed, (uint32_t)which, (uint64_t)idx) >= d.thr;
+}
+
+// MFMA over one staged K-chunk.  colb[ct] = first column (within the 256-wide B tile) of this wave's ct-th
+// 32-column accumulator tile; rows wm*64 + rt*32.
+__device__ __forceinline__ void mma_chunk(const float (*__restrict__ As)[LDA_S], const float (*__restrict__ Bs)[LDB_S],
+                                          f32x16 (&acc)[2][4], int wm, const int (&colb)[4], int lane) {
+    const int l32 = lane & 31, kh = lane >> 5;
+#pragma unroll
+    for (int kk = 0; kk < GBK / 2; ++kk) {
+        const int k = kk * 2 + kh;
+        const float a0 = As[k][wm * 64 + l32];
+        const float a1 = As[k][wm * 64 + 32 + l32];
+        float b[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) b[ct] = Bs[k][colb[ct] + l32];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            acc[0][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[ct], acc[0][ct], 0, 0, 0);
+            acc[1][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[ct], acc[1][ct], 0, 0, 0);
+        }
+    }
+}
+
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][4]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+}
+
+// MFMA 32x32 C/D layout: register r of lane l holds row (r&3) + 8*(r>>2) + 4*(l>>5), column l&31.
+__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// ================================================================================================
+// forward
+// ================================================================================================
+__global__ __launch_bounds__(256, 2) void gate_fwd_kernel(const float* __restrict__ E, int64_t ldE,
+                                                          const float* __restrict__ Wa, const float* __restrict__ ba,
+                                                          const float* __restrict__ Wb, const float* __restrict__ bb,
+                                                          const float* __restrict__ wc, float* __restrict__ part,
+                                                          float* __restrict__ act_a, float* __restrict__ act_b,
+                                                          int64_t T, int H, int n_ttiles, DropCfg drop) {
+    __shared__ GateSmem sm;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    // logical tile id: jt fastest, then head, then token tile -> the 4*H workgroups that read the same
+    // 128 token rows of E sit next to each other on one XCD (shared L2).
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int jt = lid % GATE_JT, c = (lid / GATE_JT) % H, tt = lid / (GATE_JT * H);
+    const int64_t t0 = (int64_t)tt * GBM;
+    const int j0 = jt * 128;
+
+    const float* __restrict__ Xc = E + (int64_t)c * HID;                      // + t*ldE + k
+    const float* __restrict__ Wac = Wa + ((int64_t)c * HID + j0) * HID;       // + n*512 + k
+    const float* __restrict__ Wbc = Wb + ((int64_t)c * HID + j0) * HID;
+
+    // staging maps (transposed: global rows are K-contiguous).  A: 128 rows x 4 float4; B: 256 rows x 4 float4.
+    f32x4 ra[2], rb[4];
+    auto load_regs = [&](int k0) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int f = tid + p * 256, row = f >> 2, kq = f & 3;
+            const int64_t t = t0 + row;
+            ra[p] = (t < T) ? *reinterpret_cast<const f32x4*>(Xc + t * ldE + k0 + kq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int f = tid + p * 256, row = f >> 2, kq = f & 3;  // row in [0,256): <128 -> Wa, else Wb
+            const float* src = (row < 128) ? (Wac + (int64_t)row * HID) : (Wbc + (int64_t)(row - 128) * HID);
+            rb[p] = *reinterpret_cast<const f32x4*>(src + k0 + kq * 4);
+        }
+    };
+    auto store_lds = [&](int st) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int f = tid + p * 256, row = f >> 2, kq = f & 3;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sm.A[st][kq * 4 + i][row] = ra[p][i];
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int f = tid + p * 256, row = f >> 2, kq = f & 3;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sm.B[st][kq * 4 + i][row] = rb[p][i];
+        }
+    };
+
+    f32x16 acc[2][4];
+    zero_acc(acc);
+    const int colb[4] = {wn * 64, wn * 64 + 32, 128 + wn * 64, 128 + wn * 64 + 32};  // a, a, b, b
+
+    constexpr int NCH = HID / GBK;  // 32 chunks
+    load_regs(0);
+    store_lds(0);
+    __syncthreads();
+    for (int ch = 0; ch < NCH; ++ch) {
+        if (ch + 1 < NCH) load_regs((ch + 1) * GBK);
+        mma_chunk(sm.A[ch & 1], sm.B[ch & 1], acc, wm, colb, lane);
+        if (ch + 1 < NCH) store_lds((ch + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: activations, dropout, wc-weighted row reduction ---------------------------------
+    const int l32 = lane & 31;
+    float ps[2][16];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ps[rt][r] = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        const int j = j0 + wn * 64 + ct * 32 + l32;
+        const float bav = ba[c * HID + j], bbv = bb[c * HID + j], wcv = wc[c * HID + j];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t t = t0 + wm * 64 + rt * 32 + acc_row(r, lane);
+                const float a = tanhf(acc[rt][ct][r] + bav);
+                const float b = 1.f / (1.f + expf(-(acc[rt][2 + ct][r] + bbv)));
+                if (t < T) {
+                    const int64_t idx = (t * H + c) * HID + j;
+                    if (act_a) {
+                        act_a[idx] = a;
+                        act_b[idx] = b;
+                    }
+                    const float ad = drop_keep(drop, 0, idx) ? a * drop.inv : 0.f;
+                    const float bd = drop_keep(drop, 1, idx) ? b * drop.inv : 0.f;
+                    ps[rt][r] += ad * bd * wcv;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = ps[rt][r];
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            ps[rt][r] = v;
+        }
+    float* sred = &sm.A[0][0][0];  // [2 (wn)][128 rows]; all MFMA reads finished at the loop's last barrier
+    if (l32 == 0) {
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sred[wn * GBM + wm * 64 + rt * 32 + acc_row(r, lane)] = ps[rt][r];
+    }
+    __syncthreads();
+    if (tid < GBM) {
+        const int64_t t = t0 + tid;
+        if (t < T) part[(t * H + c) * GATE_JT + jt] = sred[tid] + sred[GBM + tid];
+    }
+}
+
+__global__ void gate_finalize_kernel(const float* __restrict__ part, const float* __restrict__ bc,
+                                     float* __restrict__ scores, int64_t n, int H) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over T*H
+    if (i >= n) return;
+    const f32x4 p = *reinterpret_cast<const f32x4*>(part + i * GATE_JT);
+    scores[i] = bc[i % H] + (((p.x + p.y) + p.z) + p.w);
+}
+
+// ================================================================================================
+// backward: operand transform shared by dX and dW
+//   dza = ds * wc_j * b' * (keep_a/(1-p)) * (1 - a^2)        b' = keep_b ? b/(1-p) : 0
+//   dzb = ds * wc_j * a' * (keep_b/(1-p)) * b (1 - b)        a' = keep_a ? a/(1-p) : 0
+// ================================================================================================
+__device__ __forceinline__ void gate_dz(const DropCfg& d, float ds, float wcv, float a, float b, int64_t idx, float& dza,
+                                        float& dzb, float& pab) {
+    const float ka = drop_keep(d, 0, idx) ? d.inv : 0.f;
+    const float kb = drop_keep(d, 1, idx) ? d.inv : 0.f;
+    const float ad = a * ka, bd = b * kb;
+    const float g = ds * wcv;
+    dza = g * bd * ka * (1.f - a * a);
+    dzb = g * ad * kb * (b * (1.f - b));
+    pab = ds * ad * bd;
+}
+
+// dX: C[t, n] = sum_j dza[t,j] Wa[j,n] + dzb[t,j] Wb[j,n];  tile 128 tokens x 256 of the 512 inputs.
+__global__ __launch_bounds__(256, 2) void gate_bwd_dx_kernel(const float* __restrict__ Wa, const float* __restrict__ Wb,
+                                                             const float* __restrict__ wc,
+                                                             const float* __restrict__ act_a,
+                                                             const float* __restrict__ act_b,
+                                                             const float* __restrict__ d_scores, float* __restrict__ dE,
+                                                             int64_t ldE, int accumulate, int64_t T, int H, DropCfg drop) {
+    __shared__ GateSmem sm;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int nt = lid % 2, c = (lid / 2) % H, tt = lid / (2 * H);
+    const int64_t t0 = (int64_t)tt * GBM;
+    const int n0 = nt * GBN;
+
+    // A staging: thread -> (row = tid/2, quad = tid%2): one float4 of a and of b per 8-wide j chunk
+    const int arow = tid >> 1, aq = tid & 1;
+    const int64_t at = t0 + arow;
+    const bool arow_ok = at < T;
+    const float ds_row = arow_ok ? d_scores[at * H + c] : 0.f;
+    const float* __restrict__ pa = act_a + ((arow_ok ? at : 0) * H + c) * HID + aq * 4;
+    const float* __restrict__ pb = act_b + ((arow_ok ? at : 0) * H + c) * HID + aq * 4;
+    const float* __restrict__ wcc = wc + c * HID + aq * 4;
+    const float* __restrict__ Wac = Wa + (int64_t)c * HID * HID + n0;  // + j*512 + n
+    const float* __restrict__ Wbc = Wb + (int64_t)c * HID * HID + n0;
+
+    f32x4 va, vb, vw, rb[4];
+    auto load_regs = [&](int j0) {
+        if (arow_ok) {
+            va = *reinterpret_cast<const f32x4*>(pa + j0);
+            vb = *reinterpret_cast<const f32x4*>(pb + j0);
+        } else {
+            va = f32x4{0.f, 0.f, 0.f, 0.f};
+            vb = va;
+        }
+        vw = *reinterpret_cast<const f32x4*>(wcc + j0);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int f = tid + p * 256, r = f >> 6, cq = f & 63;  // r in [0,16): <8 -> Wa row j0+r, else Wb row j0+r-8
+            const float* src = (r < 8) ? (Wac + (int64_t)(j0 + r) * HID) : (Wbc + (int64_t)(j0 + r - 8) * HID);
+            rb[p] = *reinterpret_cast<const f32x4*>(src + cq * 4);
+        }
+    };
+    auto store_lds = [&](int st, int j0) {
+        const int64_t idx0 = (at * H + c) * HID + j0 + aq * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float dza = 0.f, dzb = 0.f, pab;
+            if (arow_ok) gate_dz(drop, ds_row, vw[i], va[i], vb[i], idx0 + i, dza, dzb, pab);
+            sm.A[st][aq * 4 + i][arow] = dza;
+            sm.A[st][8 + aq * 4 + i][arow] = dzb;
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int f = tid + p * 256, r = f >> 6, cq = f & 63;
+            *reinterpret_cast<f32x4*>(&sm.B[st][r][cq * 4]) = rb[p];
+        }
+    };
+
+    f32x16 acc[2][4];
+    zero_acc(acc);
+    const int colb[4] = {wn * 128, wn * 128 + 32, wn * 128 + 64, wn * 128 + 96};
+    constexpr int NCH = HID / 8;  // 64 chunks of (8 a-rows + 8 b-rows)
+    load_regs(0);
+    store_lds(0, 0);
+    __syncthreads();
+    for (int ch = 0; ch < NCH; ++ch) {
+        if (ch + 1 < NCH) load_regs((ch + 1) * 8);
+        mma_chunk(sm.A[ch & 1], sm.B[ch & 1], acc, wm, colb, lane);
+        if (ch + 1 < NCH) store_lds((ch + 1) & 1, (ch + 1) * 8);
+        __syncthreads();
+    }
+
+    const int l32 = lane & 31;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t t = t0 + wm * 64 + rt * 32 + acc_row(r, lane);
+            if (t < T) {
+                float* __restrict__ o = dE + t * ldE + (int64_t)c * HID + n0 + l32;
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) {
+                    float v = acc[rt][ct][r];
+                    if (accumulate) v += o[colb[ct]];
+                    o[colb[ct]] = v;
+                }
+            }
+        }
+}
+
+// dW^T tile: C[k', n] = sum_t X[t,k'] * dz[t, n]   (n < 128: dza column j0+n ; n >= 128: dzb column j0+n-128)
+// over the token range of this split.  Column sums dba, dbb, dwc are accumulated by the kt == 0 tiles.
+template <bool SUMS>
+__device__ __forceinline__ void gate_bwd_dw_body(const float* __restrict__ E, int64_t ldE,
+                                                             const float* __restrict__ wc,
+                                                             const float* __restrict__ act_a,
+                                                             const float* __restrict__ act_b,
+                                                             const float* __restrict__ d_scores,
+                                                             float* __restrict__ slabW, float* __restrict__ slabV,
+                                                             int64_t T, int H, int64_t tok_per_split, DropCfg drop) {
+    __shared__ GateSmem sm;
+    // running column sums (dba, dbb, dwc: 3 x 4 floats per thread) live in LDS, not in VGPRs: the 128
+    // accumulator registers + the staged chunk already fill the 256-register budget of 2 waves/SIMD.
+    __shared__ float colsum[SUMS ? 256 * 13 : 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    // logical id: kt (1..3, or 0 for the SUMS variant) fastest, then jt, head, split: the tiles of one
+    // (split, head) share X and a/b rows through one XCD's L2
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    constexpr int NKT = SUMS ? 1 : 3;
+    const int kt = SUMS ? 0 : 1 + lid % NKT, jt = (lid / NKT) % GATE_JT, c = (lid / (NKT * GATE_JT)) % H,
+              sp = lid / (NKT * GATE_JT * H);
+    const int k0 = kt * 128, j0 = jt * 128;
+    const int64_t ts = (int64_t)sp * tok_per_split;
+    int64_t te = ts + tok_per_split;
+    if (te > T) te = T;
+
+    // staging maps: row r = f/32 in [0,16) (two passes), quad q = f%32 (fixed per thread = tid%32)
+    const int q = tid & 31;
+    const float* __restrict__ Xc = E + (int64_t)c * HID + k0 + q * 4;
+    const f32x4 vw = *reinterpret_cast<const f32x4*>(wc + c * HID + j0 + q * 4);
+    f32x4 rx[2], va[2], vb[2];
+    float vds[2];
+    auto load_regs = [&](int64_t tb) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int r = (tid >> 5) + p * 8;
+            const int64_t t = tb + r;
+            if (t < te) {
+                rx[p] = *reinterpret_cast<const f32x4*>(Xc + t * ldE);
+                const int64_t o = (t * H + c) * HID + j0 + q * 4;
+                va[p] = *reinterpret_cast<const f32x4*>(act_a + o);
+                vb[p] = *reinterpret_cast<const f32x4*>(act_b + o);
+                vds[p] = d_scores[t * H + c];
+            } else {
+                rx[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+                va[p] = rx[p];
+                vb[p] = rx[p];
+                vds[p] = 0.f;
+            }
+        }
+    };
+    if (SUMS) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) colsum[tid * 13 + i] = 0.f;
+    }
+    auto store_lds = [&](int st, int64_t tb) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int r = (tid >> 5) + p * 8;
+            const int64_t t = tb + r;
+            *reinterpret_cast<f32x4*>(&sm.A[st][r][q * 4]) = rx[p];
+            f32x4 za = {0.f, 0.f, 0.f, 0.f}, zb = za, pp = za;
+            if (t < te) {
+                const int64_t idx0 = (t * H + c) * HID + j0 + q * 4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float dza, dzb, pab;
+                    gate_dz(drop, vds[p], vw[i], va[p][i], vb[p][i], idx0 + i, dza, dzb, pab);
+                    za[i] = dza;
+                    zb[i] = dzb;
+                    pp[i] = pab;
+                }
+            }
+            *reinterpret_cast<f32x4*>(&sm.B[st][r][q * 4]) = za;
+            *reinterpret_cast<f32x4*>(&sm.B[st][r][128 + q * 4]) = zb;
+            if (SUMS) {
+                float* cs = colsum + tid * 13;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    cs[i] += za[i];
+                    cs[4 + i] += zb[i];
+                    cs[8 + i] += pp[i];
+                }
+            }
+        }
+    };
+
+    f32x16 acc[2][4];
+    zero_acc(acc);
+    const int colb[4] = {wn * 128, wn * 128 + 32, wn * 128 + 64, wn * 128 + 96};
+    const int64_t nch = (te > ts) ? (te - ts + GBK - 1) / GBK : 0;
+    if (nch > 0) {
+        load_regs(ts);
+        store_lds(0, ts);
+    }
+    __syncthreads();
+    for (int64_t ch = 0; ch < nch; ++ch) {
+        if (ch + 1 < nch) load_regs(ts + (ch + 1) * GBK);
+        mma_chunk(sm.A[ch & 1], sm.B[ch & 1], acc, wm, colb, lane);
+        if (ch + 1 < nch) store_lds((int)((ch + 1) & 1), ts + (ch + 1) * GBK);
+        __syncthreads();
+    }
+
+    // slabW [split][head][k' 512][1024: a-cols 0..511 | b-cols 512..1023]
+    float* __restrict__ so = slabW + (((int64_t)sp * H + c) * HID) * 1024;
+    const int l32 = lane & 31;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kr = k0 + wm * 64 + rt * 32 + acc_row(r, lane);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                const int n = colb[ct] + l32;  // [0,256)
+                const int col = (n < 128) ? (j0 + n) : (512 + j0 + n - 128);
+                so[(int64_t)kr * 1024 + col] = acc[rt][ct][r];
+            }
+        }
+
+    // column sums: reduce the 8 row-groups (tid>>5) that share quad q
+    if (SUMS) {
+        __syncthreads();
+        for (int e = tid; e < 32 * 12; e += 256) {
+            const int qq = e / 12, slot = e % 12;
+            float v = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) v += colsum[(g * 32 + qq) * 13 + slot];
+            const int which = slot >> 2, i = slot & 3;  // 0 dba, 1 dbb, 2 dwc
+            slabV[(((int64_t)sp * H + c) * 3 + which) * HID + j0 + qq * 4 + i] = v;
+        }
+    }
+}
+
+// The column-sum variant needs ~300 registers: it runs at 1 wave/SIMD (1/4 of the dW tiles); the plain
+// variant fits 2 waves/SIMD.
+__global__ __launch_bounds__(256, 1) void gate_bwd_dw_sums_kernel(const float* __restrict__ E, int64_t ldE,
+                                                                  const float* __restrict__ wc,
+                                                                  const float* __restrict__ act_a,
+                                                                  const float* __restrict__ act_b,
+                                                                  const float* __restrict__ d_scores,
+                                                                  float* __restrict__ slabW, float* __restrict__ slabV,
+                                                                  int64_t T, int H, int64_t tok_per_split, DropCfg drop) {
+    gate_bwd_dw_body<true>(E, ldE, wc, act_a, act_b, d_scores, slabW, slabV, T, H, tok_per_split, drop);
+}
+__global__ __launch_bounds__(256, 2) void gate_bwd_dw_kernel(const float* __restrict__ E, int64_t ldE,
+                                                             const float* __restrict__ wc,
+                                                             const float* __restrict__ act_a,
+                                                             const float* __restrict__ act_b,
+                                                             const float* __restrict__ d_scores,
+                                                             float* __restrict__ slabW, float* __restrict__ slabV,
+                                                             int64_t T, int H, int64_t tok_per_split, DropCfg drop) {
+    gate_bwd_dw_body<false>(E, ldE, wc, act_a, act_b, d_scores, slabW, slabV, T, H, tok_per_split, drop);
+}
+
+// dWa[c][j][k] = sum_s slabW[s][c][k][j] ; dWb[c][j][k] = sum_s slabW[s][c][k][512+j]  (32x32 LDS transpose)
+__global__ __launch_bounds__(256) void gate_reduce_w_kernel(const float* __restrict__ slabW, float* __restrict__ dWa,
+                                                            float* __restrict__ dWb, int H, int S) {
+    __shared__ float tile[32][33];
+    const int c = blockIdx.z, kb = blockIdx.y * 32, nb = blockIdx.x * 32;  // nb over 1024 columns
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;                // 32 x 8
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = kb + ty + i * 8;
+        float v = 0.f;
+        for (int s = 0; s < S; ++s) v += slabW[(((int64_t)s * H + c) * HID + k) * 1024 + nb + tx];
+        tile[ty + i * 8][tx] = v;
+    }
+    __syncthreads();
+    float* __restrict__ dst = (nb < 512) ? dWa : dWb;
+    const int jb = (nb < 512) ? nb : nb - 512;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int j = jb + ty + i * 8;
+        dst[((int64_t)c * HID + j) * HID + kb + tx] = tile[tx][ty + i * 8];
+    }
+}
+
+__global__ void gate_reduce_v_kernel(const float* __restrict__ slabV, float* __restrict__ dba, float* __restrict__ dbb,
+                                     float* __restrict__ dwc, int H, int S) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over H*3*512
+    if (i >= H * 3 * HID) return;
+    const int j = i % HID, which = (i / HID) % 3, c = i / (3 * HID);
+    float v = 0.f;
+    for (int s = 0; s < S; ++s) v += slabV[(((int64_t)s * H + c) * 3 + which) * HID + j];
+    float* dst = which == 0 ? dba : (which == 1 ? dbb : dwc);
+    dst[c * HID + j] = v;
+}
+
+__global__ void gate_mask_kernel(uint8_t* __restrict__ keep, int64_t n, int which, uint64_t seed, uint32_t thr) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) keep[i] = rng_u32(seed, (uint32_t)which, (uint64_t)i) >= thr ? 1 : 0;
+}
+
+static inline DropCfg make_drop(float p, uint64_t seed, const uint8_t* ka, const uint8_t* kb) {
+    DropCfg d;
+    d.on = (p > 0.f) ? 1 : 0;
+    d.p = p;
+    d.inv = d.on ? 1.f / (1.f - p) : 1.f;
+    d.thr = drop_threshold(p);
+    d.seed = seed;
+    d.ka = ka;
+    d.kb = kb;
+    return d;
+}
+
+static inline int gate_splits(int64_t T) {
+    // ~4k tokens per split, at most 64 splits; each split a multiple of GBK tokens
+    int64_t s = (T + 4095) / 4096;
+    if (s < 1) s = 1;
+    if (s > 64) s = 64;
+    return (int)s;
+}
+static inline int64_t gate_tok_per_split(int64_t T, int S) {
+    int64_t tps = (T + S - 1) / S;
+    return ((tps + GBK - 1) / GBK) * GBK;
+}
+
+}  // namespace mdl
+
+using namespace mdl;
+
+extern "C" int64_t mdl_abmil_gate_fwd_ws_bytes(int64_t T, int H) {
+    if (T < 0 || H < 1 || H > MDL_MAX_HEADS) return MDL_E_ARG;
+    return T * H * GATE_JT * 4 + 64;
+}
+
+extern "C" int mdl_abmil_gate_fwd(const float* E, int64_t ldE, const float* Wa, const float* ba, const float* Wb,
+                                  const float* bb, const float* wc, const float* bc, float* scores, float* act_a,
+                                  float* act_b, int64_t T, int H, float p_drop, uint64_t seed, const uint8_t* keep_a,
+                                  const uint8_t* keep_b, void* ws, void* stream) {
+    if (!E || !Wa || !ba || !Wb || !bb || !wc || !bc || !scores || !ws) return MDL_E_ARG;
+    if ((act_a == nullptr) != (act_b == nullptr)) return MDL_E_ARG;
+    if ((keep_a == nullptr) != (keep_b == nullptr)) return MDL_E_ARG;
+    if (T < 0 || H < 1 || H > MDL_MAX_HEADS || ldE < (int64_t)H * HID || (ldE & 3)) return MDL_E_ARG;
+    if (!(p_drop >= 0.f && p_drop < 1.f)) return MDL_E_ARG;
+    if (!host_aligned16(E) || !host_aligned16(Wa) || !host_aligned16(Wb) || !host_aligned16(ws)) return MDL_E_ALIGN;
+    if (T == 0) return MDL_OK;
+    const int64_t n_tt = (T + GBM - 1) / GBM;
+    if (n_tt * GATE_JT * H > 0x7fffffff) return MDL_E_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const DropCfg d = make_drop(p_drop, seed, keep_a, keep_b);
+    hipLaunchKernelGGL(gate_fwd_kernel, dim3((unsigned)(n_tt * GATE_JT * H)), dim3(256), 0, s, E, ldE, Wa, ba, Wb, bb, wc,
+                       (float*)ws, act_a, act_b, T, H, (int)n_tt, d);
+    MDL_LAUNCH_CHECK();
+    const int64_t n = T * H;
+    hipLaunchKernelGGL(gate_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)ws, bc, scores,
+                       n, H);
+    MDL_LAUNCH_CHECK();
+    return MDL_OK;
+}
+
+extern "C" int64_t mdl_abmil_gate_bwd_ws_bytes(int64_t T, int H) {
+    if (T < 0 || H < 1 || H > MDL_MAX_HEADS) return MDL_E_ARG;
+    const int S = gate_splits(T);
+    return (int64_t)S * H * HID * 1024 * 4 + (int64_t)S * H * 3 * HID * 4 + 64;
+}
+
+extern "C" int mdl_abmil_gate_bwd(const float* E, int64_t ldE, const float* Wa, const float* Wb, const float* wc,
+                                  const float* act_a, const float* act_b, const float* d_scores, float* dE,
+                                  int accumulate, float* dWa, float* dWb, float* dba, float* dbb, float* dwc, int64_t T,
+                                  int H, float p_drop, uint64_t seed, const uint8_t* keep_a, const uint8_t* keep_b,
+                                  void* ws, void* stream) {
+    if (!E || !Wa || !Wb || !wc || !act_a || !act_b || !d_scores || !dE || !dWa || !dWb || !dba || !dbb || !dwc || !ws)
+        return MDL_E_ARG;
+    if ((keep_a == nullptr) != (keep_b == nullptr)) return MDL_E_ARG;
+    if (T < 0 || H < 1 || H > MDL_MAX_HEADS || ldE < (int64_t)H * HID || (ldE & 3)) return MDL_E_ARG;
+    if (!(p_drop >= 0.f && p_drop < 1.f)) return MDL_E_ARG;
+    if (!host_aligned16(E) || !host_aligned16(Wa) || !host_aligned16(Wb) || !host_aligned16(act_a) ||
+        !host_aligned16(act_b) || !host_aligned16(wc) || !host_aligned16(ws))
+        return MDL_E_ALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    const DropCfg d = make_drop(p_drop, seed, keep_a, keep_b);
+    const int S = gate_splits(T);
+    const int64_t tps = gate_tok_per_split(T, S);
+    float* slabW = (float*)ws;
+    float* slabV = slabW + (int64_t)S * H * HID * 1024;
+    if (T > 0) {
+        const int64_t n_tt = (T + GBM - 1) / GBM;
+        if (n_tt * 2 * H > 0x7fffffff) return MDL_E_UNSUPPORTED;
+        hipLaunchKernelGGL(gate_bwd_dx_kernel, dim3((unsigned)(n_tt * 2 * H)), dim3(256), 0, s, Wa, Wb, wc, act_a, act_b,
+                           d_scores, dE, ldE, accumulate, T, H, d);
+        MDL_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(gate_bwd_dw_sums_kernel, dim3((unsigned)(1 * GATE_JT * H * S)), dim3(256), 0, s, E, ldE, wc, act_a,
+                       act_b, d_scores, slabW, slabV, T, H, tps, d);
+    MDL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gate_bwd_dw_kernel, dim3((unsigned)(3 * GATE_JT * H * S)), dim3(256), 0, s, E, ldE, wc, act_a,
+                       act_b, d_scores, slabW, slabV, T, H, tps, d);
+    MDL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gate_reduce_w_kernel, dim3(32, 16, H), dim3(256), 0, s, (const float*)slabW, dWa, dWb, H, S);
+    MDL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gate_reduce_v_kernel, dim3((H * 3 * HID + 255) / 256), dim3(256), 0, s, (const float*)slabV, dba, dbb,
+                       dwc, H, S);
+    MDL_LAUNCH_CHECK();
+    return MDL_OK;
+}
+
+extern "C" int mdl_abmil_gate_dropout_mask(uint8_t* keep, int64_t T, int H, int which, float p_drop, uint64_t seed,
+                                           void* stream) {
+    if (!keep || T < 0 || H < 1 || H > MDL_MAX_HEADS || (which != 0 && which != 1)) return MDL_E_ARG;
+    if (!(p_drop >= 0.f && p_drop < 1.f)) return MDL_E_ARG;
+    const int64_t n = T * H * HID;
+    if (n == 0) return MDL_OK;
+    hipLaunchKernelGGL(gate_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, keep, n, which,
+                       seed, drop_threshold(p_drop));
+    MDL_LAUNCH_CHECK();
+    return MDL_OK;
+}

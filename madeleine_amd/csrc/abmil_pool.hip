@@ -1,0 +1,280 @@
+// abmil_pool.hip -- A3: softmax over patches + attention-weighted pooling (forward, backward).
+//
+// Replaces  F.softmax(A, dim=1)                       (reference madeleine/models/abmil.py:55)
+//      and  (embeddings * attention).sum(dim=1)       (reference madeleine/models/Model.py:416-417)
+// without materialising the [BM,N,512,H] product.  HBM-bound: the forward reads E once
+// (8 KiB + 16 B per token at H=4) and writes 8 KiB per BAG; the backward reads E once and writes dE once.
+//
+// Layout: head-major E [T, H*512] (see include/madeleine_amd.h), scores [T,H], pooled [n_bags,H*512].
+//
+// Forward  = pool_partial (grid: chunks of 128 tokens x bags; online-softmax partial per chunk)
+//          + pool_combine (grid: bags; merges the per-chunk (max, sum, weighted sum) triples in chunk
+//            order -> deterministic, no atomics).
+// Backward = pool_bwd (one wave per token row; lane-local dot with d_pooled, one 64-lane reduction
+//            per head, dE and d_scores written in the same pass).
+#include "common.hpp"
+
+namespace mdl {
+
+constexpr int POOL_CHUNK = 128;  // tokens per forward workgroup
+constexpr int POOL_BWD_TOKENS = 128;  // tokens per backward workgroup (4 waves)
+
+struct BagSpan {
+    int64_t start, len;
+};
+__device__ __forceinline__ BagSpan bag_span(int b, int64_t N, const int64_t* cu) {
+    BagSpan s;
+    if (cu) {
+        s.start = cu[b];
+        s.len = cu[b + 1] - s.start;
+    } else {
+        s.start = (int64_t)b * N;
+        s.len = N;
+    }
+    return s;
+}
+
+// blockDim.x == H*128: thread f owns channels [4f, 4f+4) (head f/128).
+template <int H>
+__global__ __launch_bounds__(H * 128) void pool_partial_kernel(const float* __restrict__ E, int64_t ldE,
+                                                               const float* __restrict__ scores,
+                                                               float* __restrict__ part_acc,
+                                                               float* __restrict__ part_m,
+                                                               float* __restrict__ part_l, int64_t N,
+                                                               const int64_t* __restrict__ cu, int max_chunks) {
+    constexpr int NT = H * 128;
+    constexpr int NW = NT / 64;
+    __shared__ float p_s[POOL_CHUNK * H];  // exp(s - m_chunk), [t][c]
+    __shared__ float red_s[NW * H];
+    __shared__ float stat_s[2 * H];
+
+    const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    const BagSpan sp = bag_span(b, N, cu);
+    const int64_t t0 = (int64_t)chunk * POOL_CHUNK;
+    if (t0 >= sp.len) return;  // block-uniform
+    const int nt = (int)((sp.len - t0 < POOL_CHUNK) ? (sp.len - t0) : POOL_CHUNK);
+
+    // ---- chunk softmax statistics: thread tid holds score (t = tid / H, c = tid % H) ----------
+    const int st = tid / H, sc = tid % H;
+    const float s = (st < nt) ? scores[(sp.start + t0 + st) * H + sc] : -INFINITY;
+    float mx = s;
+#pragma unroll
+    for (int o = 32; o >= H; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    const int lane = tid & 63, wave = tid >> 6;
+    if (lane < H) red_s[wave * H + lane] = mx;
+    __syncthreads();
+    float m = red_s[sc];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) m = fmaxf(m, red_s[w * H + sc]);
+    const float p = (st < nt) ? expf(s - m) : 0.f;
+    p_s[st * H + sc] = p;
+    float sm = p;
+#pragma unroll
+    for (int o = 32; o >= H; o >>= 1) sm += __shfl_xor(sm, o, 64);
+    __syncthreads();  // red_s reads done; p_s written
+    if (lane < H) red_s[wave * H + lane] = sm;
+    __syncthreads();
+    if (tid < H) {
+        float l = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) l += red_s[w * H + tid];
+        const int64_t o = ((int64_t)b * max_chunks + chunk) * H + tid;
+        part_m[o] = m;  // tid < H => sc == tid, st == 0
+        part_l[o] = l;
+    }
+
+    // ---- weighted accumulation: thread owns one float4 column, loops over the chunk's tokens -----
+    const int ca = tid / 128;
+    const float* __restrict__ Ep = E + (sp.start + t0) * ldE + (int64_t)tid * 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    constexpr int U = 8;
+    int t = 0;
+    for (; t + U <= nt; t += U) {
+        f32x4 x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) x[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Ep + (int64_t)(t + u) * ldE));
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float w = p_s[(t + u) * H + ca];
+            acc += w * x[u];
+        }
+    }
+    for (; t < nt; ++t) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(Ep + (int64_t)t * ldE);
+        acc += p_s[t * H + ca] * x;
+    }
+    *reinterpret_cast<f32x4*>(part_acc + ((int64_t)b * max_chunks + chunk) * (H * HID) + (int64_t)tid * 4) = acc;
+}
+
+template <int H>
+__global__ __launch_bounds__(H * 128) void pool_combine_kernel(const float* __restrict__ part_acc,
+                                                               const float* __restrict__ part_m,
+                                                               const float* __restrict__ part_l,
+                                                               float* __restrict__ pooled, float* __restrict__ stat_m,
+                                                               float* __restrict__ stat_l, int64_t N,
+                                                               const int64_t* __restrict__ cu, int max_chunks) {
+    const int b = blockIdx.x, tid = threadIdx.x, ca = tid / 128;
+    const BagSpan sp = bag_span(b, N, cu);
+    const int nchunks = (int)((sp.len + POOL_CHUNK - 1) / POOL_CHUNK);
+    f32x4 out = {0.f, 0.f, 0.f, 0.f};
+    float M = 0.f, L = 1.f;
+    if (nchunks > 0) {
+        const float* pm = part_m + (int64_t)b * max_chunks * H + ca;
+        const float* pl = part_l + (int64_t)b * max_chunks * H + ca;
+        M = pm[0];
+        for (int k = 1; k < nchunks; ++k) M = fmaxf(M, pm[(int64_t)k * H]);
+        L = 0.f;
+        const float* pa = part_acc + (int64_t)b * max_chunks * (H * HID) + (int64_t)tid * 4;
+        for (int k = 0; k < nchunks; ++k) {
+            const float f = expf(pm[(int64_t)k * H] - M);
+            L += f * pl[(int64_t)k * H];
+            out += f * *reinterpret_cast<const f32x4*>(pa + (int64_t)k * (H * HID));
+        }
+        const float rl = 1.f / L;
+        out *= rl;
+    }
+    *reinterpret_cast<f32x4*>(pooled + (int64_t)b * (H * HID) + (int64_t)tid * 4) = out;
+    if ((tid & 127) == 0) {
+        stat_m[(int64_t)b * H + ca] = M;
+        stat_l[(int64_t)b * H + ca] = L;
+    }
+}
+
+// One wave per token row.  Lane L, slot i in [0,2H): channels [i*256 + 4L, +4), head i/2.
+template <int H>
+__global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ E, int64_t ldE,
+                                                       const float* __restrict__ scores,
+                                                       const float* __restrict__ pooled,
+                                                       const float* __restrict__ stat_m,
+                                                       const float* __restrict__ stat_l,
+                                                       const float* __restrict__ d_pooled, float* __restrict__ dE,
+                                                       int accumulate, float* __restrict__ d_scores,
+                                                       int accumulate_scores, int64_t N,
+                                                       const int64_t* __restrict__ cu) {
+    const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const BagSpan sp = bag_span(b, N, cu);
+    const int64_t t0 = (int64_t)chunk * POOL_BWD_TOKENS;
+    if (t0 >= sp.len) return;
+    const int nt = (int)((sp.len - t0 < POOL_BWD_TOKENS) ? (sp.len - t0) : POOL_BWD_TOKENS);
+
+    f32x4 dp[2 * H];
+    float D[H], m[H], rl[H];
+#pragma unroll
+    for (int c = 0; c < H; ++c) D[c] = 0.f;
+    const int64_t boff = (int64_t)b * (H * HID) + lane * 4;
+#pragma unroll
+    for (int i = 0; i < 2 * H; ++i) {
+        dp[i] = *reinterpret_cast<const f32x4*>(d_pooled + boff + i * 256);
+        const f32x4 pl = *reinterpret_cast<const f32x4*>(pooled + boff + i * 256);
+        D[i / 2] += dp[i].x * pl.x + dp[i].y * pl.y + dp[i].z * pl.z + dp[i].w * pl.w;
+    }
+#pragma unroll
+    for (int c = 0; c < H; ++c) {
+        D[c] = wave_sum(D[c]);  // <pooled[b,c,:], d_pooled[b,c,:]> = sum_t w_t dw_t
+        m[c] = stat_m[(int64_t)b * H + c];
+        rl[c] = 1.f / stat_l[(int64_t)b * H + c];
+    }
+
+    for (int t = wave; t < nt; t += 4) {
+        const int64_t row = sp.start + t0 + t;
+        const float* __restrict__ er = E + row * ldE + lane * 4;
+        f32x4 x[2 * H];
+#pragma unroll
+        for (int i = 0; i < 2 * H; ++i) x[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(er + i * 256));
+        float w[H], dw[H];
+#pragma unroll
+        for (int c = 0; c < H; ++c) w[c] = expf(scores[row * H + c] - m[c]) * rl[c];
+#pragma unroll
+        for (int c = 0; c < H; ++c) {
+            const f32x4 a = x[2 * c] * dp[2 * c] + x[2 * c + 1] * dp[2 * c + 1];
+            dw[c] = wave_sum(a.x + a.y + a.z + a.w);
+        }
+        float* __restrict__ gr = dE + row * ldE + lane * 4;
+#pragma unroll
+        for (int i = 0; i < 2 * H; ++i) {
+            f32x4 g = w[i / 2] * dp[i];
+            if (accumulate) g += *reinterpret_cast<const f32x4*>(gr + i * 256);
+            *reinterpret_cast<f32x4*>(gr + i * 256) = g;
+        }
+        float ds = 0.f;
+#pragma unroll
+        for (int c = 0; c < H; ++c)
+            if (lane == c) ds = w[c] * (dw[c] - D[c]);
+        if (lane < H) {
+            if (accumulate_scores) ds += d_scores[row * H + lane];
+            d_scores[row * H + lane] = ds;
+        }
+    }
+}
+
+static inline int64_t pool_max_chunks(int64_t max_len) { return (max_len + POOL_CHUNK - 1) / POOL_CHUNK; }
+
+}  // namespace mdl
+
+using namespace mdl;
+
+extern "C" int64_t mdl_abmil_pool_ws_bytes(int64_t n_bags, int64_t max_len, int H) {
+    if (n_bags < 0 || max_len < 0 || H < 1 || H > MDL_MAX_HEADS) return MDL_E_ARG;
+    const int64_t mc = pool_max_chunks(max_len);
+    // part_acc [n_bags][mc][H*512] + part_m, part_l [n_bags][mc][H]; each region 16-byte aligned
+    const int64_t acc = n_bags * mc * H * HID * 4;
+    const int64_t st = ((n_bags * mc * H * 4 + 15) / 16) * 16;
+    return acc + 2 * st + 64;
+}
+
+#define MDL_DISPATCH_H(H, ...)                       \
+    switch (H) {                                     \
+        case 1: { constexpr int HH = 1; __VA_ARGS__; } break; \
+        case 2: { constexpr int HH = 2; __VA_ARGS__; } break; \
+        case 4: { constexpr int HH = 4; __VA_ARGS__; } break; \
+        case 8: { constexpr int HH = 8; __VA_ARGS__; } break; \
+        default: return MDL_E_UNSUPPORTED;           \
+    }
+
+extern "C" int mdl_abmil_pool_fwd(const float* E, int64_t ldE, const float* scores, float* pooled, float* stat_m,
+                                  float* stat_l, int64_t n_bags, int64_t N, const int64_t* cu_seqlens,
+                                  int64_t max_len, int H, void* ws, void* stream) {
+    if (!E || !scores || !pooled || !stat_m || !stat_l || !ws) return MDL_E_ARG;
+    if (n_bags < 0 || max_len < 0 || ldE < (int64_t)H * HID || (ldE & 3)) return MDL_E_ARG;
+    if (!cu_seqlens && N != max_len) return MDL_E_ARG;
+    if (!host_aligned16(E) || !host_aligned16(pooled) || !host_aligned16(ws)) return MDL_E_ALIGN;
+    if (n_bags == 0) return MDL_OK;
+    if (n_bags > 65535) return MDL_E_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const int mc = (int)pool_max_chunks(max_len);
+    float* part_acc = (float*)ws;
+    const int64_t st = ((n_bags * (int64_t)mc * H * 4 + 15) / 16) * 16;
+    float* part_m = (float*)((char*)ws + n_bags * (int64_t)mc * H * HID * 4);
+    float* part_l = (float*)((char*)part_m + st);
+    MDL_DISPATCH_H(H, {
+        if (mc > 0) {
+            hipLaunchKernelGGL((pool_partial_kernel<HH>), dim3(mc, (unsigned)n_bags), dim3(HH * 128), 0, s, E, ldE, scores,
+                               part_acc, part_m, part_l, N, cu_seqlens, mc);
+            MDL_LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL((pool_combine_kernel<HH>), dim3((unsigned)n_bags), dim3(HH * 128), 0, s, part_acc, part_m, part_l,
+                           pooled, stat_m, stat_l, N, cu_seqlens, mc);
+        MDL_LAUNCH_CHECK();
+    });
+    return MDL_OK;
+}
+
+extern "C" int mdl_abmil_pool_bwd(const float* E, int64_t ldE, const float* scores, const float* pooled,
+                                  const float* stat_m, const float* stat_l, const float* d_pooled, float* dE,
+                                  int accumulate, float* d_scores, int accumulate_scores, int64_t n_bags, int64_t N,
+                                  const int64_t* cu_seqlens, int64_t max_len, int H, void* stream) {
+    if (!E || !scores || !pooled || !stat_m || !stat_l || !d_pooled || !dE || !d_scores) return MDL_E_ARG;
+    if (n_bags < 0 || max_len < 0 || ldE < (int64_t)H * HID || (ldE & 3)) return MDL_E_ARG;
+    if (!cu_seqlens && N != max_len) return MDL_E_ARG;
+    if (!host_aligned16(E) || !host_aligned16(dE) || !host_aligned16(pooled) || !host_aligned16(d_pooled)) return MDL_E_ALIGN;
+    if (n_bags == 0 || max_len == 0) return MDL_OK;
+    if (n_bags > 65535) return MDL_E_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const int nc = (int)((max_len + POOL_BWD_TOKENS - 1) / POOL_BWD_TOKENS);
+    MDL_DISPATCH_H(H, {
+        hipLaunchKernelGGL((pool_bwd_kernel<HH>), dim3(nc, (unsigned)n_bags), dim3(256), 0, s, E, ldE, scores, pooled, stat_m,
+                           stat_l, d_pooled, dE, accumulate, d_scores, accumulate_scores, N, cu_seqlens);
+        MDL_LAUNCH_CHECK();
+    });
+    return MDL_OK;
+}

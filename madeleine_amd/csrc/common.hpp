@@ -1,0 +1,71 @@
+// common.hpp -- shared device helpers for the gfx950 kernels of libmadeleine_amd.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/madeleine_amd.h"
+
+#define MDL_LAUNCH_CHECK()                                  \
+    do {                                                    \
+        hipError_t _e = hipGetLastError();                  \
+        if (_e != hipSuccess) return (int)_e;               \
+    } while (0)
+
+namespace mdl {
+
+constexpr int WAVE = 64;
+constexpr int HID = MDL_HIDDEN;  // 512
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline bool host_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---- wave-level reductions (wave = 64 lanes) ---------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---- counter-based dropout RNG ------------------------------------------------------------------
+// keep(idx) is a pure function of (seed, stream, idx): forward and backward regenerate identical
+// masks without storing them.  Two rounds of a 32-bit xorshift-multiply finaliser over a 64-bit
+// counter folded with the seed; quality is ample for Bernoulli dropout masks.
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7feb352dU;
+    x ^= x >> 15;
+    x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ uint32_t rng_u32(uint64_t seed, uint32_t stream, uint64_t idx) {
+    uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
+    uint32_t k = mix32((uint32_t)seed ^ (stream * 0x9E3779B9U)) ^ mix32((uint32_t)(seed >> 32) + hi * 0x85EBCA6BU + 0x165667B1U);
+    return mix32(lo ^ k) ^ mix32(lo * 0xC2B2AE35U + k);
+}
+// threshold = floor(p * 2^32); keep iff u32 >= threshold  => P(keep) = 1 - p
+__host__ __device__ __forceinline__ uint32_t drop_threshold(float p) {
+    double t = (double)p * 4294967296.0;
+    if (t < 0) t = 0;
+    if (t > 4294967295.0) t = 4294967295.0;
+    return (uint32_t)t;
+}
+
+// XCD-aware remap (8 XCDs; block b runs on XCD b % 8): returns a logical id such that logical ids
+// [x*per, (x+1)*per) all run on XCD x, i.e. consecutive logical tiles share one L2.  Bijective for
+// any n (cdna_hip_programming.md T1).
+__device__ __forceinline__ int xcd_remap(int bid, int n) {
+    const int q = n / 8, r = n % 8, xcd = bid % 8, pos = bid / 8;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + pos;
+}
+
+}  // namespace mdl

@@ -1,0 +1,303 @@
+"""torch.autograd.Function wrappers over the C ABI (include/madeleine_amd.h).
+
+PyTorch is plumbing here: it owns device memory, the stream and the autograd graph; every numeric
+step of the hot path below runs in libmadeleine_amd.so.  All tensors are fp32, contiguous, on a
+ROCm device; anything else raises (there is no CPU or eager fallback).
+
+Layouts (see include/madeleine_amd.h): token embeddings are head-major [T, H*512]; scores [T, H].
+"""
+from typing import Optional, Tuple
+
+import torch
+
+from . import _native
+
+HID = 512
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _require(t: torch.Tensor, name: str, dtype=torch.float32):
+    if not t.is_cuda:
+        raise RuntimeError(
+            "madeleine_amd: %s must live on a ROCm device (got %s); the HIP kernels are the only backend" % (name, t.device))
+    if t.dtype != dtype:
+        raise RuntimeError("madeleine_amd: %s must be %s (got %s)" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise RuntimeError("madeleine_amd: %s must be contiguous" % name)
+    return t
+
+
+class KernelTimer:
+    """Optional per-call HIP-event timing of the C-ABI launches (bench.py's roofline leg).  Events are recorded
+    on the stream the kernels are launched on (torch's current stream); nothing is synchronised until report()."""
+
+    def __init__(self):
+        self.pairs = {}
+
+    def start(self, name):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.pairs.setdefault(name, []).append((ev0, ev1))
+        ev0.record()
+        return ev1
+
+    def report(self):
+        torch.cuda.synchronize()
+        return {k: (sum(a.elapsed_time(b) for a, b in v) / len(v), len(v)) for k, v in self.pairs.items()}
+
+
+TIMER: Optional[KernelTimer] = None
+
+
+class _timed:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        self.ev = TIMER.start(self.name) if TIMER is not None else None
+
+    def __exit__(self, *exc):
+        if self.ev is not None:
+            self.ev.record()
+        return False
+
+
+def _ws(nbytes: int, device) -> torch.Tensor:
+    if nbytes < 0:
+        raise RuntimeError("madeleine_amd: workspace query failed (%d)" % nbytes)
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+def new_dropout_seed() -> int:
+    """Draws a 63-bit seed from torch's CPU generator (deterministic under torch.manual_seed)."""
+    return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+
+
+# --------------------------------------------------------------------------------------------------
+# raw calls (no autograd)
+# --------------------------------------------------------------------------------------------------
+def gate_fwd_raw(E2d, Wa, ba, Wb, bb, wc, bc, p_drop, seed, keep_a, keep_b, save_act: bool):
+    lib = _native.lib()
+    T, H = E2d.shape[0], Wa.shape[0]
+    dev = E2d.device
+    scores = torch.empty(T, H, device=dev, dtype=torch.float32)
+    act_a = torch.empty(T, H, HID, device=dev, dtype=torch.float32) if save_act else None
+    act_b = torch.empty(T, H, HID, device=dev, dtype=torch.float32) if save_act else None
+    ws = _ws(lib.mdl_abmil_gate_fwd_ws_bytes(T, H), dev)
+    with _timed("gate_fwd"):
+        rc = lib.mdl_abmil_gate_fwd(_ptr(E2d), E2d.stride(0), _ptr(Wa), _ptr(ba), _ptr(Wb), _ptr(bb), _ptr(wc), _ptr(bc),
+                                    _ptr(scores), _ptr(act_a), _ptr(act_b), T, H, float(p_drop), int(seed),
+                                    _ptr(keep_a), _ptr(keep_b), _ptr(ws), _stream())
+    _native.check(rc, "mdl_abmil_gate_fwd")
+    return scores, act_a, act_b
+
+
+def gate_bwd_raw(E2d, Wa, Wb, wc, act_a, act_b, d_scores, dE, accumulate, p_drop, seed, keep_a, keep_b):
+    lib = _native.lib()
+    T, H = E2d.shape[0], Wa.shape[0]
+    dev = E2d.device
+    dWa, dWb = torch.empty_like(Wa), torch.empty_like(Wb)
+    dba = torch.empty(H, HID, device=dev, dtype=torch.float32)
+    dbb, dwc = torch.empty_like(dba), torch.empty_like(dba)
+    ws = _ws(lib.mdl_abmil_gate_bwd_ws_bytes(T, H), dev)
+    with _timed("gate_bwd"):
+        rc = lib.mdl_abmil_gate_bwd(_ptr(E2d), E2d.stride(0), _ptr(Wa), _ptr(Wb), _ptr(wc), _ptr(act_a), _ptr(act_b),
+                                    _ptr(d_scores), _ptr(dE), int(accumulate), _ptr(dWa), _ptr(dWb), _ptr(dba), _ptr(dbb),
+                                    _ptr(dwc), T, H, float(p_drop), int(seed), _ptr(keep_a), _ptr(keep_b), _ptr(ws), _stream())
+    _native.check(rc, "mdl_abmil_gate_bwd")
+    return dWa, dWb, dba, dbb, dwc
+
+
+def pool_fwd_raw(E2d, scores, n_bags, N, cu_seqlens, max_len):
+    lib = _native.lib()
+    H = scores.shape[-1]
+    dev = E2d.device
+    pooled = torch.empty(n_bags, H * HID, device=dev, dtype=torch.float32)
+    stat_m = torch.empty(n_bags, H, device=dev, dtype=torch.float32)
+    stat_l = torch.empty(n_bags, H, device=dev, dtype=torch.float32)
+    ws = _ws(lib.mdl_abmil_pool_ws_bytes(n_bags, max_len, H), dev)
+    with _timed("pool_fwd"):
+        rc = lib.mdl_abmil_pool_fwd(_ptr(E2d), E2d.stride(0), _ptr(scores), _ptr(pooled), _ptr(stat_m), _ptr(stat_l), n_bags,
+                                    N, _ptr(cu_seqlens), max_len, H, _ptr(ws), _stream())
+    _native.check(rc, "mdl_abmil_pool_fwd")
+    return pooled, stat_m, stat_l
+
+
+def pool_bwd_raw(E2d, scores, pooled, stat_m, stat_l, d_pooled, dE, accumulate, d_scores, accumulate_scores, n_bags, N,
+                 cu_seqlens, max_len):
+    lib = _native.lib()
+    H = scores.shape[-1]
+    with _timed("pool_bwd"):
+        rc = lib.mdl_abmil_pool_bwd(_ptr(E2d), E2d.stride(0), _ptr(scores), _ptr(pooled), _ptr(stat_m), _ptr(stat_l),
+                                    _ptr(d_pooled), _ptr(dE), int(accumulate), _ptr(d_scores), int(accumulate_scores), n_bags, N,
+                                    _ptr(cu_seqlens), max_len, H, _stream())
+    _native.check(rc, "mdl_abmil_pool_bwd")
+
+
+def _bag_geometry(E, cu_seqlens, max_len):
+    """E is [n_bags,N,C] (dense) or [T,C] with cu_seqlens int64 [n_bags+1] (ragged)."""
+    if cu_seqlens is None:
+        if E.dim() != 3:
+            raise ValueError("dense bags must be [n_bags, N, H*512]")
+        n_bags, N = E.shape[0], E.shape[1]
+        return n_bags, N, N, E.reshape(n_bags * N, E.shape[2])
+    if E.dim() != 2:
+        raise ValueError("ragged bags must be packed [T, H*512] with cu_seqlens")
+    _require(cu_seqlens, "cu_seqlens", torch.int64)
+    if max_len is None:
+        raise ValueError("max_len is required with cu_seqlens (avoids a device sync)")
+    return cu_seqlens.numel() - 1, 0, int(max_len), E
+
+
+# --------------------------------------------------------------------------------------------------
+# A2: gated attention scores
+# --------------------------------------------------------------------------------------------------
+class GateScoresFn(torch.autograd.Function):
+    """scores[T,H] = gated-attention raw scores of all heads (abmil.py:41-52 per head)."""
+
+    @staticmethod
+    def forward(ctx, E2d, Wa, ba, Wb, bb, wc, bc, p_drop, seed, keep_a, keep_b):
+        for t, n in ((E2d, "E"), (Wa, "Wa"), (ba, "ba"), (Wb, "Wb"), (bb, "bb"), (wc, "wc"), (bc, "bc")):
+            _require(t, n)
+        need = any(ctx.needs_input_grad[:7])
+        scores, act_a, act_b = gate_fwd_raw(E2d, Wa, ba, Wb, bb, wc, bc, p_drop, seed, keep_a, keep_b, need)
+        if need:
+            ctx.save_for_backward(E2d, Wa, Wb, wc, act_a, act_b)
+            ctx.drop = (p_drop, seed, keep_a, keep_b)
+        return scores
+
+    @staticmethod
+    def backward(ctx, d_scores):
+        E2d, Wa, Wb, wc, act_a, act_b = ctx.saved_tensors
+        p_drop, seed, keep_a, keep_b = ctx.drop
+        d_scores = d_scores.contiguous()
+        dE = torch.empty_like(E2d)
+        dWa, dWb, dba, dbb, dwc = gate_bwd_raw(E2d, Wa, Wb, wc, act_a, act_b, d_scores, dE, 0, p_drop, seed, keep_a, keep_b)
+        dbc = d_scores.sum(dim=0)
+        return dE, dWa, dba, dWb, dbb, dwc, dbc, None, None, None, None
+
+
+# --------------------------------------------------------------------------------------------------
+# A3: softmax over patches + pooling
+# --------------------------------------------------------------------------------------------------
+class SoftmaxPoolFn(torch.autograd.Function):
+    """pooled[b,c,:] = sum_t softmax_t(scores[b,:,c]) E[b,t,c,:]   (abmil.py:55 + Model.py:416-417)."""
+
+    @staticmethod
+    def forward(ctx, E, scores, cu_seqlens, max_len):
+        _require(E, "E")
+        _require(scores, "scores")
+        n_bags, N, max_len, E2d = _bag_geometry(E, cu_seqlens, max_len)
+        s2d = scores.reshape(E2d.shape[0], -1)
+        pooled, m, l = pool_fwd_raw(E2d, s2d, n_bags, N, cu_seqlens, max_len)
+        ctx.save_for_backward(E2d, s2d, pooled, m, l, cu_seqlens if cu_seqlens is not None else torch.empty(0))
+        ctx.geom = (n_bags, N, max_len, cu_seqlens is not None, E.shape, scores.shape)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, d_pooled):
+        E2d, s2d, pooled, m, l, cu = ctx.saved_tensors
+        n_bags, N, max_len, ragged, e_shape, s_shape = ctx.geom
+        cu = cu if ragged else None
+        dE = torch.empty_like(E2d)
+        ds = torch.empty_like(s2d)
+        pool_bwd_raw(E2d, s2d, pooled, m, l, d_pooled.contiguous(), dE, 0, ds, 0, n_bags, N, cu, max_len)
+        return dE.view(e_shape), ds.view(s_shape), None, None
+
+
+# --------------------------------------------------------------------------------------------------
+# A2 + A3 chained inside one autograd node: one dE buffer, written by the pooling backward and
+# accumulated into by the gate backward (saves a 2 x |E| read + |E| write torch add).
+# --------------------------------------------------------------------------------------------------
+class AttnPoolFn(torch.autograd.Function):
+    """(pooled [n_bags,H*512], raw scores [T,H]) = multi-head gated-ABMIL pooling (Model.py:406-417)."""
+
+    @staticmethod
+    def forward(ctx, E, Wa, ba, Wb, bb, wc, bc, p_drop, seed, keep_a, keep_b, cu_seqlens, max_len):
+        for t, n in ((E, "E"), (Wa, "Wa"), (ba, "ba"), (Wb, "Wb"), (bb, "bb"), (wc, "wc"), (bc, "bc")):
+            _require(t, n)
+        n_bags, N, max_len, E2d = _bag_geometry(E, cu_seqlens, max_len)
+        need = any(ctx.needs_input_grad[:7])
+        scores, act_a, act_b = gate_fwd_raw(E2d, Wa, ba, Wb, bb, wc, bc, p_drop, seed, keep_a, keep_b, need)
+        pooled, m, l = pool_fwd_raw(E2d, scores, n_bags, N, cu_seqlens, max_len)
+        if need:
+            ctx.save_for_backward(E2d, Wa, Wb, wc, act_a, act_b, scores, pooled, m, l,
+                                  cu_seqlens if cu_seqlens is not None else torch.empty(0))
+            ctx.cfg = (p_drop, seed, keep_a, keep_b, n_bags, N, max_len, cu_seqlens is not None, E.shape)
+        return pooled, scores
+
+    @staticmethod
+    def backward(ctx, d_pooled, d_scores_in):
+        E2d, Wa, Wb, wc, act_a, act_b, scores, pooled, m, l, cu = ctx.saved_tensors
+        p_drop, seed, keep_a, keep_b, n_bags, N, max_len, ragged, e_shape = ctx.cfg
+        cu = cu if ragged else None
+        dE = torch.empty_like(E2d)
+        if d_scores_in is not None:
+            ds = d_scores_in.contiguous().clone()
+            acc_s = 1
+        else:
+            ds = torch.empty_like(scores)
+            acc_s = 0
+        if d_pooled is None:
+            d_pooled = torch.zeros_like(pooled)
+        pool_bwd_raw(E2d, scores, pooled, m, l, d_pooled.contiguous(), dE, 0, ds, acc_s, n_bags, N, cu, max_len)
+        dWa, dWb, dba, dbb, dwc = gate_bwd_raw(E2d, Wa, Wb, wc, act_a, act_b, ds, dE, 1, p_drop, seed, keep_a, keep_b)
+        dbc = ds.sum(dim=0)
+        return dE.view(e_shape), dWa, dba, dWb, dbb, dwc, dbc, None, None, None, None, None, None
+
+
+def attn_pool(E, Wa, ba, Wb, bb, wc, bc, p_drop=0.0, seed=0, keep_a=None, keep_b=None, cu_seqlens=None, max_len=None):
+    return AttnPoolFn.apply(E, Wa, ba, Wb, bb, wc, bc, float(p_drop), int(seed), keep_a, keep_b, cu_seqlens, max_len)
+
+
+def gate_scores(E2d, Wa, ba, Wb, bb, wc, bc, p_drop=0.0, seed=0, keep_a=None, keep_b=None):
+    return GateScoresFn.apply(E2d, Wa, ba, Wb, bb, wc, bc, float(p_drop), int(seed), keep_a, keep_b)
+
+
+def softmax_pool(E, scores, cu_seqlens=None, max_len=None):
+    return SoftmaxPoolFn.apply(E, scores, cu_seqlens, max_len)
+
+
+# --------------------------------------------------------------------------------------------------
+# L1: InfoNCE (batched over problems)
+# --------------------------------------------------------------------------------------------------
+class InfoNCEFn(torch.autograd.Function):
+    """loss[S] for S padded problems Q,P [S,Kmax,D] with cnt[S] live rows each (loss.py:111-127)."""
+
+    @staticmethod
+    def forward(ctx, Q, P, cnt, temperature, symmetric):
+        _require(Q, "query")
+        _require(P, "positive_key")
+        _require(cnt, "cnt", torch.int32)
+        lib = _native.lib()
+        S, Kmax, D = Q.shape
+        loss = torch.empty(S, device=Q.device, dtype=torch.float32)
+        ws = _ws(lib.mdl_infonce_ws_bytes(S, Kmax, D), Q.device)
+        rc = lib.mdl_infonce_fwd(_ptr(Q), _ptr(P), _ptr(cnt), _ptr(loss), S, Kmax, D, float(temperature), int(symmetric),
+                                 _ptr(ws), _stream())
+        _native.check(rc, "mdl_infonce_fwd")
+        ctx.save_for_backward(cnt, ws)
+        ctx.cfg = (S, Kmax, D, float(temperature), int(symmetric))
+        return loss
+
+    @staticmethod
+    def backward(ctx, d_loss):
+        cnt, ws = ctx.saved_tensors
+        S, Kmax, D, temperature, symmetric = ctx.cfg
+        lib = _native.lib()
+        dQ = torch.empty(S, Kmax, D, device=d_loss.device, dtype=torch.float32)
+        dP = torch.empty_like(dQ)
+        rc = lib.mdl_infonce_bwd(_ptr(d_loss.contiguous()), _ptr(cnt), _ptr(dQ), _ptr(dP), S, Kmax, D, temperature,
+                                 symmetric, _ptr(ws), _stream())
+        _native.check(rc, "mdl_infonce_bwd")
+        return dQ, dP, None, None, None
+
+
+def info_nce_batched(Q, P, cnt, temperature, symmetric):
+    return InfoNCEFn.apply(Q, P, cnt, float(temperature), bool(symmetric))

@@ -1,0 +1,296 @@
+"""MADELEINE slide encoder -- MI355X-native mirror of the reference's `MADELEINE`, `ABMILEmbedder`
+and `create_model` (reference madeleine/models/Model.py:15-43, :45-216, :314-451).
+
+Same constructor / forward / encode_he contracts, same sub-module names and therefore the same
+state_dict keys and shapes (reference and HuggingFace checkpoints load unchanged, with or without a
+`module.` prefix).  What differs is where the work happens:
+
+  * pre_attn (3 x Linear+LayerNorm+GELU+Dropout) and the two projector Linears stay torch ops on
+    hipBLASLt (host plumbing; SURVEY.md section 8(f) row N1 tracks fusing them);
+  * gated attention scores + softmax-over-patches + weighted pooling, forward and backward, are the
+    hand-written HIP kernels behind madeleine_amd.functional.attn_pool.
+
+Head-major trick: the reference interleaves heads as channel j = e*H + c (rearrange
+'b t (e c) -> b t e c', Model.py:396).  We permute the ROWS of pre_attn.8 / LayerNorm 9 (and the
+COLUMNS of token_projector / projector) by a fixed index vector at forward time, so the encoder emits
+the very same numbers with channel order j' = c*512 + e.  Every kernel then reads contiguous 2 KiB
+head rows and no activation is ever permuted.  Parameters keep the reference layout.
+"""
+from collections import OrderedDict
+from typing import Dict, Optional, Union
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import functional as MF
+from .abmil import BatchedABMIL, activate
+
+HE_POSITION = 0
+PRE_DROPOUT_P = 0.1  # Model.py:354,358,362
+
+
+def _strip_module_prefix(state_dict):
+    """Model.py:31-40 / utils.py:112-120: DataParallel checkpoints carry a 'module.' prefix."""
+    if not any(k.startswith("module.") for k in state_dict):
+        return state_dict
+    return OrderedDict((k[7:] if k.startswith("module.") else k, v) for k, v in state_dict.items())
+
+
+def create_model(model_cfg: Union[str, Dict], device: Union[str, torch.device] = 'cpu',
+                 checkpoint_path: Optional[str] = None):
+    """Mirror of Model.py:15-43."""
+    model = MADELEINE(config=model_cfg, stain_encoding=False).to(device)
+    if checkpoint_path:
+        state_dict = torch.load(checkpoint_path, weights_only=False, map_location=device)
+        model.load_state_dict(_strip_module_prefix(state_dict), strict=True)
+        print("* Loaded weights successfully!")
+    return model
+
+
+class ABMILEmbedder(nn.Module):
+    """Multi-head gated-ABMIL patch aggregator (Model.py:314-451)."""
+
+    def __init__(self, pre_attention_params: dict = None, attention_params: dict = None, aggregation: str = 'regular') -> None:
+        super().__init__()
+        self.pre_attention_params = pre_attention_params
+        self.attention_params = attention_params
+        self.n_heads = attention_params['params']["n_heads"]
+        self._build_pre_attention_params(params=pre_attention_params)
+        if attention_params is not None:
+            self._build_attention_params(attn_model=attention_params['model'], params=attention_params['params'])
+        self.agg_type = aggregation
+        H = self.n_heads
+        hid = pre_attention_params['hidden_dim']
+        # perm[j'] = j with j' = c*hid + e (head-major) and j = e*H + c (reference order)
+        jp = torch.arange(hid * H)
+        self.register_buffer("_perm", (jp % hid) * H + (jp // hid), persistent=False)
+        self._injected_keep = None  # dict(pre=[3 masks, reference layout], gate=[(ka,kb) per head]) for parity tests
+
+    def _build_pre_attention_params(self, params):
+        H = self.n_heads
+        self.pre_attn = nn.Sequential(
+            nn.Linear(params['input_dim'], params['hidden_dim']),
+            nn.LayerNorm(params['hidden_dim']),
+            nn.GELU(),
+            nn.Dropout(PRE_DROPOUT_P),
+            nn.Linear(params['hidden_dim'], params['hidden_dim']),
+            nn.LayerNorm(params['hidden_dim']),
+            nn.GELU(),
+            nn.Dropout(PRE_DROPOUT_P),
+            nn.Linear(params['hidden_dim'], params['hidden_dim'] * H),
+            nn.LayerNorm(params['hidden_dim'] * H),
+            nn.GELU(),
+            nn.Dropout(PRE_DROPOUT_P),
+        )
+
+    def _build_attention_params(self, attn_model='ABMIL', params=None):
+        if attn_model == 'ABMIL':
+            self.attn = nn.ModuleList([BatchedABMIL(**params) for _ in range(self.n_heads)])
+        else:
+            raise NotImplementedError('Attention model not implemented -- Options are ABMIL')
+
+    # ------------------------------------------------------------------ internals (head-major)
+    def _drop(self, x, blk):
+        if not self.training:
+            return x
+        inj = self._injected_keep
+        if inj is not None:
+            keep = inj["pre"][blk]
+            if blk == 2:
+                keep = keep[..., self._perm]
+            return x * keep.to(x.dtype) * (1.0 / (1.0 - PRE_DROPOUT_P))
+        return F.dropout(x, PRE_DROPOUT_P, True)
+
+    def embed_tokens_headmajor(self, bags: torch.Tensor) -> torch.Tensor:
+        """pre_attn(bags) with the 2048 output channels in head-major order: [BM, N, H*512]."""
+        pa = self.pre_attn
+        x = self._drop(pa[2](pa[1](pa[0](bags))), 0)
+        x = self._drop(pa[6](pa[5](pa[4](x))), 1)
+        perm = self._perm
+        x = F.linear(x, pa[8].weight[perm], pa[8].bias[perm])
+        x = F.layer_norm(x, (perm.numel(),), pa[9].weight[perm], pa[9].bias[perm], pa[9].eps)
+        return self._drop(F.gelu(x), 2).float().contiguous()
+
+    def gate_params_stacked(self):
+        ps = [h.gate_params() for h in self.attn]
+        return tuple(torch.stack([p[i] for p in ps]) for i in range(5)) + (torch.cat([p[5] for p in ps]),)
+
+    def _gate_dropout(self, shape_bn):
+        """(p, seed, keep_a, keep_b) for this forward; masks are uint8 [T,H,512]."""
+        p = self.attn[0].dropout_p() if len(self.attn) else 0.0
+        if p == 0.0:
+            return 0.0, 0, None, None
+        inj = self._injected_keep
+        if inj is not None:
+            ka = torch.stack([g[0] for g in inj["gate"]], dim=2)  # [BM,N,H,512]
+            kb = torch.stack([g[1] for g in inj["gate"]], dim=2)
+            T = shape_bn[0] * shape_bn[1]
+            return p, 0, ka.reshape(T, self.n_heads, MF.HID).to(torch.uint8).contiguous(), \
+                kb.reshape(T, self.n_heads, MF.HID).to(torch.uint8).contiguous()
+        return p, MF.new_dropout_seed(), None, None
+
+    def pool_headmajor(self, E_hm: torch.Tensor):
+        """E_hm [BM,N,H*512] -> (pooled_hm [BM,H*512], raw scores [BM,N,H]) through the fused HIP path."""
+        for h in self.attn:
+            h._check_geometry()
+        BM, N, _ = E_hm.shape
+        wa, ba, wb, bb, wc, bc = self.gate_params_stacked()
+        p, seed, ka, kb = self._gate_dropout((BM, N))
+        pooled, scores = MF.attn_pool(E_hm, wa, ba, wb, bb, wc, bc, p, seed, ka, kb)
+        return pooled, scores.view(BM, N, self.n_heads)
+
+    def _scores_only(self, E_hm):
+        BM, N, _ = E_hm.shape
+        wa, ba, wb, bb, wc, bc = self.gate_params_stacked()
+        p, seed, ka, kb = self._gate_dropout((BM, N))
+        return MF.gate_scores(E_hm.view(BM * N, -1), wa, ba, wb, bb, wc, bc, p, seed, ka, kb).view(BM, N, self.n_heads)
+
+    def _to_reference_tokens(self, E_hm):
+        BM, N, _ = E_hm.shape
+        return E_hm.view(BM, N, self.n_heads, -1).permute(0, 1, 3, 2)  # [BM,N,512,H] (strided view)
+
+    def _to_reference_slide(self, pooled_hm):
+        lead = pooled_hm.shape[:-1]
+        return pooled_hm.view(*lead, self.n_heads, -1).transpose(-1, -2).contiguous()  # [...,512,H]
+
+    def forward_headmajor(self, bags, n_views=1):
+        """Fast path used by MADELEINE: returns (pooled_hm [BM,(V,)H*512], E_hm, raw scores [BM,N,H])."""
+        if self.agg_type != 'regular':
+            raise NotImplementedError('Agg type not supported. Options are "regular".')
+        E = self.embed_tokens_headmajor(bags)
+        act = self.attn[0].activation
+        if act == 'softmax':
+            pooled, scores = self.pool_headmajor(E)
+        else:
+            # non-default activations (abmil.py:56-61): scores from the HIP gate kernel, weighting in torch
+            scores = self._scores_only(E)
+            w = activate(scores.unsqueeze(2), act).squeeze(2)  # elementwise; dim=1 only matters for softmax
+            BM, N, H = scores.shape
+            pooled = torch.einsum('bnh,bnhe->bhe', w, E.view(BM, N, H, -1)).reshape(BM, -1)
+        if n_views == 1:
+            return pooled, E, scores
+        # intra-modality views (Model.py:419-440): two random halves, raw scores re-softmaxed per subset
+        N = E.shape[1]
+        all_indices = np.arange(N)
+        np.random.shuffle(all_indices)
+        mid = len(all_indices) // 2
+        views = [pooled.unsqueeze(1)]
+        for idx in (all_indices[:mid], all_indices[mid:]):
+            ti = torch.as_tensor(idx, device=E.device, dtype=torch.long)
+            views.append(MF.softmax_pool(E.index_select(1, ti), scores.index_select(1, ti).contiguous()).unsqueeze(1))
+        return torch.cat(views, dim=1), E, scores
+
+    # ------------------------------------------------------------------ reference-shaped API
+    def forward(self, bags: torch.Tensor, return_attention: bool = False, return_preattn_feats: bool = False, n_views=1):
+        """Model.py:375-451.  slide embeddings [BM,(V,)512,H]; raw attention [BM,N,1,H]; tokens [BM,N,512,H]."""
+        pooled, E, scores = self.forward_headmajor(bags, n_views)
+        slide = self._to_reference_slide(pooled)
+        if return_attention:
+            return slide, scores.unsqueeze(2)
+        if return_preattn_feats:
+            return slide, self._to_reference_tokens(E)
+        return slide
+
+
+class MADELEINE(nn.Module):
+    def __init__(self, config, stain_encoding=False):
+        super().__init__()
+        self.config = config
+        self.modalities = config.MODALITIES
+        self.stain_encoding = stain_encoding
+        if self.stain_encoding:
+            self.stain_encoding_dim = 32
+            self.embedding = nn.Embedding(len(self.modalities), self.stain_encoding_dim)
+        else:
+            self.stain_encoding_dim = 0
+        if self.config.wsi_encoder == "abmil":
+            pre_params = {'input_dim': self.config.patch_embedding_dim + self.stain_encoding_dim,
+                          'hidden_dim': self.config.wsi_encoder_hidden_dim}
+            attention_params = {'model': 'ABMIL',
+                                'params': {'input_dim': self.config.wsi_encoder_hidden_dim, 'hidden_dim': 512,
+                                           'dropout': True, 'activation': self.config.activation,
+                                           'n_heads': self.config.n_heads, 'n_classes': 1}}
+            width = attention_params['params']['hidden_dim'] * attention_params['params']['n_heads']
+            self.token_projector = nn.Linear(width, 128)
+            self.wsi_embedders = ABMILEmbedder(pre_params, attention_params)
+            self.projector = nn.Linear(width, attention_params['params']['hidden_dim'])
+        else:
+            raise ValueError('Unsupported wsi_encoder. Must be "abmil". Now is {}.'.format(self.config.wsi_encoder))
+
+    # ------------------------------------------------------------------ helpers
+    def _project_slide(self, pooled_hm):
+        perm = self.wsi_embedders._perm
+        return F.linear(pooled_hm, self.projector.weight[:, perm], self.projector.bias)
+
+    def _project_tokens(self, E_hm):
+        perm = self.wsi_embedders._perm
+        return F.linear(E_hm, self.token_projector.weight[:, perm], self.token_projector.bias)
+
+    def _cat_stain(self, feats, idx):
+        """feats [R,N,D], idx LongTensor [R] -> cat([feats, embedding[idx] broadcast over N])."""
+        enc = self.embedding(idx.to(feats.device)).unsqueeze(1).expand(-1, feats.shape[1], -1)
+        return torch.cat([feats, enc.to(feats.dtype)], dim=-1)
+
+    @staticmethod
+    def _require_single_modality(n_mod):
+        # the reference's eval / attention branches reshape with .view(bs*n_mod, d_out*n_heads) on a [bs,512,H]
+        # tensor (Model.py:194-196, :210-212): they raise for n_mod != 1.  Same contract here.
+        if n_mod != 1:
+            raise RuntimeError("MADELEINE.forward(train=False) expects data['feats'] of shape [B, 1, N, D] "
+                               "(one modality per call), got n_mod=%d" % n_mod)
+
+    # ------------------------------------------------------------------ public API
+    def encode_he(self, feats, device):
+        """Model.py:97-107: [B,N,D] -> [B,512]."""
+        feats = feats.to(device)
+        pooled, _, _ = self.wsi_embedders.forward_headmajor(feats)
+        return self._project_slide(pooled)
+
+    def forward(self, data, device, train=True, n_views=1, custom_stain_idx=None, return_attention=False):
+        all_wsi_feats = data['feats'].to(device)
+        all_embeddings, all_token_embeddings = {}, {}
+        emb = self.wsi_embedders
+
+        if train:  # Model.py:120-159
+            bs, n_mod, n_tokens, d_in = all_wsi_feats.shape
+            x = all_wsi_feats.view(bs * n_mod, n_tokens, d_in)
+            if self.stain_encoding:
+                # reference quirk kept on purpose (Model.py:125-131): the indicator list is stain-major while
+                # the flattened rows are case-major, so row r gets embedding index r // bs.
+                x = self._cat_stain(x, torch.arange(bs * n_mod) // bs)
+            pooled, E, _ = emb.forward_headmajor(x, n_views=n_views)
+            tok = self._project_tokens(E.view(bs, n_mod, n_tokens, -1))               # [B,M,N,128]
+            slide = self._project_slide(pooled.view(bs * n_mod, -1, pooled.shape[-1]))  # [BM,V,512]
+            slide = slide.view(bs, n_mod, -1, slide.shape[-1])
+            for idx, modality in enumerate(self.modalities):
+                s, t = slide[:, idx], tok[:, idx]
+                if modality == "HE":
+                    # reference: .unsqueeze(3).repeat(1,1,1,M-1); expand gives the same values without copies
+                    s = s.unsqueeze(3).expand(-1, -1, -1, n_mod - 1)
+                    t = t.unsqueeze(3).expand(-1, -1, -1, n_mod - 1)
+                all_embeddings[modality] = s
+                all_token_embeddings[modality] = t
+            return all_embeddings, all_token_embeddings
+
+        elif not train and not return_attention:  # Model.py:162-203
+            bs, n_mod, n_tokens, d_in = all_wsi_feats.shape
+            self._require_single_modality(n_mod)
+            for stain_idx in range(n_mod):
+                stain_name = self.modalities[custom_stain_idx] if custom_stain_idx else self.modalities[stain_idx]
+                cur = all_wsi_feats[:, stain_idx]
+                if self.stain_encoding:
+                    key = custom_stain_idx if custom_stain_idx else stain_idx
+                    cur = self._cat_stain(cur, torch.full((bs,), key, dtype=torch.long))
+                pooled, _, _ = emb.forward_headmajor(cur)
+                # the reference's .view(bs*n_mod, ...) / .view(bs, n_mod, d) only type-checks for n_mod == 1
+                all_embeddings[stain_name] = self._project_slide(pooled).view(bs, n_mod, -1)
+            return all_embeddings
+
+        else:  # Model.py:206-216
+            bs, n_mod, n_tokens, d_in = all_wsi_feats.shape
+            self._require_single_modality(n_mod)
+            pooled, _, scores = emb.forward_headmajor(all_wsi_feats[:, HE_POSITION])
+            he = self._project_slide(pooled).view(bs, n_mod, -1)
+            return he, scores.unsqueeze(2)

@@ -1,0 +1,275 @@
+"""GPU parity tests proper: every HIP kernel, called through the C ABI (ctypes, via
+madeleine_amd.functional), against the CPU oracle on the same seeded inputs.
+Tolerance: 1e-3 relative fp32 (BASELINE.json north_star); most checks are far tighter."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import restatement as R
+from tests._util import max_rel, rel_err, t
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _hm(x, H=4):
+    """reference channel order (e*H+c) -> head-major (c*512+e) on the last axis."""
+    lead = x.shape[:-1]
+    return x.reshape(*lead, 512, H).transpose(-1, -2).reshape(*lead, H * 512).contiguous()
+
+
+def _gate_weights(H, key):
+    s = 1.0 / np.sqrt(512.0)
+    wa, wb = t((H, 512, 512), key + "wa", -s, s), t((H, 512, 512), key + "wb", -s, s)
+    ba, bb = t((H, 512), key + "ba", -s, s), t((H, 512), key + "bb", -s, s)
+    wc, bc = t((H, 512), key + "wc", -s, s), t((H,), key + "bc", -s, s)
+    return wa, ba, wb, bb, wc, bc
+
+
+def _oracle_scores(E_hm, w, keep_a=None, keep_b=None):
+    """E_hm [T,H*512] head-major -> scores [T,H] with the oracle's per-head gate."""
+    wa, ba, wb, bb, wc, bc = w
+    H = wa.shape[0]
+    T = E_hm.shape[0]
+    x = E_hm.view(1, T, H, 512)
+    out = []
+    for c in range(H):
+        ka = None if keep_a is None else keep_a[:, c].view(1, T, 512).float()
+        kb = None if keep_b is None else keep_b[:, c].view(1, T, 512).float()
+        out.append(R.gate_scores(x[:, :, c], wa[c], ba[c], wb[c], bb[c], wc[c:c + 1], bc[c:c + 1], ka, kb))
+    return torch.cat(out, dim=-1).view(T, H)
+
+
+# ---------------------------------------------------------------------------------------------- A3
+@pytest.mark.parametrize("H", [4, 1])
+@pytest.mark.parametrize("BM,N", [(3, 300), (2, 128), (1, 1), (2, 1000)])
+def test_pool_fwd_bwd_dense(dev, H, BM, N):
+    from madeleine_amd import functional as MF
+    E = t((BM, N, H * 512), f"pool:E{BM}{N}{H}").requires_grad_()
+    s = (t((BM, N, H), f"pool:s{BM}{N}{H}") * 6).requires_grad_()
+    g = t((BM, H * 512), f"pool:g{BM}{N}{H}")
+    w = torch.softmax(s, dim=1)                                      # [BM,N,H]
+    ref = torch.einsum("bnh,bnhe->bhe", w, E.view(BM, N, H, 512)).reshape(BM, H * 512)
+    ref.backward(g)
+    Ed, sd = E.detach().to(dev).requires_grad_(), s.detach().to(dev).requires_grad_()
+    out = MF.softmax_pool(Ed, sd)
+    out.backward(g.to(dev))
+    assert max_rel(out, ref) < 1e-4
+    assert max_rel(Ed.grad, E.grad) < 1e-4
+    assert max_rel(sd.grad, s.grad, floor=1e-4 * float(s.grad.abs().max())) < 2e-3
+
+
+def test_pool_ragged_and_empty(dev):
+    from madeleine_amd import functional as MF
+    H = 4
+    lens = [5, 0, 257, 128, 1]
+    cu = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int64)
+    T = int(cu[-1])
+    E = t((T, H * 512), "rag:E").requires_grad_()
+    s = (t((T, H), "rag:s") * 4).requires_grad_()
+    g = t((len(lens), H * 512), "rag:g")
+    refs = []
+    for b, L in enumerate(lens):
+        sl = slice(int(cu[b]), int(cu[b + 1]))
+        if L == 0:
+            refs.append(torch.zeros(H * 512))
+            continue
+        w = torch.softmax(s[sl], dim=0)
+        refs.append(torch.einsum("nh,nhe->he", w, E[sl].view(L, H, 512)).reshape(-1))
+    ref = torch.stack(refs)
+    ref.backward(g)
+    Ed, sd = E.detach().to(dev).requires_grad_(), s.detach().to(dev).requires_grad_()
+    out = MF.softmax_pool(Ed, sd, cu.to(dev), max(lens))
+    out.backward(g.to(dev))
+    assert float(out[1].abs().max()) == 0.0
+    assert max_rel(out, ref) < 1e-4
+    assert max_rel(Ed.grad, E.grad) < 1e-4
+    assert max_rel(sd.grad, s.grad, floor=1e-4 * float(s.grad.abs().max())) < 2e-3
+
+
+def test_pool_extreme_scores(dev):
+    """softmax must be max-subtracted: scores of +-80 would overflow a naive exp."""
+    from madeleine_amd import functional as MF
+    E = t((2, 200, 2048), "ext:E")
+    s = t((2, 200, 4), "ext:s") * 80
+    ref = torch.einsum("bnh,bnhe->bhe", torch.softmax(s, dim=1), E.view(2, 200, 4, 512)).reshape(2, 2048)
+    out = MF.softmax_pool(E.to(dev), s.to(dev))
+    assert torch.isfinite(out).all()
+    assert max_rel(out, ref) < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------- A2
+@pytest.mark.parametrize("H,T", [(4, 200), (1, 130), (4, 1), (2, 384)])
+def test_gate_eval(dev, H, T):
+    from madeleine_amd import functional as MF
+    w = _gate_weights(H, f"gate{H}{T}")
+    E = t((T, H * 512), f"gate:E{H}{T}")
+    leaves = [x.clone().requires_grad_() for x in (E,) + w]
+    ref = _oracle_scores(leaves[0], leaves[1:])
+    g = t((T, H), f"gate:g{H}{T}")
+    ref.backward(g)
+    dl = [x.detach().to(dev).requires_grad_() for x in (E,) + w]
+    out = MF.gate_scores(*dl)
+    out.backward(g.to(dev))
+    assert max_rel(out, ref) < 1e-4
+    names = ["E", "Wa", "ba", "Wb", "bb", "wc", "bc"]
+    for n, a, b in zip(names, dl, leaves):
+        assert rel_err(a.grad, b.grad) < 1e-4, n
+        assert max_rel(a.grad, b.grad) < TOL, n
+
+
+def test_gate_dropout_explicit_masks(dev):
+    from madeleine_amd import functional as MF
+    from oracle import recipe
+    H, T = 4, 150
+    w = _gate_weights(H, "gdo")
+    E = t((T, H * 512), "gdo:E")
+    ka = torch.from_numpy(recipe.bernoulli((T, H, 512), "gdo:ka", 0.75)).to(torch.uint8)
+    kb = torch.from_numpy(recipe.bernoulli((T, H, 512), "gdo:kb", 0.75)).to(torch.uint8)
+    leaves = [x.clone().requires_grad_() for x in (E,) + w]
+    ref = _oracle_scores(leaves[0], leaves[1:], ka, kb)
+    g = t((T, H), "gdo:g")
+    ref.backward(g)
+    dl = [x.detach().to(dev).requires_grad_() for x in (E,) + w]
+    out = MF.gate_scores(*dl, p_drop=0.25, seed=0, keep_a=ka.to(dev), keep_b=kb.to(dev))
+    out.backward(g.to(dev))
+    assert max_rel(out, ref) < 1e-4
+    for n, a, b in zip(["E", "Wa", "ba", "Wb", "bb", "wc", "bc"], dl, leaves):
+        assert rel_err(a.grad, b.grad) < 1e-4, n
+
+
+def test_gate_dropout_rng_matches_exported_mask(dev):
+    """The in-kernel counter RNG path == the explicit-mask path fed with the exported mask, bit for bit,
+    forward and backward; keep-rate ~ 1-p; different seeds give different masks."""
+    from madeleine_amd import _native
+    from madeleine_amd import functional as MF
+    H, T, p, seed = 4, 300, 0.25, 1234567890123
+    lib = _native.lib()
+    masks = []
+    for which in (0, 1):
+        m = torch.empty(T, H, 512, dtype=torch.uint8, device=dev)
+        _native.check(lib.mdl_abmil_gate_dropout_mask(m.data_ptr(), T, H, which, p, seed,
+                                                      torch.cuda.current_stream().cuda_stream), "mask")
+        masks.append(m)
+    rate = float(masks[0].float().mean())
+    assert abs(rate - 0.75) < 0.01
+    assert not torch.equal(masks[0], masks[1])
+    w = [x.to(dev) for x in _gate_weights(H, "grng")]
+    E = t((T, H * 512), "grng:E").to(dev)
+    g = t((T, H), "grng:g").to(dev)
+    res = []
+    for kw in (dict(seed=seed), dict(seed=0, keep_a=masks[0], keep_b=masks[1])):
+        leaves = [x.clone().requires_grad_() for x in [E] + w]
+        out = MF.gate_scores(*leaves, p_drop=p, **kw)
+        out.backward(g)
+        res.append([out.detach()] + [x.grad for x in leaves])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
+# ---------------------------------------------------------------------------------------------- A2+A3 fused node
+def test_attn_pool_fused_with_score_grad(dev):
+    from madeleine_amd import functional as MF
+    H, BM, N = 4, 3, 140
+    w = _gate_weights(H, "ap")
+    E = t((BM, N, H * 512), "ap:E")
+    gp, gs = t((BM, H * 512), "ap:gp"), t((BM * N, H), "ap:gs") * 0.1
+    leaves = [x.clone().requires_grad_() for x in (E,) + w]
+    sc = _oracle_scores(leaves[0].view(BM * N, -1), leaves[1:])
+    wts = torch.softmax(sc.view(BM, N, H), dim=1)
+    pooled = torch.einsum("bnh,bnhe->bhe", wts, leaves[0].view(BM, N, H, 512)).reshape(BM, -1)
+    ((pooled * gp).sum() + (sc * gs).sum()).backward()
+    dl = [x.detach().to(dev).requires_grad_() for x in (E,) + w]
+    po, so = MF.attn_pool(*dl)
+    ((po * gp.to(dev)).sum() + (so * gs.to(dev)).sum()).backward()
+    assert max_rel(po, pooled) < 1e-4 and max_rel(so, sc) < 1e-4
+    for n, a, b in zip(["E", "Wa", "ba", "Wb", "bb", "wc", "bc"], dl, leaves):
+        assert rel_err(a.grad, b.grad) < 1e-4, n
+
+
+# ---------------------------------------------------------------------------------------------- L1
+@pytest.mark.parametrize("k", [2, 7, 33, 256])
+@pytest.mark.parametrize("T", [0.001, 0.1])
+@pytest.mark.parametrize("sym", [False, True])
+def test_infonce_vs_oracle(dev, k, T, sym):
+    from madeleine_amd import InfoNCE
+    q0, p0 = t((k, 512), f"nce:q{k}"), t((k, 512), f"nce:p{k}")
+    p0 = p0 + 0.1 * q0
+    q, p = q0.clone().requires_grad_(), p0.clone().requires_grad_()
+    ref = R.info_nce(q, p, T, sym)
+    ref.backward()
+    qd, pd = q0.to(dev).requires_grad_(), p0.to(dev).requires_grad_()
+    out = InfoNCE(temperature=T)(qd, pd, symmetric=sym)
+    out.backward()
+    assert abs(float(out) - float(ref)) <= TOL * abs(float(ref)) + 1e-5
+    assert rel_err(qd.grad, q.grad) < TOL
+    assert rel_err(pd.grad, p.grad) < TOL
+
+
+def test_infonce_golden_and_batched(dev):
+    from madeleine_amd import InfoNCE
+    from tests._util import golden
+    g = golden("infonce")
+    crit = InfoNCE(temperature=0.001)
+    ks = (2, 7, 33)
+    Q = torch.zeros(3, 33, 512)
+    P = torch.zeros(3, 33, 512)
+    for s, k in enumerate(ks):
+        q0, p0 = t((k, 512), f"nce:q{k}"), t((k, 512), f"nce:p{k}")
+        Q[s, :k], P[s, :k] = q0, p0 + 0.1 * q0
+    Qd, Pd = Q.to(dev).requires_grad_(), P.to(dev).requires_grad_()
+    cnt = torch.tensor(ks, dtype=torch.int32, device=dev)
+    losses = crit.batched(Qd, Pd, cnt, symmetric=True)
+    losses.sum().backward()
+    for s, k in enumerate(ks):
+        tag = f"k{k}/T0.001/sym1"
+        assert abs(float(losses[s]) - float(g[f"{tag}/loss"])) <= TOL * abs(float(g[f"{tag}/loss"])) + 1e-5
+        sl = slice(None) if k <= 7 else slice(0, 32)
+        assert rel_err(Qd.grad[s, :k, sl], g[f"{tag}/dq"]) < TOL
+        assert rel_err(Pd.grad[s, :k, sl], g[f"{tag}/dp"]) < TOL
+        assert float(Qd.grad[s, k:].abs().max() if k < 33 else 0.0) == 0.0
+
+
+def test_infonce_errors(dev):
+    from madeleine_amd import InfoNCE
+    crit = InfoNCE()
+    with pytest.raises(ValueError):
+        crit(torch.zeros(2, 3, 4, device=dev), torch.zeros(2, 4, device=dev))
+    with pytest.raises(ValueError):
+        crit(torch.zeros(2, 32, device=dev), torch.zeros(3, 32, device=dev))
+    with pytest.raises(ValueError):
+        crit(torch.zeros(2, 32, device=dev), torch.zeros(2, 64, device=dev))
+    with pytest.raises(RuntimeError):
+        crit(torch.zeros(2, 32), torch.zeros(2, 32))  # CPU tensors: no fallback
+
+
+# ---------------------------------------------------------------------------------------------- full sizes (C2)
+def test_pool_full_size_properties(dev):
+    """BASELINE config 2 geometry (64 bags x 4096 x 2048): size-independent properties + device-side reference."""
+    from madeleine_amd import functional as MF
+    BM, N, H = 64, 4096, 4
+    gen = torch.Generator(device=dev).manual_seed(0)
+    E = torch.randn(BM, N, H * 512, device=dev, generator=gen)
+    s = torch.randn(BM, N, H, device=dev, generator=gen) * 3
+    out = MF.softmax_pool(E, s)
+    # (1) convexity: every pooled channel lies within [min_t, max_t] of its column
+    assert bool((out <= E.amax(dim=1) + 1e-5).all()) and bool((out >= E.amin(dim=1) - 1e-5).all())
+    # (2) shift invariance of the scores
+    out2 = MF.softmax_pool(E, s + 7.5)
+    assert max_rel(out2, out) < 1e-4
+    # (3) a bag of identical tokens pools to that token whatever the scores
+    Ec = E[:, :1].expand(-1, N, -1).contiguous()
+    assert max_rel(MF.softmax_pool(Ec, s), Ec[:, 0]) < 1e-5
+    # (4) linearity in E
+    assert max_rel(MF.softmax_pool(2.5 * E, s), 2.5 * out) < 1e-5
+    # (5) device-side fp32 restatement of the same op (chunked to bound memory)
+    w = torch.softmax(s, dim=1)
+    ref = torch.stack([torch.einsum("nh,nhe->he", w[b], E[b].view(N, H, 512)).reshape(-1) for b in range(BM)])
+    assert max_rel(out, ref) < 1e-4

@@ -1,0 +1,220 @@
+"""GPU parity of the drop-in surface (MADELEINE / ABMILEmbedder / calculate_losses) against the golden
+vectors captured from the imported reference (tests/golden, oracle/gen_golden.py) and against the oracle.
+These read like the tests the reference would have had: build the module, load a state_dict, call forward."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import recipe
+from oracle import restatement as R
+from tests._util import MODS5, golden, max_rel, rel_err, t
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def cfg(mods, d_in, act="softmax"):
+    return SimpleNamespace(MODALITIES=list(mods), wsi_encoder="abmil", patch_embedding_dim=d_in,
+                           wsi_encoder_hidden_dim=512, activation=act, n_heads=4)
+
+
+def build(mods, d_in, tag, dev, stain_encoding=False, act="softmax"):
+    from madeleine_amd import MADELEINE
+    m = MADELEINE(cfg(mods, d_in, act), stain_encoding=stain_encoding)
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert shapes == R.param_shapes(len(mods), d_in, 4, stain_encoding)      # reference key names + shapes
+    sd = {k: torch.from_numpy(v) for k, v in recipe.state_dict_recipe(shapes, tag).items()}
+    m.load_state_dict(sd, strict=True)
+    return m.to(dev)
+
+
+def grads_match(g, model, prefix="", tol=TOL):
+    top = max(float(g[f"{prefix}gnorm/{k}"]) for k, _ in model.named_parameters())
+    for k, p in model.named_parameters():
+        ref_n = float(g[f"{prefix}gnorm/{k}"])
+        got = p.grad if p.grad is not None else torch.zeros_like(p)
+        assert abs(float(got.norm()) - ref_n) <= tol * ref_n + 1e-5 * top, k
+        head = torch.from_numpy(g[f"{prefix}ghead/{k}"])
+        assert rel_err(got.flatten()[:16], head) < tol or float(head.norm()) < 1e-4 * top, k
+
+
+def test_encoder_eval_and_grads(dev):
+    g = golden("encoder")
+    B, M, N, D = (int(x) for x in g["shape"])
+    mods = MODS5[:M]
+    model = build(mods, D, "w", dev).eval()
+    feats = t((B, M, N, D), "enc:feats")
+    embs, toks = model({"feats": feats}, device=dev, train=True, n_views=1)
+    for k in mods:
+        assert tuple(embs[k].shape) == g[f"emb/{k}"].shape and tuple(toks[k].shape) == g[f"tok/{k}"].shape
+        assert rel_err(embs[k], g[f"emb/{k}"]) < TOL
+        assert rel_err(toks[k], g[f"tok/{k}"]) < TOL
+    slide, raw = model.wsi_embedders(feats.view(B * M, N, D).to(dev), return_attention=True)
+    assert tuple(slide.shape) == g["slide"].shape and tuple(raw.shape) == g["raw"].shape
+    assert rel_err(slide, g["slide"]) < TOL
+    assert max_rel(raw, g["raw"]) < TOL
+    _, tokens = model.wsi_embedders(feats.view(B * M, N, D).to(dev), return_preattn_feats=True)
+    assert rel_err(tokens[:, :2], g["tokens_head"]) < TOL            # pins the head interleave [BM,N,512,H]
+    w_e, w_t = t((B, 1, 512), "enc:w_e").to(dev), t((B, N, 128), "enc:w_t").to(dev)
+    obj = sum((embs[k] * (w_e if k != "HE" else w_e.unsqueeze(3))).sum() for k in mods) + \
+        sum((toks[k] * (w_t if k != "HE" else w_t.unsqueeze(3))).sum() for k in mods) * 0.01
+    model.zero_grad()
+    obj.backward()
+    assert abs(float(obj) - float(g["obj"])) < TOL * abs(float(g["obj"]))
+    grads_match(g, model)
+
+
+def test_encoder_other_branches(dev):
+    g = golden("encoder")
+    B, M, N, D = (int(x) for x in g["shape"])
+    mods = MODS5[:M]
+    model = build(mods, D, "w", dev).eval()
+    feats = t((B, M, N, D), "enc:feats")
+    with torch.no_grad():
+        assert rel_err(model.encode_he(feats[:, 0], dev), g["encode_he"]) < TOL
+        ev = model({"feats": feats[:, :1]}, device=dev, train=False)
+        assert tuple(ev["HE"].shape) == g["eval/HE"].shape and rel_err(ev["HE"], g["eval/HE"]) < TOL
+        he, raw = model({"feats": feats[:, :1]}, device=dev, train=False, return_attention=True)
+        assert rel_err(he, g["att/HE"]) < TOL and max_rel(raw, g["att/raw"]) < TOL
+        with pytest.raises(RuntimeError):
+            model({"feats": feats}, device=dev, train=False)          # n_mod != 1: the reference raises too
+        np.random.seed(7)                                             # same numpy shuffle as the reference draws
+        e3, _ = model({"feats": feats}, device=dev, train=True, n_views=3)
+        for k in mods:
+            assert tuple(e3[k].shape) == g[f"emb3/{k}"].shape and rel_err(e3[k], g[f"emb3/{k}"]) < TOL
+        for act in ("relu", "leaky_relu", "sigmoid"):
+            m2 = build(mods, D, "w", dev, act=act).eval()
+            s2 = m2.wsi_embedders(feats.view(B * M, N, D).to(dev))
+            assert rel_err(s2, g[f"slide_act/{act}"]) < TOL
+    from madeleine_amd.abmil import activate
+    with pytest.raises(NotImplementedError):
+        activate(torch.zeros(1, 2, 1), "nope")
+    from madeleine_amd import MADELEINE
+    bad = cfg(mods, D)
+    bad.wsi_encoder = "transformer"
+    with pytest.raises(ValueError):
+        MADELEINE(bad)
+
+
+def test_stain_encoding_quirk(dev):
+    g = golden("stain_encoding")
+    B, M, N, D = (int(x) for x in g["shape"])
+    mods = MODS5[:M]
+    model = build(mods, D, "wse", dev, stain_encoding=True).eval()
+    feats = t((B, M, N, D), "se:feats")
+    with torch.no_grad():
+        embs, toks = model({"feats": feats}, device=dev, train=True)
+        for k in mods:
+            assert rel_err(embs[k], g[f"emb/{k}"]) < TOL
+            assert rel_err(toks[k][:, :3], g[f"tok_head/{k}"]) < TOL
+        ev = model({"feats": feats[:1, :1]}, device=dev, train=False)
+        assert rel_err(ev["HE"], g["eval/HE"]) < TOL
+        ev2 = model({"feats": feats[:1, 2:3]}, device=dev, train=False, custom_stain_idx=2)
+        assert rel_err(ev2[mods[2]], g["eval/custom2"]) < TOL
+
+
+def test_train_mode_injected_dropout(dev):
+    from madeleine_amd import InfoNCE
+    g = golden("train_dropout")
+    B, M, N, D = (int(x) for x in g["shape"])
+    mods = MODS5[:M]
+    BM = B * M
+    model = build(mods, D, "wdo", dev).train()
+    feats = t((B, M, N, D), "do:feats")
+    pre = [torch.from_numpy(recipe.bernoulli((BM, N, w), f"do:pre{i}", 0.9)).to(dev) for i, w in enumerate((512, 512, 2048))]
+    gate = [(torch.from_numpy(recipe.bernoulli((BM, N, 512), f"do:gate{c}a", 0.75)).to(dev),
+             torch.from_numpy(recipe.bernoulli((BM, N, 512), f"do:gate{c}b", 0.75)).to(dev)) for c in range(4)]
+    model.wsi_embedders._injected_keep = {"pre": pre, "gate": gate}
+    embs, toks = model({"feats": feats}, device=dev, train=True)
+    for k in mods:
+        assert rel_err(embs[k], g[f"emb/{k}"]) < TOL
+        assert rel_err(toks[k][:, :3], g[f"tok_head/{k}"]) < TOL
+    loss = InfoNCE(temperature=0.1)(embs["HE"][:, 0, :, 0].contiguous(), embs[mods[1]][:, 0, :].contiguous(), symmetric=True)
+    model.zero_grad()
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) < TOL * abs(float(g["loss"]))
+    grads_match(g, model)
+
+
+def test_train_mode_rng_dropout_runs_and_is_seeded(dev):
+    mods = MODS5[:2]
+    model = build(mods, 64, "wdo", dev).train()
+    feats = t((2, 2, 64, 64), "do:feats2")
+    outs = []
+    for seed in (3, 3, 4):
+        torch.manual_seed(seed)
+        embs, _ = model({"feats": feats}, device=dev, train=True)
+        outs.append(embs["HER2"].detach().clone())
+    assert torch.equal(outs[0], outs[1]) and not torch.equal(outs[0], outs[2])
+    model.eval()
+    e1, _ = model({"feats": feats}, device=dev, train=True)
+    assert torch.isfinite(e1["HE"]).all()
+
+
+def test_calculate_losses_global_golden(dev):
+    """H1 host logic + batched InfoNCE: the 5-stain mixed-mask example captured from the reference."""
+    from madeleine_amd import InfoNCE, calculate_losses
+    g = golden("calculate_losses")
+    B, M, N = 6, 5, 12
+    stains = MODS5[1:]
+    he_e = t((B, 1, 512), "cl:he_e")
+    wsi = {"HE": he_e.unsqueeze(3).repeat(1, 1, 1, M - 1).to(dev)}
+    for s in stains:
+        wsi[s] = (t((B, 1, 512), f"cl:e{s}") + 0.1 * he_e).to(dev)
+    labels = torch.from_numpy(g["labels"])
+    args = SimpleNamespace(global_loss="info-nce", symmetric_cl=True, local_loss_weight=0.7)
+    loss, flag = calculate_losses(stains, InfoNCE(temperature=0.001), None, None, wsi, {}, labels[:, 1:], args)
+    assert flag and abs(float(loss) - float(g["global/loss"])) < TOL * abs(float(g["global/loss"]))
+    # sentinel: no stain with more than one case
+    l0 = torch.zeros(B, M)
+    l0[:, 0] = 1
+    l0[2, 3] = 1
+    loss_s, flag_s = calculate_losses(stains, InfoNCE(temperature=0.001), None, None, wsi, {}, l0[:, 1:], args)
+    assert loss_s == -1 and flag_s is False
+    # intra-modality term
+    wsi3 = {k: torch.cat([v.cpu(), t(v.shape, f"cl:v1{k}"), t(v.shape, f"cl:v2{k}")], dim=1).to(dev) for k, v in wsi.items()}
+    crit = InfoNCE(temperature=0.001)
+    loss_i, _ = calculate_losses(stains, crit, None, crit, wsi3, {}, labels[:, 1:], args)
+    assert abs(float(loss_i) - float(g["intra/loss"])) < TOL * abs(float(g["intra/loss"]))
+    with pytest.raises(AssertionError):
+        bad = SimpleNamespace(global_loss="mse", symmetric_cl=True, local_loss_weight=1.0)
+        calculate_losses(stains, crit, None, None, wsi, {}, labels[:, 1:], bad)
+
+
+def test_full_step_global_golden(dev):
+    """Config-1-like plumbing: encoder + global InfoNCE + backward, parameter gradients vs the reference."""
+    from madeleine_amd import InfoNCE, calculate_losses
+    g = golden("full_step")
+    B, M, N, D = (int(x) for x in g["shape"])
+    mods = MODS5[:M]
+    model = build(mods, D, "wfs", dev).eval()
+    feats = t((B, M, N, D), "fs:feats")
+    labels = torch.from_numpy(g["labels"])
+    args = SimpleNamespace(global_loss="info-nce", symmetric_cl=True, local_loss_weight=1.0)
+    embs, toks = model({"feats": feats}, device=dev, train=True)
+    loss, flag = calculate_losses(mods[1:], InfoNCE(temperature=0.001), None, None, embs, toks, labels[:, 1:], args)
+    model.zero_grad()
+    loss.backward()
+    assert flag and abs(float(loss) - float(g["global/loss"])) < TOL * abs(float(g["global/loss"]))
+    grads_match(g, model, prefix="global/", tol=2e-3)
+
+
+def test_state_dict_roundtrip_with_module_prefix(dev, tmp_path):
+    from madeleine_amd import create_model
+    c = cfg(MODS5[:2], 64)
+    m = create_model(c, device="cpu")
+    sd = {"module." + k: v for k, v in m.state_dict().items()}      # DataParallel-style checkpoint
+    path = tmp_path / "model.pt"
+    torch.save(sd, path)
+    m2 = create_model(c, device=dev, checkpoint_path=str(path))
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, m2.state_dict()[k].cpu())
