@@ -45,10 +45,22 @@ def make_cfg(M, D):
                            wsi_encoder_hidden_dim=512, activation="softmax", n_heads=4)
 
 
+def usable_cores() -> int:
+    """Host cores this process may actually use: min(affinity mask, cgroup v2 cpu.max quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(B_sample, M, N, D, use_got, steps=2):
     """Times the CPU oracle's full step (fwd + losses + bwd + AdamW, train-mode dropout) on B_sample slides."""
     from oracle import restatement as R
-    threads = os.cpu_count() or 1
+    threads = usable_cores()
     torch.set_num_threads(threads)
     mods = MODS5[:M]
     sd = R.make_params(M, D, 4, False, seed=42)
@@ -197,7 +209,7 @@ def main():
             try:
                 out["cpu_baseline"] = cpu_baseline(min(a.cpu_sample, B), M, N, Dm, use_got)
             except Exception as e:  # never lose the GPU line because the host box is short on RAM
-                out["cpu_baseline"] = {"value": None, "unit": "slides/s", "cores": os.cpu_count(), "kind": "port",
+                out["cpu_baseline"] = {"value": None, "unit": "slides/s", "cores": usable_cores(), "kind": "port",
                                        "sample": f"failed: {type(e).__name__}: {e}"}
         print(json.dumps(out), flush=True)
 

@@ -8,13 +8,15 @@
 // the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) and every logsumexp is max-subtracted.
 //
 // Workspace (floats; Kp = Kmax rounded up to 32):
-//   Qn,Pn [S,Kp,D] | rq,rp [S,Kp] | Z [S,Kp,Kp] = logits | lse0,lse1 [S,Kp] | coef [S,Kp,Kp] | dQn,dPn [S,Kp,D]
+//   Qn,Pn [S,Kp,D] | rq,rp [S,Kp] | Z [S,Kp,Kp] = logits | m0,l0,m1,l1 [S,Kp] | coef [S,Kp,Kp] | dQn,dPn [S,Kp,D]
+// (m, l) = (max, log sum exp(z - max)) per row (0) / column (1), kept SEPARATE like torch's log_softmax: at
+// T = 0.001 the logits are O(100) and lse - z_ii is O(1e-6), below fp32 resolution at 100.
 #include "common.hpp"
 
 namespace mdl {
 
 struct NceWs {
-    float *Qn, *Pn, *rq, *rp, *Z, *lse0, *lse1, *coef, *dQn, *dPn;
+    float *Qn, *Pn, *rq, *rp, *Z, *m0, *l0, *m1, *l1, *coef, *dQn, *dPn;
     int Kp;
 };
 static inline int nce_kp(int Kmax) { return ((Kmax + 31) / 32) * 32; }
@@ -28,8 +30,10 @@ static inline NceWs nce_ws(void* ws, int S, int Kmax, int D) {
     w.rq = p; p += rows;
     w.rp = p; p += rows;
     w.Z = p; p += rows * w.Kp;
-    w.lse0 = p; p += rows;
-    w.lse1 = p; p += rows;
+    w.m0 = p; p += rows;
+    w.l0 = p; p += rows;
+    w.m1 = p; p += rows;
+    w.l1 = p; p += rows;
     w.coef = p; p += rows * w.Kp;
     w.dQn = p; p += rows * D;
     w.dPn = p; p += rows * D;
@@ -79,12 +83,17 @@ __global__ __launch_bounds__(64) void nce_logits_kernel(const float* __restrict_
 
 // one wave per (row, dir): dir 0 -> lse over columns of row i; dir 1 -> lse over rows of column i
 __global__ __launch_bounds__(64) void nce_lse_kernel(const float* __restrict__ Z, const int32_t* __restrict__ cnt,
-                                                     float* __restrict__ lse0, float* __restrict__ lse1, int Kp) {
+                                                     float* __restrict__ m0, float* __restrict__ l0,
+                                                     float* __restrict__ m1, float* __restrict__ l1, int Kp) {
     const int i = blockIdx.x % Kp, s = blockIdx.x / Kp, dir = blockIdx.y, lane = threadIdx.x;
     const int k = cnt[s];
-    float* out = (dir ? lse1 : lse0) + (int64_t)s * Kp + i;
+    float* om = (dir ? m1 : m0) + (int64_t)s * Kp + i;
+    float* ol = (dir ? l1 : l0) + (int64_t)s * Kp + i;
     if (i >= k) {
-        if (lane == 0) *out = 0.f;
+        if (lane == 0) {
+            *om = 0.f;
+            *ol = 0.f;
+        }
         return;
     }
     const float* __restrict__ z = Z + (int64_t)s * Kp * Kp + (dir ? (int64_t)i : (int64_t)i * Kp);
@@ -95,19 +104,24 @@ __global__ __launch_bounds__(64) void nce_lse_kernel(const float* __restrict__ Z
     float sm = 0.f;
     for (int j = lane; j < k; j += 64) sm += expf(z[j * stride] - mx);
     sm = wave_sum(sm);
-    if (lane == 0) *out = mx + logf(sm);
+    if (lane == 0) {
+        *om = mx;
+        *ol = logf(sm);
+    }
 }
 
-__global__ __launch_bounds__(256) void nce_loss_kernel(const float* __restrict__ Z, const float* __restrict__ lse0,
-                                                       const float* __restrict__ lse1, const int32_t* __restrict__ cnt,
+__global__ __launch_bounds__(256) void nce_loss_kernel(const float* __restrict__ Z, const float* __restrict__ m0,
+                                                       const float* __restrict__ l0, const float* __restrict__ m1,
+                                                       const float* __restrict__ l1, const int32_t* __restrict__ cnt,
                                                        float* __restrict__ loss, int Kp, int symmetric) {
     __shared__ float red[4];
     const int s = blockIdx.x, tid = threadIdx.x, k = cnt[s];
     float v = 0.f;
     for (int i = tid; i < k; i += 256) {
         const float d = Z[((int64_t)s * Kp + i) * Kp + i];
-        const float r0 = lse0[(int64_t)s * Kp + i] - d;
-        v += symmetric ? 0.5f * r0 + 0.5f * (lse1[(int64_t)s * Kp + i] - d) : r0;
+        const int64_t o = (int64_t)s * Kp + i;
+        const float r0 = l0[o] - (d - m0[o]);  // -log_softmax(z)[i] = log sum exp(z - max) - (z_ii - max)
+        v += symmetric ? 0.5f * r0 + 0.5f * (l1[o] - (d - m1[o])) : r0;
     }
     v = wave_sum(v);
     if ((tid & 63) == 0) red[tid >> 6] = v;
@@ -116,8 +130,9 @@ __global__ __launch_bounds__(256) void nce_loss_kernel(const float* __restrict__
 }
 
 // coef = dL/d(cosine_ij) = g/(k T) (w0 softmax_row + w1 softmax_col - (w0+w1) delta_ij); zero outside [0,k)^2
-__global__ void nce_coef_kernel(const float* __restrict__ Z, const float* __restrict__ lse0,
-                                const float* __restrict__ lse1, const int32_t* __restrict__ cnt,
+__global__ void nce_coef_kernel(const float* __restrict__ Z, const float* __restrict__ m0, const float* __restrict__ l0,
+                                const float* __restrict__ m1, const float* __restrict__ l1,
+                                const int32_t* __restrict__ cnt,
                                 const float* __restrict__ d_loss, float* __restrict__ coef, int Kp, float inv_T,
                                 int symmetric) {
     const int s = blockIdx.y;
@@ -128,8 +143,8 @@ __global__ void nce_coef_kernel(const float* __restrict__ Z, const float* __rest
     if (i < k && j < k) {
         const float z = Z[(int64_t)s * Kp * Kp + e];
         const float w0 = symmetric ? 0.5f : 1.f, w1 = symmetric ? 0.5f : 0.f;
-        float v = w0 * expf(z - lse0[(int64_t)s * Kp + i]);
-        if (symmetric) v += w1 * expf(z - lse1[(int64_t)s * Kp + j]);
+        float v = w0 * expf((z - m0[(int64_t)s * Kp + i]) - l0[(int64_t)s * Kp + i]);
+        if (symmetric) v += w1 * expf((z - m1[(int64_t)s * Kp + j]) - l1[(int64_t)s * Kp + j]);
         if (i == j) v -= (w0 + w1);
         c = v * d_loss[s] * inv_T / (float)k;
     }
@@ -192,7 +207,7 @@ using namespace mdl;
 extern "C" int64_t mdl_infonce_ws_bytes(int S, int Kmax, int D) {
     if (S < 0 || Kmax < 0 || D < 8 || (D % 32)) return MDL_E_ARG;
     const int64_t Kp = nce_kp(Kmax), rows = (int64_t)S * Kp;
-    return (4 * rows * D + 4 * rows + 2 * rows * Kp) * 4 + 64;
+    return (4 * rows * D + 6 * rows + 2 * rows * Kp) * 4 + 64;
 }
 
 extern "C" int mdl_infonce_fwd(const float* Q, const float* P, const int32_t* cnt, float* loss, int S, int Kmax, int D,
@@ -211,10 +226,10 @@ extern "C" int mdl_infonce_fwd(const float* Q, const float* P, const int32_t* cn
         hipLaunchKernelGGL(nce_logits_kernel, dim3(Kp / 32, Kp / 32, S), dim3(64), 0, st, w.Qn, w.Pn, w.Z, Kp, D,
                            1.f / temperature);
         MDL_LAUNCH_CHECK();
-        hipLaunchKernelGGL(nce_lse_kernel, dim3(S * Kp, symmetric ? 2 : 1), dim3(64), 0, st, w.Z, cnt, w.lse0, w.lse1, Kp);
+        hipLaunchKernelGGL(nce_lse_kernel, dim3(S * Kp, symmetric ? 2 : 1), dim3(64), 0, st, w.Z, cnt, w.m0, w.l0, w.m1, w.l1, Kp);
         MDL_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(nce_loss_kernel, dim3(S), dim3(256), 0, st, w.Z, w.lse0, w.lse1, cnt, loss, Kp, symmetric);
+    hipLaunchKernelGGL(nce_loss_kernel, dim3(S), dim3(256), 0, st, w.Z, w.m0, w.l0, w.m1, w.l1, cnt, loss, Kp, symmetric);
     MDL_LAUNCH_CHECK();
     return MDL_OK;
 }
@@ -228,8 +243,8 @@ extern "C" int mdl_infonce_bwd(const float* d_loss, const int32_t* cnt, float* d
     hipStream_t st = (hipStream_t)stream;
     const NceWs w = nce_ws(ws, S, Kmax, D);
     const int Kp = w.Kp;
-    hipLaunchKernelGGL(nce_coef_kernel, dim3((Kp * Kp + 255) / 256, S), dim3(256), 0, st, w.Z, w.lse0, w.lse1, cnt, d_loss,
-                       w.coef, Kp, 1.f / temperature, symmetric);
+    hipLaunchKernelGGL(nce_coef_kernel, dim3((Kp * Kp + 255) / 256, S), dim3(256), 0, st, w.Z, w.m0, w.l0, w.m1, w.l1, cnt,
+                       d_loss, w.coef, Kp, 1.f / temperature, symmetric);
     MDL_LAUNCH_CHECK();
     hipLaunchKernelGGL(nce_grad_kernel, dim3(D / 32, Kp / 32, S * 2), dim3(64), 0, st, w.coef, w.Qn, w.Pn, w.dQn, w.dPn, Kp, D,
                        S);

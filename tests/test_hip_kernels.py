@@ -61,9 +61,9 @@ def test_pool_fwd_bwd_dense(dev, H, BM, N):
     Ed, sd = E.detach().to(dev).requires_grad_(), s.detach().to(dev).requires_grad_()
     out = MF.softmax_pool(Ed, sd)
     out.backward(g.to(dev))
-    assert max_rel(out, ref) < 1e-4
-    assert max_rel(Ed.grad, E.grad) < 1e-4
-    assert max_rel(sd.grad, s.grad, floor=1e-4 * float(s.grad.abs().max())) < 2e-3
+    assert rel_err(out, ref) < 1e-5 and max_rel(out, ref) < TOL
+    assert rel_err(Ed.grad, E.grad) < 1e-5 and max_rel(Ed.grad, E.grad) < TOL
+    assert float((sd.grad.cpu() - s.grad).abs().max()) <= 1e-4 * float(s.grad.abs().max()) + 1e-6
 
 
 def test_pool_ragged_and_empty(dev):
@@ -89,9 +89,9 @@ def test_pool_ragged_and_empty(dev):
     out = MF.softmax_pool(Ed, sd, cu.to(dev), max(lens))
     out.backward(g.to(dev))
     assert float(out[1].abs().max()) == 0.0
-    assert max_rel(out, ref) < 1e-4
-    assert max_rel(Ed.grad, E.grad) < 1e-4
-    assert max_rel(sd.grad, s.grad, floor=1e-4 * float(s.grad.abs().max())) < 2e-3
+    assert rel_err(out, ref) < 1e-5 and max_rel(out, ref) < TOL
+    assert rel_err(Ed.grad, E.grad) < 1e-5 and max_rel(Ed.grad, E.grad) < TOL
+    assert float((sd.grad.cpu() - s.grad).abs().max()) <= 1e-4 * float(s.grad.abs().max()) + 1e-6
 
 
 def test_pool_extreme_scores(dev):
@@ -102,7 +102,7 @@ def test_pool_extreme_scores(dev):
     ref = torch.einsum("bnh,bnhe->bhe", torch.softmax(s, dim=1), E.view(2, 200, 4, 512)).reshape(2, 2048)
     out = MF.softmax_pool(E.to(dev), s.to(dev))
     assert torch.isfinite(out).all()
-    assert max_rel(out, ref) < 1e-4
+    assert rel_err(out, ref) < 1e-5 and max_rel(out, ref) < TOL
 
 
 # ---------------------------------------------------------------------------------------------- A2
@@ -118,7 +118,7 @@ def test_gate_eval(dev, H, T):
     dl = [x.detach().to(dev).requires_grad_() for x in (E,) + w]
     out = MF.gate_scores(*dl)
     out.backward(g.to(dev))
-    assert max_rel(out, ref) < 1e-4
+    assert rel_err(out, ref) < 1e-5 and max_rel(out, ref) < TOL
     names = ["E", "Wa", "ba", "Wb", "bb", "wc", "bc"]
     for n, a, b in zip(names, dl, leaves):
         assert rel_err(a.grad, b.grad) < 1e-4, n
@@ -140,7 +140,7 @@ def test_gate_dropout_explicit_masks(dev):
     dl = [x.detach().to(dev).requires_grad_() for x in (E,) + w]
     out = MF.gate_scores(*dl, p_drop=0.25, seed=0, keep_a=ka.to(dev), keep_b=kb.to(dev))
     out.backward(g.to(dev))
-    assert max_rel(out, ref) < 1e-4
+    assert rel_err(out, ref) < 1e-5 and max_rel(out, ref) < TOL
     for n, a, b in zip(["E", "Wa", "ba", "Wb", "bb", "wc", "bc"], dl, leaves):
         assert rel_err(a.grad, b.grad) < 1e-4, n
 
@@ -189,12 +189,22 @@ def test_attn_pool_fused_with_score_grad(dev):
     dl = [x.detach().to(dev).requires_grad_() for x in (E,) + w]
     po, so = MF.attn_pool(*dl)
     ((po * gp.to(dev)).sum() + (so * gs.to(dev)).sum()).backward()
-    assert max_rel(po, pooled) < 1e-4 and max_rel(so, sc) < 1e-4
+    assert rel_err(po, pooled) < 1e-5 and rel_err(so, sc) < 1e-5
     for n, a, b in zip(["E", "Wa", "ba", "Wb", "bb", "wc", "bc"], dl, leaves):
         assert rel_err(a.grad, b.grad) < 1e-4, n
 
 
 # ---------------------------------------------------------------------------------------------- L1
+def _grad_ok(hip, ref32, ref64):
+    """Within 1e-3 relative of the exact (fp64) gradient, or as accurate as the fp32 reference itself is.
+    At T=0.001 a saturated softmax makes the CE gradient `softmax - onehot` a catastrophic cancellation: the
+    fp32 reference is then only good to a few 10 % on gradients that are ~1e-6 of the usual scale, and
+    agreement with it beyond its own error is meaningless."""
+    e_hip = float((hip.detach().cpu().double() - ref64).norm())
+    e_ref = float((ref32.double() - ref64).norm())
+    assert e_hip <= max(TOL * float(ref64.norm()), 2.0 * e_ref) + 1e-30, (e_hip, e_ref, float(ref64.norm()))
+
+
 @pytest.mark.parametrize("k", [2, 7, 33, 256])
 @pytest.mark.parametrize("T", [0.001, 0.1])
 @pytest.mark.parametrize("sym", [False, True])
@@ -205,12 +215,14 @@ def test_infonce_vs_oracle(dev, k, T, sym):
     q, p = q0.clone().requires_grad_(), p0.clone().requires_grad_()
     ref = R.info_nce(q, p, T, sym)
     ref.backward()
+    q64, p64 = q0.double().requires_grad_(), p0.double().requires_grad_()
+    R.info_nce(q64, p64, T, sym).backward()
     qd, pd = q0.to(dev).requires_grad_(), p0.to(dev).requires_grad_()
     out = InfoNCE(temperature=T)(qd, pd, symmetric=sym)
     out.backward()
     assert abs(float(out) - float(ref)) <= TOL * abs(float(ref)) + 1e-5
-    assert rel_err(qd.grad, q.grad) < TOL
-    assert rel_err(pd.grad, p.grad) < TOL
+    _grad_ok(qd.grad, q.grad, q64.grad)
+    _grad_ok(pd.grad, p.grad, p64.grad)
 
 
 def test_infonce_golden_and_batched(dev):
@@ -232,8 +244,14 @@ def test_infonce_golden_and_batched(dev):
         tag = f"k{k}/T0.001/sym1"
         assert abs(float(losses[s]) - float(g[f"{tag}/loss"])) <= TOL * abs(float(g[f"{tag}/loss"])) + 1e-5
         sl = slice(None) if k <= 7 else slice(0, 32)
-        assert rel_err(Qd.grad[s, :k, sl], g[f"{tag}/dq"]) < TOL
-        assert rel_err(Pd.grad[s, :k, sl], g[f"{tag}/dp"]) < TOL
+        if k >= 33:   # k = 2, 7 are saturated at T = 0.001: their reference gradients are rounding noise (see _grad_ok)
+            assert rel_err(Qd.grad[s, :k, sl], g[f"{tag}/dq"]) < TOL
+            assert rel_err(Pd.grad[s, :k, sl], g[f"{tag}/dp"]) < TOL
+        else:
+            q64, p64 = Q[s, :k].double().requires_grad_(), P[s, :k].double().requires_grad_()
+            R.info_nce(q64, p64, 0.001, True).backward()
+            _grad_ok(Qd.grad[s, :k], torch.from_numpy(g[f"{tag}/dq"]), q64.grad)
+            _grad_ok(Pd.grad[s, :k], torch.from_numpy(g[f"{tag}/dp"]), p64.grad)
         assert float(Qd.grad[s, k:].abs().max() if k < 33 else 0.0) == 0.0
 
 
@@ -263,13 +281,13 @@ def test_pool_full_size_properties(dev):
     assert bool((out <= E.amax(dim=1) + 1e-5).all()) and bool((out >= E.amin(dim=1) - 1e-5).all())
     # (2) shift invariance of the scores
     out2 = MF.softmax_pool(E, s + 7.5)
-    assert max_rel(out2, out) < 1e-4
+    assert rel_err(out2, out) < 1e-5
     # (3) a bag of identical tokens pools to that token whatever the scores
     Ec = E[:, :1].expand(-1, N, -1).contiguous()
     assert max_rel(MF.softmax_pool(Ec, s), Ec[:, 0]) < 1e-5
     # (4) linearity in E
-    assert max_rel(MF.softmax_pool(2.5 * E, s), 2.5 * out) < 1e-5
+    assert rel_err(MF.softmax_pool(2.5 * E, s), 2.5 * out) < 1e-6
     # (5) device-side fp32 restatement of the same op (chunked to bound memory)
     w = torch.softmax(s, dim=1)
     ref = torch.stack([torch.einsum("nh,nhe->he", w[b], E[b].view(N, H, 512)).reshape(-1) for b in range(BM)])
-    assert max_rel(out, ref) < 1e-4
+    assert rel_err(out, ref) < 1e-5 and max_rel(out, ref) < TOL
