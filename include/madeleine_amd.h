@@ -132,27 +132,33 @@ int mdl_infonce_bwd(const float* d_loss, const int32_t* cnt, float* dQ, float* d
  * G0-G3 -- Graph Optimal Transport.  Replaces GOT (madeleine/utils/loss.py:278-302) =
  * cost_matrix_batch_torch (:162-176) + global-threshold ReLU (:288-292) + IPOT Wasserstein
  * (:179-207, 30 iterations, beta .5) + Gromov-Wasserstein (:236-275, 5 x 20 IPOT iterations,
- * beta .1) with cos_batch_torch intra costs (:210-233).
+ * beta .1) with cos_batch_torch intra costs (:210-233).  Called from trainer.py:42-45.
  *
- * V,Q [k,n,d] the (already sub-sampled) token sets of k cases; d <= 128.
- * Thresholds: the reference takes min/max over the WHOLE [k,n,n] cost tensor.  When `minmax_in`
- * (float[6] = cross min,max, Cs min,max, Ct min,max) is non-NULL those values are used instead of
- * the local ones -- the data-parallel driver all-gathers per-rank extrema to keep the global-batch
- * semantics of nn.DataParallel.  minmax_out float[6] receives the local extrema
- * plus, in [6..11], the flat argmin/argmax positions as floats are NOT stored -- backward recomputes.
- * out [2]: out[0] = sum_b WD_b, out[1] = sum_b GWD_b  (GOT returns out[0] + out[1]).
- * ws: mdl_got_ws_bytes(k,n,d): cost matrices and the per-iteration transport-plan history that the
- * reverse sweep replays (the reference's autograd tape holds the same tensors).
+ * V,Q [k,n,d]: the (already sub-sampled, loss.py:281-284) token sets of k cases; n <= 256, d <= 128.
+ * out [2]: out[0] = sum_b WD_b, out[1] = sum_b GWD_b   (GOT returns out[1] + out[0], a SUM over cases).
+ * Thresholds thr = min + .1 (max - min): the reference takes min/max over the WHOLE batch tensor for each of
+ * the three cost tensors (cross, intra-V, intra-Q).  minmax_out float[6] (may be NULL) receives this call's
+ * extrema (cross min,max | Cs min,max | Ct min,max).  When minmax_in (float[6], device) is non-NULL those
+ * values are used INSTEAD -- the data-parallel driver all-gathers per-rank extrema so that every rank
+ * thresholds with the global-batch values nn.DataParallel would see.
+ * ws: mdl_got_ws_bytes(k,n,d) bytes: cost matrices + the per-iteration plans T_t and scaling vectors that
+ * the reverse sweep replays (the same tensors the reference's autograd tape holds).  The backward calls
+ * must receive the forward's workspace untouched.
  */
 int64_t mdl_got_ws_bytes(int k, int n, int d);
 int mdl_got_fwd(const float* V, const float* Q, float* out, float* minmax_out, const float* minmax_in,
                 int k, int n, int d, void* ws, void* stream);
-/* d_out [2] incoming gradients of (WD sum, GWD sum); dV,dQ [k,n,d] written.  ws = forward's.
- * d_minmax [6] (optional, may be NULL): gradient wrt the six threshold extrema, needed only when
- * minmax_in was supplied (the driver routes it back to the owning rank); when minmax_in was NULL the
- * extrema are local and their gradient is folded into dV,dQ like autograd does. */
-int mdl_got_bwd(const float* V, const float* Q, const float* d_out, float* dV, float* dQ, float* d_minmax,
-                const float* minmax_in, int k, int n, int d, void* ws, void* stream);
+/* Backward: d_out [2] = incoming gradients of (WD sum, GWD sum); dV,dQ [k,n,d] are written.  Gradient flows
+ * through every unrolled IPOT iteration, the GW outer loop, the ReLU masks and the threshold extrema (to the
+ * arg-min / arg-max elements, split evenly over ties like torch's min()/max() backward). */
+int mdl_got_bwd(const float* V, const float* Q, const float* d_out, float* dV, float* dQ, int k, int n, int d,
+                void* ws, void* stream);
+/* The same in two steps, for the data-parallel path: _begin runs the reverse sweeps and reports the gradient
+ * wrt the six threshold extrema in d_minmax [6] (may be NULL); the caller sums it over ranks; _finish routes
+ * d_minmax_total [6] (NULL = this call's own) to the local elements that attain the extrema and writes dV,dQ. */
+int mdl_got_bwd_begin(const float* d_out, float* d_minmax, int k, int n, int d, void* ws, void* stream);
+int mdl_got_bwd_finish(const float* V, const float* Q, float* dV, float* dQ, const float* d_minmax_total,
+                       int k, int n, int d, void* ws, void* stream);
 
 #ifdef __cplusplus
 }

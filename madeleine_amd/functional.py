@@ -301,3 +301,61 @@ class InfoNCEFn(torch.autograd.Function):
 
 def info_nce_batched(Q, P, cnt, temperature, symmetric):
     return InfoNCEFn.apply(Q, P, cnt, float(temperature), bool(symmetric))
+
+
+# --------------------------------------------------------------------------------------------------
+# G0-G3: graph optimal transport
+# --------------------------------------------------------------------------------------------------
+class GOTFn(torch.autograd.Function):
+    """out[2] = (sum_b WD_b, sum_b GWD_b) for token sets V,Q [k,n,d] (loss.py:278-302 after the sub-sampling).
+
+    minmax_in (optional float[6] device tensor) replaces the batch-local threshold extrema (data-parallel path);
+    the second output is this call's own extrema [6] (non-differentiable)."""
+
+    @staticmethod
+    def forward(ctx, V, Q, minmax_in, reduce_dminmax):
+        _require(V, "v_")
+        _require(Q, "q_")
+        if V.shape != Q.shape or V.dim() != 3:
+            raise ValueError("GOT expects two token tensors of identical shape [k, n, d]")
+        lib = _native.lib()
+        k, n, d = V.shape
+        nbytes = lib.mdl_got_ws_bytes(k, n, d)
+        if nbytes == -3:
+            raise NotImplementedError("madeleine_amd.GOT supports n <= 256 tokens per bag and d <= 128 (got n=%d, d=%d); "
+                                      "the reference calls it with subsample=256 (trainer.py:44)" % (n, d))
+        ws = _ws(nbytes, V.device)
+        out = torch.empty(2, device=V.device, dtype=torch.float32)
+        mm = torch.empty(6, device=V.device, dtype=torch.float32)
+        with _timed("got_fwd"):
+            rc = lib.mdl_got_fwd(_ptr(V), _ptr(Q), _ptr(out), _ptr(mm), _ptr(minmax_in), k, n, d, _ptr(ws), _stream())
+        _native.check(rc, "mdl_got_fwd")
+        ctx.save_for_backward(V, Q, ws)
+        ctx.reduce_dminmax = reduce_dminmax
+        ctx.mark_non_differentiable(mm)
+        return out, mm
+
+    @staticmethod
+    def backward(ctx, d_out, _d_mm):
+        V, Q, ws = ctx.saved_tensors
+        lib = _native.lib()
+        k, n, d = V.shape
+        dV, dQ = torch.empty_like(V), torch.empty_like(Q)
+        d_out = d_out.contiguous()
+        if ctx.reduce_dminmax is None:
+            with _timed("got_bwd"):
+                rc = lib.mdl_got_bwd(_ptr(V), _ptr(Q), _ptr(d_out), _ptr(dV), _ptr(dQ), k, n, d, _ptr(ws), _stream())
+            _native.check(rc, "mdl_got_bwd")
+        else:
+            dmm = torch.empty(6, device=V.device, dtype=torch.float32)
+            rc = lib.mdl_got_bwd_begin(_ptr(d_out), _ptr(dmm), k, n, d, _ptr(ws), _stream())
+            _native.check(rc, "mdl_got_bwd_begin")
+            dmm = ctx.reduce_dminmax(dmm).contiguous()      # e.g. all_reduce(SUM) over ranks
+            rc = lib.mdl_got_bwd_finish(_ptr(V), _ptr(Q), _ptr(dV), _ptr(dQ), _ptr(dmm), k, n, d, _ptr(ws), _stream())
+            _native.check(rc, "mdl_got_bwd_finish")
+        return dV, dQ, None, None
+
+
+def got(V, Q, minmax_in=None, reduce_dminmax=None, return_extrema=False):
+    out, mm = GOTFn.apply(V, Q, minmax_in, reduce_dminmax)
+    return (out, mm) if return_extrema else out

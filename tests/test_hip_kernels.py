@@ -291,3 +291,90 @@ def test_pool_full_size_properties(dev):
     w = torch.softmax(s, dim=1)
     ref = torch.stack([torch.einsum("nh,nhe->he", w[b], E[b].view(N, H, 512)).reshape(-1) for b in range(BM)])
     assert rel_err(out, ref) < 1e-5 and max_rel(out, ref) < TOL
+
+
+# ---------------------------------------------------------------------------------------------- G0-G3
+def _got_inputs(k, N, trial_key):
+    from tests._util import golden
+    g = golden("got")
+    trial = int(g[f"k{k}/trial"])
+    v0, q0 = t((k, N, 128), f"got:v{k}:{trial}"), t((k, N, 128), f"got:q{k}:{trial}")
+    return g, v0, q0 + 0.7 * v0
+
+
+@pytest.mark.parametrize("k", [2, 7, 32])
+def test_got_vs_golden_and_oracle(dev, k):
+    """GOT value + gradients against the vectors captured from the reference (well-conditioned instances, see
+    oracle/gen_golden.py) -- including the randperm(batch) sub-sampling quirk: gradients land on tokens < k only."""
+    from madeleine_amd import GOT
+    N = 40
+    g, v0, q0 = _got_inputs(k, N, "got")
+    vd, qd = v0.to(dev).requires_grad_(), q0.to(dev).requires_grad_()
+    torch.manual_seed(100 + k)                         # same randperm(k) draw as the golden run
+    loss = GOT(vd, qd, subsample=256)
+    loss.backward()
+    ref = float(g[f"k{k}/loss"])
+    assert abs(float(loss) - ref) < TOL * abs(ref)
+    assert abs(float(vd.grad.norm()) - float(g[f"k{k}/dv_norm"])) < 5e-3 * float(g[f"k{k}/dv_norm"])
+    assert abs(float(qd.grad.norm()) - float(g[f"k{k}/dq_norm"])) < 5e-3 * float(g[f"k{k}/dq_norm"])
+    assert float(vd.grad[:, k:].abs().max()) == 0.0
+    if k <= 7:
+        assert rel_err(vd.grad[:, :k], g[f"k{k}/dv"]) < 5e-3
+        assert rel_err(qd.grad[:, :k], g[f"k{k}/dq"]) < 5e-3
+    else:
+        assert rel_err(vd.grad[:4, :k, :16], g[f"k{k}/dv"]) < 5e-3
+        assert rel_err(qd.grad[:4, :k, :16], g[f"k{k}/dq"]) < 5e-3
+
+
+def test_got_pieces_and_fp64_oracle(dev):
+    """WD and GW sums separately against an fp64 evaluation of the oracle on a small well-conditioned problem."""
+    from madeleine_amd import functional as MF
+    from tests._util import golden
+    g = golden("got")
+    k, n = 3, 9
+    trial = int(g["piece/trial"])
+    v = t((k, n, 128), f"got:pv:{trial}")
+    q = t((k, n, 128), f"got:pq:{trial}") + 0.5 * v
+    out = MF.got(v.to(dev), q.to(dev))
+    assert rel_err(out[0:1], g["piece/wd"].sum(keepdims=True).reshape(1)) < TOL
+    assert rel_err(out[1:2], g["piece/gwd"].sum(keepdims=True).reshape(1)) < TOL
+    v64, q64 = v.double().requires_grad_(), q.double().requires_grad_()
+    R.got(v64, q64).backward()
+    vd, qd = v.to(dev).requires_grad_(), q.to(dev).requires_grad_()
+    o = MF.got(vd, qd)
+    (o[0] + o[1]).backward()
+    assert rel_err(vd.grad, v64.grad) < TOL and rel_err(qd.grad, q64.grad) < TOL
+
+
+def test_got_external_thresholds_and_limits(dev):
+    """minmax_in = the batch's own extrema reproduces the local result (value and gradient); two half-batches with the
+    global extrema sum to the full batch (the data-parallel decomposition); n > 256 is refused loudly."""
+    from madeleine_amd import functional as MF
+    k, n = 6, 12
+    v = t((k, n, 128), "got:ext:v").to(dev)
+    q = (t((k, n, 128), "got:ext:q") + 0.6 * t((k, n, 128), "got:ext:v")).to(dev)
+    v1, q1 = v.clone().requires_grad_(), q.clone().requires_grad_()
+    o1, mm = MF.got(v1, q1, return_extrema=True)
+    (o1[0] + o1[1]).backward()
+    parts, grads = [], []
+    acc = {"d": torch.zeros(6, device=dev)}
+    # pass 1: collect d_minmax of both halves (what the all-reduce would sum); pass 2: finish with the total
+    halves = [(v[:3].clone().requires_grad_(), q[:3].clone().requires_grad_()),
+              (v[3:].clone().requires_grad_(), q[3:].clone().requires_grad_())]
+    dmm_parts = []
+    for vh, qh in halves:
+        o = MF.got(vh, qh, minmax_in=mm, reduce_dminmax=lambda x: (dmm_parts.append(x.clone()) or x))
+        (o[0] + o[1]).backward()
+        parts.append(o.detach())
+    total = dmm_parts[0] + dmm_parts[1]
+    for vh, qh in halves:
+        vh.grad = None
+        qh.grad = None
+        o = MF.got(vh, qh, minmax_in=mm, reduce_dminmax=lambda x: total)
+        (o[0] + o[1]).backward()
+        grads.append((vh.grad, qh.grad))
+    assert rel_err(parts[0] + parts[1], o1.detach()) < 1e-5
+    assert rel_err(torch.cat([grads[0][0], grads[1][0]]), v1.grad) < 1e-4
+    assert rel_err(torch.cat([grads[0][1], grads[1][1]]), q1.grad) < 1e-4
+    with pytest.raises(NotImplementedError):
+        MF.got(torch.zeros(1, 300, 128, device=dev), torch.zeros(1, 300, 128, device=dev))

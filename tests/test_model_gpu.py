@@ -218,3 +218,41 @@ def test_state_dict_roundtrip_with_module_prefix(dev, tmp_path):
     m2 = create_model(c, device=dev, checkpoint_path=str(path))
     for k, v in m.state_dict().items():
         assert torch.equal(v, m2.state_dict()[k].cpu())
+
+
+def test_calculate_losses_full_golden(dev):
+    """H1 with the local GOT term (weight 0.7), 5 stains, mixed masks, one stain skipped: reference value."""
+    from madeleine_amd import GOT, InfoNCE, calculate_losses
+    g = golden("calculate_losses")
+    B, M, N = 6, 5, 12
+    stains = MODS5[1:]
+    he_e, he_t = t((B, 1, 512), "cl:he_e"), t((B, N, 128), "cl:he_t")
+    wsi = {"HE": he_e.unsqueeze(3).repeat(1, 1, 1, M - 1).to(dev)}
+    tok = {"HE": he_t.unsqueeze(3).repeat(1, 1, 1, M - 1).to(dev)}
+    for s in stains:
+        wsi[s] = (t((B, 1, 512), f"cl:e{s}") + 0.1 * he_e).to(dev)
+        tok[s] = (t((B, N, 128), f"cl:t{s}") + 0.6 * he_t).to(dev)
+    labels = torch.from_numpy(g["labels"])
+    args = SimpleNamespace(global_loss="info-nce", symmetric_cl=True, local_loss_weight=0.7)
+    torch.manual_seed(5)
+    loss, flag = calculate_losses(stains, InfoNCE(temperature=0.001), GOT, None, wsi, tok, labels[:, 1:], args)
+    assert flag and abs(float(loss) - float(g["full/loss"])) < 2e-3 * abs(float(g["full/loss"]))
+
+
+def test_full_step_with_got_golden(dev):
+    """encoder + global InfoNCE + local GOT + backward: loss and parameter-gradient norms vs the reference."""
+    from madeleine_amd import GOT, InfoNCE, calculate_losses
+    g = golden("full_step")
+    B, M, N, D = (int(x) for x in g["shape"])
+    mods = MODS5[:M]
+    model = build(mods, D, "wfs", dev).eval()
+    feats = t((B, M, N, D), "fs:feats")
+    labels = torch.from_numpy(g["labels"])
+    args = SimpleNamespace(global_loss="info-nce", symmetric_cl=True, local_loss_weight=1.0)
+    embs, toks = model({"feats": feats}, device=dev, train=True)
+    torch.manual_seed(11)
+    loss, flag = calculate_losses(mods[1:], InfoNCE(temperature=0.001), GOT, None, embs, toks, labels[:, 1:], args)
+    model.zero_grad()
+    loss.backward()
+    assert flag and abs(float(loss) - float(g["loss"])) < 2e-3 * abs(float(g["loss"]))
+    grads_match(g, model, tol=1e-2)
