@@ -34,7 +34,7 @@ struct GotWs {
     // per-case regions (float offsets from the case base)
     int64_t per_case;
     int64_t oVh, oQh, orV, orQ, oC0, oCs0, oCt0, oC, oWT, oWd, oWs, oCs, oCt, ors, ort, oCg, oGT, oGd, oGs, oP1, oP2, oP3,
-        ogT, ogA, ogCs, ogCt, oG;
+        ogT, ogA, ogCs, ogCt, oG, ogC0;
     // global regions (float offsets from ws base)
     int64_t g_ext, g_thr, g_gthr, g_wd, g_gwd, g_cases;
 };
@@ -72,6 +72,7 @@ __host__ __device__ inline GotWs got_layout(int k, int n, int d) {
     w.ogCs = o; o += nn;
     w.ogCt = o; o += nn;
     w.oG = o; o += nn;
+    w.ogC0 = o; o += nn;                     // d/d(raw cross cost), written by the WD sweep, read by cost_bwd
     w.per_case = o;
     int64_t g = (int64_t)k * w.per_case;
     w.g_cases = 0;
@@ -515,7 +516,7 @@ __global__ __launch_bounds__(256) void got_wd_bwd_kernel(float* ws, const float*
                   ga, gr, gdel);
     // total dL/dC = g T_final + (through IPOT) ; mask by relu ; accumulate -sum as threshold gradient
     const float thr = ws[L.g_thr + 6];
-    float* G = base + L.oG;
+    float* G = base + L.ogC0;
     float s = 0.f;
     for (int64_t e = tid; e < (int64_t)n * n; e += 256) {
         const float gc = g * Tf[e] + base[L.oP1 + e];
@@ -706,7 +707,7 @@ __global__ __launch_bounds__(256) void got_cost_bwd_kernel(const float* __restri
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float* base = ws + (int64_t)b * L.per_case;
     const int64_t N2 = (int64_t)n * n;
-    float* G0 = base + L.oG;      // d/dC0
+    float* G0 = base + L.ogC0;    // d/dC0
     float* Gs = base + L.ogCs;    // d/dCs0
     float* Gt = base + L.ogCt;    // d/dCt0
     {
