@@ -119,9 +119,7 @@ def main():
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank])
     opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
     crit = InfoNCE(temperature=0.001)
-    got = None
-    if use_got:
-        from madeleine_amd import GOT as got  # noqa: N811
+    got_impl = MF.HipGotImpl if use_got else None
     largs = SimpleNamespace(global_loss="info-nce", symmetric_cl=True, local_loss_weight=1.0)
 
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -136,12 +134,13 @@ def main():
 
     def step():
         opt.zero_grad(set_to_none=True)
+        # presence labels of the global batch first (tiny collective, issued while the GPU queue is empty)
+        lab_g = D.all_gather_labels(labels[:, 1:], dev)
         embs, toks = net(data, device=dev)
-        lab = labels
-        if world > 1:
-            lab = D.all_gather_labels(labels, dev)
-            embs = D.gather_slide_embeddings(embs, mods)
-        loss, flag = calculate_losses(mods[1:], crit, got, None, embs, toks, lab[:, 1:], largs)
+        # one all-gather of the packed slide embeddings -> replicated global InfoNCE; rank-local GOT with
+        # global-batch thresholds (one [S,6] all-gather fwd, one all-reduce bwd); DDP all-reduces the grads.
+        loss, flag = D.calculate_losses_dp(mods[1:], crit, got_impl, embs, toks, labels[:, 1:], largs,
+                                           labels_global_withoutHE=lab_g, use_local_loss=use_got)
         loss.backward()
         opt.step()
         return loss

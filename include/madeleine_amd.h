@@ -148,6 +148,9 @@ int mdl_infonce_bwd(const float* d_loss, const int32_t* cnt, float* dQ, float* d
 int64_t mdl_got_ws_bytes(int k, int n, int d);
 int mdl_got_fwd(const float* V, const float* Q, float* out, float* minmax_out, const float* minmax_in,
                 int k, int n, int d, void* ws, void* stream);
+/* Only the first stage of the forward (normalise, raw costs, extrema): minmax_out [6] for this batch.  The
+ * data-parallel driver calls it on every rank, reduces min/max over ranks, then runs mdl_got_fwd with minmax_in. */
+int mdl_got_extrema(const float* V, const float* Q, float* minmax_out, int k, int n, int d, void* ws, void* stream);
 /* Backward: d_out [2] = incoming gradients of (WD sum, GWD sum); dV,dQ [k,n,d] are written.  Gradient flows
  * through every unrolled IPOT iteration, the GW outer loop, the ReLU masks and the threshold extrema (to the
  * arg-min / arg-max elements, split evenly over ties like torch's min()/max() backward). */

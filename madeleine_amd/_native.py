@@ -38,6 +38,7 @@ SIGNATURES = {
     "mdl_infonce_bwd": (i32, [c_f, c_p, c_f, c_f, i32, i32, i32, f32, i32, c_p, c_p]),
     "mdl_got_ws_bytes": (i64, [i32, i32, i32]),
     "mdl_got_fwd": (i32, [c_f, c_f, c_f, c_f, c_f, i32, i32, i32, c_p, c_p]),
+    "mdl_got_extrema": (i32, [c_f, c_f, c_f, i32, i32, i32, c_p, c_p]),
     "mdl_got_bwd": (i32, [c_f, c_f, c_f, c_f, c_f, i32, i32, i32, c_p, c_p]),
     "mdl_got_bwd_begin": (i32, [c_f, c_f, i32, i32, i32, c_p, c_p]),
     "mdl_got_bwd_finish": (i32, [c_f, c_f, c_f, c_f, c_f, i32, i32, i32, c_p, c_p]),

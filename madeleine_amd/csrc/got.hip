@@ -807,8 +807,8 @@ extern "C" int mdl_got_fwd(const float* V, const float* Q, float* out, float* mi
     if (!host_aligned16(ws)) return MDL_E_ALIGN;
     hipStream_t s = (hipStream_t)stream;
     if (k == 0 || n == 0) {
-        hipMemsetAsync(out, 0, 2 * sizeof(float), s);
-        return MDL_OK;
+        const hipError_t e = hipMemsetAsync(out, 0, 2 * sizeof(float), s);
+        return e == hipSuccess ? MDL_OK : (int)e;
     }
     float* w = (float*)ws;
     hipLaunchKernelGGL(got_prep_kernel, dim3(k), dim3(256), 0, s, V, Q, w, k, n, d);
@@ -824,6 +824,22 @@ extern "C" int mdl_got_fwd(const float* V, const float* Q, float* out, float* mi
     return MDL_OK;
 }
 
+extern "C" int mdl_got_extrema(const float* V, const float* Q, float* minmax_out, int k, int n, int d, void* ws,
+                               void* stream) {
+    const int rc = got_check(k, n, d);
+    if (rc) return rc;
+    if (!V || !Q || !minmax_out || !ws) return MDL_E_ARG;
+    if (!host_aligned16(ws)) return MDL_E_ALIGN;
+    if (k == 0 || n == 0) return MDL_E_ARG;  // extrema of an empty batch are undefined
+    hipStream_t s = (hipStream_t)stream;
+    float* w = (float*)ws;
+    hipLaunchKernelGGL(got_prep_kernel, dim3(k), dim3(256), 0, s, V, Q, w, k, n, d);
+    MDL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(got_minmax_kernel, dim3(1), dim3(64), 0, s, w, minmax_out, (const float*)nullptr, k, n, d);
+    MDL_LAUNCH_CHECK();
+    return MDL_OK;
+}
+
 extern "C" int mdl_got_bwd_begin(const float* d_out, float* d_minmax, int k, int n, int d, void* ws, void* stream) {
     const int rc = got_check(k, n, d);
     if (rc) return rc;
@@ -831,7 +847,10 @@ extern "C" int mdl_got_bwd_begin(const float* d_out, float* d_minmax, int k, int
     if (!host_aligned16(ws)) return MDL_E_ALIGN;
     hipStream_t s = (hipStream_t)stream;
     if (k == 0 || n == 0) {
-        if (d_minmax) hipMemsetAsync(d_minmax, 0, 6 * sizeof(float), s);
+        if (d_minmax) {
+            const hipError_t e = hipMemsetAsync(d_minmax, 0, 6 * sizeof(float), s);
+            if (e != hipSuccess) return (int)e;
+        }
         return MDL_OK;
     }
     float* w = (float*)ws;

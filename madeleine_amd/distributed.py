@@ -91,3 +91,115 @@ def gather_slide_embeddings(wsi_embs: Dict[str, torch.Tensor], modalities: Seque
         e = full[:, i]
         out[m] = e.unsqueeze(3).expand(-1, -1, -1, M - 1) if m == "HE" else e
     return out
+
+
+# --------------------------------------------------------------------------------------------------
+# local (GOT) loss with global-batch semantics
+# --------------------------------------------------------------------------------------------------
+class _GOTMulti(torch.autograd.Function):
+    """S GOT problems (one per stain) in ONE autograd node with global-batch thresholds.
+
+    forward : local extrema of every problem -> one all-gather [S,6] -> min/max over ranks -> forwards
+    backward: reverse sweeps of every problem -> one all-reduce of the extrema gradients [S,6] -> finish
+    Ranks that own no case of a stain pass an empty (k = 0) problem: they still take part in both collectives.
+    With world size 1 this is S independent reference-semantics GOT calls."""
+
+    @staticmethod
+    def forward(ctx, impl, group, *tensors):
+        S = len(tensors) // 2
+        probs = [(tensors[2 * s].contiguous(), tensors[2 * s + 1].contiguous()) for s in range(S)]
+        dev = tensors[0].device
+        inf = float("inf")
+        ext = torch.stack([impl.extrema(V, Q) if V.shape[0] > 0 else
+                           torch.tensor([inf, -inf] * 3, device=dev, dtype=tensors[0].dtype) for V, Q in probs])
+        W = world_size(group)
+        if W > 1:
+            allx = ext.new_empty((W * ext.shape[0], 6))
+            dist.all_gather_into_tensor(allx, ext.contiguous(), group=group)
+            allx = allx.view(W, ext.shape[0], 6)
+            even = (torch.arange(6, device=dev) % 2 == 0)
+            ext = torch.where(even, allx.amin(dim=0), allx.amax(dim=0))
+        outs, states = [], []
+        for s, (V, Q) in enumerate(probs):
+            if V.shape[0] == 0:
+                outs.append(torch.zeros(2, device=dev, dtype=tensors[0].dtype))
+                states.append(None)
+            else:
+                o, st = impl.forward(V, Q, ext[s])
+                outs.append(o)
+                states.append(st)
+        ctx.impl, ctx.group, ctx.states = impl, group, states
+        ctx.shapes = [(V.shape, Q.shape) for V, Q in probs]
+        return torch.stack(outs)
+
+    @staticmethod
+    def backward(ctx, d_outs):
+        impl, states = ctx.impl, ctx.states
+        dev = d_outs.device
+        dmm = torch.stack([impl.backward_begin(st, d_outs[s]) if st is not None else
+                           torch.zeros(6, device=dev, dtype=d_outs.dtype) for s, st in enumerate(states)])
+        if world_size(ctx.group) > 1:
+            dist.all_reduce(dmm, group=ctx.group)
+        grads = []
+        for s, st in enumerate(states):
+            if st is None:
+                grads += [d_outs.new_zeros(ctx.shapes[s][0]), d_outs.new_zeros(ctx.shapes[s][1])]
+            else:
+                grads += list(impl.backward_finish(st, dmm[s]))
+        return (None, None) + tuple(grads)
+
+
+def got_multi(problems, impl=None, group=None) -> torch.Tensor:
+    """problems: list of (V, Q) token tensors [k_s, n_s, d] (already sub-sampled) -> [S, 2] = (WD sum, GWD sum)."""
+    if impl is None:
+        from .functional import HipGotImpl as impl  # noqa: N813
+    flat = []
+    for V, Q in problems:
+        flat += [V, Q]
+    return _GOTMulti.apply(impl, group, *flat)
+
+
+_STEP = [0]
+
+
+def calculate_losses_dp(STAINS, loss_fn_interMod, got_impl, wsi_embs, token_embs, modality_labels_withoutHE, args,
+                        labels_global_withoutHE=None, group=None, subsample=256, shared_seed=0, use_local_loss=True):
+    """Data-parallel counterpart of calculate_losses (trainer.py:20-77) with the reference's global-batch semantics.
+
+    wsi_embs / token_embs / modality_labels_withoutHE are this rank's shard.  Returns (loss, flag) where `loss`
+    is the tensor to call .backward() on under DDP (gradient mean over ranks): the replicated global InfoNCE
+    plus W x (this rank's GOT sum); averaged over ranks its gradient equals the single-process global-batch
+    gradient of  sum_stains [InfoNCE + w * GOT]  (SURVEY.md section 8(e))."""
+    from .trainer import calculate_losses
+    W = world_size(group)
+    dev = wsi_embs["HE"].device
+    labels_l = modality_labels_withoutHE.detach().cpu()
+    labels_g = labels_global_withoutHE if labels_global_withoutHE is not None else all_gather_labels(labels_l, dev, group)
+    mods = ["HE"] + list(STAINS)
+    embs_g = gather_slide_embeddings(wsi_embs, mods, group)
+    loss_g, flag = calculate_losses(STAINS, loss_fn_interMod, None, None, embs_g, None, labels_g, args)
+    if not flag or not use_local_loss or got_impl is None:
+        return loss_g, flag
+    _STEP[0] += 1
+    problems = []
+    for s_idx, stain in enumerate(STAINS):
+        k_g = int(labels_g[:, s_idx].bool().sum().item())
+        if k_g <= 1:
+            continue
+        # reference: randperm(k_global)[:subsample] (loss.py:282) = the first min(k_g, subsample) tokens, any order
+        if k_g <= subsample:
+            tok_idx = torch.arange(k_g)
+        else:
+            gen = torch.Generator().manual_seed(int(shared_seed) * 1000003 + _STEP[0] * 131 + s_idx)
+            tok_idx = torch.randperm(k_g, generator=gen)[:subsample]
+        tok_idx = tok_idx.to(dev)
+        rows = labels_l[:, s_idx].bool().nonzero(as_tuple=True)[0].to(dev)
+        he = token_embs["HE"][:, :, :, s_idx].index_select(0, rows).index_select(1, tok_idx)
+        st = token_embs[stain].index_select(0, rows).index_select(1, tok_idx)
+        problems.append((he if he.dtype == torch.float64 else he.float(), st if st.dtype == torch.float64 else st.float()))
+    if not problems:
+        return loss_g, flag
+    outs = got_multi(problems, got_impl, group)                    # [S,2]
+    local = (outs[:, 1] + outs[:, 0]).sum() * args.local_loss_weight
+    loss = (loss_g if torch.is_tensor(loss_g) else 0.0) + float(W) * local
+    return loss, flag

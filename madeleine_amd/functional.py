@@ -356,6 +356,65 @@ class GOTFn(torch.autograd.Function):
         return dV, dQ, None, None
 
 
+def got_extrema(V, Q):
+    """Extrema [6] (cross min,max | intra-V min,max | intra-Q min,max) of this batch's raw GOT cost tensors."""
+    _require(V, "v_")
+    _require(Q, "q_")
+    lib = _native.lib()
+    k, n, d = V.shape
+    ws = _ws(lib.mdl_got_ws_bytes(k, n, d), V.device)
+    mm = torch.empty(6, device=V.device, dtype=torch.float32)
+    rc = lib.mdl_got_extrema(_ptr(V), _ptr(Q), _ptr(mm), k, n, d, _ptr(ws), _stream())
+    _native.check(rc, "mdl_got_extrema")
+    return mm
+
+
 def got(V, Q, minmax_in=None, reduce_dminmax=None, return_extrema=False):
     out, mm = GOTFn.apply(V, Q, minmax_in, reduce_dminmax)
     return (out, mm) if return_extrema else out
+
+
+class HipGotImpl:
+    """The four stages of GOT on the C ABI, as used by the multi-problem / data-parallel autograd node
+    (madeleine_amd.distributed.got_multi).  A CPU implementation with the same interface exists only in tests/."""
+
+    @staticmethod
+    def extrema(V, Q):
+        return got_extrema(V, Q)
+
+    @staticmethod
+    def forward(V, Q, minmax):
+        lib = _native.lib()
+        k, n, d = V.shape
+        nbytes = lib.mdl_got_ws_bytes(k, n, d)
+        if nbytes == -3:
+            raise NotImplementedError("madeleine_amd.GOT supports n <= 256 tokens per bag and d <= 128 (got n=%d, d=%d)" % (n, d))
+        ws = _ws(nbytes, V.device)
+        out = torch.empty(2, device=V.device, dtype=torch.float32)
+        mm = minmax.contiguous()
+        with _timed("got_fwd"):
+            rc = lib.mdl_got_fwd(_ptr(V), _ptr(Q), _ptr(out), None, _ptr(mm), k, n, d, _ptr(ws), _stream())
+        _native.check(rc, "mdl_got_fwd")
+        return out, (V, Q, ws)
+
+    @staticmethod
+    def backward_begin(state, d_out):
+        V, Q, ws = state
+        lib = _native.lib()
+        k, n, d = V.shape
+        dmm = torch.empty(6, device=V.device, dtype=torch.float32)
+        with _timed("got_bwd"):
+            rc = lib.mdl_got_bwd_begin(_ptr(d_out.contiguous()), _ptr(dmm), k, n, d, _ptr(ws), _stream())
+        _native.check(rc, "mdl_got_bwd_begin")
+        return dmm
+
+    @staticmethod
+    def backward_finish(state, dmm_total):
+        V, Q, ws = state
+        lib = _native.lib()
+        k, n, d = V.shape
+        dV, dQ = torch.empty_like(V), torch.empty_like(Q)
+        rc = lib.mdl_got_bwd_finish(_ptr(V), _ptr(Q), _ptr(dV), _ptr(dQ), _ptr(dmm_total.contiguous()), k, n, d, _ptr(ws),
+                                    _stream())
+        _native.check(rc, "mdl_got_bwd_finish")
+        return dV, dQ

@@ -291,6 +291,41 @@ def got(v_: torch.Tensor, q_: torch.Tensor, subsample: Optional[int] = None,
 
 
 # --------------------------------------------------------------------------------------
+# GOT with externally supplied threshold extrema (the data-parallel decomposition).
+# Not a reference function: with extrema=None it IS got() above (asserted in tests/test_oracle_golden.py);
+# with the global-batch extrema, per-rank sums add up to the reference's global-batch value.
+# --------------------------------------------------------------------------------------
+def got_raw_costs(v: torch.Tensor, q: torch.Tensor):
+    vn, qn = _unit_tokens(v), _unit_tokens(q)
+    return (1.0 - torch.bmm(vn, qn.transpose(1, 2)), 1.0 - torch.bmm(vn, vn.transpose(1, 2)),
+            1.0 - torch.bmm(qn, qn.transpose(1, 2)))
+
+
+def got_extrema(v: torch.Tensor, q: torch.Tensor) -> torch.Tensor:
+    c0, cs0, ct0 = got_raw_costs(v, q)
+    return torch.stack([c0.min(), c0.max(), cs0.min(), cs0.max(), ct0.min(), ct0.max()])
+
+
+def got_parts(v: torch.Tensor, q: torch.Tensor, extrema: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """-> tensor [2] = (sum_b WD_b, sum_b GWD_b); thresholds from `extrema` [6] if given, else batch-local."""
+    c0, cs0, ct0 = got_raw_costs(v, q)
+    ex = got_extrema(v, q) if extrema is None else extrema
+    thr = lambda m: ex[2 * m] + 0.1 * (ex[2 * m + 1] - ex[2 * m])  # noqa: E731
+    c = torch.relu(c0 - thr(0))
+    wd = _trace_ct(c, ipot(c, beta=0.5, iteration=30)).sum()
+    cs, ct = torch.relu(cs0 - thr(1)).transpose(1, 2), torch.relu(ct0 - thr(2)).transpose(1, 2)
+    k, n, m = cs.shape[0], cs.shape[2], ct.shape[2]
+    p = torch.full((k, n, 1), 1.0 / n, dtype=v.dtype)
+    qq = torch.full((k, m, 1), 1.0 / m, dtype=v.dtype)
+    cst = torch.bmm(cs ** 2, p) + torch.bmm(qq.transpose(1, 2), (ct ** 2).transpose(1, 2))
+    gamma = torch.bmm(p, qq.transpose(1, 2))
+    for _ in range(5):
+        gamma = ipot(cst - 2.0 * torch.bmm(torch.bmm(cs, gamma), ct.transpose(1, 2)), beta=0.1, iteration=20)
+    c_gamma = cst - 2.0 * torch.bmm(torch.bmm(cs, gamma), ct.transpose(1, 2))
+    return torch.stack([wd, _trace_ct(c_gamma, gamma.detach()).sum()])
+
+
+# --------------------------------------------------------------------------------------
 # H1: calculate_losses   (trainer.py:20-77)
 # --------------------------------------------------------------------------------------
 def calculate_losses(stains, loss_global, loss_local, loss_intra, wsi_embs, token_embs,

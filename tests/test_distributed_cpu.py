@@ -1,0 +1,144 @@
+"""World-size-2 gloo test (CPU) of the data-parallel decomposition in madeleine_amd/distributed.py:
+W-rank sharded loss / parameter gradients == single-process global-batch loss / gradients, which is the
+semantics nn.DataParallel gives the reference.  The numeric kernels are replaced by the
+CPU oracle through the same interfaces (loss callable, GOT impl), so only the host/collective logic is under test."""
+import os
+import socket
+from types import SimpleNamespace
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import restatement as R
+from tests._util import MODS5, recipe_params, t
+
+
+class OracleGotImpl:
+    """CPU stand-in for madeleine_amd.functional.HipGotImpl (same four-stage contract), built on the oracle."""
+
+    @staticmethod
+    def extrema(V, Q):
+        with torch.no_grad():
+            return R.got_extrema(V, Q)
+
+    @staticmethod
+    def forward(V, Q, minmax):
+        v, q, mm = V.detach().requires_grad_(), Q.detach().requires_grad_(), minmax.detach().requires_grad_()
+        with torch.enable_grad():
+            out = R.got_parts(v, q, mm)
+        return out.detach(), {"v": v, "q": q, "mm": mm, "out": out}
+
+    @staticmethod
+    def backward_begin(st, d_out):
+        gv, gq, gmm = torch.autograd.grad(st["out"], [st["v"], st["q"], st["mm"]], d_out)
+        st["gv"], st["gq"] = gv, gq
+        return gmm
+
+    @staticmethod
+    def backward_finish(st, dmm_total):
+        v, q = st["v"].detach().requires_grad_(), st["q"].detach().requires_grad_()
+        with torch.enable_grad():
+            e = R.got_extrema(v, q)
+        owned = (e.detach() == st["mm"].detach()).to(e.dtype)        # extrema attained on this rank
+        ev, eq = torch.autograd.grad(e, [v, q], dmm_total * owned)
+        return st["gv"] + ev, st["gq"] + eq
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+B, M, N, D = 6, 4, 14, 64
+LABELS = torch.tensor([[1, 1, 1, 0], [1, 1, 0, 1], [1, 0, 1, 1], [1, 1, 1, 1], [1, 1, 1, 0], [1, 0, 1, 1]], dtype=torch.float32)
+# HER2: k_global 4 (ranks 2/2); PGR: 5 (2/3); KI67: 4 (1/3)
+
+
+def _params64():
+    """fp64 leaves: the decomposition is exact in real arithmetic, so fp64 pins the LOGIC to ~1e-10 (in fp32 the
+    GW fixed point amplifies summation-order noise to ~1e-3 on some gradients, which would hide logic errors)."""
+    return {k: v.double().requires_grad_() for k, v in recipe_params(M, D, "wdp").items()}
+
+
+def _single_process(use_got):
+    mods = MODS5[:M]
+    sd = _params64()
+    feats = t((B, M, N, D), "dp:feats").double()
+    nce = lambda a, b, symmetric=False: R.info_nce(a, b, 0.001, symmetric)  # noqa: E731
+    embs, toks = R.madeleine_forward_train(feats, sd, mods)
+    # identity token permutation: the value does not depend on the randperm order
+    loc = (lambda a, b, subsample=None: R.got(a, b, subsample, perm=torch.arange(a.shape[0]))) if use_got else None
+    loss, flag = R.calculate_losses(mods[1:], nce, loc, None, embs, toks, LABELS[:, 1:], True, 0.7)
+    loss.backward()
+    return float(loss), {k: (v.grad.clone() if v.grad is not None else torch.zeros_like(v)) for k, v in sd.items()}
+
+
+def _worker(rank, world, port, use_got, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from madeleine_amd import distributed as DP
+        mods = MODS5[:M]
+        sd = _params64()
+        Bl = B // world
+        sl = slice(rank * Bl, (rank + 1) * Bl)
+        feats = t((B, M, N, D), "dp:feats").double()[sl]
+        nce = lambda query, positive_key, symmetric=False: R.info_nce(query, positive_key, 0.001, symmetric)  # noqa: E731
+        args = SimpleNamespace(global_loss="info-nce", symmetric_cl=True, local_loss_weight=0.7)
+        embs, toks = R.madeleine_forward_train(feats, sd, mods)
+        loss, flag = DP.calculate_losses_dp(mods[1:], nce, OracleGotImpl if use_got else None, embs, toks,
+                                            LABELS[sl, 1:], args, use_local_loss=use_got)
+        loss.backward()
+        # what DDP does: mean of the parameter gradients over ranks
+        grads = {}
+        for k, v in sd.items():
+            g = v.grad.clone() if v.grad is not None else torch.zeros_like(v)
+            dist.all_reduce(g)
+            grads[k] = g / world
+        # true loss value = replicated global part + sum over ranks of the local part (undo the W scaling)
+        with torch.no_grad():
+            embs_g = DP.gather_slide_embeddings({k: v.detach() for k, v in embs.items()}, mods)
+            labels_g = DP.all_gather_labels(LABELS[sl, 1:], torch.device("cpu"))
+            lg, _ = R.calculate_losses(mods[1:], lambda a, b, symmetric=False: R.info_nce(a, b, 0.001, symmetric), None, None,
+                                       embs_g, None, labels_g, True, 0.7)
+        local_part = (loss.detach() - lg) / world
+        dist.all_reduce(local_part)
+        if rank == 0:
+            ret["loss"] = float(lg + local_part)
+            ret["grads"] = {k: v.numpy() for k, v in grads.items()}
+            ret["flag"] = bool(flag)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("use_got", [False, True])
+def test_two_rank_gloo_equals_global_batch(use_got):
+    ref_loss, ref_grads = _single_process(use_got)
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, port, use_got, ret), nprocs=2, join=True)
+    assert ret["flag"]
+    assert abs(ret["loss"] - ref_loss) < 1e-9 * abs(ref_loss), (ret["loss"], ref_loss)
+    top = max(float(g.norm()) for g in ref_grads.values())
+    for k, g in ref_grads.items():
+        got = torch.from_numpy(ret["grads"][k])
+        err = float((got - g).norm())
+        assert err <= 1e-8 * float(g.norm()) + 1e-10 * top, (k, err, float(g.norm()))
+
+
+def test_got_parts_matches_got():
+    """the DP building block reduces to the pinned reference restatement when thresholds are batch-local"""
+    v = t((4, 9, 128), "dp:gv")
+    q = t((4, 9, 128), "dp:gq") + 0.6 * v
+    a = R.got(v, q)
+    b = R.got_parts(v, q).sum()
+    assert abs(float(a) - float(b)) < 1e-6 * abs(float(a))
+    # halves with the global extrema add up to the whole
+    ex = R.got_extrema(v, q)
+    c = R.got_parts(v[:2], q[:2], ex) + R.got_parts(v[2:], q[2:], ex)
+    assert abs(float(c.sum()) - float(a)) < 1e-5 * abs(float(a))
