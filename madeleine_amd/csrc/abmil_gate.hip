@@ -27,6 +27,20 @@ constexpr int LDA_S = GBM + 4;  // 132 floats: 16-B aligned rows, 2-way max on t
 constexpr int LDB_S = GBN + 4;  // 260
 constexpr int GATE_JT = HID / 128;  // 4 j-tiles of 128 gate columns per head
 
+// The global loads of chunk i+1 must be IN FLIGHT while chunk i's 64 MFMAs issue (4096 cycles per wave); left
+// alone, hipcc sinks them behind the MFMA block to save registers and every wave then eats the full HBM/L2
+// latency before its LDS stores (measured: 63 % of the fp32 MFMA peak).  sched_barrier(0) pins the order.
+#ifdef GATE_EXP_NOLOAD
+#define GATE_EXP_LOAD(x)
+#else
+#define GATE_EXP_LOAD(x) x
+#endif
+#ifndef GATE_NO_PIN
+#define GATE_PIN() __builtin_amdgcn_sched_barrier(0)
+#else
+#define GATE_PIN()
+#endif
+
 struct GateSmem {
     float A[2][GBK][LDA_S];
     float B[2][GBK][LDB_S];
@@ -34,18 +48,25 @@ struct GateSmem {
 
 struct DropCfg {
     float p, inv;
-    uint32_t thr;
-    uint64_t seed;
+    uint32_t thr;   // 16-bit threshold
+    uint32_t key;   // rng_key(seed)
     const uint8_t* ka;
     const uint8_t* kb;
     int on;
 };
 
-__device__ __forceinline__ bool drop_keep(const DropCfg& d, int which, int64_t idx) {
-    if (!d.on) return true;
-    const uint8_t* k = which ? d.kb : d.ka;
-    if (k) return k[idx] != 0;
-    return rng_u32(d.seed, (uint32_t)which, (uint64_t)idx) >= d.thr;
+// keep decisions of one gate element (tanh branch, sigmoid branch)
+__device__ __forceinline__ void drop_keep2(const DropCfg& d, int64_t idx, bool& ka, bool& kb) {
+    if (!d.on) {
+        ka = kb = true;
+    } else if (d.ka) {
+        ka = d.ka[idx] != 0;
+        kb = d.kb[idx] != 0;
+    } else {
+        const uint32_t h = rng_u32(d.key, (uint64_t)idx);
+        ka = (h & 0xFFFFu) >= d.thr;
+        kb = (h >> 16) >= d.thr;
+    }
 }
 
 // MFMA over one staged K-chunk.  colb[ct] = first column (within the 256-wide B tile) of this wave's ct-th
@@ -66,6 +87,49 @@ __device__ __forceinline__ void mma_chunk(const float (*__restrict__ As)[LDA_S],
             acc[0][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[ct], acc[0][ct], 0, 0, 0);
             acc[1][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[ct], acc[1][ct], 0, 0, 0);
         }
+    }
+}
+
+// One K-chunk with the NEXT chunk's staging folded into the MFMA stream.  An fp32 MFMA occupies the SIMD's matrix
+// pipe for 64 cycles but takes a few cycles to issue, so the ~200 non-MFMA instructions a chunk needs (fragment
+// ds_reads, the next chunk's global loads, its LDS stores and their address math) fit in the issue shadow of the
+// 64 MFMAs -- if they are interleaved with them instead of forming separate load / store phases during which the
+// matrix pipe idles (profiles/r01a: 66 % MFMA-busy with phases).  Fragments are double-buffered one k-step ahead;
+// global loads issue at k-step 0 and their LDS stores trail in k-steps 4..7 (>= 2048 cycles of latency cover).
+template <bool HAS_NEXT, class LoadF, class PieceF>
+__device__ __forceinline__ void mma_chunk_pipe(const float (*__restrict__ As)[LDA_S], const float (*__restrict__ Bs)[LDB_S],
+                                               f32x16 (&acc)[2][4], int wm, const int (&colb)[4], int lane,
+                                               LoadF&& issue_loads, PieceF&& store_piece) {
+    const int l32 = lane & 31, kh = lane >> 5;
+    float fa[2][2], fb[2][4];
+    auto read_frags = [&](int kk, int buf) {
+        const int k = kk * 2 + kh;
+        fa[buf][0] = As[k][wm * 64 + l32];
+        fa[buf][1] = As[k][wm * 64 + 32 + l32];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) fb[buf][ct] = Bs[k][colb[ct] + l32];
+    };
+    read_frags(0, 0);
+#pragma unroll
+    for (int kk = 0; kk < GBK / 2; ++kk) {
+        const int cur = kk & 1;
+        if (kk + 1 < GBK / 2) read_frags(kk + 1, cur ^ 1);
+        if (HAS_NEXT && kk == 0) issue_loads();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int rt = m & 1, ct = m >> 1;
+            acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][rt], fb[cur][ct], acc[rt][ct], 0, 0, 0);
+            if (HAS_NEXT) {
+                if (kk == 4 && m == 1) store_piece(0);
+                if (kk == 5 && m == 1) store_piece(1);
+                if (kk == 6 && m == 1) store_piece(2);
+                if (kk == 6 && m == 5) store_piece(3);
+                if (kk == 7 && m == 1) store_piece(4);
+                if (kk == 7 && m == 5) store_piece(5);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -91,6 +155,10 @@ __global__ __launch_bounds__(256, 2) void gate_fwd_kernel(const float* __restric
                                                           float* __restrict__ act_a, float* __restrict__ act_b,
                                                           int64_t T, int H, int n_ttiles, DropCfg drop) {
     __shared__ GateSmem sm;
+#ifdef GATE_OCC1
+    __shared__ float occ_pad[9000];  // experiment: > 80 KiB of LDS per workgroup => one workgroup per CU
+    if (T < 0) occ_pad[threadIdx.x] = 0.f, part[0] = occ_pad[(threadIdx.x * 7) % 9000];
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
     // logical tile id: jt fastest, then head, then token tile -> the 4*H workgroups that read the same
     // 128 token rows of E sit next to each other on one XCD (shared L2).
@@ -142,12 +210,35 @@ __global__ __launch_bounds__(256, 2) void gate_fwd_kernel(const float* __restric
     load_regs(0);
     store_lds(0);
     __syncthreads();
+#ifdef GATE_NO_PIPE
     for (int ch = 0; ch < NCH; ++ch) {
         if (ch + 1 < NCH) load_regs((ch + 1) * GBK);
+        GATE_PIN();
         mma_chunk(sm.A[ch & 1], sm.B[ch & 1], acc, wm, colb, lane);
+        GATE_PIN();
         if (ch + 1 < NCH) store_lds((ch + 1) & 1);
         __syncthreads();
     }
+#else
+    for (int ch = 0; ch < NCH - 1; ++ch) {
+        const int nst = (ch + 1) & 1;
+        mma_chunk_pipe<true>(
+            sm.A[ch & 1], sm.B[ch & 1], acc, wm, colb, lane, [&]() { GATE_EXP_LOAD(load_regs((ch + 1) * GBK)); },
+            [&](int piece) {  // pieces 0,1: the two A float4s; 2..5: the four B float4s (transposed scatter)
+                const int f = tid + (piece < 2 ? piece : piece - 2) * 256, row = f >> 2, kq = f & 3;
+                if (piece < 2) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) sm.A[nst][kq * 4 + i][row] = ra[piece][i];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) sm.B[nst][kq * 4 + i][row] = rb[piece - 2][i];
+                }
+            });
+        __syncthreads();
+    }
+    mma_chunk_pipe<false>(sm.A[(NCH - 1) & 1], sm.B[(NCH - 1) & 1], acc, wm, colb, lane, [&]() {}, [&](int) {});
+    __syncthreads();
+#endif
 
     // ---- epilogue: activations, dropout, wc-weighted row reduction ---------------------------------
     const int l32 = lane & 31;
@@ -165,16 +256,18 @@ __global__ __launch_bounds__(256, 2) void gate_fwd_kernel(const float* __restric
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int64_t t = t0 + wm * 64 + rt * 32 + acc_row(r, lane);
-                const float a = tanhf(acc[rt][ct][r] + bav);
-                const float b = 1.f / (1.f + expf(-(acc[rt][2 + ct][r] + bbv)));
+                const float a = fast_tanh(acc[rt][ct][r] + bav);
+                const float b = fast_sigmoid(acc[rt][2 + ct][r] + bbv);
                 if (t < T) {
                     const int64_t idx = (t * H + c) * HID + j;
                     if (act_a) {
                         act_a[idx] = a;
                         act_b[idx] = b;
                     }
-                    const float ad = drop_keep(drop, 0, idx) ? a * drop.inv : 0.f;
-                    const float bd = drop_keep(drop, 1, idx) ? b * drop.inv : 0.f;
+                    bool keep_a, keep_b;
+                    drop_keep2(drop, idx, keep_a, keep_b);
+                    const float ad = keep_a ? a * drop.inv : 0.f;
+                    const float bd = keep_b ? b * drop.inv : 0.f;
                     ps[rt][r] += ad * bd * wcv;
                 }
             }
@@ -218,8 +311,10 @@ __global__ void gate_finalize_kernel(const float* __restrict__ part, const float
 // ================================================================================================
 __device__ __forceinline__ void gate_dz(const DropCfg& d, float ds, float wcv, float a, float b, int64_t idx, float& dza,
                                         float& dzb, float& pab) {
-    const float ka = drop_keep(d, 0, idx) ? d.inv : 0.f;
-    const float kb = drop_keep(d, 1, idx) ? d.inv : 0.f;
+    bool keep_a, keep_b;
+    drop_keep2(d, idx, keep_a, keep_b);
+    const float ka = keep_a ? d.inv : 0.f;
+    const float kb = keep_b ? d.inv : 0.f;
     const float ad = a * ka, bd = b * kb;
     const float g = ds * wcv;
     dza = g * bd * ka * (1.f - a * a);
@@ -294,7 +389,9 @@ __global__ __launch_bounds__(256, 2) void gate_bwd_dx_kernel(const float* __rest
     __syncthreads();
     for (int ch = 0; ch < NCH; ++ch) {
         if (ch + 1 < NCH) load_regs((ch + 1) * 8);
+        GATE_PIN();
         mma_chunk(sm.A[ch & 1], sm.B[ch & 1], acc, wm, colb, lane);
+        GATE_PIN();
         if (ch + 1 < NCH) store_lds((ch + 1) & 1, (ch + 1) * 8);
         __syncthreads();
     }
@@ -415,7 +512,9 @@ __device__ __forceinline__ void gate_bwd_dw_body(const float* __restrict__ E, in
     __syncthreads();
     for (int64_t ch = 0; ch < nch; ++ch) {
         if (ch + 1 < nch) load_regs(ts + (ch + 1) * GBK);
+        GATE_PIN();
         mma_chunk(sm.A[ch & 1], sm.B[ch & 1], acc, wm, colb, lane);
+        GATE_PIN();
         if (ch + 1 < nch) store_lds((int)((ch + 1) & 1), ts + (ch + 1) * GBK);
         __syncthreads();
     }
@@ -505,9 +604,12 @@ __global__ void gate_reduce_v_kernel(const float* __restrict__ slabV, float* __r
     dst[c * HID + j] = v;
 }
 
-__global__ void gate_mask_kernel(uint8_t* __restrict__ keep, int64_t n, int which, uint64_t seed, uint32_t thr) {
+__global__ void gate_mask_kernel(uint8_t* __restrict__ keep, int64_t n, int which, uint32_t key, uint32_t thr) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) keep[i] = rng_u32(seed, (uint32_t)which, (uint64_t)i) >= thr ? 1 : 0;
+    if (i < n) {
+        const uint32_t h = rng_u32(key, (uint64_t)i);
+        keep[i] = ((which ? (h >> 16) : (h & 0xFFFFu)) >= thr) ? 1 : 0;
+    }
 }
 
 static inline DropCfg make_drop(float p, uint64_t seed, const uint8_t* ka, const uint8_t* kb) {
@@ -516,7 +618,7 @@ static inline DropCfg make_drop(float p, uint64_t seed, const uint8_t* ka, const
     d.p = p;
     d.inv = d.on ? 1.f / (1.f - p) : 1.f;
     d.thr = drop_threshold(p);
-    d.seed = seed;
+    d.key = (uint32_t)(seed * 0x9E3779B97F4A7C15ULL >> 32) ^ (uint32_t)seed;
     d.ka = ka;
     d.kb = kb;
     return d;
@@ -621,7 +723,7 @@ extern "C" int mdl_abmil_gate_dropout_mask(uint8_t* keep, int64_t T, int H, int 
     const int64_t n = T * H * HID;
     if (n == 0) return MDL_OK;
     hipLaunchKernelGGL(gate_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, keep, n, which,
-                       seed, drop_threshold(p_drop));
+                       make_drop(p_drop, seed, nullptr, nullptr).key, drop_threshold(p_drop));
     MDL_LAUNCH_CHECK();
     return MDL_OK;
 }

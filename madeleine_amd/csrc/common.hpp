@@ -46,18 +46,24 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     x ^= x >> 16;
     return x;
 }
-__device__ __forceinline__ uint32_t rng_u32(uint64_t seed, uint32_t stream, uint64_t idx) {
-    uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
-    uint32_t k = mix32((uint32_t)seed ^ (stream * 0x9E3779B9U)) ^ mix32((uint32_t)(seed >> 32) + hi * 0x85EBCA6BU + 0x165667B1U);
-    return mix32(lo ^ k) ^ mix32(lo * 0xC2B2AE35U + k);
+// 32 random bits for element idx: one lowbias32 round over the low word keyed by (seed, high word).  The two
+// 16-bit halves drive the two Bernoulli draws (tanh branch / sigmoid branch) of a gate element.  key = host-side mix of the seed.
+__device__ __forceinline__ uint32_t rng_u32(uint32_t key, uint64_t idx) {
+    const uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
+    return mix32(lo ^ key ^ (hi * 0x9E3779B9U));
 }
-// threshold = floor(p * 2^32); keep iff u32 >= threshold  => P(keep) = 1 - p
+// threshold = round(p * 2^16); keep iff u16 >= threshold  => P(keep) = 1 - thr/65536 (exact for p = 0.25)
 __host__ __device__ __forceinline__ uint32_t drop_threshold(float p) {
-    double t = (double)p * 4294967296.0;
+    double t = (double)p * 65536.0 + 0.5;
     if (t < 0) t = 0;
-    if (t > 4294967295.0) t = 4294967295.0;
+    if (t > 65535.0) t = 65535.0;
     return (uint32_t)t;
 }
+
+// activations of the gate epilogue: v_exp_f32 / v_rcp_f32 based, absolute error ~2e-7 (the libm forms cost ~5x the
+// instructions and the epilogue is VALU-bound beside the MFMA stream)
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)); }
 
 // XCD-aware remap (8 XCDs; block b runs on XCD b % 8): returns a logical id such that logical ids
 // [x*per, (x+1)*per) all run on XCD x, i.e. consecutive logical tiles share one L2.  Bijective for
