@@ -112,6 +112,24 @@ int mdl_abmil_pool_bwd(const float* E, int64_t ldE, const float* scores, const f
                        const int64_t* cu_seqlens, int64_t max_len, int H, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * N1 -- fused LayerNorm -> GELU(erf) -> Dropout of the pre-attention MLP.  Replaces the
+ * nn.LayerNorm / nn.GELU / nn.Dropout(0.1) triple that follows each Linear (madeleine/models/Model.py:352-354,
+ * :356-358, :360-362) and its autograd, in one HBM pass each way.
+ * x, y, dy, dx [rows, W] contiguous; W in {256, 512, 2048}; gamma, beta [W]; mean, rstd [rows] (saved for
+ * backward); LayerNorm: biased variance, rstd = 1/sqrt(var + eps).  Dropout as in the gate kernels: keep (uint8
+ * [rows,W]) injects a mask, else a counter hash of (seed, element index) -- regenerated in backward.
+ * dgamma, dbeta [W] are overwritten.  ws: mdl_ln_gelu_drop_bwd_ws_bytes(rows, W).
+ */
+int mdl_ln_gelu_drop_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean,
+                         float* rstd, int64_t rows, int W, float eps, float p_drop, uint64_t seed,
+                         const uint8_t* keep, void* stream);
+int64_t mdl_ln_gelu_drop_bwd_ws_bytes(int64_t rows, int W);
+int mdl_ln_gelu_drop_bwd(const float* x, const float* gamma, const float* beta, const float* mean,
+                         const float* rstd, const float* dy, float* dx, float* dgamma, float* dbeta,
+                         int64_t rows, int W, float p_drop, uint64_t seed, const uint8_t* keep, void* ws,
+                         void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * L1 -- InfoNCE with in-batch negatives.  Replaces InfoNCE.info_nce, negative_keys=None branch
  * (madeleine/utils/loss.py:92,111-127) for S independent problems in one launch (the reference
  * calls it once per stain from trainer.py:33).

@@ -1,0 +1,298 @@
+// preattn_act.hip -- fused LayerNorm -> GELU(erf) -> Dropout, forward and backward.
+//
+// Replaces the three elementwise modules that follow every Linear of the reference's pre-attention MLP
+//     nn.LayerNorm(W) -> nn.GELU() -> nn.Dropout(0.1)           (reference madeleine/models/Model.py:352-354,
+//                                                                  :356-358, :360-362;  W = 512, 512, 2048)
+// and their autograd.  In torch these are 3 forward + 5 backward kernels moving ~140 B per element; fused they
+// move 8 B (fwd: read x, write y) and 12 B (bwd: read x, dy, write dx) per element -- the op is purely HBM-bound.
+// LayerNorm semantics: biased variance, eps inside the sqrt (torch default 1e-5), affine.  GELU: exact erf form.
+// Dropout: inverted scaling 1/(1-p); mask = explicit uint8 [rows,W] if given, else a counter hash of
+// (seed, row*W + col) regenerated in backward (nothing stored).
+//
+// One wave per row: lane L owns columns {4L + 256 i .. +3}, i < W/256 (W = 512 -> 2 float4, 2048 -> 8 float4), so
+// a row is W/256 coalesced 1 KiB loads, the mean/variance are two 64-lane reductions, and in backward the per-
+// column sums for d(gamma), d(beta) accumulate in registers across the rows a wave walks.
+#include "common.hpp"
+
+namespace mdl {
+
+constexpr int ACT_BLOCK = 256;  // 4 waves
+
+__device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float v) {
+    const float cdf = 0.5f * (1.f + erff(v * 0.70710678118654752f));
+    const float pdf = 0.3989422804014327f * __expf(-0.5f * v * v);
+    return cdf + v * pdf;
+}
+
+struct ActDrop {
+    float inv;
+    uint32_t thr, key;
+    const uint8_t* keep;
+    int on;
+};
+__device__ __forceinline__ bool act_keep(const ActDrop& d, int64_t idx) {
+    if (!d.on) return true;
+    if (d.keep) return d.keep[idx] != 0;
+    return (rng_u32(d.key, (uint64_t)idx) & 0xFFFFu) >= d.thr;
+}
+
+// Geometry: a 256-thread block = 4 waves.  WPR waves share one row (each owns a 256*NV-column segment), so a block
+// works on 4/WPR rows at a time: W = 512 -> NV 2, WPR 1 (one wave per row); W = 2048 -> NV 2, WPR 4 (one block per
+// row; keeps the backward at ~110 VGPRs = 4 waves/SIMD instead of 256+ = 1 wave/SIMD with a whole row per wave).
+template <int WPR>
+__device__ __forceinline__ void row_allreduce2(float& a, float& b, float (*red)[4][2], int slot_wave0, int wv) {
+    a = wave_sum(a);
+    b = wave_sum(b);
+    if (WPR > 1) {
+        if ((threadIdx.x & 63) == 0) {
+            red[0][wv][0] = a;
+            red[0][wv][1] = b;
+        }
+        __syncthreads();
+        float x = 0.f, y = 0.f;
+#pragma unroll
+        for (int w = 0; w < WPR; ++w) {
+            x += red[0][slot_wave0 + w][0];
+            y += red[0][slot_wave0 + w][1];
+        }
+        a = x;
+        b = y;
+        __syncthreads();
+    }
+}
+
+template <int NV, int WPR>
+__global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_fwd_kernel(const float* __restrict__ x,
+                                                                     const float* __restrict__ gamma,
+                                                                     const float* __restrict__ beta,
+                                                                     float* __restrict__ y, float* __restrict__ mean_o,
+                                                                     float* __restrict__ rstd_o, int64_t rows, float eps,
+                                                                     ActDrop drop) {
+    constexpr int W = NV * 256 * WPR, RPB = 4 / WPR;
+    __shared__ float red[1][4][2];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, slot = wv / WPR, seg = wv % WPR;
+    const int col0 = seg * NV * 256 + lane * 4;
+    f32x4 g[NV], b[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        g[i] = *reinterpret_cast<const f32x4*>(gamma + col0 + i * 256);
+        b[i] = *reinterpret_cast<const f32x4*>(beta + col0 + i * 256);
+    }
+    for (int64_t base = (int64_t)blockIdx.x * RPB; base < rows; base += (int64_t)gridDim.x * RPB) {
+        const int64_t r = base + slot;
+        const bool live = r < rows;
+        const float* __restrict__ xr = x + (live ? r : 0) * W + col0;
+        f32x4 v[NV];
+        float s = 0.f, dummy = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            v[i] = live ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xr + i * 256)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+        row_allreduce2<WPR>(s, dummy, red, slot * WPR, wv);
+        const float mean = s * (1.f / W);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const f32x4 c = v[i] - mean;
+            q += (c.x * c.x + c.y * c.y) + (c.z * c.z + c.w * c.w);
+        }
+        row_allreduce2<WPR>(q, dummy, red, slot * WPR, wv);
+        const float rstd = rsqrtf(q * (1.f / W) + eps);
+        if (live) {
+            float* __restrict__ yr = y + r * W + col0;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t = (v[i][e] - mean) * rstd * g[i][e] + b[i][e];
+                    const float a = gelu_f(t);
+                    o[e] = act_keep(drop, r * W + col0 + i * 256 + e) ? a * drop.inv : 0.f;
+                }
+                *reinterpret_cast<f32x4*>(yr + i * 256) = o;
+            }
+            if (lane == 0 && seg == 0) {
+                mean_o[r] = mean;
+                rstd_o[r] = rstd;
+            }
+        }
+    }
+}
+
+template <int NV, int WPR>
+__global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_bwd_kernel(const float* __restrict__ x,
+                                                                     const float* __restrict__ gamma,
+                                                                     const float* __restrict__ beta,
+                                                                     const float* __restrict__ mean_i,
+                                                                     const float* __restrict__ rstd_i,
+                                                                     const float* __restrict__ dy, float* __restrict__ dx,
+                                                                     float* __restrict__ part, int64_t rows, ActDrop drop) {
+    constexpr int W = NV * 256 * WPR, RPB = 4 / WPR;
+    __shared__ float red[1][4][2];
+    __shared__ float csum[WPR == 1 ? 2 * W : 1];  // WPR == 1: the 4 waves own the same columns -> merged through LDS
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, slot = wv / WPR, seg = wv % WPR;
+    const int col0 = seg * NV * 256 + lane * 4;
+    f32x4 g[NV], b[NV], sg[NV], sb[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        g[i] = *reinterpret_cast<const f32x4*>(gamma + col0 + i * 256);
+        b[i] = *reinterpret_cast<const f32x4*>(beta + col0 + i * 256);
+        sg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        sb[i] = sg[i];
+    }
+    for (int64_t base = (int64_t)blockIdx.x * RPB; base < rows; base += (int64_t)gridDim.x * RPB) {
+        const int64_t r = base + slot;
+        const bool live = r < rows;
+        const float mean = live ? mean_i[r] : 0.f, rstd = live ? rstd_i[r] : 0.f;
+        const float* __restrict__ xr = x + (live ? r : 0) * W + col0;
+        const float* __restrict__ gr = dy + (live ? r : 0) * W + col0;
+        f32x4 xh[NV], dxh[NV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            f32x4 xv = {0.f, 0.f, 0.f, 0.f}, gv = xv;
+            if (live) {
+                xv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xr + i * 256));
+                gv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(gr + i * 256));
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float h = (xv[e] - mean) * rstd;
+                const float t = h * g[i][e] + b[i][e];
+                const float k = (live && act_keep(drop, r * W + col0 + i * 256 + e)) ? drop.inv : 0.f;
+                const float dt = gv[e] * k * gelu_grad_f(t);  // d/d(LN output)
+                sg[i][e] += dt * h;
+                sb[i][e] += dt;
+                const float dh = dt * g[i][e];
+                xh[i][e] = h;
+                dxh[i][e] = dh;
+                s1 += dh;
+                s2 += dh * h;
+            }
+        }
+        row_allreduce2<WPR>(s1, s2, red, slot * WPR, wv);
+        const float m1 = s1 * (1.f / W), m2 = s2 * (1.f / W);
+        if (live) {
+            float* __restrict__ o = dx + r * W + col0;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = rstd * (dxh[i][e] - m1 - xh[i][e] * m2);
+                *reinterpret_cast<f32x4*>(o + i * 256) = v;
+            }
+        }
+    }
+    float* __restrict__ prow = part + (int64_t)blockIdx.x * 2 * W;  // [block][dgamma W | dbeta W]
+    if (WPR == 4) {  // every wave owns its own column segment
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            *reinterpret_cast<f32x4*>(prow + col0 + i * 256) = sg[i];
+            *reinterpret_cast<f32x4*>(prow + W + col0 + i * 256) = sb[i];
+        }
+    } else {  // waves (= rows) add into one LDS row in wave order (deterministic)
+#pragma unroll
+        for (int w = 0; w < ACT_BLOCK / 64; ++w) {
+            if (wv == w) {
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    f32x4* pg = reinterpret_cast<f32x4*>(&csum[col0 + i * 256]);
+                    f32x4* pb = reinterpret_cast<f32x4*>(&csum[W + col0 + i * 256]);
+                    if (w == 0) {
+                        *pg = sg[i];
+                        *pb = sb[i];
+                    } else {
+                        *pg += sg[i];
+                        *pb += sb[i];
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        for (int c = threadIdx.x; c < 2 * W; c += ACT_BLOCK) prow[c] = csum[c];
+    }
+}
+
+__global__ void ln_reduce_kernel(const float* __restrict__ part, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                 int nblocks, int W) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= 2 * W) return;
+    float v = 0.f;
+    for (int k = 0; k < nblocks; ++k) v += part[(int64_t)k * 2 * W + c];
+    (c < W ? dgamma : dbeta)[c < W ? c : c - W] = v;
+}
+
+static inline ActDrop make_act_drop(float p, uint64_t seed, const uint8_t* keep) {
+    ActDrop d;
+    d.on = p > 0.f ? 1 : 0;
+    d.inv = d.on ? 1.f / (1.f - p) : 1.f;
+    d.thr = drop_threshold(p);
+    d.key = (uint32_t)(seed * 0x9E3779B97F4A7C15ULL >> 32) ^ (uint32_t)seed;
+    d.keep = keep;
+    return d;
+}
+static inline int act_rpb(int W) { return W >= 2048 ? 1 : 4; }  // rows per block iteration
+static inline int act_blocks(int64_t rows, int W) {
+    int64_t b = (rows + act_rpb(W) - 1) / act_rpb(W);
+    if (b > 2048) b = 2048;  // 256 CUs x 8 blocks; grid-stride over the rest
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace mdl
+
+using namespace mdl;
+
+extern "C" int64_t mdl_ln_gelu_drop_bwd_ws_bytes(int64_t rows, int W) {
+    if (rows < 0) return MDL_E_ARG;
+    if (W != 256 && W != 512 && W != 2048) return MDL_E_UNSUPPORTED;
+    return (int64_t)act_blocks(rows, W) * 2 * W * 4 + 64;
+}
+
+#define MDL_DISPATCH_W(W, ...)                                                       \
+    switch (W) {                                                                     \
+        case 256: { constexpr int NV = 1, WPR = 1; __VA_ARGS__; } break;             \
+        case 512: { constexpr int NV = 2, WPR = 1; __VA_ARGS__; } break;             \
+        case 2048: { constexpr int NV = 2, WPR = 4; __VA_ARGS__; } break;            \
+        default: return MDL_E_UNSUPPORTED;                                           \
+    }
+
+extern "C" int mdl_ln_gelu_drop_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean,
+                                    float* rstd, int64_t rows, int W, float eps, float p_drop, uint64_t seed,
+                                    const uint8_t* keep, void* stream) {
+    if (!x || !gamma || !beta || !y || !mean || !rstd || rows < 0) return MDL_E_ARG;
+    if (!(p_drop >= 0.f && p_drop < 1.f) || !(eps > 0.f)) return MDL_E_ARG;
+    if (!host_aligned16(x) || !host_aligned16(y) || !host_aligned16(gamma) || !host_aligned16(beta)) return MDL_E_ALIGN;
+    if (rows == 0) return MDL_OK;
+    const ActDrop d = make_act_drop(p_drop, seed, keep);
+    MDL_DISPATCH_W(W, {
+        hipLaunchKernelGGL((ln_gelu_drop_fwd_kernel<NV, WPR>), dim3(act_blocks(rows, W)), dim3(ACT_BLOCK), 0, (hipStream_t)stream, x,
+                           gamma, beta, y, mean, rstd, rows, eps, d);
+        MDL_LAUNCH_CHECK();
+    });
+    return MDL_OK;
+}
+
+extern "C" int mdl_ln_gelu_drop_bwd(const float* x, const float* gamma, const float* beta, const float* mean,
+                                    const float* rstd, const float* dy, float* dx, float* dgamma, float* dbeta, int64_t rows,
+                                    int W, float p_drop, uint64_t seed, const uint8_t* keep, void* ws, void* stream) {
+    if (!x || !gamma || !beta || !mean || !rstd || !dy || !dx || !dgamma || !dbeta || !ws || rows < 0) return MDL_E_ARG;
+    if (!(p_drop >= 0.f && p_drop < 1.f)) return MDL_E_ARG;
+    if (!host_aligned16(x) || !host_aligned16(dy) || !host_aligned16(dx) || !host_aligned16(gamma) || !host_aligned16(beta))
+        return MDL_E_ALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    const ActDrop d = make_act_drop(p_drop, seed, keep);
+    const int nb = rows > 0 ? act_blocks(rows, W) : 0;
+    MDL_DISPATCH_W(W, {
+        if (nb > 0) {
+            hipLaunchKernelGGL((ln_gelu_drop_bwd_kernel<NV, WPR>), dim3(nb), dim3(ACT_BLOCK), 0, s, x, gamma, beta, mean, rstd, dy, dx,
+                               (float*)ws, rows, d);
+            MDL_LAUNCH_CHECK();
+        }
+    });
+    hipLaunchKernelGGL(ln_reduce_kernel, dim3((2 * W + 255) / 256), dim3(256), 0, s, (const float*)ws, dgamma, dbeta, nb, W);
+    MDL_LAUNCH_CHECK();
+    return MDL_OK;
+}

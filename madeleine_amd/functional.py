@@ -265,6 +265,55 @@ def softmax_pool(E, scores, cu_seqlens=None, max_len=None):
 
 
 # --------------------------------------------------------------------------------------------------
+# N1: fused LayerNorm -> GELU -> Dropout (pre-attention MLP)
+# --------------------------------------------------------------------------------------------------
+class LNGeluDropFn(torch.autograd.Function):
+    """y = Dropout_p(GELU(LayerNorm(x; gamma, beta, eps)))  over the last axis (Model.py:352-354)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, p_drop, seed, keep):
+        _require(x, "x")
+        _require(gamma, "gamma")
+        _require(beta, "beta")
+        lib = _native.lib()
+        W = x.shape[-1]
+        rows = x.numel() // W
+        y = torch.empty_like(x)
+        mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        with _timed("ln_gelu_drop_fwd"):
+            rc = lib.mdl_ln_gelu_drop_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd), rows, W,
+                                          float(eps), float(p_drop), int(seed), _ptr(keep), _stream())
+        if rc == -3:
+            raise NotImplementedError("fused LayerNorm-GELU-Dropout supports widths 256/512/2048 (got %d)" % W)
+        _native.check(rc, "mdl_ln_gelu_drop_fwd")
+        ctx.save_for_backward(x, gamma, beta, mean, rstd)
+        ctx.cfg = (float(p_drop), int(seed), keep)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, mean, rstd = ctx.saved_tensors
+        p_drop, seed, keep = ctx.cfg
+        lib = _native.lib()
+        W = x.shape[-1]
+        rows = x.numel() // W
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dg, db = torch.empty_like(gamma), torch.empty_like(beta)
+        ws = _ws(lib.mdl_ln_gelu_drop_bwd_ws_bytes(rows, W), x.device)
+        with _timed("ln_gelu_drop_bwd"):
+            rc = lib.mdl_ln_gelu_drop_bwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(dy), _ptr(dx), _ptr(dg),
+                                          _ptr(db), rows, W, p_drop, seed, _ptr(keep), _ptr(ws), _stream())
+        _native.check(rc, "mdl_ln_gelu_drop_bwd")
+        return dx, dg, db, None, None, None, None
+
+
+def ln_gelu_drop(x, gamma, beta, eps=1e-5, p_drop=0.0, seed=0, keep=None):
+    return LNGeluDropFn.apply(x.contiguous(), gamma.contiguous(), beta.contiguous(), eps, p_drop, seed, keep)
+
+
+# --------------------------------------------------------------------------------------------------
 # L1: InfoNCE (batched over problems)
 # --------------------------------------------------------------------------------------------------
 class InfoNCEFn(torch.autograd.Function):

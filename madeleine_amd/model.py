@@ -92,26 +92,30 @@ class ABMILEmbedder(nn.Module):
             raise NotImplementedError('Attention model not implemented -- Options are ABMIL')
 
     # ------------------------------------------------------------------ internals (head-major)
-    def _drop(self, x, blk):
-        if not self.training:
-            return x
-        inj = self._injected_keep
-        if inj is not None:
-            keep = inj["pre"][blk]
-            if blk == 2:
-                keep = keep[..., self._perm]
-            return x * keep.to(x.dtype) * (1.0 / (1.0 - PRE_DROPOUT_P))
-        return F.dropout(x, PRE_DROPOUT_P, True)
+    def _act(self, x, ln, blk, perm=None):
+        """LayerNorm -> GELU -> Dropout(.1) of block `blk` in ONE fused HIP pass each way (functional.ln_gelu_drop)."""
+        g, b = (ln.weight, ln.bias) if perm is None else (ln.weight[perm], ln.bias[perm])
+        p, seed, keep = 0.0, 0, None
+        if self.training:
+            p = PRE_DROPOUT_P
+            inj = self._injected_keep
+            if inj is not None:
+                keep = inj["pre"][blk]
+                if perm is not None:
+                    keep = keep[..., perm]
+                keep = keep.to(torch.uint8).contiguous()
+            else:
+                seed = MF.new_dropout_seed()
+        return MF.ln_gelu_drop(x.float(), g, b, ln.eps, p, seed, keep)
 
     def embed_tokens_headmajor(self, bags: torch.Tensor) -> torch.Tensor:
         """pre_attn(bags) with the 2048 output channels in head-major order: [BM, N, H*512]."""
         pa = self.pre_attn
-        x = self._drop(pa[2](pa[1](pa[0](bags))), 0)
-        x = self._drop(pa[6](pa[5](pa[4](x))), 1)
+        x = self._act(pa[0](bags), pa[1], 0)
+        x = self._act(pa[4](x), pa[5], 1)
         perm = self._perm
         x = F.linear(x, pa[8].weight[perm], pa[8].bias[perm])
-        x = F.layer_norm(x, (perm.numel(),), pa[9].weight[perm], pa[9].bias[perm], pa[9].eps)
-        return self._drop(F.gelu(x), 2).float().contiguous()
+        return self._act(x, pa[9], 2, perm)
 
     def gate_params_stacked(self):
         ps = [h.gate_params() for h in self.attn]
