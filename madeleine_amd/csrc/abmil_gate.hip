@@ -41,6 +41,27 @@ constexpr int GATE_JT = HID / 128;  // 4 j-tiles of 128 gate columns per head
 #define GATE_PIN()
 #endif
 
+// Head <-> XCD affinity.  Workgroup b runs on XCD b % 8 (observed dispatch; used for speed only, never for
+// correctness).  XCD x works on head x % H and on the (x / H)-th interleaved share of that head's token tiles, so
+// the 2 MiB of a head's Wa|Wb stay resident in ONE XCD's 4 MiB L2 instead of all 8 MiB cycling through every L2
+// (profiles/r01a: TCC hit rate 76 % with the token-major mapping).  `li` = this workgroup's index within its XCD.
+struct XcdHead {
+    int c, share, nshare, li;
+};
+__device__ __forceinline__ XcdHead xcd_head(int bid, int H) {
+    XcdHead m;
+    const int x = bid & 7;
+    m.nshare = 8 / H;  // H in {1,2,4,8}
+    m.c = x % H;
+    m.share = x / H;
+    m.li = bid >> 3;
+    return m;
+}
+static inline int64_t xcd_head_grid(int64_t units, int per_unit, int H) {  // units = tiles of one head, split over 8/H XCDs
+    const int nshare = 8 / H;
+    return 8 * ((units + nshare - 1) / nshare) * per_unit;
+}
+
 struct GateSmem {
     float A[2][GBK][LDA_S];
     float B[2][GBK][LDB_S];
@@ -162,8 +183,9 @@ __global__ __launch_bounds__(256, 2) void gate_fwd_kernel(const float* __restric
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
     // logical tile id: jt fastest, then head, then token tile -> the 4*H workgroups that read the same
     // 128 token rows of E sit next to each other on one XCD (shared L2).
-    const int lid = xcd_remap(blockIdx.x, gridDim.x);
-    const int jt = lid % GATE_JT, c = (lid / GATE_JT) % H, tt = lid / (GATE_JT * H);
+    const XcdHead xh = xcd_head(blockIdx.x, H);
+    const int jt = xh.li % GATE_JT, c = xh.c, tt = (xh.li / GATE_JT) * xh.nshare + xh.share;
+    if (tt >= n_ttiles) return;  // block-uniform
     const int64_t t0 = (int64_t)tt * GBM;
     const int j0 = jt * 128;
 
@@ -331,9 +353,10 @@ __global__ __launch_bounds__(256, 2) void gate_bwd_dx_kernel(const float* __rest
                                                              int64_t ldE, int accumulate, int64_t T, int H, DropCfg drop) {
     __shared__ GateSmem sm;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-    const int lid = xcd_remap(blockIdx.x, gridDim.x);
-    const int nt = lid % 2, c = (lid / 2) % H, tt = lid / (2 * H);
+    const XcdHead xh = xcd_head(blockIdx.x, H);
+    const int nt = xh.li % 2, c = xh.c, tt = (xh.li / 2) * xh.nshare + xh.share;
     const int64_t t0 = (int64_t)tt * GBM;
+    if (t0 >= T) return;  // block-uniform
     const int n0 = nt * GBN;
 
     // A staging: thread -> (row = tid/2, quad = tid%2): one float4 of a and of b per 8-wide j chunk
@@ -423,7 +446,7 @@ __device__ __forceinline__ void gate_bwd_dw_body(const float* __restrict__ E, in
                                                              const float* __restrict__ act_b,
                                                              const float* __restrict__ d_scores,
                                                              float* __restrict__ slabW, float* __restrict__ slabV,
-                                                             int64_t T, int H, int64_t tok_per_split, DropCfg drop) {
+                                                             int64_t T, int H, int64_t tok_per_split, int n_splits, DropCfg drop) {
     __shared__ GateSmem sm;
     // running column sums (dba, dbb, dwc: 3 x 4 floats per thread) live in LDS, not in VGPRs: the 128
     // accumulator registers + the staged chunk already fill the 256-register budget of 2 waves/SIMD.
@@ -431,10 +454,11 @@ __device__ __forceinline__ void gate_bwd_dw_body(const float* __restrict__ E, in
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
     // logical id: kt (1..3, or 0 for the SUMS variant) fastest, then jt, head, split: the tiles of one
     // (split, head) share X and a/b rows through one XCD's L2
-    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const XcdHead xh = xcd_head(blockIdx.x, H);
     constexpr int NKT = SUMS ? 1 : 3;
-    const int kt = SUMS ? 0 : 1 + lid % NKT, jt = (lid / NKT) % GATE_JT, c = (lid / (NKT * GATE_JT)) % H,
-              sp = lid / (NKT * GATE_JT * H);
+    const int kt = SUMS ? 0 : 1 + xh.li % NKT, jt = (xh.li / NKT) % GATE_JT, c = xh.c,
+              sp = (xh.li / (NKT * GATE_JT)) * xh.nshare + xh.share;
+    if (sp >= n_splits) return;  // block-uniform
     const int k0 = kt * 128, j0 = jt * 128;
     const int64_t ts = (int64_t)sp * tok_per_split;
     int64_t te = ts + tok_per_split;
@@ -557,8 +581,8 @@ __global__ __launch_bounds__(256, 1) void gate_bwd_dw_sums_kernel(const float* _
                                                                   const float* __restrict__ act_b,
                                                                   const float* __restrict__ d_scores,
                                                                   float* __restrict__ slabW, float* __restrict__ slabV,
-                                                                  int64_t T, int H, int64_t tok_per_split, DropCfg drop) {
-    gate_bwd_dw_body<true>(E, ldE, wc, act_a, act_b, d_scores, slabW, slabV, T, H, tok_per_split, drop);
+                                                                  int64_t T, int H, int64_t tok_per_split, int n_splits, DropCfg drop) {
+    gate_bwd_dw_body<true>(E, ldE, wc, act_a, act_b, d_scores, slabW, slabV, T, H, tok_per_split, n_splits, drop);
 }
 __global__ __launch_bounds__(256, 2) void gate_bwd_dw_kernel(const float* __restrict__ E, int64_t ldE,
                                                              const float* __restrict__ wc,
@@ -566,8 +590,8 @@ __global__ __launch_bounds__(256, 2) void gate_bwd_dw_kernel(const float* __rest
                                                              const float* __restrict__ act_b,
                                                              const float* __restrict__ d_scores,
                                                              float* __restrict__ slabW, float* __restrict__ slabV,
-                                                             int64_t T, int H, int64_t tok_per_split, DropCfg drop) {
-    gate_bwd_dw_body<false>(E, ldE, wc, act_a, act_b, d_scores, slabW, slabV, T, H, tok_per_split, drop);
+                                                             int64_t T, int H, int64_t tok_per_split, int n_splits, DropCfg drop) {
+    gate_bwd_dw_body<false>(E, ldE, wc, act_a, act_b, d_scores, slabW, slabV, T, H, tok_per_split, n_splits, drop);
 }
 
 // dWa[c][j][k] = sum_s slabW[s][c][k][j] ; dWb[c][j][k] = sum_s slabW[s][c][k][512+j]  (32x32 LDS transpose)
@@ -657,10 +681,12 @@ extern "C" int mdl_abmil_gate_fwd(const float* E, int64_t ldE, const float* Wa, 
     if (!host_aligned16(E) || !host_aligned16(Wa) || !host_aligned16(Wb) || !host_aligned16(ws)) return MDL_E_ALIGN;
     if (T == 0) return MDL_OK;
     const int64_t n_tt = (T + GBM - 1) / GBM;
-    if (n_tt * GATE_JT * H > 0x7fffffff) return MDL_E_UNSUPPORTED;
+    if (H != 1 && H != 2 && H != 4 && H != 8) return MDL_E_UNSUPPORTED;
+    const int64_t grid = xcd_head_grid(n_tt, GATE_JT, H);
+    if (grid > 0x7fffffff) return MDL_E_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     const DropCfg d = make_drop(p_drop, seed, keep_a, keep_b);
-    hipLaunchKernelGGL(gate_fwd_kernel, dim3((unsigned)(n_tt * GATE_JT * H)), dim3(256), 0, s, E, ldE, Wa, ba, Wb, bb, wc,
+    hipLaunchKernelGGL(gate_fwd_kernel, dim3((unsigned)grid), dim3(256), 0, s, E, ldE, Wa, ba, Wb, bb, wc,
                        (float*)ws, act_a, act_b, T, H, (int)n_tt, d);
     MDL_LAUNCH_CHECK();
     const int64_t n = T * H;
@@ -685,6 +711,7 @@ extern "C" int mdl_abmil_gate_bwd(const float* E, int64_t ldE, const float* Wa, 
         return MDL_E_ARG;
     if ((keep_a == nullptr) != (keep_b == nullptr)) return MDL_E_ARG;
     if (T < 0 || H < 1 || H > MDL_MAX_HEADS || ldE < (int64_t)H * HID || (ldE & 3)) return MDL_E_ARG;
+    if (H != 1 && H != 2 && H != 4 && H != 8) return MDL_E_UNSUPPORTED;
     if (!(p_drop >= 0.f && p_drop < 1.f)) return MDL_E_ARG;
     if (!host_aligned16(E) || !host_aligned16(Wa) || !host_aligned16(Wb) || !host_aligned16(act_a) ||
         !host_aligned16(act_b) || !host_aligned16(wc) || !host_aligned16(ws))
@@ -697,16 +724,17 @@ extern "C" int mdl_abmil_gate_bwd(const float* E, int64_t ldE, const float* Wa, 
     float* slabV = slabW + (int64_t)S * H * HID * 1024;
     if (T > 0) {
         const int64_t n_tt = (T + GBM - 1) / GBM;
-        if (n_tt * 2 * H > 0x7fffffff) return MDL_E_UNSUPPORTED;
-        hipLaunchKernelGGL(gate_bwd_dx_kernel, dim3((unsigned)(n_tt * 2 * H)), dim3(256), 0, s, Wa, Wb, wc, act_a, act_b,
+        const int64_t grid = xcd_head_grid(n_tt, 2, H);
+        if (grid > 0x7fffffff) return MDL_E_UNSUPPORTED;
+        hipLaunchKernelGGL(gate_bwd_dx_kernel, dim3((unsigned)grid), dim3(256), 0, s, Wa, Wb, wc, act_a, act_b,
                            d_scores, dE, ldE, accumulate, T, H, d);
         MDL_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(gate_bwd_dw_sums_kernel, dim3((unsigned)(1 * GATE_JT * H * S)), dim3(256), 0, s, E, ldE, wc, act_a,
-                       act_b, d_scores, slabW, slabV, T, H, tps, d);
+    hipLaunchKernelGGL(gate_bwd_dw_sums_kernel, dim3((unsigned)xcd_head_grid(S, 1 * GATE_JT, H)), dim3(256), 0, s, E, ldE, wc,
+                       act_a, act_b, d_scores, slabW, slabV, T, H, tps, S, d);
     MDL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gate_bwd_dw_kernel, dim3((unsigned)(3 * GATE_JT * H * S)), dim3(256), 0, s, E, ldE, wc, act_a,
-                       act_b, d_scores, slabW, slabV, T, H, tps, d);
+    hipLaunchKernelGGL(gate_bwd_dw_kernel, dim3((unsigned)xcd_head_grid(S, 3 * GATE_JT, H)), dim3(256), 0, s, E, ldE, wc, act_a,
+                       act_b, d_scores, slabW, slabV, T, H, tps, S, d);
     MDL_LAUNCH_CHECK();
     hipLaunchKernelGGL(gate_reduce_w_kernel, dim3(32, 16, H), dim3(256), 0, s, (const float*)slabW, dWa, dWb, H, S);
     MDL_LAUNCH_CHECK();

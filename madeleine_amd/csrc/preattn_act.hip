@@ -215,13 +215,21 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_bwd_kernel(const float
     }
 }
 
-__global__ void ln_reduce_kernel(const float* __restrict__ part, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                 int nblocks, int W) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= 2 * W) return;
+// dgamma|dbeta[c] = sum over blocks of part[block][c]: 64 columns x 4 block-groups per workgroup (coalesced rows),
+// the 4 partial sums merged through LDS in a fixed order.
+__global__ __launch_bounds__(256) void ln_reduce_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
+                                                        float* __restrict__ dbeta, int nblocks, int W) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
     float v = 0.f;
-    for (int k = 0; k < nblocks; ++k) v += part[(int64_t)k * 2 * W + c];
-    (c < W ? dgamma : dbeta)[c < W ? c : c - W] = v;
+    if (c < 2 * W)
+        for (int k = grp; k < nblocks; k += 4) v += part[(int64_t)k * 2 * W + c];
+    red[grp][threadIdx.x & 63] = v;
+    __syncthreads();
+    if (grp == 0 && c < 2 * W) {
+        const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        (c < W ? dgamma : dbeta)[c < W ? c : c - W] = t;
+    }
 }
 
 static inline ActDrop make_act_drop(float p, uint64_t seed, const uint8_t* keep) {
@@ -292,7 +300,7 @@ extern "C" int mdl_ln_gelu_drop_bwd(const float* x, const float* gamma, const fl
             MDL_LAUNCH_CHECK();
         }
     });
-    hipLaunchKernelGGL(ln_reduce_kernel, dim3((2 * W + 255) / 256), dim3(256), 0, s, (const float*)ws, dgamma, dbeta, nb, W);
+    hipLaunchKernelGGL(ln_reduce_kernel, dim3((2 * W + 63) / 64), dim3(256), 0, s, (const float*)ws, dgamma, dbeta, nb, W);
     MDL_LAUNCH_CHECK();
     return MDL_OK;
 }
