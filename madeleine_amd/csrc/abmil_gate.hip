@@ -30,6 +30,9 @@ constexpr int GATE_JT = HID / 128;  // 4 j-tiles of 128 gate columns per head
 // The global loads of chunk i+1 must be IN FLIGHT while chunk i's 64 MFMAs issue (4096 cycles per wave); left
 // alone, hipcc sinks them behind the MFMA block to save registers and every wave then eats the full HBM/L2
 // latency before its LDS stores (measured: 63 % of the fp32 MFMA peak).  sched_barrier(0) pins the order.
+#ifndef GATE_SUMS_WPE
+#define GATE_SUMS_WPE 2
+#endif
 #ifdef GATE_EXP_NOLOAD
 #define GATE_EXP_LOAD(x)
 #else
@@ -92,7 +95,8 @@ __device__ __forceinline__ void drop_keep2(const DropCfg& d, int64_t idx, bool& 
 
 // MFMA over one staged K-chunk.  colb[ct] = first column (within the 256-wide B tile) of this wave's ct-th
 // 32-column accumulator tile; rows wm*64 + rt*32.
-__device__ __forceinline__ void mma_chunk(const float (*__restrict__ As)[LDA_S], const float (*__restrict__ Bs)[LDB_S],
+template <int LDA, int LDB>
+__device__ __forceinline__ void mma_chunk(const float (*__restrict__ As)[LDA], const float (*__restrict__ Bs)[LDB],
                                           f32x16 (&acc)[2][4], int wm, const int (&colb)[4], int lane) {
     const int l32 = lane & 31, kh = lane >> 5;
 #pragma unroll
@@ -134,7 +138,12 @@ __device__ __forceinline__ void mma_chunk_pipe(const float (*__restrict__ As)[LD
 #pragma unroll
     for (int kk = 0; kk < GBK / 2; ++kk) {
         const int cur = kk & 1;
+#ifndef GATE_X_NOFRAG
         if (kk + 1 < GBK / 2) read_frags(kk + 1, cur ^ 1);
+#else
+        fa[cur ^ 1][0] = fa[cur][0]; fa[cur ^ 1][1] = fa[cur][1];
+        for (int ct = 0; ct < 4; ++ct) fb[cur ^ 1][ct] = fb[cur][ct];
+#endif
         if (HAS_NEXT && kk == 0) issue_loads();
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -169,101 +178,107 @@ __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (
 // ================================================================================================
 // forward
 // ================================================================================================
+// Direct-to-LDS staging (global_load_lds_dwordx4): both operands of the forward GEMM are K-contiguous in global
+// memory (E rows, W rows), so a wave instruction deposits 64 x 16 B = 16 rows x 64 B (BK = 16) straight into a
+// row-major LDS image [row][16 k] -- no staging VGPRs, no ds_write pass (ablation: register staging + transposed
+// ds_write_b32 scatter cost 11 % of the kernel).  The image must be lane-linear, so bank conflicts are removed on
+// the SOURCE side: the 16-B chunk a lane fetches is XOR-swizzled, slot = kq ^ ((row >> 2) & 3), and fragment reads
+// apply the same involution.  Fragments are ds_read_b128 = 4 consecutive k of one row; the MFMA's K = 2 is fed with
+// k-pairs (k0+s | k0+4+s) from the two half-waves -- a permutation of the k order, applied to A and B alike.
+struct GateSmemD {
+    float A[2][GBM * GBK];  // 8 KiB per stage
+    float B[2][GBN * GBK];  // 16 KiB per stage
+};
+
+__device__ __forceinline__ void glds16(const float* gsrc, float* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
 __global__ __launch_bounds__(256, 2) void gate_fwd_kernel(const float* __restrict__ E, int64_t ldE,
                                                           const float* __restrict__ Wa, const float* __restrict__ ba,
                                                           const float* __restrict__ Wb, const float* __restrict__ bb,
                                                           const float* __restrict__ wc, float* __restrict__ part,
                                                           float* __restrict__ act_a, float* __restrict__ act_b,
                                                           int64_t T, int H, int n_ttiles, DropCfg drop) {
-    __shared__ GateSmem sm;
-#ifdef GATE_OCC1
-    __shared__ float occ_pad[9000];  // experiment: > 80 KiB of LDS per workgroup => one workgroup per CU
-    if (T < 0) occ_pad[threadIdx.x] = 0.f, part[0] = occ_pad[(threadIdx.x * 7) % 9000];
-#endif
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-    // logical tile id: jt fastest, then head, then token tile -> the 4*H workgroups that read the same
-    // 128 token rows of E sit next to each other on one XCD (shared L2).
+    __shared__ __attribute__((aligned(16))) GateSmemD sm;
+    const int tid = threadIdx.x, lane = tid & 63, wm = (tid >> 6) >> 1, wn = (tid >> 6) & 1;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform (LDS-DMA destination base)
     const XcdHead xh = xcd_head(blockIdx.x, H);
     const int jt = xh.li % GATE_JT, c = xh.c, tt = (xh.li / GATE_JT) * xh.nshare + xh.share;
     if (tt >= n_ttiles) return;  // block-uniform
     const int64_t t0 = (int64_t)tt * GBM;
     const int j0 = jt * 128;
 
-    const float* __restrict__ Xc = E + (int64_t)c * HID;                      // + t*ldE + k
-    const float* __restrict__ Wac = Wa + ((int64_t)c * HID + j0) * HID;       // + n*512 + k
-    const float* __restrict__ Wbc = Wb + ((int64_t)c * HID + j0) * HID;
+    // ---- LDS-DMA sources: instruction q of wave w fills slots [(w*NI+q)*64, +64); slot s = (row = s>>2, kq' = s&3)
+    //      holds global chunk kq = kq' ^ ((row>>2)&3) of that row.  Rows past T re-read row T-1 (discarded later).
+    const float* srcA[2];
+    const float* srcB[4];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int sl = (wave * 2 + q) * 64 + lane, row = sl >> 2, kq = (sl & 3) ^ ((row >> 2) & 3);
+        int64_t t = t0 + row;
+        if (t > T - 1) t = T - 1;
+        srcA[q] = E + t * ldE + (int64_t)c * HID + kq * 4;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int sl = (wave * 4 + q) * 64 + lane, row = sl >> 2, kq = (sl & 3) ^ ((row >> 2) & 3);  // row in [0,256)
+        const float* w = (row < 128) ? Wa + ((int64_t)c * HID + j0 + row) * HID : Wb + ((int64_t)c * HID + j0 + row - 128) * HID;
+        srcB[q] = w + kq * 4;
+    }
+    auto issue = [&](int st, int k0) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) glds16(srcA[q] + k0, &sm.A[st][(wave * 2 + q) * 256]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) glds16(srcB[q] + k0, &sm.B[st][(wave * 4 + q) * 256]);
+    };
 
-    // staging maps (transposed: global rows are K-contiguous).  A: 128 rows x 4 float4; B: 256 rows x 4 float4.
-    f32x4 ra[2], rb[4];
-    auto load_regs = [&](int k0) {
+    // ---- fragment addressing: lane reads row r, chunk (2g + kh) -> slot ((2g+kh) ^ sw(r)); g = 1 flips slot bit 1
+    const int l32 = lane & 31, kh = lane >> 5;
+    const int colb[4] = {wn * 64, wn * 64 + 32, 128 + wn * 64, 128 + wn * 64 + 32};  // a, a, b, b
+    int offA[2], offB[4];
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int f = tid + p * 256, row = f >> 2, kq = f & 3;
-            const int64_t t = t0 + row;
-            ra[p] = (t < T) ? *reinterpret_cast<const f32x4*>(Xc + t * ldE + k0 + kq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+    for (int rt = 0; rt < 2; ++rt) {
+        const int r = wm * 64 + rt * 32 + l32;
+        offA[rt] = r * GBK + ((kh ^ ((r >> 2) & 3)) << 2);
+    }
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int f = tid + p * 256, row = f >> 2, kq = f & 3;  // row in [0,256): <128 -> Wa, else Wb
-            const float* src = (row < 128) ? (Wac + (int64_t)row * HID) : (Wbc + (int64_t)(row - 128) * HID);
-            rb[p] = *reinterpret_cast<const f32x4*>(src + k0 + kq * 4);
-        }
-    };
-    auto store_lds = [&](int st) {
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int f = tid + p * 256, row = f >> 2, kq = f & 3;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) sm.A[st][kq * 4 + i][row] = ra[p][i];
-        }
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int f = tid + p * 256, row = f >> 2, kq = f & 3;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) sm.B[st][kq * 4 + i][row] = rb[p][i];
-        }
-    };
+    for (int ct = 0; ct < 4; ++ct) {
+        const int r = colb[ct] + l32;
+        offB[ct] = r * GBK + ((kh ^ ((r >> 2) & 3)) << 2);
+    }
 
     f32x16 acc[2][4];
     zero_acc(acc);
-    const int colb[4] = {wn * 64, wn * 64 + 32, 128 + wn * 64, 128 + wn * 64 + 32};  // a, a, b, b
-
     constexpr int NCH = HID / GBK;  // 32 chunks
-    load_regs(0);
-    store_lds(0);
+    issue(0, 0);
     __syncthreads();
-#ifdef GATE_NO_PIPE
     for (int ch = 0; ch < NCH; ++ch) {
-        if (ch + 1 < NCH) load_regs((ch + 1) * GBK);
-        GATE_PIN();
-        mma_chunk(sm.A[ch & 1], sm.B[ch & 1], acc, wm, colb, lane);
-        GATE_PIN();
-        if (ch + 1 < NCH) store_lds((ch + 1) & 1);
-        __syncthreads();
-    }
-#else
-    for (int ch = 0; ch < NCH - 1; ++ch) {
-        const int nst = (ch + 1) & 1;
-        mma_chunk_pipe<true>(
-            sm.A[ch & 1], sm.B[ch & 1], acc, wm, colb, lane, [&]() { GATE_EXP_LOAD(load_regs((ch + 1) * GBK)); },
-            [&](int piece) {  // pieces 0,1: the two A float4s; 2..5: the four B float4s (transposed scatter)
-                const int f = tid + (piece < 2 ? piece : piece - 2) * 256, row = f >> 2, kq = f & 3;
-                if (piece < 2) {
+        const int st = ch & 1;
+        if (ch + 1 < NCH) issue(st ^ 1, (ch + 1) * GBK);  // lands in the stage last read before the previous barrier
+        f32x4 fa[2][2], fb[2][4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) sm.A[nst][kq * 4 + i][row] = ra[piece][i];
-                } else {
+        for (int g = 0; g < 2; ++g) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) sm.B[nst][kq * 4 + i][row] = rb[piece - 2][i];
+            for (int rt = 0; rt < 2; ++rt) fa[g][rt] = *reinterpret_cast<const f32x4*>(&sm.A[st][offA[rt] ^ (g << 3)]);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) fb[g][ct] = *reinterpret_cast<const f32x4*>(&sm.B[st][offB[ct] ^ (g << 3)]);
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    const int rt = m & 1, ct = m >> 1;
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g][rt][e], fb[g][ct][e], acc[rt][ct], 0, 0, 0);
                 }
-            });
-        __syncthreads();
+        __syncthreads();  // drains the LDS-DMA of chunk ch+1 (vmcnt) and fences this chunk's reads
     }
-    mma_chunk_pipe<false>(sm.A[(NCH - 1) & 1], sm.B[(NCH - 1) & 1], acc, wm, colb, lane, [&]() {}, [&](int) {});
-    __syncthreads();
-#endif
 
     // ---- epilogue: activations, dropout, wc-weighted row reduction ---------------------------------
-    const int l32 = lane & 31;
+    // (l32 defined above)
     float ps[2][16];
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
@@ -304,7 +319,7 @@ __global__ __launch_bounds__(256, 2) void gate_fwd_kernel(const float* __restric
             for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
             ps[rt][r] = v;
         }
-    float* sred = &sm.A[0][0][0];  // [2 (wn)][128 rows]; all MFMA reads finished at the loop's last barrier
+    float* sred = &sm.A[0][0];  // [2 (wn)][128 rows]; all MFMA reads finished at the loop's last barrier
     if (l32 == 0) {
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
@@ -351,8 +366,15 @@ __global__ __launch_bounds__(256, 2) void gate_bwd_dx_kernel(const float* __rest
                                                              const float* __restrict__ act_b,
                                                              const float* __restrict__ d_scores, float* __restrict__ dE,
                                                              int64_t ldE, int accumulate, int64_t T, int H, DropCfg drop) {
-    __shared__ GateSmem sm;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    // A (the d(za)|d(zb) operand, computed on the fly) is register-staged into a transposed K-major image; B (16 weight
+    // rows x 256 columns per chunk, already K-major in global memory) goes global -> LDS directly, one row per wave
+    // instruction.
+    __shared__ __attribute__((aligned(16))) struct {
+        float A[2][GBK][LDA_S];
+        float B[2][GBK][GBN];
+    } sm;
+    const int tid = threadIdx.x, lane = tid & 63, wm = (tid >> 6) >> 1, wn = (tid >> 6) & 1;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const XcdHead xh = xcd_head(blockIdx.x, H);
     const int nt = xh.li % 2, c = xh.c, tt = (xh.li / 2) * xh.nshare + xh.share;
     const int64_t t0 = (int64_t)tt * GBM;
@@ -370,7 +392,15 @@ __global__ __launch_bounds__(256, 2) void gate_bwd_dx_kernel(const float* __rest
     const float* __restrict__ Wac = Wa + (int64_t)c * HID * HID + n0;  // + j*512 + n
     const float* __restrict__ Wbc = Wb + (int64_t)c * HID * HID + n0;
 
-    f32x4 va, vb, vw, rb[4];
+    f32x4 va, vb, vw;
+    auto issue_b = [&](int st, int j0) {  // 16 rows (8 of Wa, 8 of Wb) x 1 KiB, 4 per wave
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = wave * 4 + q;
+            const float* src = (r < 8) ? (Wac + (int64_t)(j0 + r) * HID) : (Wbc + (int64_t)(j0 + r - 8) * HID);
+            glds16(src + lane * 4, &sm.B[st][r][0]);
+        }
+    };
     auto load_regs = [&](int j0) {
         if (arow_ok) {
             va = *reinterpret_cast<const f32x4*>(pa + j0);
@@ -380,12 +410,6 @@ __global__ __launch_bounds__(256, 2) void gate_bwd_dx_kernel(const float* __rest
             vb = va;
         }
         vw = *reinterpret_cast<const f32x4*>(wcc + j0);
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int f = tid + p * 256, r = f >> 6, cq = f & 63;  // r in [0,16): <8 -> Wa row j0+r, else Wb row j0+r-8
-            const float* src = (r < 8) ? (Wac + (int64_t)(j0 + r) * HID) : (Wbc + (int64_t)(j0 + r - 8) * HID);
-            rb[p] = *reinterpret_cast<const f32x4*>(src + cq * 4);
-        }
     };
     auto store_lds = [&](int st, int j0) {
         const int64_t idx0 = (at * H + c) * HID + j0 + aq * 4;
@@ -396,24 +420,23 @@ __global__ __launch_bounds__(256, 2) void gate_bwd_dx_kernel(const float* __rest
             sm.A[st][aq * 4 + i][arow] = dza;
             sm.A[st][8 + aq * 4 + i][arow] = dzb;
         }
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int f = tid + p * 256, r = f >> 6, cq = f & 63;
-            *reinterpret_cast<f32x4*>(&sm.B[st][r][cq * 4]) = rb[p];
-        }
     };
 
     f32x16 acc[2][4];
     zero_acc(acc);
     const int colb[4] = {wn * 128, wn * 128 + 32, wn * 128 + 64, wn * 128 + 96};
     constexpr int NCH = HID / 8;  // 64 chunks of (8 a-rows + 8 b-rows)
+    issue_b(0, 0);
     load_regs(0);
     store_lds(0, 0);
     __syncthreads();
     for (int ch = 0; ch < NCH; ++ch) {
-        if (ch + 1 < NCH) load_regs((ch + 1) * 8);
+        if (ch + 1 < NCH) {
+            issue_b((ch + 1) & 1, (ch + 1) * 8);
+            load_regs((ch + 1) * 8);
+        }
         GATE_PIN();
-        mma_chunk(sm.A[ch & 1], sm.B[ch & 1], acc, wm, colb, lane);
+        mma_chunk<LDA_S, GBN>(sm.A[ch & 1], sm.B[ch & 1], acc, wm, colb, lane);
         GATE_PIN();
         if (ch + 1 < NCH) store_lds((ch + 1) & 1, (ch + 1) * 8);
         __syncthreads();
@@ -447,11 +470,17 @@ __device__ __forceinline__ void gate_bwd_dw_body(const float* __restrict__ E, in
                                                              const float* __restrict__ d_scores,
                                                              float* __restrict__ slabW, float* __restrict__ slabV,
                                                              int64_t T, int H, int64_t tok_per_split, int n_splits, DropCfg drop) {
-    __shared__ GateSmem sm;
+    // A (16 token rows x 128 inputs of X per chunk) goes global -> LDS directly (two 512-B rows per wave instruction);
+    // B (d(za)|d(zb), computed on the fly) is register-staged.
+    __shared__ __attribute__((aligned(16))) struct {
+        float A[2][GBK][GBM];
+        float B[2][GBK][LDB_S];
+    } sm;
     // running column sums (dba, dbb, dwc: 3 x 4 floats per thread) live in LDS, not in VGPRs: the 128
     // accumulator registers + the staged chunk already fill the 256-register budget of 2 waves/SIMD.
     __shared__ float colsum[SUMS ? 256 * 13 : 1];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int tid = threadIdx.x, lane = tid & 63, wm = (tid >> 6) >> 1, wn = (tid >> 6) & 1;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // logical id: kt (1..3, or 0 for the SUMS variant) fastest, then jt, head, split: the tiles of one
     // (split, head) share X and a/b rows through one XCD's L2
     const XcdHead xh = xcd_head(blockIdx.x, H);
@@ -468,23 +497,31 @@ __device__ __forceinline__ void gate_bwd_dw_body(const float* __restrict__ E, in
     const int q = tid & 31;
     const float* __restrict__ Xc = E + (int64_t)c * HID + k0 + q * 4;
     const f32x4 vw = *reinterpret_cast<const f32x4*>(wc + c * HID + j0 + q * 4);
-    f32x4 rx[2], va[2], vb[2];
+    f32x4 va[2], vb[2];
     float vds[2];
+    const float* __restrict__ Xg = E + (int64_t)c * HID + k0 + (lane & 31) * 4;
+    auto issue_a = [&](int st, int64_t tb) {  // rows past the split end re-read a valid row: their B rows are zero
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int r0 = (wave * 2 + q) * 2;
+            int64_t t = tb + r0 + (lane >> 5);
+            if (t > T - 1) t = T - 1;
+            glds16(Xg + t * ldE, &sm.A[st][r0][0]);
+        }
+    };
     auto load_regs = [&](int64_t tb) {
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const int r = (tid >> 5) + p * 8;
             const int64_t t = tb + r;
             if (t < te) {
-                rx[p] = *reinterpret_cast<const f32x4*>(Xc + t * ldE);
                 const int64_t o = (t * H + c) * HID + j0 + q * 4;
                 va[p] = *reinterpret_cast<const f32x4*>(act_a + o);
                 vb[p] = *reinterpret_cast<const f32x4*>(act_b + o);
                 vds[p] = d_scores[t * H + c];
             } else {
-                rx[p] = f32x4{0.f, 0.f, 0.f, 0.f};
-                va[p] = rx[p];
-                vb[p] = rx[p];
+                va[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+                vb[p] = va[p];
                 vds[p] = 0.f;
             }
         }
@@ -498,7 +535,6 @@ __device__ __forceinline__ void gate_bwd_dw_body(const float* __restrict__ E, in
         for (int p = 0; p < 2; ++p) {
             const int r = (tid >> 5) + p * 8;
             const int64_t t = tb + r;
-            *reinterpret_cast<f32x4*>(&sm.A[st][r][q * 4]) = rx[p];
             f32x4 za = {0.f, 0.f, 0.f, 0.f}, zb = za, pp = za;
             if (t < te) {
                 const int64_t idx0 = (t * H + c) * HID + j0 + q * 4;
@@ -530,14 +566,18 @@ __device__ __forceinline__ void gate_bwd_dw_body(const float* __restrict__ E, in
     const int colb[4] = {wn * 128, wn * 128 + 32, wn * 128 + 64, wn * 128 + 96};
     const int64_t nch = (te > ts) ? (te - ts + GBK - 1) / GBK : 0;
     if (nch > 0) {
+        issue_a(0, ts);
         load_regs(ts);
         store_lds(0, ts);
     }
     __syncthreads();
     for (int64_t ch = 0; ch < nch; ++ch) {
-        if (ch + 1 < nch) load_regs(ts + (ch + 1) * GBK);
+        if (ch + 1 < nch) {
+            issue_a((int)((ch + 1) & 1), ts + (ch + 1) * GBK);
+            load_regs(ts + (ch + 1) * GBK);
+        }
         GATE_PIN();
-        mma_chunk(sm.A[ch & 1], sm.B[ch & 1], acc, wm, colb, lane);
+        mma_chunk<GBM, LDB_S>(sm.A[ch & 1], sm.B[ch & 1], acc, wm, colb, lane);
         GATE_PIN();
         if (ch + 1 < nch) store_lds((int)((ch + 1) & 1), ts + (ch + 1) * GBK);
         __syncthreads();
@@ -575,7 +615,7 @@ __device__ __forceinline__ void gate_bwd_dw_body(const float* __restrict__ E, in
 
 // The column-sum variant needs ~300 registers: it runs at 1 wave/SIMD (1/4 of the dW tiles); the plain
 // variant fits 2 waves/SIMD.
-__global__ __launch_bounds__(256, 1) void gate_bwd_dw_sums_kernel(const float* __restrict__ E, int64_t ldE,
+__global__ __launch_bounds__(256, GATE_SUMS_WPE) void gate_bwd_dw_sums_kernel(const float* __restrict__ E, int64_t ldE,
                                                                   const float* __restrict__ wc,
                                                                   const float* __restrict__ act_a,
                                                                   const float* __restrict__ act_b,
