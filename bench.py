@@ -106,7 +106,8 @@ def main():
     rank, world, local_rank = D.init_from_env()
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU: the HIP kernels are the only backend"
-    dev = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    dev = torch.device("cuda", local_rank % n_dev)   # (several ranks per GPU only in gloo debug runs)
     torch.cuda.set_device(dev)
 
     B, M, N, Dm, use_got, stain_enc = CONFIGS[a.config]
@@ -116,7 +117,9 @@ def main():
     model.eval() if a.eval_mode else model.train()
     net = model
     if world > 1:
-        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank])
+        # without the local loss the token_projector takes no part in the graph (as in the reference's global-only
+        # configuration): DDP must be told, or it raises on the second step.
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], find_unused_parameters=not use_got)
     opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
     crit = InfoNCE(temperature=0.001)
     got_impl = MF.HipGotImpl if use_got else None
@@ -161,7 +164,7 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = MF.TIMER.report()
     MF.TIMER = None
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
 
     tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:

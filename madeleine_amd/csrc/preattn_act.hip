@@ -215,19 +215,30 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_bwd_kernel(const float
     }
 }
 
-// dgamma|dbeta[c] = sum over blocks of part[block][c]: 64 columns x 4 block-groups per workgroup (coalesced rows),
-// the 4 partial sums merged through LDS in a fixed order.
+// dgamma|dbeta[c] = sum over blocks of part[block][c]: 32 columns x 8 block-groups per workgroup (coalesced 128-B
+// row segments, 8 loads in flight per thread), the 8 partial sums merged through LDS in a fixed order.
 __global__ __launch_bounds__(256) void ln_reduce_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
                                                         float* __restrict__ dbeta, int nblocks, int W) {
-    __shared__ float red[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+    __shared__ float red[8][32];
+    const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
     float v = 0.f;
-    if (c < 2 * W)
-        for (int k = grp; k < nblocks; k += 4) v += part[(int64_t)k * 2 * W + c];
-    red[grp][threadIdx.x & 63] = v;
+    if (c < 2 * W) {
+        int k = grp;
+        for (; k + 56 < nblocks; k += 64) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = part[(int64_t)(k + 8 * u) * 2 * W + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v += t[u];
+        }
+        for (; k < nblocks; k += 8) v += part[(int64_t)k * 2 * W + c];
+    }
+    red[grp][cl] = v;
     __syncthreads();
     if (grp == 0 && c < 2 * W) {
-        const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        float t = red[0][cl];
+#pragma unroll
+        for (int g = 1; g < 8; ++g) t += red[g][cl];
         (c < W ? dgamma : dbeta)[c < W ? c : c - W] = t;
     }
 }
@@ -300,7 +311,7 @@ extern "C" int mdl_ln_gelu_drop_bwd(const float* x, const float* gamma, const fl
             MDL_LAUNCH_CHECK();
         }
     });
-    hipLaunchKernelGGL(ln_reduce_kernel, dim3((2 * W + 63) / 64), dim3(256), 0, s, (const float*)ws, dgamma, dbeta, nb, W);
+    hipLaunchKernelGGL(ln_reduce_kernel, dim3((2 * W + 31) / 32), dim3(256), 0, s, (const float*)ws, dgamma, dbeta, nb, W);
     MDL_LAUNCH_CHECK();
     return MDL_OK;
 }

@@ -23,7 +23,9 @@ import torch.distributed as dist
 
 
 def init_from_env(backend: Optional[str] = None):
-    """torchrun-style init (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* from the environment). Returns (rank, world, local_rank)."""
+    """torchrun-style init (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* from the environment). Returns (rank, world, local_rank).
+    MADELEINE_DIST_BACKEND overrides the backend (e.g. gloo, to run several ranks on ONE GPU for debugging)."""
+    backend = backend or os.environ.get("MADELEINE_DIST_BACKEND") or None
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -40,6 +42,35 @@ def world_size(group=None) -> int:
     return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
 
 
+def _host_staged(x: torch.Tensor, group) -> bool:
+    """gloo has no all_gather for device tensors: stage through the host (debug / single-GPU multi-process runs only;
+    the production backend is nccl = RCCL, which takes device tensors directly)."""
+    return x.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def _all_gather_cat(x: torch.Tensor, group=None) -> torch.Tensor:
+    """[n, ...] on every rank -> [W*n, ...] (rank-major)."""
+    W = dist.get_world_size(group)
+    x = x.contiguous()
+    if _host_staged(x, group):
+        xc = x.cpu()
+        out = xc.new_empty((W * xc.shape[0],) + tuple(xc.shape[1:]))
+        dist.all_gather_into_tensor(out, xc, group=group)
+        return out.to(x.device)
+    out = x.new_empty((W * x.shape[0],) + tuple(x.shape[1:]))
+    dist.all_gather_into_tensor(out, x, group=group)
+    return out
+
+
+def _all_reduce_sum(x: torch.Tensor, group=None) -> torch.Tensor:
+    if _host_staged(x, group):
+        xc = x.cpu()
+        dist.all_reduce(xc, group=group)
+        return xc.to(x.device)
+    dist.all_reduce(x, group=group)
+    return x
+
+
 class _AllGatherReplicatedLoss(torch.autograd.Function):
     """all_gather along dim 0 whose consumer is a loss evaluated identically on every rank.
 
@@ -49,10 +80,7 @@ class _AllGatherReplicatedLoss(torch.autograd.Function):
     def forward(ctx, x, group):
         W = dist.get_world_size(group)
         ctx.rank, ctx.W, ctx.n = dist.get_rank(group), W, x.shape[0]
-        x = x.contiguous()
-        out = x.new_empty((W * x.shape[0],) + tuple(x.shape[1:]))
-        dist.all_gather_into_tensor(out, x, group=group)
-        return out
+        return _all_gather_cat(x, group)
 
     @staticmethod
     def backward(ctx, g):
@@ -70,10 +98,10 @@ def all_gather_labels(labels: torch.Tensor, device, group=None) -> torch.Tensor:
     """[B_l, M] presence labels of every rank -> [W*B_l, M] on the host (tiny; issued at step start)."""
     if world_size(group) == 1:
         return labels.cpu()
-    x = labels.to(device=device, dtype=torch.float32).contiguous()
-    out = x.new_empty((world_size(group) * x.shape[0], x.shape[1]))
-    dist.all_gather_into_tensor(out, x, group=group)
-    return out.cpu()
+    x = labels.to(dtype=torch.float32).contiguous()
+    if dist.get_backend(group) != "gloo":
+        x = x.to(device)
+    return _all_gather_cat(x, group).cpu()
 
 
 def gather_slide_embeddings(wsi_embs: Dict[str, torch.Tensor], modalities: Sequence[str], group=None):
@@ -114,9 +142,7 @@ class _GOTMulti(torch.autograd.Function):
                            torch.tensor([inf, -inf] * 3, device=dev, dtype=tensors[0].dtype) for V, Q in probs])
         W = world_size(group)
         if W > 1:
-            allx = ext.new_empty((W * ext.shape[0], 6))
-            dist.all_gather_into_tensor(allx, ext.contiguous(), group=group)
-            allx = allx.view(W, ext.shape[0], 6)
+            allx = _all_gather_cat(ext, group).view(W, ext.shape[0], 6)
             even = (torch.arange(6, device=dev) % 2 == 0)
             ext = torch.where(even, allx.amin(dim=0), allx.amax(dim=0))
         outs, states = [], []
@@ -139,7 +165,7 @@ class _GOTMulti(torch.autograd.Function):
         dmm = torch.stack([impl.backward_begin(st, d_outs[s]) if st is not None else
                            torch.zeros(6, device=dev, dtype=d_outs.dtype) for s, st in enumerate(states)])
         if world_size(ctx.group) > 1:
-            dist.all_reduce(dmm, group=ctx.group)
+            dmm = _all_reduce_sum(dmm, ctx.group)
         grads = []
         for s, st in enumerate(states):
             if st is None:
