@@ -37,6 +37,8 @@ CONFIGS = {
     "c1": (4, 2, 256, 512, False, False),
     "c2": (32, 2, 4096, 512, False, False),
     "c3": (32, 5, 4096, 512, True, False),
+    # config 5 (ragged stress): N_i ~ U{1024..16384} per bag, d=768, stain-encoding tokens, full global+local loss
+    "c5": (32, 5, 0, 768, True, True),
 }
 
 
@@ -126,14 +128,22 @@ def main():
     largs = SimpleNamespace(global_loss="info-nce", symmetric_cl=True, local_loss_weight=1.0)
 
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    feats = torch.randn(B, M, N, Dm, device=dev, generator=gen)
+    ragged = N == 0
+    if ragged:
+        lg = torch.Generator().manual_seed(4321 + rank)
+        lens = torch.randint(1024, 16385, (B, M), generator=lg)
+        N = int(lens.float().mean())
+        bags = [[torch.randn(int(lens[b, m]), Dm, device=dev, generator=gen) for m in range(M)] for b in range(B)]
+        feats = None
+    else:
+        feats = torch.randn(B, M, N, Dm, device=dev, generator=gen)
     labels = torch.ones(B, M)
-    if M > 2:  # ACROBAT stain presence rates; absent stain -> all-zero bag (wsi_dataset.py:66)
+    if M > 2 and not ragged:  # ACROBAT stain presence rates; absent stain -> all-zero bag (wsi_dataset.py:66)
         rates = torch.tensor([1.0, 0.46, 0.73, 0.73, 0.73][:M])
         labels = (torch.rand(B, M, generator=torch.Generator().manual_seed(77 + rank)) < rates).float()
         labels[:, 0] = 1
         feats = feats * labels.to(dev)[:, :, None, None]
-    data = {"feats": feats, "modality_labels": labels}
+    data = {"bags": bags, "modality_labels": labels} if ragged else {"feats": feats, "modality_labels": labels}
 
     def step():
         opt.zero_grad(set_to_none=True)
@@ -174,14 +184,14 @@ def main():
     value = B * world * a.steps / elapsed
 
     if rank == 0:
-        tokens = B * M * N
+        tokens = int(lens.sum()) if ragged else B * M * N
         H = 4
         out = {
             "metric": "slides/sec (pretrain step) at B=32 N=4096 d=512; 1/2/4/8 GPU",
             "value": round(value, 3), "unit": "slides/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic (device-resident randn bags, random-init weights, manual_seed 42)",
-            "config": {"workload": f"{a.config}: {B} slides/GPU x {M} stains x {N} patches x {Dm}-d, "
+            "config": {"workload": f"{a.config}: {B} slides/GPU x {M} stains x {'ragged U[1024,16384] (mean ' + str(N) + ')' if ragged else N} patches x {Dm}-d, "
                                    f"ABMIL pool + global InfoNCE{' + local GOT' if use_got else ''}, "
                                    f"{'eval (dropout off)' if a.eval_mode else 'train mode (dropout on)'}, AdamW",
                        "global_batch": B * world, "bags_per_sec": round(value * M, 2), "parallelism": f"dp{world}",

@@ -145,6 +145,16 @@ class ABMILEmbedder(nn.Module):
         pooled, scores = MF.attn_pool(E_hm, wa, ba, wb, bb, wc, bc, p, seed, ka, kb)
         return pooled, scores.view(BM, N, self.n_heads)
 
+    def pool_headmajor_ragged(self, E_hm: torch.Tensor, cu_seqlens: torch.Tensor, max_len: int):
+        """Packed E_hm [T,H*512] + cu_seqlens int64 [n_bags+1] -> (pooled_hm [n_bags,H*512], raw scores [T,H])."""
+        for h in self.attn:
+            h._check_geometry()
+        if self.attn[0].activation != 'softmax':
+            raise NotImplementedError("ragged bags are supported for activation='softmax' (the reference's scripts)")
+        wa, ba, wb, bb, wc, bc = self.gate_params_stacked()
+        p, seed, ka, kb = self._gate_dropout((E_hm.shape[0], 1))
+        return MF.attn_pool(E_hm, wa, ba, wb, bb, wc, bc, p, seed, ka, kb, cu_seqlens, max_len)
+
     def _scores_only(self, E_hm):
         BM, N, _ = E_hm.shape
         wa, ba, wb, bb, wc, bc = self.gate_params_stacked()
@@ -252,7 +262,45 @@ class MADELEINE(nn.Module):
         pooled, _, _ = self.wsi_embedders.forward_headmajor(feats)
         return self._project_slide(pooled)
 
+    def forward_ragged(self, bags, device, n_loss_tokens=256):
+        """Variable-length bags (BASELINE config 5) -- NEW functionality: the reference can only torch.stack equal-N
+        bags (wsi_dataset.py:89-92).  `bags` is a list over cases of lists over modalities of [N_bm, D] tensors.
+        Semantics = the train branch applied to each bag on its own (incl. the stain-encoding row quirk r // B of
+        Model.py:125-131); the pooling kernels take the packed tokens + cu_seqlens, nothing is padded.
+        Returns the reference-shaped dicts, with token embeddings restricted to the first `n_loss_tokens` tokens of
+        every bag -- all the local loss ever reads (GOT sub-samples randperm(k)[:256])."""
+        bs, n_mod = len(bags), len(bags[0])
+        flat = [bags[b][m] for b in range(bs) for m in range(n_mod)]          # case-major rows, like .view(bs*n_mod,...)
+        lens = [int(x.shape[0]) for x in flat]
+        if min(lens) < n_loss_tokens:
+            raise ValueError("every bag needs at least n_loss_tokens=%d tokens (shortest has %d)" % (n_loss_tokens, min(lens)))
+        cu = torch.zeros(len(flat) + 1, dtype=torch.int64)
+        cu[1:] = torch.cumsum(torch.tensor(lens, dtype=torch.int64), 0)
+        x = torch.cat([f.to(device) for f in flat], dim=0)                     # packed [T, D]
+        if self.stain_encoding:
+            row_stain = torch.arange(bs * n_mod) // bs                          # the train-branch quirk
+            tok_stain = torch.repeat_interleave(row_stain, torch.tensor(lens)).to(device)
+            x = torch.cat([x, self.embedding(tok_stain).to(x.dtype)], dim=-1)
+        emb = self.wsi_embedders
+        E = emb.embed_tokens_headmajor(x)                                       # [T, H*512]
+        cu_d = cu.to(device)
+        pooled, _ = emb.pool_headmajor_ragged(E, cu_d, max(lens))
+        slide = self._project_slide(pooled).view(bs, n_mod, 1, -1)              # [B,M,1,512]
+        head = (cu[:-1].unsqueeze(1) + torch.arange(n_loss_tokens).unsqueeze(0)).reshape(-1).to(device)
+        tok = self._project_tokens(E.index_select(0, head)).view(bs, n_mod, n_loss_tokens, -1)   # [B,M,n,128]
+        all_embeddings, all_token_embeddings = {}, {}
+        for idx, modality in enumerate(self.modalities):
+            s, t = slide[:, idx], tok[:, idx]
+            if modality == "HE":
+                s = s.unsqueeze(3).expand(-1, -1, -1, n_mod - 1)
+                t = t.unsqueeze(3).expand(-1, -1, -1, n_mod - 1)
+            all_embeddings[modality] = s
+            all_token_embeddings[modality] = t
+        return all_embeddings, all_token_embeddings
+
     def forward(self, data, device, train=True, n_views=1, custom_stain_idx=None, return_attention=False):
+        if 'bags' in data and 'feats' not in data:   # ragged extension (see forward_ragged); keeps DDP's forward hook path
+            return self.forward_ragged(data['bags'], device)
         all_wsi_feats = data['feats'].to(device)
         all_embeddings, all_token_embeddings = {}, {}
         emb = self.wsi_embedders
