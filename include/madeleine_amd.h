@@ -71,13 +71,14 @@ int mdl_abmil_gate_fwd(const float* E, int64_t ldE, const float* Wa, const float
 /* Backward of the above.  d_scores [T,H] incoming gradient.
  * dE [T,H*512] (row stride ldE): gradient wrt the token embeddings through the gates; written when
  *    accumulate == 0, added to the existing contents when accumulate != 0.
- * dWa,dWb [H,512,512]; dba,dbb,dwc [H,512]  (overwritten).  dbc = sum_t d_scores is left to the caller.
- * ws: mdl_abmil_gate_bwd_ws_bytes(T,H) bytes (split-K slabs). */
+ * dWa,dWb [H,512,512]; dba,dbb,dwc [H,512]; dbc [H] (may be NULL)  -- all overwritten.
+ * ws: mdl_abmil_gate_bwd_ws_bytes(T,H) bytes: d(za)|d(zb) [T+16,H,1024] (computed once, then both GEMMs are pure
+ *     LDS-DMA contractions) + split-K slabs + column-sum partials. */
 int64_t mdl_abmil_gate_bwd_ws_bytes(int64_t T, int H);
 int mdl_abmil_gate_bwd(const float* E, int64_t ldE, const float* Wa, const float* Wb, const float* wc,
                        const float* act_a, const float* act_b, const float* d_scores, float* dE,
                        int accumulate, float* dWa, float* dWb, float* dba, float* dbb, float* dwc,
-                       int64_t T, int H, float p_drop, uint64_t seed, const uint8_t* keep_a,
+                       float* dbc, int64_t T, int H, float p_drop, uint64_t seed, const uint8_t* keep_a,
                        const uint8_t* keep_b, void* ws, void* stream);
 
 /* Materialises the keep-mask the two calls above derive from (seed, p_drop) when keep_a/keep_b are NULL:

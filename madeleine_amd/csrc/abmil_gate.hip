@@ -65,11 +65,6 @@ static inline int64_t xcd_head_grid(int64_t units, int per_unit, int H) {  // un
     return 8 * ((units + nshare - 1) / nshare) * per_unit;
 }
 
-struct GateSmem {
-    float A[2][GBK][LDA_S];
-    float B[2][GBK][LDB_S];
-};  // 50,176 bytes
-
 struct DropCfg {
     float p, inv;
     uint32_t thr;   // 16-bit threshold
@@ -112,54 +107,6 @@ __device__ __forceinline__ void mma_chunk(const float (*__restrict__ As)[LDA], c
             acc[0][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[ct], acc[0][ct], 0, 0, 0);
             acc[1][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[ct], acc[1][ct], 0, 0, 0);
         }
-    }
-}
-
-// One K-chunk with the NEXT chunk's staging folded into the MFMA stream.  An fp32 MFMA occupies the SIMD's matrix
-// pipe for 64 cycles but takes a few cycles to issue, so the ~200 non-MFMA instructions a chunk needs (fragment
-// ds_reads, the next chunk's global loads, its LDS stores and their address math) fit in the issue shadow of the
-// 64 MFMAs -- if they are interleaved with them instead of forming separate load / store phases during which the
-// matrix pipe idles (profiles/r01a: 66 % MFMA-busy with phases).  Fragments are double-buffered one k-step ahead;
-// global loads issue at k-step 0 and their LDS stores trail in k-steps 4..7 (>= 2048 cycles of latency cover).
-template <bool HAS_NEXT, class LoadF, class PieceF>
-__device__ __forceinline__ void mma_chunk_pipe(const float (*__restrict__ As)[LDA_S], const float (*__restrict__ Bs)[LDB_S],
-                                               f32x16 (&acc)[2][4], int wm, const int (&colb)[4], int lane,
-                                               LoadF&& issue_loads, PieceF&& store_piece) {
-    const int l32 = lane & 31, kh = lane >> 5;
-    float fa[2][2], fb[2][4];
-    auto read_frags = [&](int kk, int buf) {
-        const int k = kk * 2 + kh;
-        fa[buf][0] = As[k][wm * 64 + l32];
-        fa[buf][1] = As[k][wm * 64 + 32 + l32];
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) fb[buf][ct] = Bs[k][colb[ct] + l32];
-    };
-    read_frags(0, 0);
-#pragma unroll
-    for (int kk = 0; kk < GBK / 2; ++kk) {
-        const int cur = kk & 1;
-#ifndef GATE_X_NOFRAG
-        if (kk + 1 < GBK / 2) read_frags(kk + 1, cur ^ 1);
-#else
-        fa[cur ^ 1][0] = fa[cur][0]; fa[cur ^ 1][1] = fa[cur][1];
-        for (int ct = 0; ct < 4; ++ct) fb[cur ^ 1][ct] = fb[cur][ct];
-#endif
-        if (HAS_NEXT && kk == 0) issue_loads();
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            const int rt = m & 1, ct = m >> 1;
-            acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][rt], fb[cur][ct], acc[rt][ct], 0, 0, 0);
-            if (HAS_NEXT) {
-                if (kk == 4 && m == 1) store_piece(0);
-                if (kk == 5 && m == 1) store_piece(1);
-                if (kk == 6 && m == 1) store_piece(2);
-                if (kk == 6 && m == 5) store_piece(3);
-                if (kk == 7 && m == 1) store_piece(4);
-                if (kk == 7 && m == 5) store_piece(5);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -342,10 +289,15 @@ __global__ void gate_finalize_kernel(const float* __restrict__ part, const float
 }
 
 // ================================================================================================
-// backward: operand transform shared by dX and dW
+// backward, stage 1: d(za) | d(zb) once per step (+ every column sum), so that dX and dW are pure GEMMs
 //   dza = ds * wc_j * b' * (keep_a/(1-p)) * (1 - a^2)        b' = keep_b ? b/(1-p) : 0
 //   dzb = ds * wc_j * a' * (keep_b/(1-p)) * b (1 - b)        a' = keep_a ? a/(1-p) : 0
+// (ablation: computing this transform inside the staging of both GEMMs, x2 and x4 redundantly, cost 4.2 ms of
+//  the 21.9 ms backward at config 2; as one HBM-bound pass it is 8.6 GB ~ 1.8 ms and the column sums ride along.)
+// dz layout: [T + GBK][H][1024] = (dza[512] | dzb[512]); the GBK pad rows are zero (K-tail of the dW GEMM).
 // ================================================================================================
+constexpr int DZ_ROWS = 256;  // token rows per workgroup
+
 __device__ __forceinline__ void gate_dz(const DropCfg& d, float ds, float wcv, float a, float b, int64_t idx, float& dza,
                                         float& dzb, float& pab) {
     bool keep_a, keep_b;
@@ -359,18 +311,72 @@ __device__ __forceinline__ void gate_dz(const DropCfg& d, float ds, float wcv, f
     pab = ds * ad * bd;
 }
 
-// dX: C[t, n] = sum_j dza[t,j] Wa[j,n] + dzb[t,j] Wb[j,n];  tile 128 tokens x 256 of the 512 inputs.
-__global__ __launch_bounds__(256, 2) void gate_bwd_dx_kernel(const float* __restrict__ Wa, const float* __restrict__ Wb,
-                                                             const float* __restrict__ wc,
-                                                             const float* __restrict__ act_a,
-                                                             const float* __restrict__ act_b,
-                                                             const float* __restrict__ d_scores, float* __restrict__ dE,
-                                                             int64_t ldE, int accumulate, int64_t T, int H, DropCfg drop) {
-    // A (the d(za)|d(zb) operand, computed on the fly) is register-staged into a transposed K-major image; B (16 weight
-    // rows x 256 columns per chunk, already K-major in global memory) goes global -> LDS directly, one row per wave
-    // instruction.
+// grid (row blocks, H), 256 threads = 128 j-quads x 2 row phases.  slabV [nblk][H][4][512]: dba | dbb | dwc | (dbc at [0]).
+__global__ __launch_bounds__(256) void gate_dz_kernel(const float* __restrict__ wc, const float* __restrict__ act_a,
+                                                      const float* __restrict__ act_b, const float* __restrict__ d_scores,
+                                                      float* __restrict__ dz, float* __restrict__ slabV, int64_t T, int H,
+                                                      DropCfg drop) {
+    __shared__ float red[128][13];
+    const int tid = threadIdx.x, q = tid & 127, ph = tid >> 7, c = blockIdx.y;
+    const int64_t r0 = (int64_t)blockIdx.x * DZ_ROWS;
+    int64_t r1 = r0 + DZ_ROWS;
+    if (r1 > T) r1 = T;
+    const f32x4 vw = *reinterpret_cast<const f32x4*>(wc + c * HID + q * 4);
+    f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = sa, sw = sa;
+    float sds = 0.f;
+    for (int64_t r = r0 + ph; r < r1; r += 2) {
+        const float ds = d_scores[r * H + c];
+        const int64_t o = (r * H + c) * HID + q * 4;
+        const f32x4 va = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(act_a + o));
+        const f32x4 vb = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(act_b + o));
+        f32x4 za, zb;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float x, y, w;
+            gate_dz(drop, ds, vw[i], va[i], vb[i], o + i, x, y, w);
+            za[i] = x;
+            zb[i] = y;
+            sw[i] += w;
+        }
+        sa += za;
+        sb += zb;
+        sds += ds;
+        float* __restrict__ out = dz + (r * H + c) * 1024 + q * 4;
+        *reinterpret_cast<f32x4*>(out) = za;
+        *reinterpret_cast<f32x4*>(out + HID) = zb;
+    }
+    if (ph == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            red[q][i] = sa[i];
+            red[q][4 + i] = sb[i];
+            red[q][8 + i] = sw[i];
+        }
+        red[q][12] = sds;
+    }
+    __syncthreads();
+    if (ph == 0) {
+        float* __restrict__ o = slabV + ((int64_t)blockIdx.x * H + c) * 4 * HID + q * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            o[i] = sa[i] + red[q][i];
+            o[HID + i] = sb[i] + red[q][4 + i];
+            o[2 * HID + i] = sw[i] + red[q][8 + i];
+        }
+        if (q == 0) o[3 * HID] = sds + red[0][12];
+    }
+}
+
+// ================================================================================================
+// backward, stage 2: dE[t, c, :] (+)= dz[t, c, :] . [Wa_c ; Wb_c]     GEMM [T, 1024] x [1024, 512], both operands by LDS-DMA
+// A = dz rows (K-contiguous): swizzled row image like the forward; B = 16 weight rows x 256 columns per chunk (K-major
+// in global memory already): one 1-KiB row per wave instruction.  k order within a chunk: (8g+e | 8g+4+e) per half-wave.
+// ================================================================================================
+__global__ __launch_bounds__(256, 2) void gate_bwd_dx_kernel(const float* __restrict__ dz, const float* __restrict__ Wa,
+                                                             const float* __restrict__ Wb, float* __restrict__ dE,
+                                                             int64_t ldE, int accumulate, int64_t T, int H) {
     __shared__ __attribute__((aligned(16))) struct {
-        float A[2][GBK][LDA_S];
+        float A[2][GBM * GBK];
         float B[2][GBK][GBN];
     } sm;
     const int tid = threadIdx.x, lane = tid & 63, wm = (tid >> 6) >> 1, wn = (tid >> 6) & 1;
@@ -381,68 +387,60 @@ __global__ __launch_bounds__(256, 2) void gate_bwd_dx_kernel(const float* __rest
     if (t0 >= T) return;  // block-uniform
     const int n0 = nt * GBN;
 
-    // A staging: thread -> (row = tid/2, quad = tid%2): one float4 of a and of b per 8-wide j chunk
-    const int arow = tid >> 1, aq = tid & 1;
-    const int64_t at = t0 + arow;
-    const bool arow_ok = at < T;
-    const float ds_row = arow_ok ? d_scores[at * H + c] : 0.f;
-    const float* __restrict__ pa = act_a + ((arow_ok ? at : 0) * H + c) * HID + aq * 4;
-    const float* __restrict__ pb = act_b + ((arow_ok ? at : 0) * H + c) * HID + aq * 4;
-    const float* __restrict__ wcc = wc + c * HID + aq * 4;
-    const float* __restrict__ Wac = Wa + (int64_t)c * HID * HID + n0;  // + j*512 + n
-    const float* __restrict__ Wbc = Wb + (int64_t)c * HID * HID + n0;
-
-    f32x4 va, vb, vw;
-    auto issue_b = [&](int st, int j0) {  // 16 rows (8 of Wa, 8 of Wb) x 1 KiB, 4 per wave
+    const float* srcA[2];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int r = wave * 4 + q;
-            const float* src = (r < 8) ? (Wac + (int64_t)(j0 + r) * HID) : (Wbc + (int64_t)(j0 + r - 8) * HID);
-            glds16(src + lane * 4, &sm.B[st][r][0]);
-        }
-    };
-    auto load_regs = [&](int j0) {
-        if (arow_ok) {
-            va = *reinterpret_cast<const f32x4*>(pa + j0);
-            vb = *reinterpret_cast<const f32x4*>(pb + j0);
-        } else {
-            va = f32x4{0.f, 0.f, 0.f, 0.f};
-            vb = va;
-        }
-        vw = *reinterpret_cast<const f32x4*>(wcc + j0);
-    };
-    auto store_lds = [&](int st, int j0) {
-        const int64_t idx0 = (at * H + c) * HID + j0 + aq * 4;
+    for (int q = 0; q < 2; ++q) {
+        const int sl = (wave * 2 + q) * 64 + lane, row = sl >> 2, kq = (sl & 3) ^ ((row >> 2) & 3);
+        int64_t t = t0 + row;
+        if (t > T - 1) t = T - 1;
+        srcA[q] = dz + (t * H + c) * 1024 + kq * 4;
+    }
+    const float* __restrict__ Wac = Wa + (int64_t)c * HID * HID + n0 + lane * 4;  // + j*512
+    const float* __restrict__ Wbc = Wb + (int64_t)c * HID * HID + n0 + lane * 4;
+    auto issue = [&](int st, int k0) {  // k0 in [0,1024): first 512 = Wa rows, then Wb rows (a chunk never straddles)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float dza = 0.f, dzb = 0.f, pab;
-            if (arow_ok) gate_dz(drop, ds_row, vw[i], va[i], vb[i], idx0 + i, dza, dzb, pab);
-            sm.A[st][aq * 4 + i][arow] = dza;
-            sm.A[st][8 + aq * 4 + i][arow] = dzb;
-        }
+        for (int q = 0; q < 2; ++q) glds16(srcA[q] + k0, &sm.A[st][(wave * 2 + q) * 256]);
+        const float* wsrc = (k0 < HID) ? (Wac + (int64_t)k0 * HID) : (Wbc + (int64_t)(k0 - HID) * HID);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) glds16(wsrc + (int64_t)(wave * 4 + q) * HID, &sm.B[st][wave * 4 + q][0]);
     };
 
+    const int l32 = lane & 31, kh = lane >> 5;
+    const int colb[4] = {wn * 128, wn * 128 + 32, wn * 128 + 64, wn * 128 + 96};
+    int offA[2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const int r = wm * 64 + rt * 32 + l32;
+        offA[rt] = r * GBK + ((kh ^ ((r >> 2) & 3)) << 2);
+    }
     f32x16 acc[2][4];
     zero_acc(acc);
-    const int colb[4] = {wn * 128, wn * 128 + 32, wn * 128 + 64, wn * 128 + 96};
-    constexpr int NCH = HID / 8;  // 64 chunks of (8 a-rows + 8 b-rows)
-    issue_b(0, 0);
-    load_regs(0);
-    store_lds(0, 0);
+    constexpr int NCH = 2 * HID / GBK;  // 64 chunks
+    issue(0, 0);
     __syncthreads();
     for (int ch = 0; ch < NCH; ++ch) {
-        if (ch + 1 < NCH) {
-            issue_b((ch + 1) & 1, (ch + 1) * 8);
-            load_regs((ch + 1) * 8);
+        const int st = ch & 1;
+        if (ch + 1 < NCH) issue(st ^ 1, (ch + 1) * GBK);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            f32x4 fa[2];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) fa[rt] = *reinterpret_cast<const f32x4*>(&sm.A[st][offA[rt] ^ (g << 3)]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float fb[4];
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) fb[ct] = sm.B[st][8 * g + 4 * kh + e][colb[ct] + l32];
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    const int rt = m & 1, ct = m >> 1;
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[rt][e], fb[ct], acc[rt][ct], 0, 0, 0);
+                }
+            }
         }
-        GATE_PIN();
-        mma_chunk<LDA_S, GBN>(sm.A[ch & 1], sm.B[ch & 1], acc, wm, colb, lane);
-        GATE_PIN();
-        if (ch + 1 < NCH) store_lds((ch + 1) & 1, (ch + 1) * 8);
         __syncthreads();
     }
 
-    const int l32 = lane & 31;
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
@@ -460,47 +458,32 @@ __global__ __launch_bounds__(256, 2) void gate_bwd_dx_kernel(const float* __rest
         }
 }
 
-// dW^T tile: C[k', n] = sum_t X[t,k'] * dz[t, n]   (n < 128: dza column j0+n ; n >= 128: dzb column j0+n-128)
-// over the token range of this split.  Column sums dba, dbb, dwc are accumulated by the kt == 0 tiles.
-template <bool SUMS>
-__device__ __forceinline__ void gate_bwd_dw_body(const float* __restrict__ E, int64_t ldE,
-                                                             const float* __restrict__ wc,
-                                                             const float* __restrict__ act_a,
-                                                             const float* __restrict__ act_b,
-                                                             const float* __restrict__ d_scores,
-                                                             float* __restrict__ slabW, float* __restrict__ slabV,
-                                                             int64_t T, int H, int64_t tok_per_split, int n_splits, DropCfg drop) {
-    // A (16 token rows x 128 inputs of X per chunk) goes global -> LDS directly (two 512-B rows per wave instruction);
-    // B (d(za)|d(zb), computed on the fly) is register-staged.
+// ================================================================================================
+// backward, stage 3: dW^T tile  C[k', n] = sum_t X[t, k'] dz[t, n]   (n < 128: dza column j0+n ; else dzb column j0+n-128)
+// over the token range of this split; both operands are K-major in global memory -> LDS-DMA, natural images.
+// ================================================================================================
+__global__ __launch_bounds__(256, 2) void gate_bwd_dw_kernel(const float* __restrict__ E, int64_t ldE,
+                                                             const float* __restrict__ dz, float* __restrict__ slabW,
+                                                             int64_t T, int H, int64_t tok_per_split, int n_splits) {
     __shared__ __attribute__((aligned(16))) struct {
         float A[2][GBK][GBM];
-        float B[2][GBK][LDB_S];
+        float B[2][GBK][GBN];
     } sm;
-    // running column sums (dba, dbb, dwc: 3 x 4 floats per thread) live in LDS, not in VGPRs: the 128
-    // accumulator registers + the staged chunk already fill the 256-register budget of 2 waves/SIMD.
-    __shared__ float colsum[SUMS ? 256 * 13 : 1];
     const int tid = threadIdx.x, lane = tid & 63, wm = (tid >> 6) >> 1, wn = (tid >> 6) & 1;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // logical id: kt (1..3, or 0 for the SUMS variant) fastest, then jt, head, split: the tiles of one
-    // (split, head) share X and a/b rows through one XCD's L2
     const XcdHead xh = xcd_head(blockIdx.x, H);
-    constexpr int NKT = SUMS ? 1 : 3;
-    const int kt = SUMS ? 0 : 1 + xh.li % NKT, jt = (xh.li / NKT) % GATE_JT, c = xh.c,
-              sp = (xh.li / (NKT * GATE_JT)) * xh.nshare + xh.share;
+    const int kt = xh.li % 4, jt = (xh.li / 4) % GATE_JT, c = xh.c, sp = (xh.li / (4 * GATE_JT)) * xh.nshare + xh.share;
     if (sp >= n_splits) return;  // block-uniform
     const int k0 = kt * 128, j0 = jt * 128;
     const int64_t ts = (int64_t)sp * tok_per_split;
     int64_t te = ts + tok_per_split;
     if (te > T) te = T;
 
-    // staging maps: row r = f/32 in [0,16) (two passes), quad q = f%32 (fixed per thread = tid%32)
-    const int q = tid & 31;
-    const float* __restrict__ Xc = E + (int64_t)c * HID + k0 + q * 4;
-    const f32x4 vw = *reinterpret_cast<const f32x4*>(wc + c * HID + j0 + q * 4);
-    f32x4 va[2], vb[2];
-    float vds[2];
+    // A: two 512-B rows of X per wave instruction (rows past T re-read row T-1: their dz rows are the zero pad)
+    // B: one row per wave instruction: lanes 0-31 -> dza segment, lanes 32-63 -> dzb segment
     const float* __restrict__ Xg = E + (int64_t)c * HID + k0 + (lane & 31) * 4;
-    auto issue_a = [&](int st, int64_t tb) {  // rows past the split end re-read a valid row: their B rows are zero
+    const float* __restrict__ Zg = dz + (int64_t)c * 1024 + j0 + (lane & 31) * 4 + (lane >> 5) * HID;
+    auto issue = [&](int st, int64_t tb) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int r0 = (wave * 2 + q) * 2;
@@ -508,56 +491,10 @@ __device__ __forceinline__ void gate_bwd_dw_body(const float* __restrict__ E, in
             if (t > T - 1) t = T - 1;
             glds16(Xg + t * ldE, &sm.A[st][r0][0]);
         }
-    };
-    auto load_regs = [&](int64_t tb) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int r = (tid >> 5) + p * 8;
-            const int64_t t = tb + r;
-            if (t < te) {
-                const int64_t o = (t * H + c) * HID + j0 + q * 4;
-                va[p] = *reinterpret_cast<const f32x4*>(act_a + o);
-                vb[p] = *reinterpret_cast<const f32x4*>(act_b + o);
-                vds[p] = d_scores[t * H + c];
-            } else {
-                va[p] = f32x4{0.f, 0.f, 0.f, 0.f};
-                vb[p] = va[p];
-                vds[p] = 0.f;
-            }
-        }
-    };
-    if (SUMS) {
-#pragma unroll
-        for (int i = 0; i < 12; ++i) colsum[tid * 13 + i] = 0.f;
-    }
-    auto store_lds = [&](int st, int64_t tb) {
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int r = (tid >> 5) + p * 8;
-            const int64_t t = tb + r;
-            f32x4 za = {0.f, 0.f, 0.f, 0.f}, zb = za, pp = za;
-            if (t < te) {
-                const int64_t idx0 = (t * H + c) * HID + j0 + q * 4;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float dza, dzb, pab;
-                    gate_dz(drop, vds[p], vw[i], va[p][i], vb[p][i], idx0 + i, dza, dzb, pab);
-                    za[i] = dza;
-                    zb[i] = dzb;
-                    pp[i] = pab;
-                }
-            }
-            *reinterpret_cast<f32x4*>(&sm.B[st][r][q * 4]) = za;
-            *reinterpret_cast<f32x4*>(&sm.B[st][r][128 + q * 4]) = zb;
-            if (SUMS) {
-                float* cs = colsum + tid * 13;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    cs[i] += za[i];
-                    cs[4 + i] += zb[i];
-                    cs[8 + i] += pp[i];
-                }
-            }
+        for (int q = 0; q < 4; ++q) {
+            const int r = wave * 4 + q;
+            glds16(Zg + (tb + r) * (int64_t)H * 1024, &sm.B[st][r][0]);  // tb + r <= T + GBK - 1: inside the zero pad
         }
     };
 
@@ -565,21 +502,12 @@ __device__ __forceinline__ void gate_bwd_dw_body(const float* __restrict__ E, in
     zero_acc(acc);
     const int colb[4] = {wn * 128, wn * 128 + 32, wn * 128 + 64, wn * 128 + 96};
     const int64_t nch = (te > ts) ? (te - ts + GBK - 1) / GBK : 0;
-    if (nch > 0) {
-        issue_a(0, ts);
-        load_regs(ts);
-        store_lds(0, ts);
-    }
+    if (nch > 0) issue(0, ts);
     __syncthreads();
     for (int64_t ch = 0; ch < nch; ++ch) {
-        if (ch + 1 < nch) {
-            issue_a((int)((ch + 1) & 1), ts + (ch + 1) * GBK);
-            load_regs(ts + (ch + 1) * GBK);
-        }
-        GATE_PIN();
-        mma_chunk<GBM, LDB_S>(sm.A[ch & 1], sm.B[ch & 1], acc, wm, colb, lane);
-        GATE_PIN();
-        if (ch + 1 < nch) store_lds((int)((ch + 1) & 1), ts + (ch + 1) * GBK);
+        const int st = (int)(ch & 1);
+        if (ch + 1 < nch) issue(st ^ 1, ts + (ch + 1) * GBK);
+        mma_chunk<GBM, GBN>(sm.A[st], sm.B[st], acc, wm, colb, lane);
         __syncthreads();
     }
 
@@ -598,40 +526,6 @@ __device__ __forceinline__ void gate_bwd_dw_body(const float* __restrict__ E, in
                 so[(int64_t)kr * 1024 + col] = acc[rt][ct][r];
             }
         }
-
-    // column sums: reduce the 8 row-groups (tid>>5) that share quad q
-    if (SUMS) {
-        __syncthreads();
-        for (int e = tid; e < 32 * 12; e += 256) {
-            const int qq = e / 12, slot = e % 12;
-            float v = 0.f;
-#pragma unroll
-            for (int g = 0; g < 8; ++g) v += colsum[(g * 32 + qq) * 13 + slot];
-            const int which = slot >> 2, i = slot & 3;  // 0 dba, 1 dbb, 2 dwc
-            slabV[(((int64_t)sp * H + c) * 3 + which) * HID + j0 + qq * 4 + i] = v;
-        }
-    }
-}
-
-// The column-sum variant needs ~300 registers: it runs at 1 wave/SIMD (1/4 of the dW tiles); the plain
-// variant fits 2 waves/SIMD.
-__global__ __launch_bounds__(256, GATE_SUMS_WPE) void gate_bwd_dw_sums_kernel(const float* __restrict__ E, int64_t ldE,
-                                                                  const float* __restrict__ wc,
-                                                                  const float* __restrict__ act_a,
-                                                                  const float* __restrict__ act_b,
-                                                                  const float* __restrict__ d_scores,
-                                                                  float* __restrict__ slabW, float* __restrict__ slabV,
-                                                                  int64_t T, int H, int64_t tok_per_split, int n_splits, DropCfg drop) {
-    gate_bwd_dw_body<true>(E, ldE, wc, act_a, act_b, d_scores, slabW, slabV, T, H, tok_per_split, n_splits, drop);
-}
-__global__ __launch_bounds__(256, 2) void gate_bwd_dw_kernel(const float* __restrict__ E, int64_t ldE,
-                                                             const float* __restrict__ wc,
-                                                             const float* __restrict__ act_a,
-                                                             const float* __restrict__ act_b,
-                                                             const float* __restrict__ d_scores,
-                                                             float* __restrict__ slabW, float* __restrict__ slabV,
-                                                             int64_t T, int H, int64_t tok_per_split, int n_splits, DropCfg drop) {
-    gate_bwd_dw_body<false>(E, ldE, wc, act_a, act_b, d_scores, slabW, slabV, T, H, tok_per_split, n_splits, drop);
 }
 
 // dWa[c][j][k] = sum_s slabW[s][c][k][j] ; dWb[c][j][k] = sum_s slabW[s][c][k][512+j]  (32x32 LDS transpose)
@@ -658,14 +552,18 @@ __global__ __launch_bounds__(256) void gate_reduce_w_kernel(const float* __restr
 }
 
 __global__ void gate_reduce_v_kernel(const float* __restrict__ slabV, float* __restrict__ dba, float* __restrict__ dbb,
-                                     float* __restrict__ dwc, int H, int S) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over H*3*512
-    if (i >= H * 3 * HID) return;
-    const int j = i % HID, which = (i / HID) % 3, c = i / (3 * HID);
+                                     float* __restrict__ dwc, float* __restrict__ dbc, int H, int S) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over H*4*512
+    if (i >= H * 4 * HID) return;
+    const int j = i % HID, which = (i / HID) % 4, c = i / (4 * HID);
+    if (which == 3 && j != 0) return;
     float v = 0.f;
-    for (int s = 0; s < S; ++s) v += slabV[(((int64_t)s * H + c) * 3 + which) * HID + j];
-    float* dst = which == 0 ? dba : (which == 1 ? dbb : dwc);
-    dst[c * HID + j] = v;
+    for (int s = 0; s < S; ++s) v += slabV[(((int64_t)s * H + c) * 4 + which) * HID + j];
+    if (which == 3) {
+        if (dbc) dbc[c] = v;
+    } else {
+        (which == 0 ? dba : (which == 1 ? dbb : dwc))[c * HID + j] = v;
+    }
 }
 
 __global__ void gate_mask_kernel(uint8_t* __restrict__ keep, int64_t n, int which, uint32_t key, uint32_t thr) {
@@ -736,17 +634,20 @@ extern "C" int mdl_abmil_gate_fwd(const float* E, int64_t ldE, const float* Wa, 
     return MDL_OK;
 }
 
+static inline int64_t dz_blocks(int64_t T) { return (T + DZ_ROWS - 1) / DZ_ROWS; }
+
 extern "C" int64_t mdl_abmil_gate_bwd_ws_bytes(int64_t T, int H) {
     if (T < 0 || H < 1 || H > MDL_MAX_HEADS) return MDL_E_ARG;
     const int S = gate_splits(T);
-    return (int64_t)S * H * HID * 1024 * 4 + (int64_t)S * H * 3 * HID * 4 + 64;
+    // dz [(T + GBK)][H][1024] | slabW [S][H][512][1024] | slabV [dz_blocks][H][4][512]
+    return ((T + GBK) * H * 1024 + (int64_t)S * H * HID * 1024 + dz_blocks(T) * H * 4 * HID) * 4 + 64;
 }
 
 extern "C" int mdl_abmil_gate_bwd(const float* E, int64_t ldE, const float* Wa, const float* Wb, const float* wc,
                                   const float* act_a, const float* act_b, const float* d_scores, float* dE,
-                                  int accumulate, float* dWa, float* dWb, float* dba, float* dbb, float* dwc, int64_t T,
-                                  int H, float p_drop, uint64_t seed, const uint8_t* keep_a, const uint8_t* keep_b,
-                                  void* ws, void* stream) {
+                                  int accumulate, float* dWa, float* dWb, float* dba, float* dbb, float* dwc, float* dbc,
+                                  int64_t T, int H, float p_drop, uint64_t seed, const uint8_t* keep_a,
+                                  const uint8_t* keep_b, void* ws, void* stream) {
     if (!E || !Wa || !Wb || !wc || !act_a || !act_b || !d_scores || !dE || !dWa || !dWb || !dba || !dbb || !dwc || !ws)
         return MDL_E_ARG;
     if ((keep_a == nullptr) != (keep_b == nullptr)) return MDL_E_ARG;
@@ -760,26 +661,33 @@ extern "C" int mdl_abmil_gate_bwd(const float* E, int64_t ldE, const float* Wa, 
     const DropCfg d = make_drop(p_drop, seed, keep_a, keep_b);
     const int S = gate_splits(T);
     const int64_t tps = gate_tok_per_split(T, S);
-    float* slabW = (float*)ws;
+    float* dz = (float*)ws;
+    float* slabW = dz + (T + GBK) * H * 1024;
     float* slabV = slabW + (int64_t)S * H * HID * 1024;
+    const int64_t nblk = dz_blocks(T);
+    {   // zero pad rows of dz (K-tail of the dW GEMM)
+        const hipError_t e = hipMemsetAsync(dz + T * H * 1024, 0, (size_t)GBK * H * 1024 * sizeof(float), s);
+        if (e != hipSuccess) return (int)e;
+    }
     if (T > 0) {
+        if (nblk > 0x7fffffff) return MDL_E_UNSUPPORTED;
+        hipLaunchKernelGGL(gate_dz_kernel, dim3((unsigned)nblk, H), dim3(256), 0, s, wc, act_a, act_b, d_scores, dz, slabV, T, H,
+                           d);
+        MDL_LAUNCH_CHECK();
         const int64_t n_tt = (T + GBM - 1) / GBM;
         const int64_t grid = xcd_head_grid(n_tt, 2, H);
         if (grid > 0x7fffffff) return MDL_E_UNSUPPORTED;
-        hipLaunchKernelGGL(gate_bwd_dx_kernel, dim3((unsigned)grid), dim3(256), 0, s, Wa, Wb, wc, act_a, act_b,
-                           d_scores, dE, ldE, accumulate, T, H, d);
+        hipLaunchKernelGGL(gate_bwd_dx_kernel, dim3((unsigned)grid), dim3(256), 0, s, (const float*)dz, Wa, Wb, dE, ldE,
+                           accumulate, T, H);
         MDL_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(gate_bwd_dw_sums_kernel, dim3((unsigned)xcd_head_grid(S, 1 * GATE_JT, H)), dim3(256), 0, s, E, ldE, wc,
-                       act_a, act_b, d_scores, slabW, slabV, T, H, tps, S, d);
-    MDL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gate_bwd_dw_kernel, dim3((unsigned)xcd_head_grid(S, 3 * GATE_JT, H)), dim3(256), 0, s, E, ldE, wc, act_a,
-                       act_b, d_scores, slabW, slabV, T, H, tps, S, d);
+    hipLaunchKernelGGL(gate_bwd_dw_kernel, dim3((unsigned)xcd_head_grid(S, 4 * GATE_JT, H)), dim3(256), 0, s, E, ldE,
+                       (const float*)dz, slabW, T, H, tps, S);
     MDL_LAUNCH_CHECK();
     hipLaunchKernelGGL(gate_reduce_w_kernel, dim3(32, 16, H), dim3(256), 0, s, (const float*)slabW, dWa, dWb, H, S);
     MDL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gate_reduce_v_kernel, dim3((H * 3 * HID + 255) / 256), dim3(256), 0, s, (const float*)slabV, dba, dbb,
-                       dwc, H, S);
+    hipLaunchKernelGGL(gate_reduce_v_kernel, dim3((H * 4 * HID + 255) / 256), dim3(256), 0, s, (const float*)slabV, dba, dbb,
+                       dwc, dbc, H, (int)nblk);
     MDL_LAUNCH_CHECK();
     return MDL_OK;
 }

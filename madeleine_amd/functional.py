@@ -105,13 +105,15 @@ def gate_bwd_raw(E2d, Wa, Wb, wc, act_a, act_b, d_scores, dE, accumulate, p_drop
     dWa, dWb = torch.empty_like(Wa), torch.empty_like(Wb)
     dba = torch.empty(H, HID, device=dev, dtype=torch.float32)
     dbb, dwc = torch.empty_like(dba), torch.empty_like(dba)
+    dbc = torch.empty(H, device=dev, dtype=torch.float32)
     ws = _ws(lib.mdl_abmil_gate_bwd_ws_bytes(T, H), dev)
     with _timed("gate_bwd"):
         rc = lib.mdl_abmil_gate_bwd(_ptr(E2d), E2d.stride(0), _ptr(Wa), _ptr(Wb), _ptr(wc), _ptr(act_a), _ptr(act_b),
                                     _ptr(d_scores), _ptr(dE), int(accumulate), _ptr(dWa), _ptr(dWb), _ptr(dba), _ptr(dbb),
-                                    _ptr(dwc), T, H, float(p_drop), int(seed), _ptr(keep_a), _ptr(keep_b), _ptr(ws), _stream())
+                                    _ptr(dwc), _ptr(dbc), T, H, float(p_drop), int(seed), _ptr(keep_a), _ptr(keep_b),
+                                    _ptr(ws), _stream())
     _native.check(rc, "mdl_abmil_gate_bwd")
-    return dWa, dWb, dba, dbb, dwc
+    return dWa, dWb, dba, dbb, dwc, dbc
 
 
 def pool_fwd_raw(E2d, scores, n_bags, N, cu_seqlens, max_len):
@@ -178,8 +180,8 @@ class GateScoresFn(torch.autograd.Function):
         p_drop, seed, keep_a, keep_b = ctx.drop
         d_scores = d_scores.contiguous()
         dE = torch.empty_like(E2d)
-        dWa, dWb, dba, dbb, dwc = gate_bwd_raw(E2d, Wa, Wb, wc, act_a, act_b, d_scores, dE, 0, p_drop, seed, keep_a, keep_b)
-        dbc = d_scores.sum(dim=0)
+        dWa, dWb, dba, dbb, dwc, dbc = gate_bwd_raw(E2d, Wa, Wb, wc, act_a, act_b, d_scores, dE, 0, p_drop, seed, keep_a,
+                                                    keep_b)
         return dE, dWa, dba, dWb, dbb, dwc, dbc, None, None, None, None
 
 
@@ -247,8 +249,7 @@ class AttnPoolFn(torch.autograd.Function):
         if d_pooled is None:
             d_pooled = torch.zeros_like(pooled)
         pool_bwd_raw(E2d, scores, pooled, m, l, d_pooled.contiguous(), dE, 0, ds, acc_s, n_bags, N, cu, max_len)
-        dWa, dWb, dba, dbb, dwc = gate_bwd_raw(E2d, Wa, Wb, wc, act_a, act_b, ds, dE, 1, p_drop, seed, keep_a, keep_b)
-        dbc = ds.sum(dim=0)
+        dWa, dWb, dba, dbb, dwc, dbc = gate_bwd_raw(E2d, Wa, Wb, wc, act_a, act_b, ds, dE, 1, p_drop, seed, keep_a, keep_b)
         return dE.view(e_shape), dWa, dba, dWb, dbb, dwc, dbc, None, None, None, None, None, None
 
 

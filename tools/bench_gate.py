@@ -44,7 +44,7 @@ for it in range(a.iters + 1):
         rc = h.mdl_abmil_gate_fwd(P(E), E.stride(0), P(Wa), P(ba), P(Wb), P(bb), P(wc), P(bc), P(scores), P(aa), P(ab), T, H, a.p, 7, None, None, P(wsf), st)
         assert rc == 0, rc
         e[1].record()
-        rc = h.mdl_abmil_gate_bwd(P(E), E.stride(0), P(Wa), P(Wb), P(wc), P(aa), P(ab), P(ds), P(dE), 0, P(dWa), P(dWb), P(dba), P(dbb), P(dwc), T, H, a.p, 7, None, None, P(wsb), st)
+        rc = h.mdl_abmil_gate_bwd(P(E), E.stride(0), P(Wa), P(Wb), P(wc), P(aa), P(ab), P(ds), P(dE), 0, P(dWa), P(dWb), P(dba), P(dbb), P(dwc), None, T, H, a.p, 7, None, None, P(wsb), st)
         assert rc == 0, rc
         e[2].record()
         torch.cuda.synchronize()
