@@ -60,7 +60,8 @@ const char* mdl_version(void);
  * dropout: p_drop in [0,1). keep_a/keep_b (uint8 [T,H,512], 1 = keep) inject explicit masks (parity
  *          tests); when NULL and p_drop > 0 a counter-based hash of (seed, element index) decides.
  *          p_drop == 0 (module.eval()) => identity.
- * ws     workspace of mdl_abmil_gate_fwd_ws_bytes(T,H) bytes (score partials per 128-wide j tile).
+ * ws     workspace of mdl_abmil_gate_fwd_ws_bytes(T,H) bytes (K-major copy of the weights + score partials per
+ *        128-wide j tile).
  */
 int64_t mdl_abmil_gate_fwd_ws_bytes(int64_t T, int H);
 int mdl_abmil_gate_fwd(const float* E, int64_t ldE, const float* Wa, const float* ba, const float* Wb,

@@ -125,30 +125,44 @@ __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (
 // ================================================================================================
 // forward
 // ================================================================================================
-// Direct-to-LDS staging (global_load_lds_dwordx4): both operands of the forward GEMM are K-contiguous in global
-// memory (E rows, W rows), so a wave instruction deposits 64 x 16 B = 16 rows x 64 B (BK = 16) straight into a
-// row-major LDS image [row][16 k] -- no staging VGPRs, no ds_write pass (ablation: register staging + transposed
-// ds_write_b32 scatter cost 11 % of the kernel).  The image must be lane-linear, so bank conflicts are removed on
-// the SOURCE side: the 16-B chunk a lane fetches is XOR-swizzled, slot = kq ^ ((row >> 2) & 3), and fragment reads
-// apply the same involution.  Fragments are ds_read_b128 = 4 consecutive k of one row; the MFMA's K = 2 is fed with
-// k-pairs (k0+s | k0+4+s) from the two half-waves -- a permutation of the k order, applied to A and B alike.
-struct GateSmemD {
-    float A[2][GBM * GBK];  // 8 KiB per stage
-    float B[2][GBN * GBK];  // 16 KiB per stage
-};
-
+// Direct-to-LDS staging (global_load_lds_dwordx4).  A = E rows (K-contiguous): a wave instruction deposits 64 x 16 B
+// = 16 rows x 64 B (BK = 16) straight into a row-major LDS image [row][16 k] -- no staging VGPRs, no ds_write pass
+// (ablation: register staging + transposed ds_write_b32 scatter cost 11 % of the kernel).  The image must be
+// lane-linear, so bank conflicts are removed on the SOURCE side: the 16-B chunk a lane fetches is XOR-swizzled,
+// slot = kq ^ ((row >> 2) & 3), and the ds_read_b128 fragment reads apply the same involution; the MFMA's K = 2 is
+// fed with k-pairs (8g+e | 8g+4+e) from the two half-waves (a permutation of the k order, applied to A and B alike).
+// B = the gate weights, transposed once per call into a K-major image WT [H][512 k][a j 0..511 | b j 0..511]
+// (gate_wt_kernel, 8 MiB): a chunk is then 16 rows x (128 a | 128 b) columns, one 1-KiB row per wave instruction,
+// read back with conflict-free ds_read_b32 -- which keeps the kernel at ~160 VGPRs = 3 waves/SIMD.
 __device__ __forceinline__ void glds16(const float* gsrc, float* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// WT[c][k][j] = Wa[c][j][k], WT[c][k][512 + j] = Wb[c][j][k]   (32 x 32 LDS transpose)
+__global__ __launch_bounds__(256) void gate_wt_kernel(const float* __restrict__ Wa, const float* __restrict__ Wb,
+                                                      float* __restrict__ WT) {
+    __shared__ float tile[32][33];
+    const int c = blockIdx.z, jb = blockIdx.y * 32, kb = blockIdx.x * 32;  // jb over 1024 (a | b), kb over 512
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float* __restrict__ W = (jb < HID) ? Wa + ((int64_t)c * HID + jb) * HID : Wb + ((int64_t)c * HID + jb - HID) * HID;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tile[ty + i * 8][tx] = W[(int64_t)(ty + i * 8) * HID + kb + tx];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) WT[((int64_t)c * HID + kb + ty + i * 8) * 1024 + jb + tx] = tile[tx][ty + i * 8];
+}
+
 __global__ __launch_bounds__(256, 2) void gate_fwd_kernel(const float* __restrict__ E, int64_t ldE,
-                                                          const float* __restrict__ Wa, const float* __restrict__ ba,
-                                                          const float* __restrict__ Wb, const float* __restrict__ bb,
-                                                          const float* __restrict__ wc, float* __restrict__ part,
-                                                          float* __restrict__ act_a, float* __restrict__ act_b,
-                                                          int64_t T, int H, int n_ttiles, DropCfg drop) {
-    __shared__ __attribute__((aligned(16))) GateSmemD sm;
+                                                          const float* __restrict__ WT, const float* __restrict__ ba,
+                                                          const float* __restrict__ bb, const float* __restrict__ wc,
+                                                          float* __restrict__ part, float* __restrict__ act_a,
+                                                          float* __restrict__ act_b, int64_t T, int H, int n_ttiles,
+                                                          DropCfg drop) {
+    __shared__ __attribute__((aligned(16))) struct {
+        float A[2][GBM * GBK];  // 8 KiB per stage
+        float B[2][GBK][GBN];   // 16 KiB per stage
+    } sm;
     const int tid = threadIdx.x, lane = tid & 63, wm = (tid >> 6) >> 1, wn = (tid >> 6) & 1;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform (LDS-DMA destination base)
     const XcdHead xh = xcd_head(blockIdx.x, H);
@@ -157,10 +171,9 @@ __global__ __launch_bounds__(256, 2) void gate_fwd_kernel(const float* __restric
     const int64_t t0 = (int64_t)tt * GBM;
     const int j0 = jt * 128;
 
-    // ---- LDS-DMA sources: instruction q of wave w fills slots [(w*NI+q)*64, +64); slot s = (row = s>>2, kq' = s&3)
-    //      holds global chunk kq = kq' ^ ((row>>2)&3) of that row.  Rows past T re-read row T-1 (discarded later).
+    // LDS-DMA sources.  A: instruction q of wave w fills slots [(2w+q)*64, +64); slot s = (row = s>>2, kq' = s&3) holds
+    // global chunk kq = kq' ^ ((row>>2)&3) of that row; rows past T re-read row T-1 (discarded in the epilogue).
     const float* srcA[2];
-    const float* srcB[4];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int sl = (wave * 2 + q) * 64 + lane, row = sl >> 2, kq = (sl & 3) ^ ((row >> 2) & 3);
@@ -168,32 +181,22 @@ __global__ __launch_bounds__(256, 2) void gate_fwd_kernel(const float* __restric
         if (t > T - 1) t = T - 1;
         srcA[q] = E + t * ldE + (int64_t)c * HID + kq * 4;
     }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int sl = (wave * 4 + q) * 64 + lane, row = sl >> 2, kq = (sl & 3) ^ ((row >> 2) & 3);  // row in [0,256)
-        const float* w = (row < 128) ? Wa + ((int64_t)c * HID + j0 + row) * HID : Wb + ((int64_t)c * HID + j0 + row - 128) * HID;
-        srcB[q] = w + kq * 4;
-    }
+    // B: row k of WT, lanes 0-31 -> a columns j0.., lanes 32-63 -> b columns 512 + j0..
+    const float* __restrict__ srcB = WT + (int64_t)c * HID * 1024 + j0 + (lane & 31) * 4 + (lane >> 5) * HID;
     auto issue = [&](int st, int k0) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) glds16(srcA[q] + k0, &sm.A[st][(wave * 2 + q) * 256]);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) glds16(srcB[q] + k0, &sm.B[st][(wave * 4 + q) * 256]);
+        for (int q = 0; q < 4; ++q) glds16(srcB + (int64_t)(k0 + wave * 4 + q) * 1024, &sm.B[st][wave * 4 + q][0]);
     };
 
-    // ---- fragment addressing: lane reads row r, chunk (2g + kh) -> slot ((2g+kh) ^ sw(r)); g = 1 flips slot bit 1
     const int l32 = lane & 31, kh = lane >> 5;
     const int colb[4] = {wn * 64, wn * 64 + 32, 128 + wn * 64, 128 + wn * 64 + 32};  // a, a, b, b
-    int offA[2], offB[4];
+    int offA[2];
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
         const int r = wm * 64 + rt * 32 + l32;
         offA[rt] = r * GBK + ((kh ^ ((r >> 2) & 3)) << 2);
-    }
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-        const int r = colb[ct] + l32;
-        offB[ct] = r * GBK + ((kh ^ ((r >> 2) & 3)) << 2);
     }
 
     f32x16 acc[2][4];
@@ -204,46 +207,49 @@ __global__ __launch_bounds__(256, 2) void gate_fwd_kernel(const float* __restric
     for (int ch = 0; ch < NCH; ++ch) {
         const int st = ch & 1;
         if (ch + 1 < NCH) issue(st ^ 1, (ch + 1) * GBK);  // lands in the stage last read before the previous barrier
-        f32x4 fa[2][2], fb[2][4];
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
+            f32x4 fa[2];
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt) fa[g][rt] = *reinterpret_cast<const f32x4*>(&sm.A[st][offA[rt] ^ (g << 3)]);
+            for (int rt = 0; rt < 2; ++rt) fa[rt] = *reinterpret_cast<const f32x4*>(&sm.A[st][offA[rt] ^ (g << 3)]);
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) fb[g][ct] = *reinterpret_cast<const f32x4*>(&sm.B[st][offB[ct] ^ (g << 3)]);
-        }
+            for (int e = 0; e < 4; ++e) {
+                float fb[4];
 #pragma unroll
-        for (int g = 0; g < 2; ++g)
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
+                for (int ct = 0; ct < 4; ++ct) fb[ct] = sm.B[st][8 * g + 4 * kh + e][colb[ct] + l32];
 #pragma unroll
                 for (int m = 0; m < 8; ++m) {
                     const int rt = m & 1, ct = m >> 1;
-                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g][rt][e], fb[g][ct][e], acc[rt][ct], 0, 0, 0);
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[rt][e], fb[ct], acc[rt][ct], 0, 0, 0);
                 }
+            }
+        }
         __syncthreads();  // drains the LDS-DMA of chunk ch+1 (vmcnt) and fences this chunk's reads
     }
 
-    // ---- epilogue: activations, dropout, wc-weighted row reduction ---------------------------------
-    // (l32 defined above)
-    float ps[2][16];
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ps[rt][r] = 0.f;
+    // ---- epilogue: activations, dropout, wc-weighted row reduction (one 32-row tile at a time: 16 live partials) ----
+    float* sred = &sm.A[0][0];  // [2 (wn)][128 rows]; all MFMA reads finished at the loop's last barrier
+    float bav[2], bbv[2], wcv[2];
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
         const int j = j0 + wn * 64 + ct * 32 + l32;
-        const float bav = ba[c * HID + j], bbv = bb[c * HID + j], wcv = wc[c * HID + j];
+        bav[ct] = ba[c * HID + j];
+        bbv[ct] = bb[c * HID + j];
+        wcv[ct] = wc[c * HID + j];
+    }
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
+    for (int rt = 0; rt < 2; ++rt) {
+        float ps[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t t = t0 + wm * 64 + rt * 32 + acc_row(r, lane);
-                const float a = fast_tanh(acc[rt][ct][r] + bav);
-                const float b = fast_sigmoid(acc[rt][2 + ct][r] + bbv);
+        for (int r = 0; r < 16; ++r) {
+            const int64_t t = t0 + wm * 64 + rt * 32 + acc_row(r, lane);
+            float sum = 0.f;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                const float a = fast_tanh(acc[rt][ct][r] + bav[ct]);
+                const float b = fast_sigmoid(acc[rt][2 + ct][r] + bbv[ct]);
                 if (t < T) {
-                    const int64_t idx = (t * H + c) * HID + j;
+                    const int64_t idx = (t * H + c) * HID + j0 + wn * 64 + ct * 32 + l32;
                     if (act_a) {
                         act_a[idx] = a;
                         act_b[idx] = b;
@@ -252,26 +258,18 @@ __global__ __launch_bounds__(256, 2) void gate_fwd_kernel(const float* __restric
                     drop_keep2(drop, idx, keep_a, keep_b);
                     const float ad = keep_a ? a * drop.inv : 0.f;
                     const float bd = keep_b ? b * drop.inv : 0.f;
-                    ps[rt][r] += ad * bd * wcv;
+                    sum += ad * bd * wcv[ct];
                 }
             }
+            ps[r] = sum;
         }
-    }
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            float v = ps[rt][r];
+            float v = ps[r];
 #pragma unroll
             for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-            ps[rt][r] = v;
+            if (l32 == 0) sred[wn * GBM + wm * 64 + rt * 32 + acc_row(r, lane)] = v;
         }
-    float* sred = &sm.A[0][0];  // [2 (wn)][128 rows]; all MFMA reads finished at the loop's last barrier
-    if (l32 == 0) {
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sred[wn * GBM + wm * 64 + rt * 32 + acc_row(r, lane)] = ps[rt][r];
     }
     __syncthreads();
     if (tid < GBM) {
@@ -604,7 +602,8 @@ using namespace mdl;
 
 extern "C" int64_t mdl_abmil_gate_fwd_ws_bytes(int64_t T, int H) {
     if (T < 0 || H < 1 || H > MDL_MAX_HEADS) return MDL_E_ARG;
-    return T * H * GATE_JT * 4 + 64;
+    // WT [H][512][1024] (transposed weights) | score partials [T][H][4]
+    return ((int64_t)H * HID * 1024 + T * H * GATE_JT) * 4 + 64;
 }
 
 extern "C" int mdl_abmil_gate_fwd(const float* E, int64_t ldE, const float* Wa, const float* ba, const float* Wb,
@@ -624,11 +623,15 @@ extern "C" int mdl_abmil_gate_fwd(const float* E, int64_t ldE, const float* Wa, 
     if (grid > 0x7fffffff) return MDL_E_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     const DropCfg d = make_drop(p_drop, seed, keep_a, keep_b);
-    hipLaunchKernelGGL(gate_fwd_kernel, dim3((unsigned)grid), dim3(256), 0, s, E, ldE, Wa, ba, Wb, bb, wc,
-                       (float*)ws, act_a, act_b, T, H, (int)n_tt, d);
+    float* WT = (float*)ws;
+    float* part = WT + (int64_t)H * HID * 1024;
+    hipLaunchKernelGGL(gate_wt_kernel, dim3(16, 32, H), dim3(256), 0, s, Wa, Wb, WT);
+    MDL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gate_fwd_kernel, dim3((unsigned)grid), dim3(256), 0, s, E, ldE, (const float*)WT, ba, bb, wc, part, act_a,
+                       act_b, T, H, (int)n_tt, d);
     MDL_LAUNCH_CHECK();
     const int64_t n = T * H;
-    hipLaunchKernelGGL(gate_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)ws, bc, scores,
+    hipLaunchKernelGGL(gate_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)part, bc, scores,
                        n, H);
     MDL_LAUNCH_CHECK();
     return MDL_OK;
