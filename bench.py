@@ -59,6 +59,30 @@ def usable_cores() -> int:
     return max(1, n)
 
 
+def pool_traffic_from_profiles(tokens_c2=64 * 4096):
+    """HBM bytes per launch of the A3 forward from the committed PMC passes (profiles/*_pool_pmc_{fetch,write}.txt:
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`, separate passes, same geometry as config 2).  FETCH_SIZE is in
+    KiB and on gfx950 counts half of a wide coalesced read stream (MI355X_MICROARCH.md, HBM section) -> x2."""
+    import glob
+    import re
+
+    def avg(kind, counter):
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_pool_pmc_{kind}.txt")))
+        if not files:
+            return None
+        tot = 0.0
+        for kern in ("pool_partial_kernel", "pool_combine_kernel"):
+            m = re.search(kern + r"\S*\s+" + counter + r"\s+\d+\s+[0-9.]+\s+([0-9.]+)", open(files[-1]).read())
+            if not m:
+                return None
+            tot += float(m.group(1))
+        return tot
+    f, w = avg("fetch", "FETCH_SIZE"), avg("write", "WRITE_SIZE")
+    if f is None or w is None:
+        return None
+    return int((2.0 * f + w) * 1024)
+
+
 def cpu_baseline(B_sample, M, N, D, use_got, steps=2):
     """Times the CPU oracle's full step (fwd + losses + bwd + AdamW, train-mode dropout) on B_sample slides."""
     from oracle import restatement as R
@@ -203,7 +227,8 @@ def main():
             ach = alg / (ms * 1e-3) / 1e9
             out["roofline"] = {"kernel": "abmil_pool_fwd (pool_partial + pool_combine)", "bound": "hbm",
                                "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                               "frac": round(ach / HBM_PEAK_GBS, 4),
+                               "traffic": pool_traffic_from_profiles() if (a.config == "c2" and world == 1) else None,
                                "algorithmic_bytes_per_launch": alg, "avg_ms": round(ms, 4), "launches": n}
         if "gate_fwd" in prof and "gate_bwd" in prof:
             msf, _ = prof["gate_fwd"]

@@ -549,18 +549,41 @@ __global__ __launch_bounds__(256) void gate_reduce_w_kernel(const float* __restr
     }
 }
 
-__global__ void gate_reduce_v_kernel(const float* __restrict__ slabV, float* __restrict__ dba, float* __restrict__ dbb,
-                                     float* __restrict__ dwc, float* __restrict__ dbc, int H, int S) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over H*4*512
-    if (i >= H * 4 * HID) return;
+// dba | dbb | dwc [H,512] and dbc [H] = sum over row blocks of slabV [S][H][4][512]: 32 columns x 8 block-groups per
+// workgroup, 8 loads in flight per thread, groups merged through LDS in a fixed order.
+__global__ __launch_bounds__(256) void gate_reduce_v_kernel(const float* __restrict__ slabV, float* __restrict__ dba,
+                                                            float* __restrict__ dbb, float* __restrict__ dwc,
+                                                            float* __restrict__ dbc, int H, int S) {
+    __shared__ float red[8][32];
+    const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + cl;  // over H*4*512
     const int j = i % HID, which = (i / HID) % 4, c = i / (4 * HID);
-    if (which == 3 && j != 0) return;
+    const bool live = i < H * 4 * HID && !(which == 3 && j != 0);
     float v = 0.f;
-    for (int s = 0; s < S; ++s) v += slabV[(((int64_t)s * H + c) * 4 + which) * HID + j];
-    if (which == 3) {
-        if (dbc) dbc[c] = v;
-    } else {
-        (which == 0 ? dba : (which == 1 ? dbb : dwc))[c * HID + j] = v;
+    if (live) {
+        const float* __restrict__ src = slabV + ((int64_t)c * 4 + which) * HID + j;
+        const int64_t stride = (int64_t)H * 4 * HID;
+        int s = grp;
+        for (; s + 56 < S; s += 64) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = src[(int64_t)(s + 8 * u) * stride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v += t[u];
+        }
+        for (; s < S; s += 8) v += src[(int64_t)s * stride];
+    }
+    red[grp][cl] = v;
+    __syncthreads();
+    if (grp == 0 && live) {
+        float t = red[0][cl];
+#pragma unroll
+        for (int g = 1; g < 8; ++g) t += red[g][cl];
+        if (which == 3) {
+            if (dbc) dbc[c] = t;
+        } else {
+            (which == 0 ? dba : (which == 1 ? dbb : dwc))[c * HID + j] = t;
+        }
     }
 }
 
@@ -689,7 +712,7 @@ extern "C" int mdl_abmil_gate_bwd(const float* E, int64_t ldE, const float* Wa, 
     MDL_LAUNCH_CHECK();
     hipLaunchKernelGGL(gate_reduce_w_kernel, dim3(32, 16, H), dim3(256), 0, s, (const float*)slabW, dWa, dWb, H, S);
     MDL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gate_reduce_v_kernel, dim3((H * 4 * HID + 255) / 256), dim3(256), 0, s, (const float*)slabV, dba, dbb,
+    hipLaunchKernelGGL(gate_reduce_v_kernel, dim3((H * 4 * HID + 31) / 32), dim3(256), 0, s, (const float*)slabV, dba, dbb,
                        dwc, dbc, H, (int)nblk);
     MDL_LAUNCH_CHECK();
     return MDL_OK;
