@@ -3,46 +3,24 @@
 // Replaces BatchedABMIL.forward (reference madeleine/models/abmil.py:41-68) called once per head from
 // ABMILEmbedder.forward (reference madeleine/models/Model.py:406-409):
 //     a = Dropout(.25)(tanh(x Wa^T + ba));  b = Dropout(.25)(sigmoid(x Wb^T + bb));  s = (a*b) wc^T + bc
-// Three fp32 contractions per head dominate the path (4.19 MFLOP/token fwd); they run
-// on v_mfma_f32_32x32x2_f32 (exact fp32 = an fmaf chain, 157 TFLOP/s peak) with the activation, dropout
-// and the wc-reduction fused into the epilogue (forward) / the operand staging (backward), so za, zb,
-// a*b and d(za), d(zb) never touch HBM.
+// Three fp32 contractions per head dominate the path (4.19 MFLOP/token fwd); they run on
+// v_mfma_f32_32x32x2_f32 (exact fp32 = an fmaf chain, 157 TFLOP/s peak).
 //
-//   forward : S_part[t, jt] = sum_{j in tile jt} a'_j b'_j wc_j          GEMM [T,512] x [512, 128a|128b]
-//   dX      : dE[t,c,:]     = dza[t,:] Wa + dzb[t,:] Wb                   GEMM [T, 512a|512b] x [1024,512]
-//   dW      : dWa = dza^T X, dWb = dzb^T X  (+ dba, dbb, dwc column sums) GEMM [512, T] x [T, 128a|128b], split over T
+//   forward : S_part[t, jt] = sum_{j in tile jt} a'_j b'_j wc_j      GEMM [T,512] x [512, 128a|128b], fused epilogue
+//   dz      : d(za)|d(zb) [T,H,1024] + column sums dba, dbb, dwc, dbc HBM-bound pass (once per step)
+//   dX      : dE[t,c,:]  (+)= dz[t,c,:] . [Wa;Wb]                     GEMM [T,1024] x [1024,512]
+//   dW      : [dWa;dWb]^T = X^T dz                                    GEMM [512,T] x [T,128a|128b], split over T
 //
-// One block tile shape for all three: 128 x 256 outputs, BK = 16, 256 threads = 4 waves (2 x 2), each
-// wave 64 x 128 = 2 x 4 MFMA 32x32 accumulators (128 acc registers).  LDS tiles are K-major
-// ([k][row]) so every MFMA fragment read is 32 consecutive floats per half-wave (conflict-free
-// ds_read_b32); global->register staging of chunk i+1 overlaps the MFMAs of chunk i, two LDS stages,
-// one barrier per chunk.  fp32 MFMA issues once per 64 cycles per SIMD, so LDS/global traffic is far
-// from limiting; 2 workgroups per CU keep the matrix pipe busy across barriers.
+// One block tile shape for the three GEMMs: 128 x 256 outputs, BK = 16, 256 threads = 4 waves (2 x 2), each wave
+// 64 x 128 = 2 x 4 MFMA 32x32 accumulators (128 registers).  Every operand reaches LDS by LDS-DMA
+// (global_load_lds_dwordx4: no staging VGPRs, no ds_write pass), two LDS stages of 24 KiB, the next chunk's DMA is
+// issued before the current chunk's 64 MFMAs, one barrier per chunk; ~160 VGPRs => 3 workgroups per CU.
 #include "common.hpp"
 
 namespace mdl {
 
 constexpr int GBM = 128, GBN = 256, GBK = 16;
-constexpr int LDA_S = GBM + 4;  // 132 floats: 16-B aligned rows, 2-way max on transposed stores
-constexpr int LDB_S = GBN + 4;  // 260
 constexpr int GATE_JT = HID / 128;  // 4 j-tiles of 128 gate columns per head
-
-// The global loads of chunk i+1 must be IN FLIGHT while chunk i's 64 MFMAs issue (4096 cycles per wave); left
-// alone, hipcc sinks them behind the MFMA block to save registers and every wave then eats the full HBM/L2
-// latency before its LDS stores (measured: 63 % of the fp32 MFMA peak).  sched_barrier(0) pins the order.
-#ifndef GATE_SUMS_WPE
-#define GATE_SUMS_WPE 2
-#endif
-#ifdef GATE_EXP_NOLOAD
-#define GATE_EXP_LOAD(x)
-#else
-#define GATE_EXP_LOAD(x) x
-#endif
-#ifndef GATE_NO_PIN
-#define GATE_PIN() __builtin_amdgcn_sched_barrier(0)
-#else
-#define GATE_PIN()
-#endif
 
 // Head <-> XCD affinity.  Workgroup b runs on XCD b % 8 (observed dispatch; used for speed only, never for
 // correctness).  XCD x works on head x % H and on the (x / H)-th interleaved share of that head's token tiles, so

@@ -124,6 +124,47 @@ def gather_slide_embeddings(wsi_embs: Dict[str, torch.Tensor], modalities: Seque
 # --------------------------------------------------------------------------------------------------
 # local (GOT) loss with global-batch semantics
 # --------------------------------------------------------------------------------------------------
+_SIDE_STREAMS = {}
+
+
+class _fan_out:
+    """Run independent launches on side HIP streams and join them back into the current stream:
+        with _fan_out(device, n) as lanes:
+            with lanes(i): launch_i()
+    Each lane first waits for the work already queued on the current stream; on exit the current stream waits for
+    every lane.  Tensors allocated inside a lane are only consumed after the join (same allocator stream semantics
+    as torch.cuda.stream + wait_stream).  On CPU tensors (gloo tests) it is a no-op."""
+
+    def __init__(self, device, n):
+        self.on = torch.device(device).type == "cuda" and n > 1
+        self.device, self.n = device, n
+
+    def __enter__(self):
+        if self.on:
+            key = (str(self.device), self.n)
+            if key not in _SIDE_STREAMS:
+                _SIDE_STREAMS[key] = [torch.cuda.Stream(device=self.device) for _ in range(self.n)]
+            self.streams = _SIDE_STREAMS[key]
+            self.main = torch.cuda.current_stream(self.device)
+            self.used = set()
+        return self._lane
+
+    def _lane(self, i):
+        import contextlib
+        if not self.on:
+            return contextlib.nullcontext()
+        st = self.streams[i]
+        st.wait_stream(self.main)
+        self.used.add(i)
+        return torch.cuda.stream(st)
+
+    def __exit__(self, *exc):
+        if self.on:
+            for i in self.used:
+                self.main.wait_stream(self.streams[i])
+        return False
+
+
 class _GOTMulti(torch.autograd.Function):
     """S GOT problems (one per stain) in ONE autograd node with global-batch thresholds.
 
@@ -146,14 +187,16 @@ class _GOTMulti(torch.autograd.Function):
             even = (torch.arange(6, device=dev) % 2 == 0)
             ext = torch.where(even, allx.amin(dim=0), allx.amax(dim=0))
         outs, states = [], []
-        for s, (V, Q) in enumerate(probs):
-            if V.shape[0] == 0:
-                outs.append(torch.zeros(2, device=dev, dtype=tensors[0].dtype))
-                states.append(None)
-            else:
-                o, st = impl.forward(V, Q, ext[s])
-                outs.append(o)
-                states.append(st)
+        with _fan_out(dev, S) as lanes:   # stains are independent: one HIP stream each (k <= 32 workgroups per problem)
+            for s, (V, Q) in enumerate(probs):
+                if V.shape[0] == 0:
+                    outs.append(torch.zeros(2, device=dev, dtype=tensors[0].dtype))
+                    states.append(None)
+                else:
+                    with lanes(s):
+                        o, st = impl.forward(V, Q, ext[s])
+                    outs.append(o)
+                    states.append(st)
         ctx.impl, ctx.group, ctx.states = impl, group, states
         ctx.shapes = [(V.shape, Q.shape) for V, Q in probs]
         return torch.stack(outs)
@@ -162,16 +205,26 @@ class _GOTMulti(torch.autograd.Function):
     def backward(ctx, d_outs):
         impl, states = ctx.impl, ctx.states
         dev = d_outs.device
-        dmm = torch.stack([impl.backward_begin(st, d_outs[s]) if st is not None else
-                           torch.zeros(6, device=dev, dtype=d_outs.dtype) for s, st in enumerate(states)])
+        d_outs = d_outs.contiguous()
+        parts = []
+        with _fan_out(dev, len(states)) as lanes:
+            for s, st in enumerate(states):
+                if st is None:
+                    parts.append(torch.zeros(6, device=dev, dtype=d_outs.dtype))
+                else:
+                    with lanes(s):
+                        parts.append(impl.backward_begin(st, d_outs[s]))
+        dmm = torch.stack(parts)
         if world_size(ctx.group) > 1:
             dmm = _all_reduce_sum(dmm, ctx.group)
         grads = []
-        for s, st in enumerate(states):
-            if st is None:
-                grads += [d_outs.new_zeros(ctx.shapes[s][0]), d_outs.new_zeros(ctx.shapes[s][1])]
-            else:
-                grads += list(impl.backward_finish(st, dmm[s]))
+        with _fan_out(dev, len(states)) as lanes:
+            for s, st in enumerate(states):
+                if st is None:
+                    grads += [d_outs.new_zeros(ctx.shapes[s][0]), d_outs.new_zeros(ctx.shapes[s][1])]
+                else:
+                    with lanes(s):
+                        grads += list(impl.backward_finish(st, dmm[s]))
         return (None, None) + tuple(grads)
 
 
