@@ -147,6 +147,7 @@ def main():
         # configuration): DDP must be told, or it raises on the second step.
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], find_unused_parameters=not use_got)
     opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
+    torch.manual_seed(1000 + rank)   # dropout seeds are drawn from torch's CPU generator: decorrelate the ranks
     crit = InfoNCE(temperature=0.001)
     got_impl = MF.HipGotImpl if use_got else None
     largs = SimpleNamespace(global_loss="info-nce", symmetric_cl=True, local_loss_weight=1.0)

@@ -286,6 +286,14 @@ extern "C" int mdl_ln_gelu_drop_fwd(const float* x, const float* gamma, const fl
     if (!host_aligned16(x) || !host_aligned16(y) || !host_aligned16(gamma) || !host_aligned16(beta)) return MDL_E_ALIGN;
     if (rows == 0) return MDL_OK;
     const ActDrop d = make_act_drop(p_drop, seed, keep);
+    if (W == 2048) {  // forward: a whole 2048-wide row per wave (153 VGPRs, no block barriers) beats 4 waves per row
+        int64_t nb = (rows + 3) / 4;
+        if (nb > 2048) nb = 2048;
+        hipLaunchKernelGGL((ln_gelu_drop_fwd_kernel<8, 1>), dim3((unsigned)nb), dim3(ACT_BLOCK), 0, (hipStream_t)stream, x, gamma,
+                           beta, y, mean, rstd, rows, eps, d);
+        MDL_LAUNCH_CHECK();
+        return MDL_OK;
+    }
     MDL_DISPATCH_W(W, {
         hipLaunchKernelGGL((ln_gelu_drop_fwd_kernel<NV, WPR>), dim3(act_blocks(rows, W)), dim3(ACT_BLOCK), 0, (hipStream_t)stream, x,
                            gamma, beta, y, mean, rstd, rows, eps, d);
