@@ -312,3 +312,36 @@ def test_forward_ragged_backward_and_losses(dev):
         a, b = grads[0][1][k], grads[1][1][k]
         assert torch.isfinite(b).all()
         assert float((a - b).norm()) <= 2e-3 * float(a.norm()) + 1e-6, k
+
+
+def test_train_loop_h2(dev, capsys):
+    """H2: the mirrored train_loop (trainer.py:80-144) drives fwd / losses / backward / AdamW / schedulers over a
+    dataloader of collate()-shaped batches, skips an H&E-only batch, and returns (epoch loss, smooth rank)."""
+    import madeleine_amd.trainer as TR
+    from madeleine_amd import GOT, InfoNCE, train_loop
+    TR.DEVICE = dev
+    B, M, N, D = 4, 3, 260, 64
+    mods = MODS5[:M]
+    model = build(mods, D, "wfs", dev)
+    args = SimpleNamespace(STAINS=mods[1:], precision="float32", warmup_epochs=1, global_loss="info-nce", symmetric_cl=True,
+                           local_loss_weight=1.0)
+    full = torch.ones(B, M)
+    he_only = torch.zeros(B, M)
+    he_only[:, 0] = 1
+    batches = [{"feats": t((B, M, N, D), f"tl:{i}"), "modality_labels": lab, "slide_ids": [str(j) for j in range(B)]}
+               for i, lab in enumerate((full, he_only, full))]
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    warm = torch.optim.lr_scheduler.LinearLR(opt, start_factor=1e-5, total_iters=4)          # setup_components.py:204
+    cos = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=10, eta_min=1e-8)            # :201
+    before = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    torch.manual_seed(0)
+    ep_loss, rank = train_loop(args, InfoNCE(temperature=0.001), GOT, None, model, 0, batches, opt, warm, cos)
+    out = capsys.readouterr().out
+    assert "Skipping batch with only HE" in out and "Loss for batch: 0" in out
+    assert model.training and np.isfinite(ep_loss) and ep_loss > 0 and rank > 0
+    changed = sum(int(not torch.equal(before[k], v)) for k, v in model.state_dict().items())
+    assert changed >= 30                                             # every trained tensor moved
+    assert warm.last_epoch == 2                                      # two optimiser steps (one batch skipped), warm-up branch
+    # epoch > warmup_epochs uses the cosine scheduler instead
+    ep2, _ = train_loop(args, InfoNCE(temperature=0.001), None, None, model, 5, batches[:1], opt, warm, cos)
+    assert cos.last_epoch == 1 and np.isfinite(ep2)
