@@ -108,3 +108,30 @@ def test_utils_mirror():
         set_model_precision("int8")
     r = smooth_rank_measure(torch.eye(8))
     assert abs(r - 8.0) < 0.05
+
+
+def test_dataset_collate_contract():
+    """N4: item / collate contract of wsi_dataset.py (fixed-N resample, zero bag for an absent stain, stacking)."""
+    import pandas as pd
+    from madeleine_amd.data import SlideDataset, SyntheticSlideDataset, collate
+    df = pd.DataFrame({"slide_id": ["a", "b"], "HE": [1, 1], "ER": [1, 0], "split": ["train", "val"]})
+    seen = []
+
+    def loader(path):
+        seen.append(path)
+        return torch.arange(10 * 4, dtype=torch.float32).view(10, 4) if path.endswith("a_HE.h5") else torch.ones(3, 4)
+
+    ds = SlideDataset("x", None, "/feats", ["HE", "ER"], embedding_size=4, sample=6, feature_loader=loader, dataframe=df)
+    a, b = ds[0], ds[1]
+    assert [f.shape for f in a["feats"]] == [torch.Size([6, 4])] * 2 and a["modality_labels"] == [1, 1]
+    assert len(set(map(tuple, a["feats"][0].tolist()))) == 6            # randperm: no replacement when the bag is long enough
+    assert float(b["feats"][1].abs().sum()) == 0.0 and b["feats"][1].shape == (6, 4)   # absent stain -> resampled zero bag
+    assert seen == ["/feats/a_HE.h5", "/feats/a_ER.h5", "/feats/b_HE_val.h5"]            # split suffix, absent file not read
+    batch = collate([a, b])
+    assert batch["feats"].shape == (2, 2, 6, 4) and batch["modality_labels"].tolist() == [[1, 1], [1, 0]]
+    assert batch["slide_ids"] == ["a", "b"]
+    syn = SyntheticSlideDataset(5, MODS5, 8, 16, seed=1)
+    item = syn[3]
+    assert len(item["feats"]) == 5 and item["feats"][0].shape == (8, 16) and item["modality_labels"][0] == 1
+    for m, lab in enumerate(item["modality_labels"]):
+        assert (float(item["feats"][m].abs().sum()) == 0.0) == (lab == 0)

@@ -345,3 +345,16 @@ def test_train_loop_h2(dev, capsys):
     # epoch > warmup_epochs uses the cosine scheduler instead
     ep2, _ = train_loop(args, InfoNCE(temperature=0.001), None, None, model, 5, batches[:1], opt, warm, cos)
     assert cos.last_epoch == 1 and np.isfinite(ep2)
+
+
+def test_device_prefetcher(dev):
+    """N4: pinned double-buffered H2D staging yields the same batches, resident on the device, in order."""
+    from torch.utils.data import DataLoader
+    from madeleine_amd.data import DevicePrefetcher, SyntheticSlideDataset, collate
+    ds = SyntheticSlideDataset(10, MODS5[:3], 64, 32, seed=2)
+    ref = list(DataLoader(ds, batch_size=4, shuffle=False, collate_fn=collate, num_workers=0))
+    got = list(DevicePrefetcher(DataLoader(ds, batch_size=4, shuffle=False, collate_fn=collate, num_workers=0), dev, depth=2))
+    assert len(got) == len(ref) == 3
+    for g, r in zip(got, ref):
+        assert g["feats"].is_cuda and torch.equal(g["feats"].cpu(), r["feats"])
+        assert torch.equal(g["modality_labels"], r["modality_labels"]) and g["slide_ids"] == r["slide_ids"]
