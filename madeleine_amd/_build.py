@@ -18,7 +18,7 @@ def sources():
 
 
 def _deps():
-    return [HEADER] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+    return [HEADER] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".inc"))]
 
 
 def _stale(target, deps):

@@ -346,6 +346,23 @@ def test_got_pieces_and_fp64_oracle(dev):
     assert rel_err(vd.grad, v64.grad) < TOL and rel_err(qd.grad, q64.grad) < TOL
 
 
+@pytest.mark.parametrize("k,n", [(2, 70), (3, 130), (2, 200), (2, 256)])
+def test_got_large_n_vs_fp64_oracle(dev, k, n):
+    """The register-resident IPOT / matrix-core paths of every n-class (n <= 64, <= 128, <= 256; 1024- and 512-thread
+    builds) against an fp64 evaluation of the oracle: both distances and the token gradients."""
+    from madeleine_amd import functional as MF
+    v = t((k, n, 128), f"got:big:v{n}:0")
+    q = t((k, n, 128), f"got:big:q{n}:0") + 0.7 * v
+    v64, q64 = v.double().requires_grad_(), q.double().requires_grad_()
+    ref = R.got(v64, q64)
+    ref.backward()
+    vd, qd = v.to(dev).requires_grad_(), q.to(dev).requires_grad_()
+    o = MF.got(vd, qd)
+    (o[0] + o[1]).backward()
+    assert abs(float(o.sum()) - float(ref)) < TOL * abs(float(ref))
+    assert rel_err(vd.grad, v64.grad) < TOL and rel_err(qd.grad, q64.grad) < TOL
+
+
 def test_got_external_thresholds_and_limits(dev):
     """minmax_in = the batch's own extrema reproduces the local result (value and gradient); two half-batches with the
     global extrema sum to the full batch (the data-parallel decomposition); n > 256 is refused loudly."""

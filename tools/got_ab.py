@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""A/B of two builds of the GOT kernels through the raw C ABI: python tools/got_ab.py OLD.so [NEW.so]
+Prints value / gradient agreement and fwd / bwd times at several (k, n)."""
+import ctypes, os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from madeleine_amd import _native
+
+
+def load(path):
+    L = ctypes.CDLL(path)
+    for name, (res, args) in _native.SIGNATURES.items():
+        if name.startswith("mdl_got"):
+            f = getattr(L, name); f.restype = res; f.argtypes = args
+    return L
+
+
+def run(L, v, q, reps=2):
+    k, n, d = v.shape
+    dev = v.device
+    ws = torch.empty(L.mdl_got_ws_bytes(k, n, d), dtype=torch.uint8, device=dev)
+    out = torch.empty(2, device=dev); dv = torch.empty_like(v); dq = torch.empty_like(q)
+    go = torch.ones(2, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    best = (1e9, 1e9)
+    for _ in range(reps):
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        e[0].record()
+        rc = L.mdl_got_fwd(v.data_ptr(), q.data_ptr(), out.data_ptr(), None, None, k, n, d, ws.data_ptr(), st); assert rc == 0, rc
+        e[1].record()
+        rc = L.mdl_got_bwd(v.data_ptr(), q.data_ptr(), go.data_ptr(), dv.data_ptr(), dq.data_ptr(), k, n, d, ws.data_ptr(), st); assert rc == 0, rc
+        e[2].record(); torch.cuda.synchronize()
+        best = (min(best[0], e[0].elapsed_time(e[1])), min(best[1], e[1].elapsed_time(e[2])))
+    return out.clone(), dv.clone(), dq.clone(), best
+
+
+def rel(a, b):
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+if __name__ == "__main__":
+    old = load(sys.argv[1])
+    new = load(sys.argv[2]) if len(sys.argv) > 2 else load(_native.lib_path())
+    dev = torch.device("cuda:0")
+    for (k, n) in ((7, 7), (32, 32), (8, 64), (8, 128), (4, 129), (32, 192), (32, 256)):
+        g = torch.Generator(device=dev).manual_seed(k * 1000 + n)
+        v = torch.randn(k, n, 128, device=dev, generator=g)
+        q = torch.randn(k, n, 128, device=dev, generator=g) + 0.7 * v
+        oo, dvo, dqo, to = run(old, v, q)
+        on, dvn, dqn, tn = run(new, v, q)
+        print(f"k={k:3d} n={n:3d}  wd {float(oo[0]):.6f}/{float(on[0]):.6f} gw {float(oo[1]):.6f}/{float(on[1]):.6f}  "
+              f"dV rel {rel(dvn, dvo):.2e} dQ rel {rel(dqn, dqo):.2e}   old {to[0]:7.2f}+{to[1]:7.2f} ms  new {tn[0]:7.2f}+{tn[1]:7.2f} ms", flush=True)
