@@ -126,6 +126,10 @@ def main():
                     help="batches start in host memory and go through the pinned double-buffered H2D stager "
                          "(PCIe-inclusive rate; NOT the headline value, which is measured on device-resident bags)")
     ap.add_argument("--cpu-sample", type=int, default=4, help="slides in the bounded CPU-oracle sample")
+    ap.add_argument("--precision", default="float32", choices=["float32", "bfloat16"],
+                    help="float32 = the parity path (headline value).  bfloat16 = the reference's `precision: bfloat16` "
+                         "runs: forward + losses under torch.autocast, bf16 activation storage + bf16 MFMA in the kernels")
+    ap.add_argument("--no-bf16-leg", action="store_true", help="skip the short secondary bf16-mode measurement")
     a = ap.parse_args()
 
     from madeleine_amd import InfoNCE, MADELEINE, calculate_losses
@@ -185,18 +189,19 @@ def main():
                 i += 1
         host_iter = iter(DevicePrefetcher(host_batches(), dev, depth=2))
 
-    def step():
+    def step(bf16=(a.precision == "bfloat16")):
         nonlocal data
         if host_iter is not None:
             data = next(host_iter)
         opt.zero_grad(set_to_none=True)
         # presence labels of the global batch first (tiny collective, issued while the GPU queue is empty)
         lab_g = D.all_gather_labels(labels[:, 1:], dev)
-        embs, toks = net(data, device=dev)
-        # one all-gather of the packed slide embeddings -> replicated global InfoNCE; rank-local GOT with
-        # global-batch thresholds (one [S,6] all-gather fwd, one all-reduce bwd); DDP all-reduces the grads.
-        loss, flag = D.calculate_losses_dp(mods[1:], crit, got_impl, embs, toks, labels[:, 1:], largs,
-                                           labels_global_withoutHE=lab_g, use_local_loss=use_got)
+        with torch.autocast(device_type="cuda", dtype=torch.bfloat16, enabled=bf16):   # as trainer.py:101-103
+            embs, toks = net(data, device=dev)
+            # one all-gather of the packed slide embeddings -> replicated global InfoNCE; rank-local GOT with
+            # global-batch thresholds (one [S,6] all-gather fwd, one all-reduce bwd); DDP all-reduces the grads.
+            loss, flag = D.calculate_losses_dp(mods[1:], crit, got_impl, embs, toks, labels[:, 1:], largs,
+                                               labels_global_withoutHE=lab_g, use_local_loss=use_got)
         loss.backward()
         opt.step()
         return loss
@@ -218,6 +223,25 @@ def main():
     prof = MF.TIMER.report()
     MF.TIMER = None
     final_loss = float(loss.detach())
+    bf16_leg = None
+    if a.precision == "float32" and world == 1 and not a.no_bf16_leg and host_iter is None:
+        # short secondary measurement of the bf16 mode (same model, same batch); reported beside, never as, `value`
+        for _ in range(2):
+            step(True)
+        fence()
+        MF.TIMER = MF.KernelTimer()
+        nb = max(3, min(10, a.steps))
+        tb = time.perf_counter()
+        for _ in range(nb):
+            lb = step(True)
+        fence()
+        eb = time.perf_counter() - tb
+        pb = MF.TIMER.report()
+        MF.TIMER = None
+        bf16_leg = {"value": round(B * nb / eb, 3), "unit": "slides/s", "ms_per_step": round(1e3 * eb / nb, 3), "steps": nb,
+                    "dtype": "bf16 activation storage + v_mfma_f32_32x32x16_bf16, fp32 accumulate/epilogues/params "
+                             "(torch.autocast(bfloat16), the reference's `precision: bfloat16`)",
+                    "final_loss": float(lb.detach()), "kernel_ms": {k: round(v[0], 4) for k, v in pb.items()}}
     if host_iter is not None:
         host_iter.close()   # stops and joins the stager thread
 
@@ -235,7 +259,7 @@ def main():
             "metric": "slides/sec (pretrain step) at B=32 N=4096 d=512; 1/2/4/8 GPU",
             "value": round(value, 3), "unit": "slides/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if a.precision == "float32" else "bf16 (storage + MFMA operands; fp32 accumulate)",
             "data": ("synthetic (HOST-resident randn bags through the pinned double-buffered H2D stager, PCIe-inclusive)"
                      if host_iter is not None else
                      "synthetic (device-resident randn bags, random-init weights, manual_seed 42)"),
@@ -247,7 +271,8 @@ def main():
         }
         if "pool_fwd" in prof:
             ms, n = prof["pool_fwd"]
-            alg = tokens * (H * 512 * 4 + H * 4) + B * M * H * 512 * 4
+            esz = 4 if a.precision == "float32" else 2
+            alg = tokens * (H * 512 * esz + H * 4) + B * M * H * 512 * 4
             ach = alg / (ms * 1e-3) / 1e9
             out["roofline"] = {"kernel": "abmil_pool_fwd (pool_partial + pool_combine)", "bound": "hbm",
                                "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -261,11 +286,15 @@ def main():
             tf_f = flop_f / (msf * 1e-3) / 1e12
             tf_b = 2 * flop_f / (msb * 1e-3) / 1e12
             tf = 3 * flop_f / ((msf + msb) * 1e-3) / 1e12
-            out["roofline_mfma"] = {"kernel": "abmil_gate fwd + bwd(dX, dW) on v_mfma_f32_32x32x2_f32", "bound": "mfma",
-                                    "achieved": round(tf, 2), "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                                    "frac": round(tf / F32_MFMA_PEAK_TF, 4), "fwd_tflops": round(tf_f, 2),
+            mpeak = F32_MFMA_PEAK_TF if a.precision == "float32" else 2500.0
+            out["roofline_mfma"] = {"kernel": "abmil_gate fwd + bwd(dX, dW) on " + ("v_mfma_f32_32x32x2_f32" if a.precision == "float32"
+                                                                                     else "v_mfma_f32_32x32x16_bf16"), "bound": "mfma",
+                                    "achieved": round(tf, 2), "peak": mpeak, "unit": "TFLOP/s",
+                                    "frac": round(tf / mpeak, 4), "fwd_tflops": round(tf_f, 2),
                                     "bwd_tflops": round(tf_b, 2), "fwd_ms": round(msf, 3), "bwd_ms": round(msb, 3)}
         out["kernel_ms"] = {k: round(v[0], 4) for k, v in prof.items()}
+        if bf16_leg is not None:
+            out["bf16_mode"] = bf16_leg
         if world == 1 and not a.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(min(a.cpu_sample, B), M, N, Dm, use_got)

@@ -183,6 +183,40 @@ int mdl_got_bwd_begin(const float* d_out, float* d_minmax, int k, int n, int d, 
 int mdl_got_bwd_finish(const float* V, const float* Q, float* dV, float* dQ, const float* d_minmax_total,
                        int k, int n, int d, void* ws, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * bf16 mode -- the reference's `precision: bfloat16` runs (torch autocast around the forward,
+ * madeleine/utils/trainer.py:101-103, scripts/launch_pretrain_withStainEncodings.sh): activations are STORED in
+ * bf16 (uint16_t bit patterns of torch.bfloat16: E, the gate activations, dE, the LayerNorm input/output), the
+ * contractions run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation, every epilogue / reduction / statistic is
+ * fp32, parameters and their gradients stay fp32.  Same argument meaning as the fp32 entry points above; ldE counts
+ * bf16 elements and must be a multiple of 8.  mdl_abmil_gate_bwd_bf16 requires ldE == H*512 (it transposes E).
+ * The fp32 entry points remain the parity path (1e-3 rel of the reference's fp32 results); this mode is held to
+ * the reference-under-autocast accuracy (tests/test_bf16_gpu.py).
+ */
+int mdl_ln_gelu_drop_fwd_bf16(const uint16_t* x, const float* gamma, const float* beta, uint16_t* y, float* mean, float* rstd,
+                              int64_t rows, int W, float eps, float p_drop, uint64_t seed, const uint8_t* keep, void* stream);
+int mdl_ln_gelu_drop_bwd_bf16(const uint16_t* x, const float* gamma, const float* beta, const float* mean, const float* rstd,
+                              const uint16_t* dy, uint16_t* dx, float* dgamma, float* dbeta, int64_t rows, int W,
+                              float p_drop, uint64_t seed, const uint8_t* keep, void* ws, void* stream);
+int mdl_abmil_pool_fwd_bf16(const uint16_t* E, int64_t ldE, const float* scores, float* pooled, float* stat_m,
+                            float* stat_l, int64_t n_bags, int64_t N, const int64_t* cu_seqlens, int64_t max_len, int H,
+                            void* ws, void* stream);
+int mdl_abmil_pool_bwd_bf16(const uint16_t* E, int64_t ldE, const float* scores, const float* pooled, const float* stat_m,
+                            const float* stat_l, const float* d_pooled, uint16_t* dE, int accumulate, float* d_scores,
+                            int accumulate_scores, int64_t n_bags, int64_t N, const int64_t* cu_seqlens, int64_t max_len,
+                            int H, void* stream);
+int64_t mdl_abmil_gate_fwd_bf16_ws_bytes(int64_t T, int H);
+int mdl_abmil_gate_fwd_bf16(const uint16_t* E, int64_t ldE, const float* Wa, const float* ba, const float* Wb,
+                            const float* bb, const float* wc, const float* bc, float* scores, uint16_t* act_a,
+                            uint16_t* act_b, int64_t T, int H, float p_drop, uint64_t seed, const uint8_t* keep_a,
+                            const uint8_t* keep_b, void* ws, void* stream);
+int64_t mdl_abmil_gate_bwd_bf16_ws_bytes(int64_t T, int H);
+int mdl_abmil_gate_bwd_bf16(const uint16_t* E, int64_t ldE, const float* Wa, const float* Wb, const float* wc,
+                            const uint16_t* act_a, const uint16_t* act_b, const float* d_scores, uint16_t* dE,
+                            int accumulate, float* dWa, float* dWb, float* dba, float* dbb, float* dwc, float* dbc,
+                            int64_t T, int H, float p_drop, uint64_t seed, const uint8_t* keep_a, const uint8_t* keep_b,
+                            void* ws, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

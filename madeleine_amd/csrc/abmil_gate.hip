@@ -15,56 +15,11 @@
 // 64 x 128 = 2 x 4 MFMA 32x32 accumulators (128 registers).  Every operand reaches LDS by LDS-DMA
 // (global_load_lds_dwordx4: no staging VGPRs, no ds_write pass), two LDS stages of 24 KiB, the next chunk's DMA is
 // issued before the current chunk's 64 MFMAs, one barrier per chunk; ~160 VGPRs => 3 workgroups per CU.
-#include "common.hpp"
+#include "gate_common.hpp"
 
 namespace mdl {
 
 constexpr int GBM = 128, GBN = 256, GBK = 16;
-constexpr int GATE_JT = HID / 128;  // 4 j-tiles of 128 gate columns per head
-
-// Head <-> XCD affinity.  Workgroup b runs on XCD b % 8 (observed dispatch; used for speed only, never for
-// correctness).  XCD x works on head x % H and on the (x / H)-th interleaved share of that head's token tiles, so
-// the 2 MiB of a head's Wa|Wb stay resident in ONE XCD's 4 MiB L2 instead of all 8 MiB cycling through every L2
-// (profiles/r01a: TCC hit rate 76 % with the token-major mapping).  `li` = this workgroup's index within its XCD.
-struct XcdHead {
-    int c, share, nshare, li;
-};
-__device__ __forceinline__ XcdHead xcd_head(int bid, int H) {
-    XcdHead m;
-    const int x = bid & 7;
-    m.nshare = 8 / H;  // H in {1,2,4,8}
-    m.c = x % H;
-    m.share = x / H;
-    m.li = bid >> 3;
-    return m;
-}
-static inline int64_t xcd_head_grid(int64_t units, int per_unit, int H) {  // units = tiles of one head, split over 8/H XCDs
-    const int nshare = 8 / H;
-    return 8 * ((units + nshare - 1) / nshare) * per_unit;
-}
-
-struct DropCfg {
-    float p, inv;
-    uint32_t thr;   // 16-bit threshold
-    uint32_t key;   // rng_key(seed)
-    const uint8_t* ka;
-    const uint8_t* kb;
-    int on;
-};
-
-// keep decisions of one gate element (tanh branch, sigmoid branch)
-__device__ __forceinline__ void drop_keep2(const DropCfg& d, int64_t idx, bool& ka, bool& kb) {
-    if (!d.on) {
-        ka = kb = true;
-    } else if (d.ka) {
-        ka = d.ka[idx] != 0;
-        kb = d.kb[idx] != 0;
-    } else {
-        const uint32_t h = rng_u32(d.key, (uint64_t)idx);
-        ka = (h & 0xFFFFu) >= d.thr;
-        kb = (h >> 16) >= d.thr;
-    }
-}
 
 // MFMA over one staged K-chunk.  colb[ct] = first column (within the 256-wide B tile) of this wave's ct-th
 // 32-column accumulator tile; rows wm*64 + rt*32.
@@ -97,9 +52,6 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][4]) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 }
 
-// MFMA 32x32 C/D layout: register r of lane l holds row (r&3) + 8*(r>>2) + 4*(l>>5), column l&31.
-__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
-
 // ================================================================================================
 // forward
 // ================================================================================================
@@ -112,11 +64,6 @@ __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (
 // B = the gate weights, transposed once per call into a K-major image WT [H][512 k][a j 0..511 | b j 0..511]
 // (gate_wt_kernel, 8 MiB): a chunk is then 16 rows x (128 a | 128 b) columns, one 1-KiB row per wave instruction,
 // read back with conflict-free ds_read_b32 -- which keeps the kernel at ~160 VGPRs = 3 waves/SIMD.
-__device__ __forceinline__ void glds16(const float* gsrc, float* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-
 // WT[c][k][j] = Wa[c][j][k], WT[c][k][512 + j] = Wb[c][j][k]   (32 x 32 LDS transpose)
 __global__ __launch_bounds__(256) void gate_wt_kernel(const float* __restrict__ Wa, const float* __restrict__ Wb,
                                                       float* __restrict__ WT) {
@@ -272,77 +219,6 @@ __global__ void gate_finalize_kernel(const float* __restrict__ part, const float
 //  the 21.9 ms backward at config 2; as one HBM-bound pass it is 8.6 GB ~ 1.8 ms and the column sums ride along.)
 // dz layout: [T + GBK][H][1024] = (dza[512] | dzb[512]); the GBK pad rows are zero (K-tail of the dW GEMM).
 // ================================================================================================
-constexpr int DZ_ROWS = 256;  // token rows per workgroup
-
-__device__ __forceinline__ void gate_dz(const DropCfg& d, float ds, float wcv, float a, float b, int64_t idx, float& dza,
-                                        float& dzb, float& pab) {
-    bool keep_a, keep_b;
-    drop_keep2(d, idx, keep_a, keep_b);
-    const float ka = keep_a ? d.inv : 0.f;
-    const float kb = keep_b ? d.inv : 0.f;
-    const float ad = a * ka, bd = b * kb;
-    const float g = ds * wcv;
-    dza = g * bd * ka * (1.f - a * a);
-    dzb = g * ad * kb * (b * (1.f - b));
-    pab = ds * ad * bd;
-}
-
-// grid (row blocks, H), 256 threads = 128 j-quads x 2 row phases.  slabV [nblk][H][4][512]: dba | dbb | dwc | (dbc at [0]).
-__global__ __launch_bounds__(256) void gate_dz_kernel(const float* __restrict__ wc, const float* __restrict__ act_a,
-                                                      const float* __restrict__ act_b, const float* __restrict__ d_scores,
-                                                      float* __restrict__ dz, float* __restrict__ slabV, int64_t T, int H,
-                                                      DropCfg drop) {
-    __shared__ float red[128][13];
-    const int tid = threadIdx.x, q = tid & 127, ph = tid >> 7, c = blockIdx.y;
-    const int64_t r0 = (int64_t)blockIdx.x * DZ_ROWS;
-    int64_t r1 = r0 + DZ_ROWS;
-    if (r1 > T) r1 = T;
-    const f32x4 vw = *reinterpret_cast<const f32x4*>(wc + c * HID + q * 4);
-    f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = sa, sw = sa;
-    float sds = 0.f;
-    for (int64_t r = r0 + ph; r < r1; r += 2) {
-        const float ds = d_scores[r * H + c];
-        const int64_t o = (r * H + c) * HID + q * 4;
-        const f32x4 va = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(act_a + o));
-        const f32x4 vb = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(act_b + o));
-        f32x4 za, zb;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float x, y, w;
-            gate_dz(drop, ds, vw[i], va[i], vb[i], o + i, x, y, w);
-            za[i] = x;
-            zb[i] = y;
-            sw[i] += w;
-        }
-        sa += za;
-        sb += zb;
-        sds += ds;
-        float* __restrict__ out = dz + (r * H + c) * 1024 + q * 4;
-        *reinterpret_cast<f32x4*>(out) = za;
-        *reinterpret_cast<f32x4*>(out + HID) = zb;
-    }
-    if (ph == 1) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            red[q][i] = sa[i];
-            red[q][4 + i] = sb[i];
-            red[q][8 + i] = sw[i];
-        }
-        red[q][12] = sds;
-    }
-    __syncthreads();
-    if (ph == 0) {
-        float* __restrict__ o = slabV + ((int64_t)blockIdx.x * H + c) * 4 * HID + q * 4;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            o[i] = sa[i] + red[q][i];
-            o[HID + i] = sb[i] + red[q][4 + i];
-            o[2 * HID + i] = sw[i] + red[q][8 + i];
-        }
-        if (q == 0) o[3 * HID] = sds + red[0][12];
-    }
-}
-
 // ================================================================================================
 // backward, stage 2: dE[t, c, :] (+)= dz[t, c, :] . [Wa_c ; Wb_c]     GEMM [T, 1024] x [1024, 512], both operands by LDS-DMA
 // A = dz rows (K-contiguous): swizzled row image like the forward; B = 16 weight rows x 256 columns per chunk (K-major
@@ -573,28 +449,25 @@ __global__ void gate_mask_kernel(uint8_t* __restrict__ keep, int64_t n, int whic
     }
 }
 
-static inline DropCfg make_drop(float p, uint64_t seed, const uint8_t* ka, const uint8_t* kb) {
-    DropCfg d;
-    d.on = (p > 0.f) ? 1 : 0;
-    d.p = p;
-    d.inv = d.on ? 1.f / (1.f - p) : 1.f;
-    d.thr = drop_threshold(p);
-    d.key = (uint32_t)(seed * 0x9E3779B97F4A7C15ULL >> 32) ^ (uint32_t)seed;
-    d.ka = ka;
-    d.kb = kb;
-    return d;
-}
-
-static inline int gate_splits(int64_t T) {
-    // ~4k tokens per split, at most 64 splits; each split a multiple of GBK tokens
-    int64_t s = (T + 4095) / 4096;
-    if (s < 1) s = 1;
-    if (s > 64) s = 64;
-    return (int)s;
-}
 static inline int64_t gate_tok_per_split(int64_t T, int S) {
     int64_t tps = (T + S - 1) / S;
     return ((tps + GBK - 1) / GBK) * GBK;
+}
+
+int gate_launch_finalize(const float* part, const float* bc, float* scores, int64_t n, int H, hipStream_t s) {
+    hipLaunchKernelGGL(gate_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, bc, scores, n, H);
+    MDL_LAUNCH_CHECK();
+    return MDL_OK;
+}
+int gate_launch_reduce_w(const float* slabW, float* dWa, float* dWb, int H, int S, hipStream_t s) {
+    hipLaunchKernelGGL(gate_reduce_w_kernel, dim3(32, 16, H), dim3(256), 0, s, slabW, dWa, dWb, H, S);
+    MDL_LAUNCH_CHECK();
+    return MDL_OK;
+}
+int gate_launch_reduce_v(const float* slabV, float* dba, float* dbb, float* dwc, float* dbc, int H, int S, hipStream_t s) {
+    hipLaunchKernelGGL(gate_reduce_v_kernel, dim3((H * 4 * HID + 31) / 32), dim3(256), 0, s, slabV, dba, dbb, dwc, dbc, H, S);
+    MDL_LAUNCH_CHECK();
+    return MDL_OK;
 }
 
 }  // namespace mdl
@@ -675,7 +548,7 @@ extern "C" int mdl_abmil_gate_bwd(const float* E, int64_t ldE, const float* Wa, 
     }
     if (T > 0) {
         if (nblk > 0x7fffffff) return MDL_E_UNSUPPORTED;
-        hipLaunchKernelGGL(gate_dz_kernel, dim3((unsigned)nblk, H), dim3(256), 0, s, wc, act_a, act_b, d_scores, dz, slabV, T, H,
+        hipLaunchKernelGGL((gate_dz_kernel<float, float>), dim3((unsigned)nblk, H), dim3(256), 0, s, wc, act_a, act_b, d_scores, dz, slabV, T, H,
                            d);
         MDL_LAUNCH_CHECK();
         const int64_t n_tt = (T + GBM - 1) / GBM;

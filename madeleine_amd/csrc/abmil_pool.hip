@@ -35,8 +35,8 @@ __device__ __forceinline__ BagSpan bag_span(int b, int64_t N, const int64_t* cu)
 }
 
 // blockDim.x == H*128: thread f owns channels [4f, 4f+4) (head f/128).
-template <int H>
-__global__ __launch_bounds__(H * 128) void pool_partial_kernel(const float* __restrict__ E, int64_t ldE,
+template <int H, class TE>
+__global__ __launch_bounds__(H * 128) void pool_partial_kernel(const TE* __restrict__ E, int64_t ldE,
                                                                const float* __restrict__ scores,
                                                                float* __restrict__ part_acc,
                                                                float* __restrict__ part_m,
@@ -85,14 +85,14 @@ __global__ __launch_bounds__(H * 128) void pool_partial_kernel(const float* __re
 
     // ---- weighted accumulation: thread owns one float4 column, loops over the chunk's tokens -----
     const int ca = tid / 128;
-    const float* __restrict__ Ep = E + (sp.start + t0) * ldE + (int64_t)tid * 4;
+    const TE* __restrict__ Ep = E + (sp.start + t0) * ldE + (int64_t)tid * 4;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     constexpr int U = 8;
     int t = 0;
     for (; t + U <= nt; t += U) {
         f32x4 x[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) x[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Ep + (int64_t)(t + u) * ldE));
+        for (int u = 0; u < U; ++u) x[u] = ld4_nt(Ep + (int64_t)(t + u) * ldE);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const float w = p_s[(t + u) * H + ca];
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(H * 128) void pool_partial_kernel(const float* __re
         }
     }
     for (; t < nt; ++t) {
-        const f32x4 x = *reinterpret_cast<const f32x4*>(Ep + (int64_t)t * ldE);
+        const f32x4 x = ld4(Ep + (int64_t)t * ldE);
         acc += p_s[t * H + ca] * x;
     }
     *reinterpret_cast<f32x4*>(part_acc + ((int64_t)b * max_chunks + chunk) * (H * HID) + (int64_t)tid * 4) = acc;
@@ -141,13 +141,13 @@ __global__ __launch_bounds__(H * 128) void pool_combine_kernel(const float* __re
 }
 
 // One wave per token row.  Lane L, slot i in [0,2H): channels [i*256 + 4L, +4), head i/2.
-template <int H>
-__global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ E, int64_t ldE,
+template <int H, class TE>
+__global__ __launch_bounds__(256) void pool_bwd_kernel(const TE* __restrict__ E, int64_t ldE,
                                                        const float* __restrict__ scores,
                                                        const float* __restrict__ pooled,
                                                        const float* __restrict__ stat_m,
                                                        const float* __restrict__ stat_l,
-                                                       const float* __restrict__ d_pooled, float* __restrict__ dE,
+                                                       const float* __restrict__ d_pooled, TE* __restrict__ dE,
                                                        int accumulate, float* __restrict__ d_scores,
                                                        int accumulate_scores, int64_t N,
                                                        const int64_t* __restrict__ cu) {
@@ -177,10 +177,10 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
 
     for (int t = wave; t < nt; t += 4) {
         const int64_t row = sp.start + t0 + t;
-        const float* __restrict__ er = E + row * ldE + lane * 4;
+        const TE* __restrict__ er = E + row * ldE + lane * 4;
         f32x4 x[2 * H];
 #pragma unroll
-        for (int i = 0; i < 2 * H; ++i) x[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(er + i * 256));
+        for (int i = 0; i < 2 * H; ++i) x[i] = ld4_nt(er + i * 256);
         float w[H], dw[H];
 #pragma unroll
         for (int c = 0; c < H; ++c) w[c] = expf(scores[row * H + c] - m[c]) * rl[c];
@@ -189,12 +189,12 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
             const f32x4 a = x[2 * c] * dp[2 * c] + x[2 * c + 1] * dp[2 * c + 1];
             dw[c] = wave_sum(a.x + a.y + a.z + a.w);
         }
-        float* __restrict__ gr = dE + row * ldE + lane * 4;
+        TE* __restrict__ gr = dE + row * ldE + lane * 4;
 #pragma unroll
         for (int i = 0; i < 2 * H; ++i) {
             f32x4 g = w[i / 2] * dp[i];
-            if (accumulate) g += *reinterpret_cast<const f32x4*>(gr + i * 256);
-            *reinterpret_cast<f32x4*>(gr + i * 256) = g;
+            if (accumulate) g += ld4(gr + i * 256);
+            st4(gr + i * 256, g);
         }
         float ds = 0.f;
 #pragma unroll
@@ -231,9 +231,9 @@ extern "C" int64_t mdl_abmil_pool_ws_bytes(int64_t n_bags, int64_t max_len, int 
         default: return MDL_E_UNSUPPORTED;           \
     }
 
-extern "C" int mdl_abmil_pool_fwd(const float* E, int64_t ldE, const float* scores, float* pooled, float* stat_m,
-                                  float* stat_l, int64_t n_bags, int64_t N, const int64_t* cu_seqlens,
-                                  int64_t max_len, int H, void* ws, void* stream) {
+template <class TE>
+static int pool_fwd_launch(const TE* E, int64_t ldE, const float* scores, float* pooled, float* stat_m, float* stat_l,
+                           int64_t n_bags, int64_t N, const int64_t* cu_seqlens, int64_t max_len, int H, void* ws, void* stream) {
     if (!E || !scores || !pooled || !stat_m || !stat_l || !ws) return MDL_E_ARG;
     if (n_bags < 0 || max_len < 0 || ldE < (int64_t)H * HID || (ldE & 3)) return MDL_E_ARG;
     if (!cu_seqlens && N != max_len) return MDL_E_ARG;
@@ -248,7 +248,7 @@ extern "C" int mdl_abmil_pool_fwd(const float* E, int64_t ldE, const float* scor
     float* part_l = (float*)((char*)part_m + st);
     MDL_DISPATCH_H(H, {
         if (mc > 0) {
-            hipLaunchKernelGGL((pool_partial_kernel<HH>), dim3(mc, (unsigned)n_bags), dim3(HH * 128), 0, s, E, ldE, scores,
+            hipLaunchKernelGGL((pool_partial_kernel<HH, TE>), dim3(mc, (unsigned)n_bags), dim3(HH * 128), 0, s, E, ldE, scores,
                                part_acc, part_m, part_l, N, cu_seqlens, mc);
             MDL_LAUNCH_CHECK();
         }
@@ -259,10 +259,11 @@ extern "C" int mdl_abmil_pool_fwd(const float* E, int64_t ldE, const float* scor
     return MDL_OK;
 }
 
-extern "C" int mdl_abmil_pool_bwd(const float* E, int64_t ldE, const float* scores, const float* pooled,
-                                  const float* stat_m, const float* stat_l, const float* d_pooled, float* dE,
-                                  int accumulate, float* d_scores, int accumulate_scores, int64_t n_bags, int64_t N,
-                                  const int64_t* cu_seqlens, int64_t max_len, int H, void* stream) {
+template <class TE>
+static int pool_bwd_launch(const TE* E, int64_t ldE, const float* scores, const float* pooled, const float* stat_m,
+                           const float* stat_l, const float* d_pooled, TE* dE, int accumulate, float* d_scores,
+                           int accumulate_scores, int64_t n_bags, int64_t N, const int64_t* cu_seqlens, int64_t max_len, int H,
+                           void* stream) {
     if (!E || !scores || !pooled || !stat_m || !stat_l || !d_pooled || !dE || !d_scores) return MDL_E_ARG;
     if (n_bags < 0 || max_len < 0 || ldE < (int64_t)H * HID || (ldE & 3)) return MDL_E_ARG;
     if (!cu_seqlens && N != max_len) return MDL_E_ARG;
@@ -272,9 +273,38 @@ extern "C" int mdl_abmil_pool_bwd(const float* E, int64_t ldE, const float* scor
     hipStream_t s = (hipStream_t)stream;
     const int nc = (int)((max_len + POOL_BWD_TOKENS - 1) / POOL_BWD_TOKENS);
     MDL_DISPATCH_H(H, {
-        hipLaunchKernelGGL((pool_bwd_kernel<HH>), dim3(nc, (unsigned)n_bags), dim3(256), 0, s, E, ldE, scores, pooled, stat_m,
+        hipLaunchKernelGGL((pool_bwd_kernel<HH, TE>), dim3(nc, (unsigned)n_bags), dim3(256), 0, s, E, ldE, scores, pooled, stat_m,
                            stat_l, d_pooled, dE, accumulate, d_scores, accumulate_scores, N, cu_seqlens);
         MDL_LAUNCH_CHECK();
     });
     return MDL_OK;
+}
+
+extern "C" int mdl_abmil_pool_fwd(const float* E, int64_t ldE, const float* scores, float* pooled, float* stat_m,
+                                  float* stat_l, int64_t n_bags, int64_t N, const int64_t* cu_seqlens,
+                                  int64_t max_len, int H, void* ws, void* stream) {
+    return pool_fwd_launch<float>(E, ldE, scores, pooled, stat_m, stat_l, n_bags, N, cu_seqlens, max_len, H, ws, stream);
+}
+
+extern "C" int mdl_abmil_pool_bwd(const float* E, int64_t ldE, const float* scores, const float* pooled,
+                                  const float* stat_m, const float* stat_l, const float* d_pooled, float* dE,
+                                  int accumulate, float* d_scores, int accumulate_scores, int64_t n_bags, int64_t N,
+                                  const int64_t* cu_seqlens, int64_t max_len, int H, void* stream) {
+    return pool_bwd_launch<float>(E, ldE, scores, pooled, stat_m, stat_l, d_pooled, dE, accumulate, d_scores, accumulate_scores,
+                                  n_bags, N, cu_seqlens, max_len, H, stream);
+}
+
+extern "C" int mdl_abmil_pool_fwd_bf16(const uint16_t* E, int64_t ldE, const float* scores, float* pooled, float* stat_m,
+                                       float* stat_l, int64_t n_bags, int64_t N, const int64_t* cu_seqlens, int64_t max_len,
+                                       int H, void* ws, void* stream) {
+    return pool_fwd_launch<bf16_t>((const bf16_t*)E, ldE, scores, pooled, stat_m, stat_l, n_bags, N, cu_seqlens, max_len, H, ws,
+                                   stream);
+}
+
+extern "C" int mdl_abmil_pool_bwd_bf16(const uint16_t* E, int64_t ldE, const float* scores, const float* pooled,
+                                       const float* stat_m, const float* stat_l, const float* d_pooled, uint16_t* dE,
+                                       int accumulate, float* d_scores, int accumulate_scores, int64_t n_bags, int64_t N,
+                                       const int64_t* cu_seqlens, int64_t max_len, int H, void* stream) {
+    return pool_bwd_launch<bf16_t>((const bf16_t*)E, ldE, scores, pooled, stat_m, stat_l, d_pooled, (bf16_t*)dE, accumulate,
+                                   d_scores, accumulate_scores, n_bags, N, cu_seqlens, max_len, H, stream);
 }

@@ -18,6 +18,20 @@ constexpr int HID = MDL_HIDDEN;  // 512
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// 4 consecutive elements <-> f32x4 for the two storage types of the activation tensors (fp32 parity mode, bf16 mode:
+// v_cvt_pk_bf16_f32 round-to-nearest-even on store, a 16-bit shift on load).  p must be 16-B (fp32) / 8-B (bf16) aligned.
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 ld4(const bf16_t* p) { return __builtin_convertvector(*reinterpret_cast<const bf16x4*>(p), f32x4); }
+__device__ __forceinline__ f32x4 ld4_nt(const float* p) { return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)); }
+__device__ __forceinline__ f32x4 ld4_nt(const bf16_t* p) {
+    return __builtin_convertvector(__builtin_nontemporal_load(reinterpret_cast<const bf16x4*>(p)), f32x4);
+}
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void st4(bf16_t* p, f32x4 v) { *reinterpret_cast<bf16x4*>(p) = __builtin_convertvector(v, bf16x4); }
 
 __device__ __forceinline__ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 inline bool host_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -1,0 +1,159 @@
+// gate_common.hpp -- pieces shared by the fp32 (abmil_gate.hip) and bf16 (abmil_gate_bf16.hip) gate kernels
+#pragma once
+#include "common.hpp"
+
+namespace mdl {
+
+constexpr int GATE_JT = HID / 128;  // 4 j-tiles of 128 gate columns per head
+
+// Head <-> XCD affinity.  Workgroup b runs on XCD b % 8 (observed dispatch; used for speed only, never for
+// correctness).  XCD x works on head x % H and on the (x / H)-th interleaved share of that head's token tiles, so
+// the 2 MiB of a head's Wa|Wb stay resident in ONE XCD's 4 MiB L2 instead of all 8 MiB cycling through every L2
+// (profiles/r01a: TCC hit rate 76 % with the token-major mapping).  `li` = this workgroup's index within its XCD.
+struct XcdHead {
+    int c, share, nshare, li;
+};
+__device__ __forceinline__ XcdHead xcd_head(int bid, int H) {
+    XcdHead m;
+    const int x = bid & 7;
+    m.nshare = 8 / H;  // H in {1,2,4,8}
+    m.c = x % H;
+    m.share = x / H;
+    m.li = bid >> 3;
+    return m;
+}
+static inline int64_t xcd_head_grid(int64_t units, int per_unit, int H) {  // units = tiles of one head, split over 8/H XCDs
+    const int nshare = 8 / H;
+    return 8 * ((units + nshare - 1) / nshare) * per_unit;
+}
+
+struct DropCfg {
+    float p, inv;
+    uint32_t thr;   // 16-bit threshold
+    uint32_t key;   // rng_key(seed)
+    const uint8_t* ka;
+    const uint8_t* kb;
+    int on;
+};
+
+// keep decisions of one gate element (tanh branch, sigmoid branch)
+__device__ __forceinline__ void drop_keep2(const DropCfg& d, int64_t idx, bool& ka, bool& kb) {
+    if (!d.on) {
+        ka = kb = true;
+    } else if (d.ka) {
+        ka = d.ka[idx] != 0;
+        kb = d.kb[idx] != 0;
+    } else {
+        const uint32_t h = rng_u32(d.key, (uint64_t)idx);
+        ka = (h & 0xFFFFu) >= d.thr;
+        kb = (h >> 16) >= d.thr;
+    }
+}
+
+// MFMA 32x32 C/D layout: register r of lane l holds row (r&3) + 8*(r>>2) + 4*(l>>5), column l&31.
+__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ void gate_dz(const DropCfg& d, float ds, float wcv, float a, float b, int64_t idx, float& dza,
+                                        float& dzb, float& pab) {
+    bool keep_a, keep_b;
+    drop_keep2(d, idx, keep_a, keep_b);
+    const float ka = keep_a ? d.inv : 0.f;
+    const float kb = keep_b ? d.inv : 0.f;
+    const float ad = a * ka, bd = b * kb;
+    const float g = ds * wcv;
+    dza = g * bd * ka * (1.f - a * a);
+    dzb = g * ad * kb * (b * (1.f - b));
+    pab = ds * ad * bd;
+}
+
+static inline DropCfg make_drop(float p, uint64_t seed, const uint8_t* ka, const uint8_t* kb) {
+    DropCfg d;
+    d.on = (p > 0.f) ? 1 : 0;
+    d.p = p;
+    d.inv = d.on ? 1.f / (1.f - p) : 1.f;
+    d.thr = drop_threshold(p);
+    d.key = (uint32_t)(seed * 0x9E3779B97F4A7C15ULL >> 32) ^ (uint32_t)seed;
+    d.ka = ka;
+    d.kb = kb;
+    return d;
+}
+
+static inline int gate_splits(int64_t T) {
+    // ~4k tokens per split, at most 64 splits; each split a multiple of GBK tokens
+    int64_t s = (T + 4095) / 4096;
+    if (s < 1) s = 1;
+    if (s > 64) s = 64;
+    return (int)s;
+}
+
+constexpr int DZ_ROWS = 256;  // token rows per workgroup
+
+// grid (row blocks, H), 256 threads = 128 j-quads x 2 row phases.  slabV [nblk][H][4][512]: dba | dbb | dwc | (dbc at [0]).
+template <class TI, class TO>
+__global__ __launch_bounds__(256) void gate_dz_kernel(const float* __restrict__ wc, const TI* __restrict__ act_a,
+                                                      const TI* __restrict__ act_b, const float* __restrict__ d_scores,
+                                                      TO* __restrict__ dz, float* __restrict__ slabV, int64_t T, int H,
+                                                      DropCfg drop) {
+    __shared__ float red[128][13];
+    const int tid = threadIdx.x, q = tid & 127, ph = tid >> 7, c = blockIdx.y;
+    const int64_t r0 = (int64_t)blockIdx.x * DZ_ROWS;
+    int64_t r1 = r0 + DZ_ROWS;
+    if (r1 > T) r1 = T;
+    const f32x4 vw = *reinterpret_cast<const f32x4*>(wc + c * HID + q * 4);
+    f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = sa, sw = sa;
+    float sds = 0.f;
+    for (int64_t r = r0 + ph; r < r1; r += 2) {
+        const float ds = d_scores[r * H + c];
+        const int64_t o = (r * H + c) * HID + q * 4;
+        const f32x4 va = ld4_nt(act_a + o);
+        const f32x4 vb = ld4_nt(act_b + o);
+        f32x4 za, zb;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float x, y, w;
+            gate_dz(drop, ds, vw[i], va[i], vb[i], o + i, x, y, w);
+            za[i] = x;
+            zb[i] = y;
+            sw[i] += w;
+        }
+        sa += za;
+        sb += zb;
+        sds += ds;
+        TO* __restrict__ out = dz + (r * H + c) * 1024 + q * 4;
+        st4(out, za);
+        st4(out + HID, zb);
+    }
+    if (ph == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            red[q][i] = sa[i];
+            red[q][4 + i] = sb[i];
+            red[q][8 + i] = sw[i];
+        }
+        red[q][12] = sds;
+    }
+    __syncthreads();
+    if (ph == 0) {
+        float* __restrict__ o = slabV + ((int64_t)blockIdx.x * H + c) * 4 * HID + q * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            o[i] = sa[i] + red[q][i];
+            o[HID + i] = sb[i] + red[q][4 + i];
+            o[2 * HID + i] = sw[i] + red[q][8 + i];
+        }
+        if (q == 0) o[3 * HID] = sds + red[0][12];
+    }
+}
+
+
+// launchers of the reduction / finalize kernels defined in abmil_gate.hip (shared with the bf16 path)
+int gate_launch_finalize(const float* part, const float* bc, float* scores, int64_t n, int H, hipStream_t s);
+int gate_launch_reduce_w(const float* slabW, float* dWa, float* dWb, int H, int S, hipStream_t s);
+int gate_launch_reduce_v(const float* slabV, float* dba, float* dbb, float* dwc, float* dbc, int H, int S, hipStream_t s);
+
+}  // namespace mdl

@@ -62,11 +62,11 @@ __device__ __forceinline__ void row_allreduce2(float& a, float& b, float (*red)[
     }
 }
 
-template <int NV, int WPR>
-__global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_fwd_kernel(const float* __restrict__ x,
+template <int NV, int WPR, class IO>
+__global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_fwd_kernel(const IO* __restrict__ x,
                                                                      const float* __restrict__ gamma,
                                                                      const float* __restrict__ beta,
-                                                                     float* __restrict__ y, float* __restrict__ mean_o,
+                                                                     IO* __restrict__ y, float* __restrict__ mean_o,
                                                                      float* __restrict__ rstd_o, int64_t rows, float eps,
                                                                      ActDrop drop) {
     constexpr int W = NV * 256 * WPR, RPB = 4 / WPR;
@@ -82,12 +82,12 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_fwd_kernel(const float
     for (int64_t base = (int64_t)blockIdx.x * RPB; base < rows; base += (int64_t)gridDim.x * RPB) {
         const int64_t r = base + slot;
         const bool live = r < rows;
-        const float* __restrict__ xr = x + (live ? r : 0) * W + col0;
+        const IO* __restrict__ xr = x + (live ? r : 0) * W + col0;
         f32x4 v[NV];
         float s = 0.f, dummy = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            v[i] = live ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xr + i * 256)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            v[i] = live ? ld4_nt(xr + i * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
             s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
         }
         row_allreduce2<WPR>(s, dummy, red, slot * WPR, wv);
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_fwd_kernel(const float
         row_allreduce2<WPR>(q, dummy, red, slot * WPR, wv);
         const float rstd = rsqrtf(q * (1.f / W) + eps);
         if (live) {
-            float* __restrict__ yr = y + r * W + col0;
+            IO* __restrict__ yr = y + r * W + col0;
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 f32x4 o;
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_fwd_kernel(const float
                     const float a = gelu_f(t);
                     o[e] = act_keep(drop, r * W + col0 + i * 256 + e) ? a * drop.inv : 0.f;
                 }
-                *reinterpret_cast<f32x4*>(yr + i * 256) = o;
+                st4(yr + i * 256, o);
             }
             if (lane == 0 && seg == 0) {
                 mean_o[r] = mean;
@@ -121,13 +121,13 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_fwd_kernel(const float
     }
 }
 
-template <int NV, int WPR>
-__global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_bwd_kernel(const float* __restrict__ x,
+template <int NV, int WPR, class IO>
+__global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_bwd_kernel(const IO* __restrict__ x,
                                                                      const float* __restrict__ gamma,
                                                                      const float* __restrict__ beta,
                                                                      const float* __restrict__ mean_i,
                                                                      const float* __restrict__ rstd_i,
-                                                                     const float* __restrict__ dy, float* __restrict__ dx,
+                                                                     const IO* __restrict__ dy, IO* __restrict__ dx,
                                                                      float* __restrict__ part, int64_t rows, ActDrop drop) {
     constexpr int W = NV * 256 * WPR, RPB = 4 / WPR;
     __shared__ float red[1][4][2];
@@ -146,16 +146,16 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_bwd_kernel(const float
         const int64_t r = base + slot;
         const bool live = r < rows;
         const float mean = live ? mean_i[r] : 0.f, rstd = live ? rstd_i[r] : 0.f;
-        const float* __restrict__ xr = x + (live ? r : 0) * W + col0;
-        const float* __restrict__ gr = dy + (live ? r : 0) * W + col0;
+        const IO* __restrict__ xr = x + (live ? r : 0) * W + col0;
+        const IO* __restrict__ gr = dy + (live ? r : 0) * W + col0;
         f32x4 xh[NV], dxh[NV];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             f32x4 xv = {0.f, 0.f, 0.f, 0.f}, gv = xv;
             if (live) {
-                xv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xr + i * 256));
-                gv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(gr + i * 256));
+                xv = ld4_nt(xr + i * 256);
+                gv = ld4_nt(gr + i * 256);
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -175,13 +175,13 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_bwd_kernel(const float
         row_allreduce2<WPR>(s1, s2, red, slot * WPR, wv);
         const float m1 = s1 * (1.f / W), m2 = s2 * (1.f / W);
         if (live) {
-            float* __restrict__ o = dx + r * W + col0;
+            IO* __restrict__ o = dx + r * W + col0;
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = rstd * (dxh[i][e] - m1 - xh[i][e] * m2);
-                *reinterpret_cast<f32x4*>(o + i * 256) = v;
+                st4(o + i * 256, v);
             }
         }
     }
@@ -278,9 +278,9 @@ extern "C" int64_t mdl_ln_gelu_drop_bwd_ws_bytes(int64_t rows, int W) {
         default: return MDL_E_UNSUPPORTED;                                           \
     }
 
-extern "C" int mdl_ln_gelu_drop_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean,
-                                    float* rstd, int64_t rows, int W, float eps, float p_drop, uint64_t seed,
-                                    const uint8_t* keep, void* stream) {
+template <class IO>
+static int ln_fwd_launch(const IO* x, const float* gamma, const float* beta, IO* y, float* mean, float* rstd, int64_t rows, int W,
+                         float eps, float p_drop, uint64_t seed, const uint8_t* keep, void* stream) {
     if (!x || !gamma || !beta || !y || !mean || !rstd || rows < 0) return MDL_E_ARG;
     if (!(p_drop >= 0.f && p_drop < 1.f) || !(eps > 0.f)) return MDL_E_ARG;
     if (!host_aligned16(x) || !host_aligned16(y) || !host_aligned16(gamma) || !host_aligned16(beta)) return MDL_E_ALIGN;
@@ -289,22 +289,23 @@ extern "C" int mdl_ln_gelu_drop_fwd(const float* x, const float* gamma, const fl
     if (W == 2048) {  // forward: a whole 2048-wide row per wave (153 VGPRs, no block barriers) beats 4 waves per row
         int64_t nb = (rows + 3) / 4;
         if (nb > 2048) nb = 2048;
-        hipLaunchKernelGGL((ln_gelu_drop_fwd_kernel<8, 1>), dim3((unsigned)nb), dim3(ACT_BLOCK), 0, (hipStream_t)stream, x, gamma,
-                           beta, y, mean, rstd, rows, eps, d);
+        hipLaunchKernelGGL((ln_gelu_drop_fwd_kernel<8, 1, IO>), dim3((unsigned)nb), dim3(ACT_BLOCK), 0, (hipStream_t)stream, x,
+                           gamma, beta, y, mean, rstd, rows, eps, d);
         MDL_LAUNCH_CHECK();
         return MDL_OK;
     }
     MDL_DISPATCH_W(W, {
-        hipLaunchKernelGGL((ln_gelu_drop_fwd_kernel<NV, WPR>), dim3(act_blocks(rows, W)), dim3(ACT_BLOCK), 0, (hipStream_t)stream, x,
-                           gamma, beta, y, mean, rstd, rows, eps, d);
+        hipLaunchKernelGGL((ln_gelu_drop_fwd_kernel<NV, WPR, IO>), dim3(act_blocks(rows, W)), dim3(ACT_BLOCK), 0,
+                           (hipStream_t)stream, x, gamma, beta, y, mean, rstd, rows, eps, d);
         MDL_LAUNCH_CHECK();
     });
     return MDL_OK;
 }
 
-extern "C" int mdl_ln_gelu_drop_bwd(const float* x, const float* gamma, const float* beta, const float* mean,
-                                    const float* rstd, const float* dy, float* dx, float* dgamma, float* dbeta, int64_t rows,
-                                    int W, float p_drop, uint64_t seed, const uint8_t* keep, void* ws, void* stream) {
+template <class IO>
+static int ln_bwd_launch(const IO* x, const float* gamma, const float* beta, const float* mean, const float* rstd, const IO* dy,
+                         IO* dx, float* dgamma, float* dbeta, int64_t rows, int W, float p_drop, uint64_t seed,
+                         const uint8_t* keep, void* ws, void* stream) {
     if (!x || !gamma || !beta || !mean || !rstd || !dy || !dx || !dgamma || !dbeta || !ws || rows < 0) return MDL_E_ARG;
     if (!(p_drop >= 0.f && p_drop < 1.f)) return MDL_E_ARG;
     if (!host_aligned16(x) || !host_aligned16(dy) || !host_aligned16(dx) || !host_aligned16(gamma) || !host_aligned16(beta))
@@ -314,12 +315,38 @@ extern "C" int mdl_ln_gelu_drop_bwd(const float* x, const float* gamma, const fl
     const int nb = rows > 0 ? act_blocks(rows, W) : 0;
     MDL_DISPATCH_W(W, {
         if (nb > 0) {
-            hipLaunchKernelGGL((ln_gelu_drop_bwd_kernel<NV, WPR>), dim3(nb), dim3(ACT_BLOCK), 0, s, x, gamma, beta, mean, rstd, dy, dx,
-                               (float*)ws, rows, d);
+            hipLaunchKernelGGL((ln_gelu_drop_bwd_kernel<NV, WPR, IO>), dim3(nb), dim3(ACT_BLOCK), 0, s, x, gamma, beta, mean, rstd, dy,
+                               dx, (float*)ws, rows, d);
             MDL_LAUNCH_CHECK();
         }
     });
     hipLaunchKernelGGL(ln_reduce_kernel, dim3((2 * W + 31) / 32), dim3(256), 0, s, (const float*)ws, dgamma, dbeta, nb, W);
     MDL_LAUNCH_CHECK();
     return MDL_OK;
+}
+
+extern "C" int mdl_ln_gelu_drop_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean,
+                                    float* rstd, int64_t rows, int W, float eps, float p_drop, uint64_t seed,
+                                    const uint8_t* keep, void* stream) {
+    return ln_fwd_launch<float>(x, gamma, beta, y, mean, rstd, rows, W, eps, p_drop, seed, keep, stream);
+}
+
+extern "C" int mdl_ln_gelu_drop_bwd(const float* x, const float* gamma, const float* beta, const float* mean,
+                                    const float* rstd, const float* dy, float* dx, float* dgamma, float* dbeta, int64_t rows,
+                                    int W, float p_drop, uint64_t seed, const uint8_t* keep, void* ws, void* stream) {
+    return ln_bwd_launch<float>(x, gamma, beta, mean, rstd, dy, dx, dgamma, dbeta, rows, W, p_drop, seed, keep, ws, stream);
+}
+
+extern "C" int mdl_ln_gelu_drop_fwd_bf16(const uint16_t* x, const float* gamma, const float* beta, uint16_t* y, float* mean,
+                                         float* rstd, int64_t rows, int W, float eps, float p_drop, uint64_t seed,
+                                         const uint8_t* keep, void* stream) {
+    return ln_fwd_launch<bf16_t>((const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, W, eps, p_drop, seed, keep, stream);
+}
+
+extern "C" int mdl_ln_gelu_drop_bwd_bf16(const uint16_t* x, const float* gamma, const float* beta, const float* mean,
+                                         const float* rstd, const uint16_t* dy, uint16_t* dx, float* dgamma, float* dbeta,
+                                         int64_t rows, int W, float p_drop, uint64_t seed, const uint8_t* keep, void* ws,
+                                         void* stream) {
+    return ln_bwd_launch<bf16_t>((const bf16_t*)x, gamma, beta, mean, rstd, (const bf16_t*)dy, (bf16_t*)dx, dgamma, dbeta, rows, W,
+                                 p_drop, seed, keep, ws, stream);
 }

@@ -1,8 +1,9 @@
 """torch.autograd.Function wrappers over the C ABI (include/madeleine_amd.h).
 
 PyTorch is plumbing here: it owns device memory, the stream and the autograd graph; every numeric
-step of the hot path below runs in libmadeleine_amd.so.  All tensors are fp32, contiguous, on a
-ROCm device; anything else raises (there is no CPU or eager fallback).
+step of the hot path below runs in libmadeleine_amd.so.  Tensors are contiguous, on a ROCm device, fp32 --
+or, for the activation tensors of the bf16 mode (E, LayerNorm input/output), bfloat16, which selects the *_bf16 entry
+points; anything else raises (there is no CPU or eager fallback).
 
 Layouts (see include/madeleine_amd.h): token embeddings are head-major [T, H*512]; scores [T, H].
 """
@@ -21,6 +22,20 @@ def _ptr(t: Optional[torch.Tensor]):
 
 def _stream():
     return torch.cuda.current_stream().cuda_stream
+
+
+ACT_DTYPES = (torch.float32, torch.bfloat16)   # storage types of the activation tensors (parity mode / bf16 mode)
+
+
+def _sfx(t: torch.Tensor) -> str:
+    """C-ABI entry-point suffix for the storage type of an activation tensor."""
+    return "_bf16" if t.dtype == torch.bfloat16 else ""
+
+
+def _require_act(t: torch.Tensor, name: str):
+    if t.dtype not in ACT_DTYPES:
+        raise RuntimeError("madeleine_amd: %s must be float32 or bfloat16 (got %s)" % (name, t.dtype))
+    return _require(t, name, t.dtype)
 
 
 def _require(t: torch.Tensor, name: str, dtype=torch.float32):
@@ -87,11 +102,12 @@ def gate_fwd_raw(E2d, Wa, ba, Wb, bb, wc, bc, p_drop, seed, keep_a, keep_b, save
     T, H = E2d.shape[0], Wa.shape[0]
     dev = E2d.device
     scores = torch.empty(T, H, device=dev, dtype=torch.float32)
-    act_a = torch.empty(T, H, HID, device=dev, dtype=torch.float32) if save_act else None
-    act_b = torch.empty(T, H, HID, device=dev, dtype=torch.float32) if save_act else None
-    ws = _ws(lib.mdl_abmil_gate_fwd_ws_bytes(T, H), dev)
+    act_a = torch.empty(T, H, HID, device=dev, dtype=E2d.dtype) if save_act else None
+    act_b = torch.empty(T, H, HID, device=dev, dtype=E2d.dtype) if save_act else None
+    sfx = _sfx(E2d)
+    ws = _ws(getattr(lib, "mdl_abmil_gate_fwd%s_ws_bytes" % sfx)(T, H), dev)
     with _timed("gate_fwd"):
-        rc = lib.mdl_abmil_gate_fwd(_ptr(E2d), E2d.stride(0), _ptr(Wa), _ptr(ba), _ptr(Wb), _ptr(bb), _ptr(wc), _ptr(bc),
+        rc = getattr(lib, "mdl_abmil_gate_fwd" + sfx)(_ptr(E2d), E2d.stride(0), _ptr(Wa), _ptr(ba), _ptr(Wb), _ptr(bb), _ptr(wc), _ptr(bc),
                                     _ptr(scores), _ptr(act_a), _ptr(act_b), T, H, float(p_drop), int(seed),
                                     _ptr(keep_a), _ptr(keep_b), _ptr(ws), _stream())
     _native.check(rc, "mdl_abmil_gate_fwd")
@@ -106,9 +122,10 @@ def gate_bwd_raw(E2d, Wa, Wb, wc, act_a, act_b, d_scores, dE, accumulate, p_drop
     dba = torch.empty(H, HID, device=dev, dtype=torch.float32)
     dbb, dwc = torch.empty_like(dba), torch.empty_like(dba)
     dbc = torch.empty(H, device=dev, dtype=torch.float32)
-    ws = _ws(lib.mdl_abmil_gate_bwd_ws_bytes(T, H), dev)
+    sfx = _sfx(E2d)
+    ws = _ws(getattr(lib, "mdl_abmil_gate_bwd%s_ws_bytes" % sfx)(T, H), dev)
     with _timed("gate_bwd"):
-        rc = lib.mdl_abmil_gate_bwd(_ptr(E2d), E2d.stride(0), _ptr(Wa), _ptr(Wb), _ptr(wc), _ptr(act_a), _ptr(act_b),
+        rc = getattr(lib, "mdl_abmil_gate_bwd" + sfx)(_ptr(E2d), E2d.stride(0), _ptr(Wa), _ptr(Wb), _ptr(wc), _ptr(act_a), _ptr(act_b),
                                     _ptr(d_scores), _ptr(dE), int(accumulate), _ptr(dWa), _ptr(dWb), _ptr(dba), _ptr(dbb),
                                     _ptr(dwc), _ptr(dbc), T, H, float(p_drop), int(seed), _ptr(keep_a), _ptr(keep_b),
                                     _ptr(ws), _stream())
@@ -125,7 +142,7 @@ def pool_fwd_raw(E2d, scores, n_bags, N, cu_seqlens, max_len):
     stat_l = torch.empty(n_bags, H, device=dev, dtype=torch.float32)
     ws = _ws(lib.mdl_abmil_pool_ws_bytes(n_bags, max_len, H), dev)
     with _timed("pool_fwd"):
-        rc = lib.mdl_abmil_pool_fwd(_ptr(E2d), E2d.stride(0), _ptr(scores), _ptr(pooled), _ptr(stat_m), _ptr(stat_l), n_bags,
+        rc = getattr(lib, "mdl_abmil_pool_fwd" + _sfx(E2d))(_ptr(E2d), E2d.stride(0), _ptr(scores), _ptr(pooled), _ptr(stat_m), _ptr(stat_l), n_bags,
                                     N, _ptr(cu_seqlens), max_len, H, _ptr(ws), _stream())
     _native.check(rc, "mdl_abmil_pool_fwd")
     return pooled, stat_m, stat_l
@@ -136,7 +153,7 @@ def pool_bwd_raw(E2d, scores, pooled, stat_m, stat_l, d_pooled, dE, accumulate, 
     lib = _native.lib()
     H = scores.shape[-1]
     with _timed("pool_bwd"):
-        rc = lib.mdl_abmil_pool_bwd(_ptr(E2d), E2d.stride(0), _ptr(scores), _ptr(pooled), _ptr(stat_m), _ptr(stat_l),
+        rc = getattr(lib, "mdl_abmil_pool_bwd" + _sfx(E2d))(_ptr(E2d), E2d.stride(0), _ptr(scores), _ptr(pooled), _ptr(stat_m), _ptr(stat_l),
                                     _ptr(d_pooled), _ptr(dE), int(accumulate), _ptr(d_scores), int(accumulate_scores), n_bags, N,
                                     _ptr(cu_seqlens), max_len, H, _stream())
     _native.check(rc, "mdl_abmil_pool_bwd")
@@ -165,7 +182,8 @@ class GateScoresFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, E2d, Wa, ba, Wb, bb, wc, bc, p_drop, seed, keep_a, keep_b):
-        for t, n in ((E2d, "E"), (Wa, "Wa"), (ba, "ba"), (Wb, "Wb"), (bb, "bb"), (wc, "wc"), (bc, "bc")):
+        _require_act(E2d, "E")
+        for t, n in ((Wa, "Wa"), (ba, "ba"), (Wb, "Wb"), (bb, "bb"), (wc, "wc"), (bc, "bc")):
             _require(t, n)
         need = any(ctx.needs_input_grad[:7])
         scores, act_a, act_b = gate_fwd_raw(E2d, Wa, ba, Wb, bb, wc, bc, p_drop, seed, keep_a, keep_b, need)
@@ -178,7 +196,7 @@ class GateScoresFn(torch.autograd.Function):
     def backward(ctx, d_scores):
         E2d, Wa, Wb, wc, act_a, act_b = ctx.saved_tensors
         p_drop, seed, keep_a, keep_b = ctx.drop
-        d_scores = d_scores.contiguous()
+        d_scores = d_scores.float().contiguous()
         dE = torch.empty_like(E2d)
         dWa, dWb, dba, dbb, dwc, dbc = gate_bwd_raw(E2d, Wa, Wb, wc, act_a, act_b, d_scores, dE, 0, p_drop, seed, keep_a,
                                                     keep_b)
@@ -193,7 +211,7 @@ class SoftmaxPoolFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, E, scores, cu_seqlens, max_len):
-        _require(E, "E")
+        _require_act(E, "E")
         _require(scores, "scores")
         n_bags, N, max_len, E2d = _bag_geometry(E, cu_seqlens, max_len)
         s2d = scores.reshape(E2d.shape[0], -1)
@@ -209,7 +227,7 @@ class SoftmaxPoolFn(torch.autograd.Function):
         cu = cu if ragged else None
         dE = torch.empty_like(E2d)
         ds = torch.empty_like(s2d)
-        pool_bwd_raw(E2d, s2d, pooled, m, l, d_pooled.contiguous(), dE, 0, ds, 0, n_bags, N, cu, max_len)
+        pool_bwd_raw(E2d, s2d, pooled, m, l, d_pooled.float().contiguous(), dE, 0, ds, 0, n_bags, N, cu, max_len)
         return dE.view(e_shape), ds.view(s_shape), None, None
 
 
@@ -222,7 +240,8 @@ class AttnPoolFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, E, Wa, ba, Wb, bb, wc, bc, p_drop, seed, keep_a, keep_b, cu_seqlens, max_len):
-        for t, n in ((E, "E"), (Wa, "Wa"), (ba, "ba"), (Wb, "Wb"), (bb, "bb"), (wc, "wc"), (bc, "bc")):
+        _require_act(E, "E")
+        for t, n in ((Wa, "Wa"), (ba, "ba"), (Wb, "Wb"), (bb, "bb"), (wc, "wc"), (bc, "bc")):
             _require(t, n)
         n_bags, N, max_len, E2d = _bag_geometry(E, cu_seqlens, max_len)
         need = any(ctx.needs_input_grad[:7])
@@ -241,14 +260,14 @@ class AttnPoolFn(torch.autograd.Function):
         cu = cu if ragged else None
         dE = torch.empty_like(E2d)
         if d_scores_in is not None:
-            ds = d_scores_in.contiguous().clone()
+            ds = d_scores_in.float().contiguous().clone()
             acc_s = 1
         else:
             ds = torch.empty_like(scores)
             acc_s = 0
         if d_pooled is None:
             d_pooled = torch.zeros_like(pooled)
-        pool_bwd_raw(E2d, scores, pooled, m, l, d_pooled.contiguous(), dE, 0, ds, acc_s, n_bags, N, cu, max_len)
+        pool_bwd_raw(E2d, scores, pooled, m, l, d_pooled.float().contiguous(), dE, 0, ds, acc_s, n_bags, N, cu, max_len)
         dWa, dWb, dba, dbb, dwc, dbc = gate_bwd_raw(E2d, Wa, Wb, wc, act_a, act_b, ds, dE, 1, p_drop, seed, keep_a, keep_b)
         return dE.view(e_shape), dWa, dba, dWb, dbb, dwc, dbc, None, None, None, None, None, None
 
@@ -273,7 +292,7 @@ class LNGeluDropFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, eps, p_drop, seed, keep):
-        _require(x, "x")
+        _require_act(x, "x")
         _require(gamma, "gamma")
         _require(beta, "beta")
         lib = _native.lib()
@@ -283,7 +302,7 @@ class LNGeluDropFn(torch.autograd.Function):
         mean = torch.empty(rows, device=x.device, dtype=torch.float32)
         rstd = torch.empty_like(mean)
         with _timed("ln_gelu_drop_fwd"):
-            rc = lib.mdl_ln_gelu_drop_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd), rows, W,
+            rc = getattr(lib, "mdl_ln_gelu_drop_fwd" + _sfx(x))(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd), rows, W,
                                           float(eps), float(p_drop), int(seed), _ptr(keep), _stream())
         if rc == -3:
             raise NotImplementedError("fused LayerNorm-GELU-Dropout supports widths 256/512/2048 (got %d)" % W)
@@ -299,12 +318,12 @@ class LNGeluDropFn(torch.autograd.Function):
         lib = _native.lib()
         W = x.shape[-1]
         rows = x.numel() // W
-        dy = dy.contiguous()
+        dy = dy.to(x.dtype).contiguous()
         dx = torch.empty_like(x)
         dg, db = torch.empty_like(gamma), torch.empty_like(beta)
         ws = _ws(lib.mdl_ln_gelu_drop_bwd_ws_bytes(rows, W), x.device)
         with _timed("ln_gelu_drop_bwd"):
-            rc = lib.mdl_ln_gelu_drop_bwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(dy), _ptr(dx), _ptr(dg),
+            rc = getattr(lib, "mdl_ln_gelu_drop_bwd" + _sfx(x))(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(dy), _ptr(dx), _ptr(dg),
                                           _ptr(db), rows, W, p_drop, seed, _ptr(keep), _ptr(ws), _stream())
         _native.check(rc, "mdl_ln_gelu_drop_bwd")
         return dx, dg, db, None, None, None, None

@@ -65,7 +65,7 @@ class InfoNCE(nn.Module):
 
     def batched(self, Q, P, cnt, symmetric=False):
         """S problems at once: Q,P [S,Kmax,D] padded, cnt int32 [S] -> loss [S] (mean reduction)."""
-        return MF.info_nce_batched(Q, P, cnt, self.temperature, symmetric)
+        return MF.info_nce_batched(Q.float().contiguous(), P.float().contiguous(), cnt, self.temperature, symmetric)
 
 
 def init_intra_wsi_loss_function(config):

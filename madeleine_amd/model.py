@@ -31,6 +31,11 @@ HE_POSITION = 0
 PRE_DROPOUT_P = 0.1  # Model.py:354,358,362
 
 
+def bf16_mode() -> bool:
+    """True inside torch.autocast(device_type='cuda', dtype=torch.bfloat16): selects the kernels' bf16 mode."""
+    return torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16
+
+
 def _strip_module_prefix(state_dict):
     """Model.py:31-40 / utils.py:112-120: DataParallel checkpoints carry a 'module.' prefix."""
     if not any(k.startswith("module.") for k in state_dict):
@@ -106,14 +111,25 @@ class ABMILEmbedder(nn.Module):
                 keep = keep.to(torch.uint8).contiguous()
             else:
                 seed = MF.new_dropout_seed()
-        return MF.ln_gelu_drop(x.float(), g, b, ln.eps, p, seed, keep)
+        return MF.ln_gelu_drop(x if x.dtype == torch.bfloat16 else x.float(), g, b, ln.eps, p, seed, keep)
 
     def embed_tokens_headmajor(self, bags: torch.Tensor) -> torch.Tensor:
-        """pre_attn(bags) with the 2048 output channels in head-major order: [BM, N, H*512]."""
+        """pre_attn(bags) with the 2048 output channels in head-major order: [BM, N, H*512].
+
+        Under torch.autocast(bfloat16) -- the reference's `precision: bfloat16` runs (trainer.py:101-103) -- the
+        activations are kept in bf16 end to end (Linear outputs, the fused LayerNorm-GELU-Dropout input/output and E):
+        the bf16 mode of the HIP kernels; LayerNorm statistics, GELU and every reduction stay fp32 inside the kernels."""
         pa = self.pre_attn
+        perm = self._perm
+        if bf16_mode():
+            with torch.autocast(device_type="cuda", enabled=False):
+                bf = torch.bfloat16
+                x = self._act(F.linear(bags.to(bf), pa[0].weight.to(bf), pa[0].bias.to(bf)), pa[1], 0)
+                x = self._act(F.linear(x, pa[4].weight.to(bf), pa[4].bias.to(bf)), pa[5], 1)
+                x = F.linear(x, pa[8].weight[perm].to(bf), pa[8].bias[perm].to(bf))
+                return self._act(x, pa[9], 2, perm)
         x = self._act(pa[0](bags), pa[1], 0)
         x = self._act(pa[4](x), pa[5], 1)
-        perm = self._perm
         x = F.linear(x, pa[8].weight[perm], pa[8].bias[perm])
         return self._act(x, pa[9], 2, perm)
 

@@ -1,0 +1,160 @@
+"""bf16 mode of the HIP kernels (the reference's `precision: bfloat16` autocast runs): every *_bf16 entry point against
+its fp32 sibling on the SAME (bf16-representable) inputs, and the whole encoder under torch.autocast against the
+oracle -- which must be at least as close to the fp32 truth as the oracle itself evaluated under CPU autocast(bf16),
+i.e. as the reference's own bf16 runs.  Tolerances are bf16-sized (2^-8 = 3.9e-3 per rounding) and written out below."""
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+from oracle import recipe
+from oracle import restatement as R
+from tests._util import MODS5, rel_err, t
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+EPS_BF16 = 2.0 ** -8
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _bf(x):
+    """fp32 tensor rounded to bf16-representable values."""
+    return x.to(BF).float()
+
+
+@pytest.mark.parametrize("W,rows", [(512, 300), (2048, 77)])
+def test_ln_gelu_drop_bf16_vs_fp32_kernel(dev, W, rows):
+    from madeleine_amd import functional as MF
+    x = _bf(t((rows, W), f"bf:ln:x{W}") * 2.0).to(dev)
+    g = (1.0 + 0.2 * t((W,), f"bf:ln:g{W}")).to(dev).requires_grad_()
+    b = (0.1 * t((W,), f"bf:ln:b{W}")).to(dev).requires_grad_()
+    dy = _bf(t((rows, W), f"bf:ln:dy{W}")).to(dev)
+    outs = {}
+    for name, xx in (("f32", x.clone().requires_grad_()), ("bf16", x.to(BF).requires_grad_())):
+        g.grad = b.grad = None
+        y = MF.ln_gelu_drop(xx, g, b, 1e-5, 0.1, 1234, None)       # same seed -> same counter-hash mask
+        y.backward(dy.to(y.dtype))
+        outs[name] = (y.detach().float(), xx.grad.float(), g.grad.clone(), b.grad.clone())
+    assert outs["bf16"][0].dtype == torch.float32
+    # y and dx differ by one bf16 rounding of the output; dgamma/dbeta are fp32 sums of identical per-element terms
+    assert rel_err(outs["bf16"][0], outs["f32"][0]) < EPS_BF16
+    assert rel_err(outs["bf16"][1], outs["f32"][1]) < EPS_BF16
+    assert rel_err(outs["bf16"][2], outs["f32"][2]) < 1e-5 and rel_err(outs["bf16"][3], outs["f32"][3]) < 1e-5
+
+
+def test_pool_bf16_vs_fp32_kernel(dev):
+    from madeleine_amd import functional as MF
+    BM, N, H = 3, 333, 4
+    E = _bf(t((BM, N, H * 512), "bf:pool:E")).to(dev)
+    s = (3.0 * t((BM, N, H), "bf:pool:s")).to(dev)
+    dp = t((BM, H * 512), "bf:pool:dp").to(dev)
+    res = {}
+    for name, EE in (("f32", E.clone().requires_grad_()), ("bf16", E.to(BF).requires_grad_())):
+        ss = s.clone().requires_grad_()
+        pooled = MF.softmax_pool(EE, ss)
+        pooled.backward(dp)
+        res[name] = (pooled.detach(), EE.grad.float(), ss.grad)
+    assert res["bf16"][0].dtype == torch.float32
+    assert rel_err(res["bf16"][0], res["f32"][0]) < 1e-6              # same inputs, fp32 accumulation: same result
+    assert rel_err(res["bf16"][2], res["f32"][2]) < 1e-5
+    assert rel_err(res["bf16"][1], res["f32"][1]) < EPS_BF16           # dE rounded once to bf16
+
+
+@pytest.mark.parametrize("T,p", [(300, 0.0), (1000, 0.25), (5, 0.25)])
+def test_gate_bf16_vs_fp32_kernel(dev, T, p):
+    """bf16 MFMA gate (fwd, dX, dW through the transposed copies, column sums) against the fp32 gate kernels fed the
+    same bf16-representable E and weights.  Differences: fp32 accumulation order, the bf16 rounding of the stored
+    activations a, b (forward uses the rounded values too) and of dz / dE."""
+    from madeleine_amd import functional as MF
+    H = 4
+    E = _bf(t((T, H * 512), f"bf:gate:E{T}")).to(dev)
+    Wa = _bf(0.05 * t((H, 512, 512), "bf:gate:Wa")).to(dev)
+    Wb = _bf(0.05 * t((H, 512, 512), "bf:gate:Wb")).to(dev)
+    ba, bb = (0.1 * t((H, 512), "bf:gate:ba")).to(dev), (0.1 * t((H, 512), "bf:gate:bb")).to(dev)
+    wc, bc = (0.1 * t((H, 512), "bf:gate:wc")).to(dev), (0.1 * t((H,), "bf:gate:bc")).to(dev)
+    ds = t((T, H), f"bf:gate:ds{T}").to(dev)
+    res = {}
+    for name, EE in (("f32", E.clone()), ("bf16", E.to(BF))):
+        ps = [x.clone().requires_grad_() for x in (Wa, ba, Wb, bb, wc, bc)]
+        EE.requires_grad_()
+        sc = MF.gate_scores(EE, *ps, p_drop=p, seed=77)
+        sc.backward(ds)
+        res[name] = [sc.detach(), EE.grad.float()] + [x.grad for x in ps]
+    scale = float(res["f32"][0].abs().max())
+    assert float((res["bf16"][0] - res["f32"][0]).abs().max()) < 2 * EPS_BF16 * scale   # scores [T,H]
+    names = ["scores", "dE", "dWa", "dba", "dWb", "dbb", "dwc", "dbc"]
+    for i in range(1, 8):
+        tol = 5e-3 if names[i] != "dbc" else 1e-5       # dbc = sum(ds): no bf16 quantity involved
+        assert rel_err(res["bf16"][i], res["f32"][i]) < tol, names[i]
+
+
+def _cfg(mods, d_in):
+    return SimpleNamespace(MODALITIES=list(mods), wsi_encoder="abmil", patch_embedding_dim=d_in,
+                           wsi_encoder_hidden_dim=512, activation="softmax", n_heads=4)
+
+
+def _build(mods, d_in, tag, dev):
+    from madeleine_amd import MADELEINE
+    m = MADELEINE(_cfg(mods, d_in))
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    sd = {k: torch.from_numpy(v) for k, v in recipe.state_dict_recipe(shapes, tag).items()}
+    m.load_state_dict(sd, strict=True)
+    return m.to(dev), sd
+
+
+def test_encoder_autocast_vs_oracle(dev):
+    """Slide / token embeddings under torch.autocast(bf16): error against the fp32 oracle no larger than (2x) the error
+    of the oracle itself run under CPU autocast -- the accuracy the reference's bf16 runs have."""
+    mods = MODS5[:2]
+    B, M, N, D = 3, 2, 200, 512
+    model, sd = _build(mods, D, "w", dev)
+    model.eval()
+    feats = t((B, M, N, D), "bf:enc:feats")
+    ref_e, ref_t = R.madeleine_forward_train(feats, sd, mods)
+    with torch.autocast(device_type="cpu", dtype=BF):
+        ac_e, ac_t = R.madeleine_forward_train(feats, sd, mods)
+    with torch.autocast(device_type="cuda", dtype=BF):
+        e, tk = model({"feats": feats}, device=dev, train=True)
+    for k in mods:
+        err_ours, err_ref = rel_err(e[k].float(), ref_e[k]), rel_err(ac_e[k].float(), ref_e[k])
+        assert err_ours < max(2.0 * err_ref, 2 * EPS_BF16), (k, err_ours, err_ref)
+        err_ours, err_ref = rel_err(tk[k].float(), ref_t[k]), rel_err(ac_t[k].float(), ref_t[k])
+        assert err_ours < max(2.0 * err_ref, 2 * EPS_BF16), (k, err_ours, err_ref)
+
+
+def test_train_step_autocast_grads_track_fp32(dev):
+    """One pretrain step (train mode, dropout on, InfoNCE at T = 0.1) under autocast: finite loss, and parameter
+    gradients pointing the same way as the fp32 mode's (same dropout seeds): cosine > 0.99 for every weight matrix,
+    > 0.9 for the bias / LayerNorm vectors (sums over the batch of mutually cancelling bf16 terms)."""
+    from madeleine_amd import InfoNCE, calculate_losses
+    mods = MODS5[:3]
+    B, M, N, D = 6, 3, 160, 512
+    feats = t((B, M, N, D), "bf:step:feats")
+    labels = torch.ones(B, M)
+    args = SimpleNamespace(global_loss="info-nce", symmetric_cl=True, local_loss_weight=1.0)
+    crit = InfoNCE(temperature=0.1)
+    grads = {}
+    for mode in ("fp32", "bf16"):
+        model, _ = _build(mods, D, "w", dev)
+        model.train()
+        torch.manual_seed(5)                                   # same dropout seeds in both modes
+        with torch.autocast(device_type="cuda", dtype=BF, enabled=(mode == "bf16")):
+            embs, toks = model({"feats": feats}, device=dev, train=True)
+            loss, flag = calculate_losses(mods[1:], crit, None, None, embs, toks, labels[:, 1:], args)
+        assert flag and torch.isfinite(loss)
+        loss.backward()
+        grads[mode] = {k: p.grad.detach().float().flatten() for k, p in model.named_parameters() if p.grad is not None}
+        grads[mode]["__loss__"] = float(loss.detach())
+        ndim = {k: p.dim() for k, p in model.named_parameters()}
+    assert abs(grads["bf16"]["__loss__"] - grads["fp32"]["__loss__"]) < 0.05 * abs(grads["fp32"]["__loss__"]) + 1e-3
+    for k, g32 in grads["fp32"].items():
+        if k == "__loss__" or float(g32.norm()) < 1e-6 * max(float(v.norm()) for kk, v in grads["fp32"].items() if kk != "__loss__"):
+            continue
+        cos = float(torch.dot(grads["bf16"][k], g32) / (grads["bf16"][k].norm() * g32.norm()).clamp_min(1e-30))
+        assert cos > (0.99 if ndim[k] >= 2 else 0.9), (k, cos)
