@@ -7,7 +7,7 @@
 // move 8 B (fwd: read x, write y) and 12 B (bwd: read x, dy, write dx) per element -- the op is purely HBM-bound.
 // LayerNorm semantics: biased variance, eps inside the sqrt (torch default 1e-5), affine.  GELU: exact erf form.
 // Dropout: inverted scaling 1/(1-p); mask = explicit uint8 [rows,W] if given, else a counter hash of
-// (seed, row*W + col) regenerated in backward (nothing stored).
+// (seed, row*W + col) regenerated in backward (nothing stored; one hash per element pair).
 //
 // One wave per row: lane L owns columns {4L + 256 i .. +3}, i < W/256 (W = 512 -> 2 float4, 2048 -> 8 float4), so
 // a row is W/256 coalesced 1 KiB loads, the mean/variance are two 64-lane reductions, and in backward the per-
@@ -18,11 +18,29 @@ namespace mdl {
 
 constexpr int ACT_BLOCK = 256;  // 4 waves
 
-__device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }
+// Standard normal CDF through the Numerical-Recipes erfc fit  erfc(z) = t exp(-z^2 + P(t)), t = 1/(1 + z/2)  (fractional
+// error < 1.2e-7 everywhere in exact arithmetic, < 2e-6 evaluated in fp32): one v_rcp, one v_exp and 10 FMAs instead of
+// libm erff's ~50 instructions with branches -- these kernels were VALU-bound on erff, not HBM-bound.  The erfc form keeps
+// the RELATIVE accuracy of the far negative tail (GELU(x) -> x * Phi(x), Phi tiny).
+__device__ __forceinline__ float norm_cdf_f(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.5f, z, 1.f));
+    float p = 0.17087277f;
+    p = fmaf(t, p, -0.82215223f);
+    p = fmaf(t, p, 1.48851587f);
+    p = fmaf(t, p, -1.13520398f);
+    p = fmaf(t, p, 0.27886807f);
+    p = fmaf(t, p, -0.18628806f);
+    p = fmaf(t, p, 0.09678418f);
+    p = fmaf(t, p, 0.37409196f);
+    p = fmaf(t, p, 1.00002368f);
+    const float h = 0.5f * t * __expf(fmaf(-z, z, fmaf(t, p, -1.26551223f)));   // = erfc(z) / 2
+    return x < 0.f ? h : 1.f - h;
+}
+__device__ __forceinline__ float gelu_f(float v) { return v * norm_cdf_f(v); }
 __device__ __forceinline__ float gelu_grad_f(float v) {
-    const float cdf = 0.5f * (1.f + erff(v * 0.70710678118654752f));
     const float pdf = 0.3989422804014327f * __expf(-0.5f * v * v);
-    return cdf + v * pdf;
+    return norm_cdf_f(v) + v * pdf;
 }
 
 struct ActDrop {
@@ -31,10 +49,28 @@ struct ActDrop {
     const uint8_t* keep;
     int on;
 };
-__device__ __forceinline__ bool act_keep(const ActDrop& d, int64_t idx) {
-    if (!d.on) return true;
-    if (d.keep) return d.keep[idx] != 0;
-    return (rng_u32(d.key, (uint64_t)idx) & 0xFFFFu) >= d.thr;
+// Keep decisions of the 4 consecutive elements [idx4, idx4 + 4) of a row (idx4 % 4 == 0): ONE counter hash per element
+// PAIR -- the even element takes the low 16 bits, the odd one the high 16 bits -- and 32-bit index arithmetic inside a
+// row (a row never straddles a 2^32 boundary because W divides 2^32).  row_key = key ^ (hi32(row * W) * golden).
+__device__ __forceinline__ void act_keep4(const ActDrop& d, uint32_t row_key, uint32_t lo4, int64_t idx4, bool (&k)[4]) {
+    if (!d.on) {
+        k[0] = k[1] = k[2] = k[3] = true;
+    } else if (d.keep) {
+        const uint32_t m = *reinterpret_cast<const uint32_t*>(d.keep + idx4);
+        k[0] = (m & 0xFFu) != 0;
+        k[1] = (m & 0xFF00u) != 0;
+        k[2] = (m & 0xFF0000u) != 0;
+        k[3] = (m >> 24) != 0;
+    } else {
+        const uint32_t h0 = mix32(lo4 ^ row_key), h1 = mix32((lo4 + 2u) ^ row_key);
+        k[0] = (h0 & 0xFFFFu) >= d.thr;
+        k[1] = (h0 >> 16) >= d.thr;
+        k[2] = (h1 & 0xFFFFu) >= d.thr;
+        k[3] = (h1 >> 16) >= d.thr;
+    }
+}
+__device__ __forceinline__ uint32_t act_row_key(const ActDrop& d, int64_t row_base) {
+    return d.key ^ ((uint32_t)((uint64_t)row_base >> 32) * 0x9E3779B9U);
 }
 
 // Geometry: a 256-thread block = 4 waves.  WPR waves share one row (each owns a 256*NV-column segment), so a block
@@ -79,17 +115,30 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_fwd_kernel(const IO* _
         g[i] = *reinterpret_cast<const f32x4*>(gamma + col0 + i * 256);
         b[i] = *reinterpret_cast<const f32x4*>(beta + col0 + i * 256);
     }
+    // the next row's loads are issued before the current row's reductions / epilogue: a wave always has a row in flight
+    // (one row at a time left the kernel latency-bound at ~50 % of the HBM rate)
+    f32x4 vn[NV];
+    {
+        const int64_t r = (int64_t)blockIdx.x * RPB + slot;
+        const IO* __restrict__ xr = x + (r < rows ? r : 0) * W + col0;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) vn[i] = (r < rows) ? ld4_nt(xr + i * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     for (int64_t base = (int64_t)blockIdx.x * RPB; base < rows; base += (int64_t)gridDim.x * RPB) {
         const int64_t r = base + slot;
         const bool live = r < rows;
-        const IO* __restrict__ xr = x + (live ? r : 0) * W + col0;
         f32x4 v[NV];
         float s = 0.f, dummy = 0.f;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            v[i] = live ? ld4_nt(xr + i * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
-            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        for (int i = 0; i < NV; ++i) v[i] = vn[i];
+        {
+            const int64_t rn = r + (int64_t)gridDim.x * RPB;
+            const IO* __restrict__ xn = x + (rn < rows ? rn : 0) * W + col0;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) vn[i] = (rn < rows) ? ld4_nt(xn + i * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
         row_allreduce2<WPR>(s, dummy, red, slot * WPR, wv);
         const float mean = s * (1.f / W);
         float q = 0.f;
@@ -102,14 +151,18 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_fwd_kernel(const IO* _
         const float rstd = rsqrtf(q * (1.f / W) + eps);
         if (live) {
             IO* __restrict__ yr = y + r * W + col0;
+            const int64_t rb = r * W;
+            const uint32_t rkey = act_row_key(drop, rb);
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 f32x4 o;
+                bool kp[4];
+                act_keep4(drop, rkey, (uint32_t)rb + (uint32_t)(col0 + i * 256), rb + col0 + i * 256, kp);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float t = (v[i][e] - mean) * rstd * g[i][e] + b[i][e];
                     const float a = gelu_f(t);
-                    o[e] = act_keep(drop, r * W + col0 + i * 256 + e) ? a * drop.inv : 0.f;
+                    o[e] = kp[e] ? a * drop.inv : 0.f;
                 }
                 st4(yr + i * 256, o);
             }
@@ -142,26 +195,53 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_bwd_kernel(const IO* _
         sg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         sb[i] = sg[i];
     }
+    f32x4 xn[NV], gn[NV];   // next row, prefetched (see the forward kernel)
+    {
+        const int64_t r = (int64_t)blockIdx.x * RPB + slot;
+        const bool ok = r < rows;
+        const IO* __restrict__ xr = x + (ok ? r : 0) * W + col0;
+        const IO* __restrict__ gr = dy + (ok ? r : 0) * W + col0;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            xn[i] = ok ? ld4_nt(xr + i * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+            gn[i] = ok ? ld4_nt(gr + i * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
     for (int64_t base = (int64_t)blockIdx.x * RPB; base < rows; base += (int64_t)gridDim.x * RPB) {
         const int64_t r = base + slot;
         const bool live = r < rows;
         const float mean = live ? mean_i[r] : 0.f, rstd = live ? rstd_i[r] : 0.f;
-        const IO* __restrict__ xr = x + (live ? r : 0) * W + col0;
-        const IO* __restrict__ gr = dy + (live ? r : 0) * W + col0;
-        f32x4 xh[NV], dxh[NV];
-        float s1 = 0.f, s2 = 0.f;
+        f32x4 xc[NV], gc[NV];
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            f32x4 xv = {0.f, 0.f, 0.f, 0.f}, gv = xv;
-            if (live) {
-                xv = ld4_nt(xr + i * 256);
-                gv = ld4_nt(gr + i * 256);
+            xc[i] = xn[i];
+            gc[i] = gn[i];
+        }
+        {
+            const int64_t rn = r + (int64_t)gridDim.x * RPB;
+            const bool ok = rn < rows;
+            const IO* __restrict__ xr = x + (ok ? rn : 0) * W + col0;
+            const IO* __restrict__ gr = dy + (ok ? rn : 0) * W + col0;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                xn[i] = ok ? ld4_nt(xr + i * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+                gn[i] = ok ? ld4_nt(gr + i * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
+        }
+        f32x4 xh[NV], dxh[NV];
+        float s1 = 0.f, s2 = 0.f;
+        const int64_t rb = (live ? r : 0) * W;
+        const uint32_t rkey = act_row_key(drop, rb);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const f32x4 xv = xc[i], gv = gc[i];
+            bool kp[4];
+            act_keep4(drop, rkey, (uint32_t)rb + (uint32_t)(col0 + i * 256), rb + col0 + i * 256, kp);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float h = (xv[e] - mean) * rstd;
                 const float t = h * g[i][e] + b[i][e];
-                const float k = (live && act_keep(drop, r * W + col0 + i * 256 + e)) ? drop.inv : 0.f;
+                const float k = (live && kp[e]) ? drop.inv : 0.f;
                 const float dt = gv[e] * k * gelu_grad_f(t);  // d/d(LN output)
                 sg[i][e] += dt * h;
                 sb[i][e] += dt;
