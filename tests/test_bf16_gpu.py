@@ -158,3 +158,36 @@ def test_train_step_autocast_grads_track_fp32(dev):
             continue
         cos = float(torch.dot(grads["bf16"][k], g32) / (grads["bf16"][k].norm() * g32.norm()).clamp_min(1e-30))
         assert cos > (0.99 if ndim[k] >= 2 else 0.9), (k, cos)
+
+
+def test_other_branches_under_autocast(dev):
+    """Ragged bags, the 3-view branch, encode_he and the eval branch under autocast: same shapes as the
+    fp32 mode and values within bf16-sized error of it (eval mode: no dropout)."""
+    from madeleine_amd import MADELEINE
+    import numpy as np
+    mods = MODS5[:3]
+    D = 64
+    m = MADELEINE(_cfg(mods, D))
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in recipe.state_dict_recipe(shapes, "w").items()})
+    m = m.to(dev).eval()
+    lens = [[300, 257, 411], [256, 999, 300]]
+    bags = [[t((n, D), f"bf:rag:{b}:{i}").to(dev) for i, n in enumerate(row)] for b, row in enumerate(lens)]
+    feats = t((2, 3, 128, D), "bf:views:feats")
+    outs = {}
+    for mode in ("fp32", "bf16"):
+        with torch.autocast(device_type="cuda", dtype=BF, enabled=(mode == "bf16")):
+            e_r, t_r = m.forward_ragged(bags, dev)
+            np.random.seed(3)
+            e_v, _ = m({"feats": feats}, device=dev, train=True, n_views=3)
+            he = m.encode_he(feats[:, 0], dev)
+            ev = m({"feats": feats[:, :1]}, device=dev, train=False)
+        outs[mode] = (e_r, t_r, e_v, he, ev)
+    for k in mods:
+        for i in range(3):
+            a, b = outs["bf16"][i][k], outs["fp32"][i][k]
+            assert a.shape == b.shape
+            assert rel_err(a.float(), b.float()) < 3e-2, (k, i, rel_err(a.float(), b.float()))
+    assert outs["bf16"][2]["HE"].shape[1] == 3                      # [B, V=3, 512, M-1]
+    assert rel_err(outs["bf16"][3].float(), outs["fp32"][3]) < 3e-2
+    assert rel_err(outs["bf16"][4]["HE"].float(), outs["fp32"][4]["HE"]) < 3e-2
