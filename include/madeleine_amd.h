@@ -121,13 +121,16 @@ int mdl_abmil_pool_bwd(const float* E, int64_t ldE, const float* scores, const f
  * backward); LayerNorm: biased variance, rstd = 1/sqrt(var + eps).  Dropout as in the gate kernels: keep (uint8
  * [rows,W]) injects a mask, else a counter hash of (seed, element index) -- regenerated in backward.
  * dgamma, dbeta [W] are overwritten.  ws: mdl_ln_gelu_drop_bwd_ws_bytes(rows, W).
+ * bias [W] (may be NULL): the bias of the preceding Linear, added to x before the LayerNorm (y = f(x + bias)) so the
+ * GEMM runs bias-free; dbias [W] (may be NULL) receives its gradient = the column sums of dx, saving the separate
+ * reduction pass over dx that autograd's Linear backward would launch.
  */
-int mdl_ln_gelu_drop_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean,
-                         float* rstd, int64_t rows, int W, float eps, float p_drop, uint64_t seed,
+int mdl_ln_gelu_drop_fwd(const float* x, const float* bias, const float* gamma, const float* beta, float* y,
+                         float* mean, float* rstd, int64_t rows, int W, float eps, float p_drop, uint64_t seed,
                          const uint8_t* keep, void* stream);
 int64_t mdl_ln_gelu_drop_bwd_ws_bytes(int64_t rows, int W);
-int mdl_ln_gelu_drop_bwd(const float* x, const float* gamma, const float* beta, const float* mean,
-                         const float* rstd, const float* dy, float* dx, float* dgamma, float* dbeta,
+int mdl_ln_gelu_drop_bwd(const float* x, const float* bias, const float* gamma, const float* beta, const float* mean,
+                         const float* rstd, const float* dy, float* dx, float* dgamma, float* dbeta, float* dbias,
                          int64_t rows, int W, float p_drop, uint64_t seed, const uint8_t* keep, void* ws,
                          void* stream);
 
@@ -193,11 +196,12 @@ int mdl_got_bwd_finish(const float* V, const float* Q, float* dV, float* dQ, con
  * The fp32 entry points remain the parity path (1e-3 rel of the reference's fp32 results); this mode is held to
  * the reference-under-autocast accuracy (tests/test_bf16_gpu.py).
  */
-int mdl_ln_gelu_drop_fwd_bf16(const uint16_t* x, const float* gamma, const float* beta, uint16_t* y, float* mean, float* rstd,
-                              int64_t rows, int W, float eps, float p_drop, uint64_t seed, const uint8_t* keep, void* stream);
-int mdl_ln_gelu_drop_bwd_bf16(const uint16_t* x, const float* gamma, const float* beta, const float* mean, const float* rstd,
-                              const uint16_t* dy, uint16_t* dx, float* dgamma, float* dbeta, int64_t rows, int W,
-                              float p_drop, uint64_t seed, const uint8_t* keep, void* ws, void* stream);
+int mdl_ln_gelu_drop_fwd_bf16(const uint16_t* x, const float* bias, const float* gamma, const float* beta, uint16_t* y,
+                              float* mean, float* rstd, int64_t rows, int W, float eps, float p_drop, uint64_t seed,
+                              const uint8_t* keep, void* stream);
+int mdl_ln_gelu_drop_bwd_bf16(const uint16_t* x, const float* bias, const float* gamma, const float* beta, const float* mean,
+                              const float* rstd, const uint16_t* dy, uint16_t* dx, float* dgamma, float* dbeta, float* dbias,
+                              int64_t rows, int W, float p_drop, uint64_t seed, const uint8_t* keep, void* ws, void* stream);
 int mdl_abmil_pool_fwd_bf16(const uint16_t* E, int64_t ldE, const float* scores, float* pooled, float* stat_m,
                             float* stat_l, int64_t n_bags, int64_t N, const int64_t* cu_seqlens, int64_t max_len, int H,
                             void* ws, void* stream);

@@ -33,9 +33,9 @@ SIGNATURES = {
     "mdl_abmil_pool_ws_bytes": (i64, [i64, i64, i32]),
     "mdl_abmil_pool_fwd": (i32, [c_f, i64, c_f, c_f, c_f, c_f, i64, i64, c_p, i64, i32, c_p, c_p]),
     "mdl_abmil_pool_bwd": (i32, [c_f, i64, c_f, c_f, c_f, c_f, c_f, c_f, i32, c_f, i32, i64, i64, c_p, i64, i32, c_p]),
-    "mdl_ln_gelu_drop_fwd": (i32, [c_f, c_f, c_f, c_f, c_f, c_f, i64, i32, f32, f32, u64, c_p, c_p]),
+    "mdl_ln_gelu_drop_fwd": (i32, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, i64, i32, f32, f32, u64, c_p, c_p]),
     "mdl_ln_gelu_drop_bwd_ws_bytes": (i64, [i64, i32]),
-    "mdl_ln_gelu_drop_bwd": (i32, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i64, i32, f32, u64, c_p, c_p, c_p]),
+    "mdl_ln_gelu_drop_bwd": (i32, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i64, i32, f32, u64, c_p, c_p, c_p]),
     "mdl_infonce_ws_bytes": (i64, [i32, i32, i32]),
     "mdl_infonce_fwd": (i32, [c_f, c_f, c_p, c_f, i32, i32, i32, f32, i32, c_p, c_p]),
     "mdl_infonce_bwd": (i32, [c_f, c_p, c_f, c_f, i32, i32, i32, f32, i32, c_p, c_p]),
@@ -46,8 +46,9 @@ SIGNATURES = {
     "mdl_got_bwd_begin": (i32, [c_f, c_f, i32, i32, i32, c_p, c_p]),
     "mdl_got_bwd_finish": (i32, [c_f, c_f, c_f, c_f, c_f, i32, i32, i32, c_p, c_p]),
     # bf16 mode (same argument lists as the fp32 entry points; activation pointers are bf16)
-    "mdl_ln_gelu_drop_fwd_bf16": (i32, [c_f, c_f, c_f, c_f, c_f, c_f, i64, i32, f32, f32, u64, c_p, c_p]),
-    "mdl_ln_gelu_drop_bwd_bf16": (i32, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i64, i32, f32, u64, c_p, c_p, c_p]),
+    "mdl_ln_gelu_drop_fwd_bf16": (i32, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, i64, i32, f32, f32, u64, c_p, c_p]),
+    "mdl_ln_gelu_drop_bwd_bf16": (i32, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i64, i32, f32, u64, c_p, c_p,
+                                        c_p]),
     "mdl_abmil_pool_fwd_bf16": (i32, [c_f, i64, c_f, c_f, c_f, c_f, i64, i64, c_p, i64, i32, c_p, c_p]),
     "mdl_abmil_pool_bwd_bf16": (i32, [c_f, i64, c_f, c_f, c_f, c_f, c_f, c_f, i32, c_f, i32, i64, i64, c_p, i64, i32, c_p]),
     "mdl_abmil_gate_fwd_bf16_ws_bytes": (i64, [i64, i32]),

@@ -100,6 +100,7 @@ __device__ __forceinline__ void row_allreduce2(float& a, float& b, float (*red)[
 
 template <int NV, int WPR, class IO>
 __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_fwd_kernel(const IO* __restrict__ x,
+                                                                     const float* __restrict__ bias,
                                                                      const float* __restrict__ gamma,
                                                                      const float* __restrict__ beta,
                                                                      IO* __restrict__ y, float* __restrict__ mean_o,
@@ -109,11 +110,12 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_fwd_kernel(const IO* _
     __shared__ float red[1][4][2];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, slot = wv / WPR, seg = wv % WPR;
     const int col0 = seg * NV * 256 + lane * 4;
-    f32x4 g[NV], b[NV];
+    f32x4 g[NV], b[NV], lb[NV];   // lb: bias of the preceding Linear (added here instead of in the GEMM epilogue)
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         g[i] = *reinterpret_cast<const f32x4*>(gamma + col0 + i * 256);
         b[i] = *reinterpret_cast<const f32x4*>(beta + col0 + i * 256);
+        lb[i] = bias ? *reinterpret_cast<const f32x4*>(bias + col0 + i * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     // the next row's loads are issued before the current row's reductions / epilogue: a wave always has a row in flight
     // (one row at a time left the kernel latency-bound at ~50 % of the HBM rate)
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_fwd_kernel(const IO* _
         f32x4 v[NV];
         float s = 0.f, dummy = 0.f;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) v[i] = vn[i];
+        for (int i = 0; i < NV; ++i) v[i] = vn[i] + lb[i];
         {
             const int64_t rn = r + (int64_t)gridDim.x * RPB;
             const IO* __restrict__ xn = x + (rn < rows ? rn : 0) * W + col0;
@@ -176,6 +178,7 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_fwd_kernel(const IO* _
 
 template <int NV, int WPR, class IO>
 __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_bwd_kernel(const IO* __restrict__ x,
+                                                                     const float* __restrict__ bias,
                                                                      const float* __restrict__ gamma,
                                                                      const float* __restrict__ beta,
                                                                      const float* __restrict__ mean_i,
@@ -184,16 +187,18 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_bwd_kernel(const IO* _
                                                                      float* __restrict__ part, int64_t rows, ActDrop drop) {
     constexpr int W = NV * 256 * WPR, RPB = 4 / WPR;
     __shared__ float red[1][4][2];
-    __shared__ float csum[WPR == 1 ? 2 * W : 1];  // WPR == 1: the 4 waves own the same columns -> merged through LDS
+    __shared__ float csum[WPR == 1 ? 3 * W : 1];  // WPR == 1: the 4 waves own the same columns -> merged through LDS
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, slot = wv / WPR, seg = wv % WPR;
     const int col0 = seg * NV * 256 + lane * 4;
-    f32x4 g[NV], b[NV], sg[NV], sb[NV];
+    f32x4 g[NV], b[NV], lb[NV], sg[NV], sb[NV], sx[NV];   // sx: column sums of dx = gradient of the Linear's bias
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         g[i] = *reinterpret_cast<const f32x4*>(gamma + col0 + i * 256);
         b[i] = *reinterpret_cast<const f32x4*>(beta + col0 + i * 256);
+        lb[i] = bias ? *reinterpret_cast<const f32x4*>(bias + col0 + i * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
         sg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         sb[i] = sg[i];
+        sx[i] = sg[i];
     }
     f32x4 xn[NV], gn[NV];   // next row, prefetched (see the forward kernel)
     {
@@ -234,7 +239,7 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_bwd_kernel(const IO* _
         const uint32_t rkey = act_row_key(drop, rb);
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const f32x4 xv = xc[i], gv = gc[i];
+            const f32x4 xv = xc[i] + lb[i], gv = gc[i];
             bool kp[4];
             act_keep4(drop, rkey, (uint32_t)rb + (uint32_t)(col0 + i * 256), rb + col0 + i * 256, kp);
 #pragma unroll
@@ -261,16 +266,18 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_bwd_kernel(const IO* _
                 f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = rstd * (dxh[i][e] - m1 - xh[i][e] * m2);
+                sx[i] += v;
                 st4(o + i * 256, v);
             }
         }
     }
-    float* __restrict__ prow = part + (int64_t)blockIdx.x * 2 * W;  // [block][dgamma W | dbeta W]
+    float* __restrict__ prow = part + (int64_t)blockIdx.x * 3 * W;  // [block][dgamma W | dbeta W | dbias W]
     if (WPR == 4) {  // every wave owns its own column segment
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             *reinterpret_cast<f32x4*>(prow + col0 + i * 256) = sg[i];
             *reinterpret_cast<f32x4*>(prow + W + col0 + i * 256) = sb[i];
+            *reinterpret_cast<f32x4*>(prow + 2 * W + col0 + i * 256) = sx[i];
         }
     } else {  // waves (= rows) add into one LDS row in wave order (deterministic)
 #pragma unroll
@@ -280,46 +287,52 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_bwd_kernel(const IO* _
                 for (int i = 0; i < NV; ++i) {
                     f32x4* pg = reinterpret_cast<f32x4*>(&csum[col0 + i * 256]);
                     f32x4* pb = reinterpret_cast<f32x4*>(&csum[W + col0 + i * 256]);
+                    f32x4* px = reinterpret_cast<f32x4*>(&csum[2 * W + col0 + i * 256]);
                     if (w == 0) {
                         *pg = sg[i];
                         *pb = sb[i];
+                        *px = sx[i];
                     } else {
                         *pg += sg[i];
                         *pb += sb[i];
+                        *px += sx[i];
                     }
                 }
             }
             __syncthreads();
         }
-        for (int c = threadIdx.x; c < 2 * W; c += ACT_BLOCK) prow[c] = csum[c];
+        for (int c = threadIdx.x; c < 3 * W; c += ACT_BLOCK) prow[c] = csum[c];
     }
 }
 
-// dgamma|dbeta[c] = sum over blocks of part[block][c]: 32 columns x 8 block-groups per workgroup (coalesced 128-B
+// dgamma|dbeta|dbias[c] = sum over blocks of part[block][c]: 32 columns x 8 block-groups per workgroup (coalesced 128-B
 // row segments, 8 loads in flight per thread), the 8 partial sums merged through LDS in a fixed order.
 __global__ __launch_bounds__(256) void ln_reduce_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
-                                                        float* __restrict__ dbeta, int nblocks, int W) {
+                                                        float* __restrict__ dbeta, float* __restrict__ dbias, int nblocks,
+                                                        int W) {
     __shared__ float red[8][32];
     const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
     float v = 0.f;
-    if (c < 2 * W) {
+    if (c < 3 * W) {
         int k = grp;
         for (; k + 56 < nblocks; k += 64) {
             float t[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) t[u] = part[(int64_t)(k + 8 * u) * 2 * W + c];
+            for (int u = 0; u < 8; ++u) t[u] = part[(int64_t)(k + 8 * u) * 3 * W + c];
 #pragma unroll
             for (int u = 0; u < 8; ++u) v += t[u];
         }
-        for (; k < nblocks; k += 8) v += part[(int64_t)k * 2 * W + c];
+        for (; k < nblocks; k += 8) v += part[(int64_t)k * 3 * W + c];
     }
     red[grp][cl] = v;
     __syncthreads();
-    if (grp == 0 && c < 2 * W) {
+    if (grp == 0 && c < 3 * W) {
         float t = red[0][cl];
 #pragma unroll
         for (int g = 1; g < 8; ++g) t += red[g][cl];
-        (c < W ? dgamma : dbeta)[c < W ? c : c - W] = t;
+        if (c < W) dgamma[c] = t;
+        else if (c < 2 * W) dbeta[c - W] = t;
+        else if (dbias) dbias[c - 2 * W] = t;
     }
 }
 
@@ -347,7 +360,7 @@ using namespace mdl;
 extern "C" int64_t mdl_ln_gelu_drop_bwd_ws_bytes(int64_t rows, int W) {
     if (rows < 0) return MDL_E_ARG;
     if (W != 256 && W != 512 && W != 2048) return MDL_E_UNSUPPORTED;
-    return (int64_t)act_blocks(rows, W) * 2 * W * 4 + 64;
+    return (int64_t)act_blocks(rows, W) * 3 * W * 4 + 64;
 }
 
 #define MDL_DISPATCH_W(W, ...)                                                       \
@@ -359,74 +372,79 @@ extern "C" int64_t mdl_ln_gelu_drop_bwd_ws_bytes(int64_t rows, int W) {
     }
 
 template <class IO>
-static int ln_fwd_launch(const IO* x, const float* gamma, const float* beta, IO* y, float* mean, float* rstd, int64_t rows, int W,
+static int ln_fwd_launch(const IO* x, const float* bias, const float* gamma, const float* beta, IO* y, float* mean, float* rstd, int64_t rows, int W,
                          float eps, float p_drop, uint64_t seed, const uint8_t* keep, void* stream) {
     if (!x || !gamma || !beta || !y || !mean || !rstd || rows < 0) return MDL_E_ARG;
     if (!(p_drop >= 0.f && p_drop < 1.f) || !(eps > 0.f)) return MDL_E_ARG;
-    if (!host_aligned16(x) || !host_aligned16(y) || !host_aligned16(gamma) || !host_aligned16(beta)) return MDL_E_ALIGN;
+    if (!host_aligned16(x) || !host_aligned16(y) || !host_aligned16(gamma) || !host_aligned16(beta) || !host_aligned16(bias))
+        return MDL_E_ALIGN;
     if (rows == 0) return MDL_OK;
     const ActDrop d = make_act_drop(p_drop, seed, keep);
     if (W == 2048) {  // forward: a whole 2048-wide row per wave (153 VGPRs, no block barriers) beats 4 waves per row
         int64_t nb = (rows + 3) / 4;
         if (nb > 2048) nb = 2048;
         hipLaunchKernelGGL((ln_gelu_drop_fwd_kernel<8, 1, IO>), dim3((unsigned)nb), dim3(ACT_BLOCK), 0, (hipStream_t)stream, x,
-                           gamma, beta, y, mean, rstd, rows, eps, d);
+                           bias, gamma, beta, y, mean, rstd, rows, eps, d);
         MDL_LAUNCH_CHECK();
         return MDL_OK;
     }
     MDL_DISPATCH_W(W, {
         hipLaunchKernelGGL((ln_gelu_drop_fwd_kernel<NV, WPR, IO>), dim3(act_blocks(rows, W)), dim3(ACT_BLOCK), 0,
-                           (hipStream_t)stream, x, gamma, beta, y, mean, rstd, rows, eps, d);
+                           (hipStream_t)stream, x, bias, gamma, beta, y, mean, rstd, rows, eps, d);
         MDL_LAUNCH_CHECK();
     });
     return MDL_OK;
 }
 
 template <class IO>
-static int ln_bwd_launch(const IO* x, const float* gamma, const float* beta, const float* mean, const float* rstd, const IO* dy,
-                         IO* dx, float* dgamma, float* dbeta, int64_t rows, int W, float p_drop, uint64_t seed,
+static int ln_bwd_launch(const IO* x, const float* bias, const float* gamma, const float* beta, const float* mean, const float* rstd,
+                         const IO* dy, IO* dx, float* dgamma, float* dbeta, float* dbias, int64_t rows, int W, float p_drop, uint64_t seed,
                          const uint8_t* keep, void* ws, void* stream) {
     if (!x || !gamma || !beta || !mean || !rstd || !dy || !dx || !dgamma || !dbeta || !ws || rows < 0) return MDL_E_ARG;
     if (!(p_drop >= 0.f && p_drop < 1.f)) return MDL_E_ARG;
-    if (!host_aligned16(x) || !host_aligned16(dy) || !host_aligned16(dx) || !host_aligned16(gamma) || !host_aligned16(beta))
+    if (!host_aligned16(x) || !host_aligned16(dy) || !host_aligned16(dx) || !host_aligned16(gamma) || !host_aligned16(beta) ||
+        !host_aligned16(bias))
         return MDL_E_ALIGN;
     hipStream_t s = (hipStream_t)stream;
     const ActDrop d = make_act_drop(p_drop, seed, keep);
     const int nb = rows > 0 ? act_blocks(rows, W) : 0;
     MDL_DISPATCH_W(W, {
         if (nb > 0) {
-            hipLaunchKernelGGL((ln_gelu_drop_bwd_kernel<NV, WPR, IO>), dim3(nb), dim3(ACT_BLOCK), 0, s, x, gamma, beta, mean, rstd, dy,
+            hipLaunchKernelGGL((ln_gelu_drop_bwd_kernel<NV, WPR, IO>), dim3(nb), dim3(ACT_BLOCK), 0, s, x, bias, gamma, beta, mean, rstd, dy,
                                dx, (float*)ws, rows, d);
             MDL_LAUNCH_CHECK();
         }
     });
-    hipLaunchKernelGGL(ln_reduce_kernel, dim3((2 * W + 31) / 32), dim3(256), 0, s, (const float*)ws, dgamma, dbeta, nb, W);
+    hipLaunchKernelGGL(ln_reduce_kernel, dim3((3 * W + 31) / 32), dim3(256), 0, s, (const float*)ws, dgamma, dbeta, dbias, nb, W);
     MDL_LAUNCH_CHECK();
     return MDL_OK;
 }
 
-extern "C" int mdl_ln_gelu_drop_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean,
-                                    float* rstd, int64_t rows, int W, float eps, float p_drop, uint64_t seed,
+extern "C" int mdl_ln_gelu_drop_fwd(const float* x, const float* bias, const float* gamma, const float* beta, float* y,
+                                    float* mean, float* rstd, int64_t rows, int W, float eps, float p_drop, uint64_t seed,
                                     const uint8_t* keep, void* stream) {
-    return ln_fwd_launch<float>(x, gamma, beta, y, mean, rstd, rows, W, eps, p_drop, seed, keep, stream);
+    return ln_fwd_launch<float>(x, bias, gamma, beta, y, mean, rstd, rows, W, eps, p_drop, seed, keep, stream);
 }
 
-extern "C" int mdl_ln_gelu_drop_bwd(const float* x, const float* gamma, const float* beta, const float* mean,
-                                    const float* rstd, const float* dy, float* dx, float* dgamma, float* dbeta, int64_t rows,
-                                    int W, float p_drop, uint64_t seed, const uint8_t* keep, void* ws, void* stream) {
-    return ln_bwd_launch<float>(x, gamma, beta, mean, rstd, dy, dx, dgamma, dbeta, rows, W, p_drop, seed, keep, ws, stream);
+extern "C" int mdl_ln_gelu_drop_bwd(const float* x, const float* bias, const float* gamma, const float* beta, const float* mean,
+                                    const float* rstd, const float* dy, float* dx, float* dgamma, float* dbeta, float* dbias,
+                                    int64_t rows, int W, float p_drop, uint64_t seed, const uint8_t* keep, void* ws,
+                                    void* stream) {
+    return ln_bwd_launch<float>(x, bias, gamma, beta, mean, rstd, dy, dx, dgamma, dbeta, dbias, rows, W, p_drop, seed, keep, ws,
+                                stream);
 }
 
-extern "C" int mdl_ln_gelu_drop_fwd_bf16(const uint16_t* x, const float* gamma, const float* beta, uint16_t* y, float* mean,
-                                         float* rstd, int64_t rows, int W, float eps, float p_drop, uint64_t seed,
-                                         const uint8_t* keep, void* stream) {
-    return ln_fwd_launch<bf16_t>((const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, W, eps, p_drop, seed, keep, stream);
+extern "C" int mdl_ln_gelu_drop_fwd_bf16(const uint16_t* x, const float* bias, const float* gamma, const float* beta,
+                                         uint16_t* y, float* mean, float* rstd, int64_t rows, int W, float eps, float p_drop,
+                                         uint64_t seed, const uint8_t* keep, void* stream) {
+    return ln_fwd_launch<bf16_t>((const bf16_t*)x, bias, gamma, beta, (bf16_t*)y, mean, rstd, rows, W, eps, p_drop, seed, keep,
+                                 stream);
 }
 
-extern "C" int mdl_ln_gelu_drop_bwd_bf16(const uint16_t* x, const float* gamma, const float* beta, const float* mean,
-                                         const float* rstd, const uint16_t* dy, uint16_t* dx, float* dgamma, float* dbeta,
-                                         int64_t rows, int W, float p_drop, uint64_t seed, const uint8_t* keep, void* ws,
-                                         void* stream) {
-    return ln_bwd_launch<bf16_t>((const bf16_t*)x, gamma, beta, mean, rstd, (const bf16_t*)dy, (bf16_t*)dx, dgamma, dbeta, rows, W,
-                                 p_drop, seed, keep, ws, stream);
+extern "C" int mdl_ln_gelu_drop_bwd_bf16(const uint16_t* x, const float* bias, const float* gamma, const float* beta,
+                                         const float* mean, const float* rstd, const uint16_t* dy, uint16_t* dx, float* dgamma,
+                                         float* dbeta, float* dbias, int64_t rows, int W, float p_drop, uint64_t seed,
+                                         const uint8_t* keep, void* ws, void* stream) {
+    return ln_bwd_launch<bf16_t>((const bf16_t*)x, bias, gamma, beta, mean, rstd, (const bf16_t*)dy, (bf16_t*)dx, dgamma, dbeta,
+                                 dbias, rows, W, p_drop, seed, keep, ws, stream);
 }

@@ -288,13 +288,17 @@ def softmax_pool(E, scores, cu_seqlens=None, max_len=None):
 # N1: fused LayerNorm -> GELU -> Dropout (pre-attention MLP)
 # --------------------------------------------------------------------------------------------------
 class LNGeluDropFn(torch.autograd.Function):
-    """y = Dropout_p(GELU(LayerNorm(x; gamma, beta, eps)))  over the last axis (Model.py:352-354)."""
+    """y = Dropout_p(GELU(LayerNorm(x + bias; gamma, beta, eps)))  over the last axis (Model.py:351-354).
+    `bias` (optional) is the bias of the preceding Linear: the GEMM then runs bias-free and the bias gradient (column
+    sums of dx) comes out of the same backward pass instead of a separate reduction over dx."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, p_drop, seed, keep):
+    def forward(ctx, x, gamma, beta, eps, p_drop, seed, keep, bias):
         _require_act(x, "x")
         _require(gamma, "gamma")
         _require(beta, "beta")
+        if bias is not None:
+            _require(bias, "bias")
         lib = _native.lib()
         W = x.shape[-1]
         rows = x.numel() // W
@@ -302,35 +306,40 @@ class LNGeluDropFn(torch.autograd.Function):
         mean = torch.empty(rows, device=x.device, dtype=torch.float32)
         rstd = torch.empty_like(mean)
         with _timed("ln_gelu_drop_fwd"):
-            rc = getattr(lib, "mdl_ln_gelu_drop_fwd" + _sfx(x))(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd), rows, W,
-                                          float(eps), float(p_drop), int(seed), _ptr(keep), _stream())
+            rc = getattr(lib, "mdl_ln_gelu_drop_fwd" + _sfx(x))(_ptr(x), _ptr(bias), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean),
+                                                              _ptr(rstd), rows, W, float(eps), float(p_drop), int(seed),
+                                                              _ptr(keep), _stream())
         if rc == -3:
             raise NotImplementedError("fused LayerNorm-GELU-Dropout supports widths 256/512/2048 (got %d)" % W)
         _native.check(rc, "mdl_ln_gelu_drop_fwd")
-        ctx.save_for_backward(x, gamma, beta, mean, rstd)
-        ctx.cfg = (float(p_drop), int(seed), keep)
+        ctx.save_for_backward(x, gamma, beta, mean, rstd, bias if bias is not None else torch.empty(0))
+        ctx.cfg = (float(p_drop), int(seed), keep, bias is not None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, gamma, beta, mean, rstd = ctx.saved_tensors
-        p_drop, seed, keep = ctx.cfg
+        x, gamma, beta, mean, rstd, bias = ctx.saved_tensors
+        p_drop, seed, keep, has_bias = ctx.cfg
+        bias = bias if has_bias else None
         lib = _native.lib()
         W = x.shape[-1]
         rows = x.numel() // W
         dy = dy.to(x.dtype).contiguous()
         dx = torch.empty_like(x)
         dg, db = torch.empty_like(gamma), torch.empty_like(beta)
+        dbias = torch.empty_like(bias) if has_bias else None
         ws = _ws(lib.mdl_ln_gelu_drop_bwd_ws_bytes(rows, W), x.device)
         with _timed("ln_gelu_drop_bwd"):
-            rc = getattr(lib, "mdl_ln_gelu_drop_bwd" + _sfx(x))(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(dy), _ptr(dx), _ptr(dg),
-                                          _ptr(db), rows, W, p_drop, seed, _ptr(keep), _ptr(ws), _stream())
+            rc = getattr(lib, "mdl_ln_gelu_drop_bwd" + _sfx(x))(_ptr(x), _ptr(bias), _ptr(gamma), _ptr(beta), _ptr(mean),
+                                                              _ptr(rstd), _ptr(dy), _ptr(dx), _ptr(dg), _ptr(db), _ptr(dbias),
+                                                              rows, W, p_drop, seed, _ptr(keep), _ptr(ws), _stream())
         _native.check(rc, "mdl_ln_gelu_drop_bwd")
-        return dx, dg, db, None, None, None, None
+        return dx, dg, db, None, None, None, None, dbias
 
 
-def ln_gelu_drop(x, gamma, beta, eps=1e-5, p_drop=0.0, seed=0, keep=None):
-    return LNGeluDropFn.apply(x.contiguous(), gamma.contiguous(), beta.contiguous(), eps, p_drop, seed, keep)
+def ln_gelu_drop(x, gamma, beta, eps=1e-5, p_drop=0.0, seed=0, keep=None, bias=None):
+    return LNGeluDropFn.apply(x.contiguous(), gamma.contiguous(), beta.contiguous(), eps, p_drop, seed, keep,
+                              None if bias is None else bias.contiguous())
 
 
 # --------------------------------------------------------------------------------------------------

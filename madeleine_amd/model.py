@@ -97,9 +97,12 @@ class ABMILEmbedder(nn.Module):
             raise NotImplementedError('Attention model not implemented -- Options are ABMIL')
 
     # ------------------------------------------------------------------ internals (head-major)
-    def _act(self, x, ln, blk, perm=None):
-        """LayerNorm -> GELU -> Dropout(.1) of block `blk` in ONE fused HIP pass each way (functional.ln_gelu_drop)."""
+    def _act(self, x, ln, blk, perm=None, lin_bias=None):
+        """(+ bias of the preceding Linear) -> LayerNorm -> GELU -> Dropout(.1) of block `blk` in ONE fused HIP pass each
+        way (functional.ln_gelu_drop); the Linear itself runs bias-free."""
         g, b = (ln.weight, ln.bias) if perm is None else (ln.weight[perm], ln.bias[perm])
+        if lin_bias is not None and perm is not None:
+            lin_bias = lin_bias[perm]
         p, seed, keep = 0.0, 0, None
         if self.training:
             p = PRE_DROPOUT_P
@@ -111,7 +114,7 @@ class ABMILEmbedder(nn.Module):
                 keep = keep.to(torch.uint8).contiguous()
             else:
                 seed = MF.new_dropout_seed()
-        return MF.ln_gelu_drop(x if x.dtype == torch.bfloat16 else x.float(), g, b, ln.eps, p, seed, keep)
+        return MF.ln_gelu_drop(x if x.dtype == torch.bfloat16 else x.float(), g, b, ln.eps, p, seed, keep, lin_bias)
 
     def embed_tokens_headmajor(self, bags: torch.Tensor) -> torch.Tensor:
         """pre_attn(bags) with the 2048 output channels in head-major order: [BM, N, H*512].
@@ -124,14 +127,12 @@ class ABMILEmbedder(nn.Module):
         if bf16_mode():
             with torch.autocast(device_type="cuda", enabled=False):
                 bf = torch.bfloat16
-                x = self._act(F.linear(bags.to(bf), pa[0].weight.to(bf), pa[0].bias.to(bf)), pa[1], 0)
-                x = self._act(F.linear(x, pa[4].weight.to(bf), pa[4].bias.to(bf)), pa[5], 1)
-                x = F.linear(x, pa[8].weight[perm].to(bf), pa[8].bias[perm].to(bf))
-                return self._act(x, pa[9], 2, perm)
-        x = self._act(pa[0](bags), pa[1], 0)
-        x = self._act(pa[4](x), pa[5], 1)
-        x = F.linear(x, pa[8].weight[perm], pa[8].bias[perm])
-        return self._act(x, pa[9], 2, perm)
+                x = self._act(F.linear(bags.to(bf), pa[0].weight.to(bf)), pa[1], 0, None, pa[0].bias)
+                x = self._act(F.linear(x, pa[4].weight.to(bf)), pa[5], 1, None, pa[4].bias)
+                return self._act(F.linear(x, pa[8].weight[perm].to(bf)), pa[9], 2, perm, pa[8].bias)
+        x = self._act(F.linear(bags, pa[0].weight), pa[1], 0, None, pa[0].bias)
+        x = self._act(F.linear(x, pa[4].weight), pa[5], 1, None, pa[4].bias)
+        return self._act(F.linear(x, pa[8].weight[perm]), pa[9], 2, perm, pa[8].bias)
 
     def gate_params_stacked(self):
         ps = [h.gate_params() for h in self.attn]

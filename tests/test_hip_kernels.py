@@ -399,27 +399,33 @@ def test_got_external_thresholds_and_limits(dev):
 
 # ---------------------------------------------------------------------------------------------- N1 fused LN-GELU-Dropout
 @pytest.mark.parametrize("W,rows", [(512, 300), (2048, 77), (512, 1)])
-@pytest.mark.parametrize("mode", ["eval", "mask"])
+@pytest.mark.parametrize("mode", ["eval", "mask", "mask+bias"])
 def test_ln_gelu_drop_vs_torch(dev, W, rows, mode):
+    """mask+bias: the preceding Linear's bias is added inside the kernel and its gradient (column sums of dx) comes out of
+    the same backward pass."""
     import torch.nn.functional as F
     from madeleine_amd import functional as MF
     from oracle import recipe
     x = (t((rows, W), f"ln:x{W}{rows}") * 3 + 0.5).requires_grad_()
     g = (1 + 0.2 * t((W,), f"ln:g{W}")).requires_grad_()
     b = (0.3 * t((W,), f"ln:b{W}")).requires_grad_()
+    lb = (0.7 * t((W,), f"ln:lb{W}")).requires_grad_() if mode == "mask+bias" else None
     dy = t((rows, W), f"ln:dy{W}{rows}")
-    keep = torch.from_numpy(recipe.bernoulli((rows, W), f"ln:k{W}{rows}", 0.9)) if mode == "mask" else None
-    ref = F.gelu(F.layer_norm(x, (W,), g, b, 1e-5))
+    keep = torch.from_numpy(recipe.bernoulli((rows, W), f"ln:k{W}{rows}", 0.9)) if mode != "eval" else None
+    ref = F.gelu(F.layer_norm(x if lb is None else x + lb, (W,), g, b, 1e-5))
     if keep is not None:
         ref = ref * keep / 0.9
     ref.backward(dy)
     xd, gd, bd = (v.detach().to(dev).requires_grad_() for v in (x, g, b))
+    lbd = None if lb is None else lb.detach().to(dev).requires_grad_()
     out = MF.ln_gelu_drop(xd, gd, bd, 1e-5, 0.1 if keep is not None else 0.0, 0,
-                          None if keep is None else keep.to(torch.uint8).to(dev))
+                          None if keep is None else keep.to(torch.uint8).to(dev), lbd)
     out.backward(dy.to(dev))
     assert rel_err(out, ref) < 1e-5 and max_rel(out, ref) < TOL
     assert rel_err(xd.grad, x.grad) < 1e-4
     assert rel_err(gd.grad, g.grad) < 1e-4 and rel_err(bd.grad, b.grad) < 1e-4
+    if lb is not None:
+        assert rel_err(lbd.grad, lb.grad) < 1e-4
 
 
 def test_ln_gelu_drop_rng_is_consistent(dev):
