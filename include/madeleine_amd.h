@@ -113,6 +113,20 @@ int mdl_abmil_pool_bwd(const float* E, int64_t ldE, const float* scores, const f
                        int accumulate, float* d_scores, int accumulate_scores, int64_t n_bags, int64_t N,
                        const int64_t* cu_seqlens, int64_t max_len, int H, void* stream);
 
+/* Fused backward of A2 + A3 ("abmil_attnpool_bwd").  Call sequence:
+ *   1. mdl_abmil_pool_bwd(..., dE = NULL, ...)   -> d_scores only (one read of E; dE may be NULL in that call)
+ *   2. mdl_abmil_attnpool_bwd(...)               -> dE, dWa, dWb, dba, dbb, dwc, dbc
+ * Step 2 = mdl_abmil_gate_bwd whose dX epilogue adds the pooling term  w[t,c] * d_pooled[bag(t), c, :]
+ * (w = exp(scores - stat_m) / stat_l) while writing dE once -- instead of the pooling backward writing dE and the gate
+ * backward reading it back to accumulate (saves one write + one read of |E|).  row_bag int32 [T] gives the bag of
+ * every token row (ragged bags); row_bag == NULL means dense bags of N tokens (bag = t / N).  ws as mdl_abmil_gate_bwd. */
+int mdl_abmil_attnpool_bwd(const float* E, int64_t ldE, const float* Wa, const float* Wb, const float* wc,
+                           const float* act_a, const float* act_b, const float* d_scores, float* dE, float* dWa,
+                           float* dWb, float* dba, float* dbb, float* dwc, float* dbc, int64_t T, int H, float p_drop,
+                           uint64_t seed, const uint8_t* keep_a, const uint8_t* keep_b, const float* scores,
+                           const float* stat_m, const float* stat_l, const float* d_pooled, const int32_t* row_bag,
+                           int64_t N, void* ws, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * N1 -- fused LayerNorm -> GELU(erf) -> Dropout of the pre-attention MLP.  Replaces the
  * nn.LayerNorm / nn.GELU / nn.Dropout(0.1) triple that follows each Linear (madeleine/models/Model.py:352-354,
@@ -220,6 +234,12 @@ int mdl_abmil_gate_bwd_bf16(const uint16_t* E, int64_t ldE, const float* Wa, con
                             int accumulate, float* dWa, float* dWb, float* dba, float* dbb, float* dwc, float* dbc,
                             int64_t T, int H, float p_drop, uint64_t seed, const uint8_t* keep_a, const uint8_t* keep_b,
                             void* ws, void* stream);
+int mdl_abmil_attnpool_bwd_bf16(const uint16_t* E, int64_t ldE, const float* Wa, const float* Wb, const float* wc,
+                                const uint16_t* act_a, const uint16_t* act_b, const float* d_scores, uint16_t* dE,
+                                float* dWa, float* dWb, float* dba, float* dbb, float* dwc, float* dbc, int64_t T, int H,
+                                float p_drop, uint64_t seed, const uint8_t* keep_a, const uint8_t* keep_b,
+                                const float* scores, const float* stat_m, const float* stat_l, const float* d_pooled,
+                                const int32_t* row_bag, int64_t N, void* ws, void* stream);
 
 #ifdef __cplusplus
 }

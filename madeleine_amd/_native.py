@@ -29,6 +29,8 @@ SIGNATURES = {
     "mdl_abmil_gate_bwd_ws_bytes": (i64, [i64, i32]),
     "mdl_abmil_gate_bwd": (i32, [c_f, i64, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, c_f, c_f, c_f, c_f, c_f, c_f, i64, i32, f32,
                                  u64, c_p, c_p, c_p, c_p]),
+    "mdl_abmil_attnpool_bwd": (i32, [c_f, i64, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i64, i32, f32, u64, c_p, c_p, c_f, c_f,
+                                     c_f, c_f, c_p, i64, c_p, c_p]),
     "mdl_abmil_gate_dropout_mask": (i32, [c_p, i64, i32, i32, f32, u64, c_p]),
     "mdl_abmil_pool_ws_bytes": (i64, [i64, i64, i32]),
     "mdl_abmil_pool_fwd": (i32, [c_f, i64, c_f, c_f, c_f, c_f, i64, i64, c_p, i64, i32, c_p, c_p]),
@@ -55,6 +57,8 @@ SIGNATURES = {
     "mdl_abmil_gate_fwd_bf16": (i32, [c_f, i64, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i64, i32, f32, u64, c_p, c_p, c_p,
                                       c_p]),
     "mdl_abmil_gate_bwd_bf16_ws_bytes": (i64, [i64, i32]),
+    "mdl_abmil_attnpool_bwd_bf16": (i32, [c_f, i64, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i64, i32, f32, u64, c_p, c_p, c_f, c_f,
+                                     c_f, c_f, c_p, i64, c_p, c_p]),
     "mdl_abmil_gate_bwd_bf16": (i32, [c_f, i64, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, c_f, c_f, c_f, c_f, c_f, c_f, i64, i32,
                                       f32, u64, c_p, c_p, c_p, c_p]),
 }

@@ -226,7 +226,7 @@ __global__ void gate_finalize_kernel(const float* __restrict__ part, const float
 // ================================================================================================
 __global__ __launch_bounds__(256, 2) void gate_bwd_dx_kernel(const float* __restrict__ dz, const float* __restrict__ Wa,
                                                              const float* __restrict__ Wb, float* __restrict__ dE,
-                                                             int64_t ldE, int accumulate, int64_t T, int H) {
+                                                             int64_t ldE, int accumulate, int64_t T, int H, PoolTerm pt) {
     __shared__ __attribute__((aligned(16))) struct {
         float A[2][GBM * GBK];
         float B[2][GBK][GBN];
@@ -300,11 +300,19 @@ __global__ __launch_bounds__(256, 2) void gate_bwd_dx_kernel(const float* __rest
             const int64_t t = t0 + wm * 64 + rt * 32 + acc_row(r, lane);
             if (t < T) {
                 float* __restrict__ o = dE + t * ldE + (int64_t)c * HID + n0 + l32;
+                if (pt.scores) {  // fused A3 term: + w[t,c] * d_pooled[bag(t), c, :]  (cache-resident row, no dE re-read)
+                    int bag;
+                    const float w = pool_term_weight(pt, t, c, H, bag);
+                    const float* __restrict__ dp = pt.d_pooled + ((int64_t)bag * H + c) * HID + n0 + l32;
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) {
-                    float v = acc[rt][ct][r];
-                    if (accumulate) v += o[colb[ct]];
-                    o[colb[ct]] = v;
+                    for (int ct = 0; ct < 4; ++ct) o[colb[ct]] = fmaf(w, dp[colb[ct]], acc[rt][ct][r]);
+                } else {
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) {
+                        float v = acc[rt][ct][r];
+                        if (accumulate) v += o[colb[ct]];
+                        o[colb[ct]] = v;
+                    }
                 }
             }
         }
@@ -520,11 +528,10 @@ extern "C" int64_t mdl_abmil_gate_bwd_ws_bytes(int64_t T, int H) {
     return ((T + GBK) * H * 1024 + (int64_t)S * H * HID * 1024 + dz_blocks(T) * H * 4 * HID) * 4 + 64;
 }
 
-extern "C" int mdl_abmil_gate_bwd(const float* E, int64_t ldE, const float* Wa, const float* Wb, const float* wc,
-                                  const float* act_a, const float* act_b, const float* d_scores, float* dE,
-                                  int accumulate, float* dWa, float* dWb, float* dba, float* dbb, float* dwc, float* dbc,
-                                  int64_t T, int H, float p_drop, uint64_t seed, const uint8_t* keep_a,
-                                  const uint8_t* keep_b, void* ws, void* stream) {
+static int gate_bwd_impl(const float* E, int64_t ldE, const float* Wa, const float* Wb, const float* wc, const float* act_a,
+                         const float* act_b, const float* d_scores, float* dE, int accumulate, float* dWa, float* dWb, float* dba,
+                         float* dbb, float* dwc, float* dbc, int64_t T, int H, float p_drop, uint64_t seed, const uint8_t* keep_a,
+                         const uint8_t* keep_b, void* ws, void* stream, const PoolTerm& pt) {
     if (!E || !Wa || !Wb || !wc || !act_a || !act_b || !d_scores || !dE || !dWa || !dWb || !dba || !dbb || !dwc || !ws)
         return MDL_E_ARG;
     if ((keep_a == nullptr) != (keep_b == nullptr)) return MDL_E_ARG;
@@ -555,7 +562,7 @@ extern "C" int mdl_abmil_gate_bwd(const float* E, int64_t ldE, const float* Wa, 
         const int64_t grid = xcd_head_grid(n_tt, 2, H);
         if (grid > 0x7fffffff) return MDL_E_UNSUPPORTED;
         hipLaunchKernelGGL(gate_bwd_dx_kernel, dim3((unsigned)grid), dim3(256), 0, s, (const float*)dz, Wa, Wb, dE, ldE,
-                           accumulate, T, H);
+                           accumulate, T, H, pt);
         MDL_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(gate_bwd_dw_kernel, dim3((unsigned)xcd_head_grid(S, 4 * GATE_JT, H)), dim3(256), 0, s, E, ldE,
@@ -567,6 +574,26 @@ extern "C" int mdl_abmil_gate_bwd(const float* E, int64_t ldE, const float* Wa, 
                        dwc, dbc, H, (int)nblk);
     MDL_LAUNCH_CHECK();
     return MDL_OK;
+}
+
+extern "C" int mdl_abmil_gate_bwd(const float* E, int64_t ldE, const float* Wa, const float* Wb, const float* wc,
+                                  const float* act_a, const float* act_b, const float* d_scores, float* dE,
+                                  int accumulate, float* dWa, float* dWb, float* dba, float* dbb, float* dwc, float* dbc,
+                                  int64_t T, int H, float p_drop, uint64_t seed, const uint8_t* keep_a,
+                                  const uint8_t* keep_b, void* ws, void* stream) {
+    return gate_bwd_impl(E, ldE, Wa, Wb, wc, act_a, act_b, d_scores, dE, accumulate, dWa, dWb, dba, dbb, dwc, dbc, T, H, p_drop,
+                         seed, keep_a, keep_b, ws, stream, PoolTerm{nullptr, nullptr, nullptr, nullptr, nullptr, 1});
+}
+
+extern "C" int mdl_abmil_attnpool_bwd(const float* E, int64_t ldE, const float* Wa, const float* Wb, const float* wc,
+                                      const float* act_a, const float* act_b, const float* d_scores, float* dE, float* dWa,
+                                      float* dWb, float* dba, float* dbb, float* dwc, float* dbc, int64_t T, int H,
+                                      float p_drop, uint64_t seed, const uint8_t* keep_a, const uint8_t* keep_b,
+                                      const float* scores, const float* stat_m, const float* stat_l, const float* d_pooled,
+                                      const int32_t* row_bag, int64_t N, void* ws, void* stream) {
+    if (!scores || !stat_m || !stat_l || !d_pooled || (!row_bag && N < 1)) return MDL_E_ARG;
+    return gate_bwd_impl(E, ldE, Wa, Wb, wc, act_a, act_b, d_scores, dE, 0, dWa, dWb, dba, dbb, dwc, dbc, T, H, p_drop, seed, keep_a,
+                         keep_b, ws, stream, PoolTerm{scores, stat_m, stat_l, d_pooled, row_bag, N});
 }
 
 extern "C" int mdl_abmil_gate_dropout_mask(uint8_t* keep, int64_t T, int H, int which, float p_drop, uint64_t seed,

@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void gate_fwd_bf16_kernel(const bf16_t* __r
 // ================================================================================================
 __global__ __launch_bounds__(256, 2) void gate_dx_bf16_kernel(const bf16_t* __restrict__ dz, const bf16_t* __restrict__ WN,
                                                               bf16_t* __restrict__ dE, int64_t ldE, int accumulate, int64_t T,
-                                                              int H) {
+                                                              int H, PoolTerm pt) {
     __shared__ SmemNT sm;
     const int tid = threadIdx.x, lane = tid & 63, wm = (tid >> 6) >> 1, wn = (tid >> 6) & 1;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -300,11 +300,19 @@ __global__ __launch_bounds__(256, 2) void gate_dx_bf16_kernel(const bf16_t* __re
             const int64_t t = t0 + wm * 64 + rt * 32 + acc_row(r, lane);
             if (t < T) {
                 bf16_t* __restrict__ o = dE + t * ldE + (int64_t)c * HID + n0 + l32;
+                if (pt.scores) {  // fused A3 term: + w[t,c] * d_pooled[bag(t), c, :]
+                    int bag;
+                    const float w = pool_term_weight(pt, t, c, H, bag);
+                    const float* __restrict__ dp = pt.d_pooled + ((int64_t)bag * H + c) * HID + n0 + l32;
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) {
-                    float v = acc[rt][ct][r];
-                    if (accumulate) v += (float)o[colb[ct]];
-                    o[colb[ct]] = (bf16_t)v;
+                    for (int ct = 0; ct < 4; ++ct) o[colb[ct]] = (bf16_t)fmaf(w, dp[colb[ct]], acc[rt][ct][r]);
+                } else {
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) {
+                        float v = acc[rt][ct][r];
+                        if (accumulate) v += (float)o[colb[ct]];
+                        o[colb[ct]] = (bf16_t)v;
+                    }
                 }
             }
         }
@@ -435,11 +443,11 @@ extern "C" int64_t mdl_abmil_gate_bwd_bf16_ws_bytes(int64_t T, int H) {
     return bwd_ws(T, H).total;
 }
 
-extern "C" int mdl_abmil_gate_bwd_bf16(const uint16_t* E, int64_t ldE, const float* Wa, const float* Wb, const float* wc,
-                                       const uint16_t* act_a, const uint16_t* act_b, const float* d_scores, uint16_t* dE,
-                                       int accumulate, float* dWa, float* dWb, float* dba, float* dbb, float* dwc, float* dbc,
-                                       int64_t T, int H, float p_drop, uint64_t seed, const uint8_t* keep_a,
-                                       const uint8_t* keep_b, void* ws, void* stream) {
+static int gate_bwd_bf16_impl(const uint16_t* E, int64_t ldE, const float* Wa, const float* Wb, const float* wc,
+                              const uint16_t* act_a, const uint16_t* act_b, const float* d_scores, uint16_t* dE, int accumulate,
+                              float* dWa, float* dWb, float* dba, float* dbb, float* dwc, float* dbc, int64_t T, int H, float p_drop,
+                              uint64_t seed, const uint8_t* keep_a, const uint8_t* keep_b, void* ws, void* stream,
+                              const PoolTerm& pt) {
     if (!E || !Wa || !Wb || !wc || !act_a || !act_b || !d_scores || !dE || !dWa || !dWb || !dba || !dbb || !dwc || !ws)
         return MDL_E_ARG;
     if ((keep_a == nullptr) != (keep_b == nullptr)) return MDL_E_ARG;
@@ -471,7 +479,7 @@ extern "C" int mdl_abmil_gate_bwd_bf16(const uint16_t* E, int64_t ldE, const flo
         const int64_t grid = xcd_head_grid(n_tt, 2, H);
         if (grid > 0x7fffffff) return MDL_E_UNSUPPORTED;
         hipLaunchKernelGGL(gate_dx_bf16_kernel, dim3((unsigned)grid), dim3(256), 0, s, (const bf16_t*)dz, (const bf16_t*)WN,
-                           (bf16_t*)dE, ldE, accumulate, T, H);
+                           (bf16_t*)dE, ldE, accumulate, T, H, pt);
         MDL_LAUNCH_CHECK();
     }
     // transposed copies for the token contraction (zero-filled up to Tpad), then dW over S splits of the tokens
@@ -487,4 +495,24 @@ extern "C" int mdl_abmil_gate_bwd_bf16(const uint16_t* E, int64_t ldE, const flo
     int rc = gate_launch_reduce_w(slabW, dWa, dWb, H, L.S, s);
     if (rc) return rc;
     return gate_launch_reduce_v(slabV, dba, dbb, dwc, dbc, H, (int)L.nblk, s);
+}
+
+extern "C" int mdl_abmil_gate_bwd_bf16(const uint16_t* E, int64_t ldE, const float* Wa, const float* Wb, const float* wc,
+                                       const uint16_t* act_a, const uint16_t* act_b, const float* d_scores, uint16_t* dE,
+                                       int accumulate, float* dWa, float* dWb, float* dba, float* dbb, float* dwc, float* dbc,
+                                       int64_t T, int H, float p_drop, uint64_t seed, const uint8_t* keep_a,
+                                       const uint8_t* keep_b, void* ws, void* stream) {
+    return gate_bwd_bf16_impl(E, ldE, Wa, Wb, wc, act_a, act_b, d_scores, dE, accumulate, dWa, dWb, dba, dbb, dwc, dbc, T, H, p_drop,
+                              seed, keep_a, keep_b, ws, stream, PoolTerm{nullptr, nullptr, nullptr, nullptr, nullptr, 1});
+}
+
+extern "C" int mdl_abmil_attnpool_bwd_bf16(const uint16_t* E, int64_t ldE, const float* Wa, const float* Wb, const float* wc,
+                                           const uint16_t* act_a, const uint16_t* act_b, const float* d_scores, uint16_t* dE,
+                                           float* dWa, float* dWb, float* dba, float* dbb, float* dwc, float* dbc, int64_t T, int H,
+                                           float p_drop, uint64_t seed, const uint8_t* keep_a, const uint8_t* keep_b,
+                                           const float* scores, const float* stat_m, const float* stat_l, const float* d_pooled,
+                                           const int32_t* row_bag, int64_t N, void* ws, void* stream) {
+    if (!scores || !stat_m || !stat_l || !d_pooled || (!row_bag && N < 1)) return MDL_E_ARG;
+    return gate_bwd_bf16_impl(E, ldE, Wa, Wb, wc, act_a, act_b, d_scores, dE, 0, dWa, dWb, dba, dbb, dwc, dbc, T, H, p_drop, seed,
+                              keep_a, keep_b, ws, stream, PoolTerm{scores, stat_m, stat_l, d_pooled, row_bag, N});
 }

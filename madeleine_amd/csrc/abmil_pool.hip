@@ -189,12 +189,14 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const TE* __restrict__ E,
             const f32x4 a = x[2 * c] * dp[2 * c] + x[2 * c + 1] * dp[2 * c + 1];
             dw[c] = wave_sum(a.x + a.y + a.z + a.w);
         }
-        TE* __restrict__ gr = dE + row * ldE + lane * 4;
+        if (dE) {  // dE == nullptr: scores-only pass (the dE term is folded into the gate's dX epilogue, mdl_abmil_attnpool_bwd)
+            TE* __restrict__ gr = dE + row * ldE + lane * 4;
 #pragma unroll
-        for (int i = 0; i < 2 * H; ++i) {
-            f32x4 g = w[i / 2] * dp[i];
-            if (accumulate) g += ld4(gr + i * 256);
-            st4(gr + i * 256, g);
+            for (int i = 0; i < 2 * H; ++i) {
+                f32x4 g = w[i / 2] * dp[i];
+                if (accumulate) g += ld4(gr + i * 256);
+                st4(gr + i * 256, g);
+            }
         }
         float ds = 0.f;
 #pragma unroll
@@ -264,7 +266,7 @@ static int pool_bwd_launch(const TE* E, int64_t ldE, const float* scores, const 
                            const float* stat_l, const float* d_pooled, TE* dE, int accumulate, float* d_scores,
                            int accumulate_scores, int64_t n_bags, int64_t N, const int64_t* cu_seqlens, int64_t max_len, int H,
                            void* stream) {
-    if (!E || !scores || !pooled || !stat_m || !stat_l || !d_pooled || !dE || !d_scores) return MDL_E_ARG;
+    if (!E || !scores || !pooled || !stat_m || !stat_l || !d_pooled || !d_scores) return MDL_E_ARG;   // dE may be NULL
     if (n_bags < 0 || max_len < 0 || ldE < (int64_t)H * HID || (ldE & 3)) return MDL_E_ARG;
     if (!cu_seqlens && N != max_len) return MDL_E_ARG;
     if (!host_aligned16(E) || !host_aligned16(dE) || !host_aligned16(pooled) || !host_aligned16(d_pooled)) return MDL_E_ALIGN;

@@ -151,6 +151,21 @@ __global__ __launch_bounds__(256) void gate_dz_kernel(const float* __restrict__ 
 }
 
 
+// Optional pooling term of the fused A2+A3 backward: dE[t, c, :] = (dz . W)[t, c, :] + w[t, c] * d_pooled[bag(t), c, :]
+// with w = softmax weight of token t in its bag = exp(score - m) / l.  scores == nullptr: no pooling term.
+struct PoolTerm {
+    const float* scores;    // [T, H] raw scores
+    const float* stat_m;    // [n_bags, H]
+    const float* stat_l;    // [n_bags, H]
+    const float* d_pooled;  // [n_bags, H*512]
+    const int* row_bag;     // [T] bag index of every token row, or nullptr for dense bags of N tokens
+    int64_t N;
+};
+__device__ __forceinline__ float pool_term_weight(const PoolTerm& pt, int64_t t, int c, int H, int& bag) {
+    bag = pt.row_bag ? pt.row_bag[t] : (int)(t / pt.N);
+    return expf(pt.scores[t * H + c] - pt.stat_m[(int64_t)bag * H + c]) * (1.f / pt.stat_l[(int64_t)bag * H + c]);
+}
+
 // launchers of the reduction / finalize kernels defined in abmil_gate.hip (shared with the bf16 path)
 int gate_launch_finalize(const float* part, const float* bc, float* scores, int64_t n, int H, hipStream_t s);
 int gate_launch_reduce_w(const float* slabW, float* dWa, float* dWb, int H, int S, hipStream_t s);

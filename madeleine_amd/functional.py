@@ -133,6 +133,28 @@ def gate_bwd_raw(E2d, Wa, Wb, wc, act_a, act_b, d_scores, dE, accumulate, p_drop
     return dWa, dWb, dba, dbb, dwc, dbc
 
 
+def attnpool_bwd_raw(E2d, Wa, Wb, wc, act_a, act_b, d_scores, dE, p_drop, seed, keep_a, keep_b, scores, stat_m, stat_l, d_pooled,
+                     row_bag, N):
+    """Gate backward whose dX epilogue also adds the pooling term (mdl_abmil_attnpool_bwd): dE is written once."""
+    lib = _native.lib()
+    T, H = E2d.shape[0], Wa.shape[0]
+    dev = E2d.device
+    dWa, dWb = torch.empty_like(Wa), torch.empty_like(Wb)
+    dba = torch.empty(H, HID, device=dev, dtype=torch.float32)
+    dbb, dwc = torch.empty_like(dba), torch.empty_like(dba)
+    dbc = torch.empty(H, device=dev, dtype=torch.float32)
+    sfx = _sfx(E2d)
+    ws = _ws(getattr(lib, "mdl_abmil_gate_bwd%s_ws_bytes" % sfx)(T, H), dev)
+    with _timed("gate_bwd"):
+        rc = getattr(lib, "mdl_abmil_attnpool_bwd" + sfx)(_ptr(E2d), E2d.stride(0), _ptr(Wa), _ptr(Wb), _ptr(wc), _ptr(act_a),
+                                                         _ptr(act_b), _ptr(d_scores), _ptr(dE), _ptr(dWa), _ptr(dWb), _ptr(dba),
+                                                         _ptr(dbb), _ptr(dwc), _ptr(dbc), T, H, float(p_drop), int(seed),
+                                                         _ptr(keep_a), _ptr(keep_b), _ptr(scores), _ptr(stat_m), _ptr(stat_l),
+                                                         _ptr(d_pooled), _ptr(row_bag), int(N), _ptr(ws), _stream())
+    _native.check(rc, "mdl_abmil_attnpool_bwd")
+    return dWa, dWb, dba, dbb, dwc, dbc
+
+
 def pool_fwd_raw(E2d, scores, n_bags, N, cu_seqlens, max_len):
     lib = _native.lib()
     H = scores.shape[-1]
@@ -232,8 +254,8 @@ class SoftmaxPoolFn(torch.autograd.Function):
 
 
 # --------------------------------------------------------------------------------------------------
-# A2 + A3 chained inside one autograd node: one dE buffer, written by the pooling backward and
-# accumulated into by the gate backward (saves a 2 x |E| read + |E| write torch add).
+# A2 + A3 chained inside one autograd node: the pooling backward only produces d_scores, and its dE term
+# w * d_pooled is added in the gate backward's dX epilogue -- dE is written exactly once.
 # --------------------------------------------------------------------------------------------------
 class AttnPoolFn(torch.autograd.Function):
     """(pooled [n_bags,H*512], raw scores [T,H]) = multi-head gated-ABMIL pooling (Model.py:406-417)."""
@@ -267,8 +289,14 @@ class AttnPoolFn(torch.autograd.Function):
             acc_s = 0
         if d_pooled is None:
             d_pooled = torch.zeros_like(pooled)
-        pool_bwd_raw(E2d, scores, pooled, m, l, d_pooled.float().contiguous(), dE, 0, ds, acc_s, n_bags, N, cu, max_len)
-        dWa, dWb, dba, dbb, dwc, dbc = gate_bwd_raw(E2d, Wa, Wb, wc, act_a, act_b, ds, dE, 1, p_drop, seed, keep_a, keep_b)
+        d_pooled = d_pooled.float().contiguous()
+        # scores-only pooling backward (one read of E), then the gate backward whose dX epilogue adds the pooling term
+        pool_bwd_raw(E2d, scores, pooled, m, l, d_pooled, None, 0, ds, acc_s, n_bags, N, cu, max_len)
+        row_bag = None
+        if ragged:   # bag index of every packed token row, on the device (no sync)
+            row_bag = torch.searchsorted(cu[1:].contiguous(), torch.arange(E2d.shape[0], device=E2d.device), right=True).to(torch.int32)
+        dWa, dWb, dba, dbb, dwc, dbc = attnpool_bwd_raw(E2d, Wa, Wb, wc, act_a, act_b, ds, dE, p_drop, seed, keep_a, keep_b,
+                                                        scores, m, l, d_pooled, row_bag, N if not ragged else 0)
         return dE.view(e_shape), dWa, dba, dWb, dbb, dwc, dbc, None, None, None, None, None, None
 
 
