@@ -1,8 +1,7 @@
 // got.hip -- C ABI of the Graph Optimal Transport kernels (G0-G3, reference madeleine/utils/loss.py:162-302).
-// The kernels live in got_impl.inc, compiled twice (got_t512.hip / got_t1024.hip) for two workgroup sizes; this
-// file validates arguments and picks the build per geometry (measured on MI355X, tools/got_ab.py):
-//   forward : n <= 128 -> 1024 threads, n > 128 -> 512 threads      backward: 1024 threads
-// Both builds share one workspace layout, so a forward of one build can be reversed by the other.
+// The kernels live in got_impl.inc, parametrised by the workgroup size and compiled in got_t1024.hip (1024 threads =
+// 16 waves x 128 VGPRs; a 512-thread build with 256 VGPRs per wave measured slower at every n once the chain for
+// n > 128 was split into per-phase launches, tools/got_ab.py); this file validates arguments and launches.
 #include "common.hpp"
 
 namespace mdl {
@@ -14,7 +13,6 @@ namespace mdl {
     int launch_bwd_finish(const float*, const float*, float*, float*, float*, const float*, int, int, int, hipStream_t);      \
     int64_t ws_floats(int, int, int);                                                                                         \
     }
-MDL_GOT_DECL(got512)
 MDL_GOT_DECL(got1024)
 #undef MDL_GOT_DECL
 constexpr int GOT_MAXN = 256;
@@ -28,8 +26,6 @@ static int got_check(int k, int n, int d) {
     if (n > GOT_MAXN || d > GOT_MAXD) return MDL_E_UNSUPPORTED;
     return MDL_OK;
 }
-
-static inline bool fwd_uses_512(int n) { return n > 128; }
 
 extern "C" int64_t mdl_got_ws_bytes(int k, int n, int d) {
     const int rc = got_check(k, n, d);
@@ -51,7 +47,7 @@ extern "C" int mdl_got_fwd(const float* V, const float* Q, float* out, float* mi
     float* w = (float*)ws;
     rc = got1024::launch_prep(V, Q, w, minmax_out, minmax_in, k, n, d, s);
     if (rc) return rc;
-    return fwd_uses_512(n) ? got512::launch_main(w, out, k, n, d, s) : got1024::launch_main(w, out, k, n, d, s);
+    return got1024::launch_main(w, out, k, n, d, s);
 }
 
 extern "C" int mdl_got_extrema(const float* V, const float* Q, float* minmax_out, int k, int n, int d, void* ws,
