@@ -14,7 +14,8 @@ run() {  # name, summary-top-n, rocprof args..., -- command
     { echo "# $TAG $name: rocprofv3 $*" | sed "s#$R/##g"; python $R/tools/rocpd_summary.py /tmp/prof_$name/*/*.db $top; } > $OUT/${TAG}_$name.txt 2>&1
     rm -rf /tmp/prof_$name
 }
-run bench_c2_kernel_stats 40 --kernel-trace --stats -d /tmp/prof_bench_c2_kernel_stats -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline
+run bench_c2_kernel_stats 40 --kernel-trace --stats -d /tmp/prof_bench_c2_kernel_stats -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-bf16-leg
+run bench_c2_bf16_kernel_stats 45 --kernel-trace --stats -d /tmp/prof_bench_c2_bf16_kernel_stats -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-bf16-leg --precision bfloat16
 run kernels_c2_stats 25 --kernel-trace --stats -d /tmp/prof_kernels_c2_stats -- python $R/tools/prof_kernels.py --iters 5
 run pool_pmc_fetch 8 --pmc FETCH_SIZE --kernel-trace -d /tmp/prof_pool_pmc_fetch -- python $R/tools/prof_kernels.py --iters 2 --only pool
 run pool_pmc_write 8 --pmc WRITE_SIZE --kernel-trace -d /tmp/prof_pool_pmc_write -- python $R/tools/prof_kernels.py --iters 2 --only pool

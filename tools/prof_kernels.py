@@ -38,11 +38,14 @@ for it in range(a.iters):
         pooled, m, l = MF.pool_fwd_raw(E2, scores, BM, N, None, N)
         dE = torch.empty_like(E2)
         ds = torch.empty_like(scores)
-        MF.pool_bwd_raw(E2, scores, pooled, m, l, dpool, dE, 0, ds, 0, BM, N, None, N)
+        # product path (functional.AttnPoolFn.backward): scores-only pooling backward, its dE term is added by the gate dX
+        MF.pool_bwd_raw(E2, scores, pooled, m, l, dpool, None if a.only == "all" else dE, 0, ds, 0, BM, N, None, N)
     if a.only in ("all", "gate"):
         if a.only == "gate":
             dE = torch.empty_like(E2)
             ds = torch.randn(BM * N, H, device=dev, generator=g)
-        MF.gate_bwd_raw(E2, Wa, Wb, wc, aa, ab, ds, dE, 1 if a.only == "all" else 0, 0.25, 123 + it, None, None)
+            MF.gate_bwd_raw(E2, Wa, Wb, wc, aa, ab, ds, dE, 0, 0.25, 123 + it, None, None)
+        else:
+            MF.attnpool_bwd_raw(E2, Wa, Wb, wc, aa, ab, ds, dE, 0.25, 123 + it, None, None, scores, m, l, dpool, None, N)
 torch.cuda.synchronize()
 print("done", a.iters)
