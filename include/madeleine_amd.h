@@ -166,6 +166,21 @@ int mdl_infonce_bwd(const float* d_loss, const int32_t* cnt, float* dQ, float* d
                     float temperature, int symmetric, void* ws, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * N1 -- the Linear layers of the pre-attention MLP (madeleine/models/Model.py:351, :355, :359)
+ * as exact-fp32 contractions on the matrix cores, bias-free (the bias and its gradient are handled by
+ * mdl_ln_gelu_drop_*).  X [T,K] (row stride ldx), W [N,K] contiguous (torch's Linear.weight), Y [T,N] (row stride ldy).
+ * Supported: N % 256 == 0, K % 32 == 0 (returns MDL_E_UNSUPPORTED otherwise; the host wrapper then uses the library GEMM).
+ *   mdl_linear_fwd : Y = X W^T
+ *   mdl_linear_bwd : dW [N,K] = dY^T X  (always);  dX [T,K] = dY W  when dX != NULL (needs K % 256 == 0)
+ */
+int64_t mdl_linear_fwd_ws_bytes(int64_t T, int N, int K);
+int mdl_linear_fwd(const float* X, int64_t ldx, const float* W, float* Y, int64_t ldy, int64_t T, int N, int K, void* ws,
+                   void* stream);
+int64_t mdl_linear_bwd_ws_bytes(int64_t T, int N, int K);
+int mdl_linear_bwd(const float* X, int64_t ldx, const float* W, const float* dY, int64_t ldy, float* dX, int64_t lddx,
+                   float* dW, int64_t T, int N, int K, void* ws, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * G0-G3 -- Graph Optimal Transport.  Replaces GOT (madeleine/utils/loss.py:278-302) =
  * cost_matrix_batch_torch (:162-176) + global-threshold ReLU (:288-292) + IPOT Wasserstein
  * (:179-207, 30 iterations, beta .5) + Gromov-Wasserstein (:236-275, 5 x 20 IPOT iterations,

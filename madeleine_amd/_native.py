@@ -38,6 +38,10 @@ SIGNATURES = {
     "mdl_ln_gelu_drop_fwd": (i32, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, i64, i32, f32, f32, u64, c_p, c_p]),
     "mdl_ln_gelu_drop_bwd_ws_bytes": (i64, [i64, i32]),
     "mdl_ln_gelu_drop_bwd": (i32, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i64, i32, f32, u64, c_p, c_p, c_p]),
+    "mdl_linear_fwd_ws_bytes": (i64, [i64, i32, i32]),
+    "mdl_linear_fwd": (i32, [c_f, i64, c_f, c_f, i64, i64, i32, i32, c_p, c_p]),
+    "mdl_linear_bwd_ws_bytes": (i64, [i64, i32, i32]),
+    "mdl_linear_bwd": (i32, [c_f, i64, c_f, c_f, i64, c_f, i64, c_f, i64, i32, i32, c_p, c_p]),
     "mdl_infonce_ws_bytes": (i64, [i32, i32, i32]),
     "mdl_infonce_fwd": (i32, [c_f, c_f, c_p, c_f, i32, i32, i32, f32, i32, c_p, c_p]),
     "mdl_infonce_bwd": (i32, [c_f, c_p, c_f, c_f, i32, i32, i32, f32, i32, c_p, c_p]),

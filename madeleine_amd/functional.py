@@ -371,6 +371,60 @@ def ln_gelu_drop(x, gamma, beta, eps=1e-5, p_drop=0.0, seed=0, keep=None, bias=N
 
 
 # --------------------------------------------------------------------------------------------------
+# N1: bias-free Linear of the pre-attention MLP on the fp32 matrix cores
+# --------------------------------------------------------------------------------------------------
+class LinearFn(torch.autograd.Function):
+    """Y = X W^T (Model.py:351, :355, :359 without the bias, which ln_gelu_drop adds); X [T,K], W [N,K]."""
+
+    @staticmethod
+    def forward(ctx, x, W):
+        _require(x, "x")
+        _require(W, "weight")
+        lib = _native.lib()
+        T, K = x.shape
+        N = W.shape[0]
+        y = torch.empty(T, N, device=x.device, dtype=torch.float32)
+        ws = _ws(lib.mdl_linear_fwd_ws_bytes(T, N, K), x.device)
+        with _timed("linear_fwd"):
+            rc = lib.mdl_linear_fwd(_ptr(x), x.stride(0), _ptr(W), _ptr(y), N, T, N, K, _ptr(ws), _stream())
+        _native.check(rc, "mdl_linear_fwd")
+        ctx.save_for_backward(x, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        lib = _native.lib()
+        T, K = x.shape
+        N = W.shape[0]
+        dy = dy.float().contiguous()
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dW = torch.empty_like(W)
+        ws = _ws(lib.mdl_linear_bwd_ws_bytes(T, N, K), x.device)
+        with _timed("linear_bwd"):
+            rc = lib.mdl_linear_bwd(_ptr(x), x.stride(0), _ptr(W), _ptr(dy), N, _ptr(dx), K, _ptr(dW), T, N, K, _ptr(ws),
+                                    _stream())
+        _native.check(rc, "mdl_linear_bwd")
+        return dx, dW
+
+
+def linear_supported(x, W) -> bool:
+    """Geometries of mdl_linear_*: N % 256 == 0, K % 32 == 0, and K % 256 == 0 when the input needs a gradient."""
+    N, K = W.shape
+    return (x.dtype == torch.float32 and W.dtype == torch.float32 and N % 256 == 0 and K % 32 == 0 and
+            (K % 256 == 0 or not x.requires_grad))
+
+
+def linear(x, W):
+    """Bias-free Linear over the last axis through the HIP kernels; other geometries / dtypes use the library GEMM."""
+    if not linear_supported(x, W):
+        return torch.nn.functional.linear(x, W)
+    lead = x.shape[:-1]
+    y = LinearFn.apply(x.reshape(-1, x.shape[-1]).contiguous(), W.contiguous())
+    return y.view(*lead, W.shape[0])
+
+
+# --------------------------------------------------------------------------------------------------
 # L1: InfoNCE (batched over problems)
 # --------------------------------------------------------------------------------------------------
 class InfoNCEFn(torch.autograd.Function):

@@ -130,9 +130,9 @@ class ABMILEmbedder(nn.Module):
                 x = self._act(F.linear(bags.to(bf), pa[0].weight.to(bf)), pa[1], 0, None, pa[0].bias)
                 x = self._act(F.linear(x, pa[4].weight.to(bf)), pa[5], 1, None, pa[4].bias)
                 return self._act(F.linear(x, pa[8].weight[perm].to(bf)), pa[9], 2, perm, pa[8].bias)
-        x = self._act(F.linear(bags, pa[0].weight), pa[1], 0, None, pa[0].bias)
-        x = self._act(F.linear(x, pa[4].weight), pa[5], 1, None, pa[4].bias)
-        return self._act(F.linear(x, pa[8].weight[perm]), pa[9], 2, perm, pa[8].bias)
+        x = self._act(MF.linear(bags.float(), pa[0].weight), pa[1], 0, None, pa[0].bias)
+        x = self._act(MF.linear(x, pa[4].weight), pa[5], 1, None, pa[4].bias)
+        return self._act(MF.linear(x, pa[8].weight[perm]), pa[9], 2, perm, pa[8].bias)
 
     def gate_params_stacked(self):
         ps = [h.gate_params() for h in self.attn]

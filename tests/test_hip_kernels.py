@@ -451,3 +451,33 @@ def test_ln_gelu_drop_rng_is_consistent(dev):
     sel[r, c] = 1.0
     yy.backward(sel)
     assert float(x.grad.abs().max()) == 0.0
+
+
+# ---------------------------------------------------------------------------------------------- N1 Linear (fp32 MFMA)
+@pytest.mark.parametrize("T,N,K,need_dx", [(300, 512, 512, True), (1000, 2048, 512, True), (77, 512, 544, False),
+                                           (130, 512, 800, False), (5, 256, 256, True)])
+def test_linear_vs_torch(dev, T, N, K, need_dx):
+    """Bias-free Linear fwd / dX / dW on the fp32 matrix cores against torch in fp64 (ragged T: tile and split tails; K not a
+    multiple of the 128-row dW tile; transposes detected by the asymmetric shapes)."""
+    from madeleine_amd import functional as MF
+    x = t((T, K), f"lin:x{T}{K}")
+    W = 0.05 * t((N, K), f"lin:w{N}{K}")
+    dy = t((T, N), f"lin:dy{T}{N}")
+    x64, W64 = x.double().requires_grad_(), W.double().requires_grad_()
+    (x64 @ W64.t()).backward(dy.double())
+    xd = x.to(dev).requires_grad_(need_dx)
+    Wd = W.to(dev).requires_grad_()
+    assert MF.linear_supported(xd, Wd)
+    y = MF.linear(xd, Wd)
+    y.backward(dy.to(dev))
+    assert rel_err(y, x64.detach() @ W64.detach().t()) < 1e-6
+    assert rel_err(Wd.grad, W64.grad) < 1e-6
+    if need_dx:
+        assert rel_err(xd.grad, x64.grad) < 1e-6
+
+
+def test_linear_unsupported_geometry_uses_library(dev):
+    from madeleine_amd import functional as MF
+    x, W = t((10, 100), "lin:ux").to(dev), t((128, 100), "lin:uw").to(dev)
+    assert not MF.linear_supported(x, W)
+    assert rel_err(MF.linear(x, W), x @ W.t()) < 1e-6
