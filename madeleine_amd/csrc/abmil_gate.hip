@@ -523,7 +523,7 @@ static inline int64_t dz_blocks(int64_t T) { return (T + DZ_ROWS - 1) / DZ_ROWS;
 
 extern "C" int64_t mdl_abmil_gate_bwd_ws_bytes(int64_t T, int H) {
     if (T < 0 || H < 1 || H > MDL_MAX_HEADS) return MDL_E_ARG;
-    const int S = gate_splits(T);
+    const int S = gate_splits(T, H);
     // dz [(T + GBK)][H][1024] | slabW [S][H][512][1024] | slabV [dz_blocks][H][4][512]
     return ((T + GBK) * H * 1024 + (int64_t)S * H * HID * 1024 + dz_blocks(T) * H * 4 * HID) * 4 + 64;
 }
@@ -543,7 +543,7 @@ static int gate_bwd_impl(const float* E, int64_t ldE, const float* Wa, const flo
         return MDL_E_ALIGN;
     hipStream_t s = (hipStream_t)stream;
     const DropCfg d = make_drop(p_drop, seed, keep_a, keep_b);
-    const int S = gate_splits(T);
+    const int S = gate_splits(T, H);
     const int64_t tps = gate_tok_per_split(T, S);
     float* dz = (float*)ws;
     float* slabW = dz + (T + GBK) * H * 1024;

@@ -384,7 +384,7 @@ struct BwdWs {
 };
 static inline BwdWs bwd_ws(int64_t T, int H) {
     BwdWs w;
-    w.S = gate_splits(T);
+    w.S = gate_splits(T, H);
     int64_t tps = (T + w.S - 1) / w.S;
     w.tps = ((tps + 63) / 64) * 64;  // a multiple of the 64-row transpose tile (and of BBK)
     if (w.tps < 64) w.tps = 64;

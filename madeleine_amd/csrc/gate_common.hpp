@@ -83,13 +83,23 @@ static inline DropCfg make_drop(float p, uint64_t seed, const uint8_t* ka, const
     return d;
 }
 
-static inline int gate_splits(int64_t T) {
-    // ~4k tokens per split, at most 64 splits; each split a multiple of GBK tokens
+// Token splits of the dW-type contractions.  Base: ~4k tokens per split.  When there is enough work the count is rounded up
+// so that the total number of output tiles (tiles_per_split x splits) is a whole number of "rounds" of the 768 workgroup
+// slots of the chip (256 CUs x 3 resident workgroups of this tile engine): 4096 equal tiles on 768 slots is 5.33 rounds,
+// i.e. a last round that is 2/3 idle; 3072 or 768 tiles are exact.  Splits stay >= 1024 tokens and <= 192.
+static inline int splits_for(int64_t T, int tiles_per_split) {
     int64_t s = (T + 4095) / 4096;
     if (s < 1) s = 1;
     if (s > 64) s = 64;
+    const int64_t slots = 768;
+    if (s * tiles_per_split >= slots / 2) {
+        const int64_t rounds = (s * tiles_per_split + slots - 1) / slots;
+        const int64_t want = (rounds * slots + tiles_per_split - 1) / tiles_per_split;
+        if (want <= 192 && T / want >= 1024) s = want;
+    }
     return (int)s;
 }
+static inline int gate_splits(int64_t T, int H) { return splits_for(T, 16 * H); }  // 4 k-tiles x 4 column tiles per head
 
 constexpr int DZ_ROWS = 256;  // token rows per workgroup
 

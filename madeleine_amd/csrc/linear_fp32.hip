@@ -208,12 +208,7 @@ __global__ __launch_bounds__(256) void lin_reduce_kernel(const float* __restrict
     for (int i = 0; i < 4; ++i) dW[(int64_t)(nb + ty + i * 8) * K + kb + tx] = tile[tx][ty + i * 8];
 }
 
-static inline int lin_splits(int64_t T) {
-    int64_t s = (T + 4095) / 4096;
-    if (s < 1) s = 1;
-    if (s > 64) s = 64;
-    return (int)s;
-}
+static inline int lin_splits(int64_t T, int N, int K) { return splits_for(T, ((K + LBM - 1) / LBM) * (N / LBN)); }
 static inline int64_t lin_tps(int64_t T, int S) {
     const int64_t tps = (T + S - 1) / S;
     return ((tps + LBK - 1) / LBK) * LBK;
@@ -257,7 +252,7 @@ extern "C" int mdl_linear_fwd(const float* X, int64_t ldx, const float* W, float
 extern "C" int64_t mdl_linear_bwd_ws_bytes(int64_t T, int N, int K) {
     const int rc = lin_check(T, N, K);
     if (rc) return rc;
-    const int S = lin_splits(T);
+    const int S = lin_splits(T, N, K);
     return up16b((int64_t)S * K * N * 4) + up16b((int64_t)(N > K ? N : K) * 4 + 1024) + 64;  // slabs | zero row
 }
 
@@ -272,7 +267,7 @@ extern "C" int mdl_linear_bwd(const float* X, int64_t ldx, const float* W, const
         !host_aligned16(dX))
         return MDL_E_ALIGN;
     hipStream_t s = (hipStream_t)stream;
-    const int S = lin_splits(T);
+    const int S = lin_splits(T, N, K);
     const int64_t tps = lin_tps(T, S);
     float* slab = (float*)ws;
     float* zrow = (float*)((char*)ws + up16b((int64_t)S * K * N * 4));
