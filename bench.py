@@ -132,7 +132,7 @@ def main():
     ap.add_argument("--no-bf16-leg", action="store_true", help="skip the short secondary bf16-mode measurement")
     a = ap.parse_args()
 
-    from madeleine_amd import InfoNCE, MADELEINE, calculate_losses
+    from madeleine_amd import InfoNCE, MADELEINE
     from madeleine_amd import distributed as D
     from madeleine_amd import functional as MF
 

@@ -7,7 +7,7 @@ points; anything else raises (there is no CPU or eager fallback).
 
 Layouts (see include/madeleine_amd.h): token embeddings are head-major [T, H*512]; scores [T, H].
 """
-from typing import Optional, Tuple
+from typing import Optional
 
 import torch
 
