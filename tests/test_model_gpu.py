@@ -345,6 +345,11 @@ def test_train_loop_h2(dev, capsys):
     # epoch > warmup_epochs uses the cosine scheduler instead
     ep2, _ = train_loop(args, InfoNCE(temperature=0.001), None, None, model, 5, batches[:1], opt, warm, cos)
     assert cos.last_epoch == 1 and np.isfinite(ep2)
+    # precision "bfloat16" (the reference's launch scripts): same loop under autocast -> the kernels' bf16 mode, with the
+    # local GOT loss and the intra-modality 3-view terms switched on
+    args.precision = "bfloat16"
+    ep3, rank3 = train_loop(args, InfoNCE(temperature=0.1), GOT, InfoNCE(temperature=0.1), model, 6, batches[:1], opt, warm, cos)
+    assert np.isfinite(ep3) and ep3 > 0 and rank3 > 0 and cos.last_epoch == 2
 
 
 def test_device_prefetcher(dev):
