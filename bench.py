@@ -152,7 +152,10 @@ def main():
     if world > 1:
         # without the local loss the token_projector takes no part in the graph (as in the reference's global-only
         # configuration): DDP must be told, or it raises on the second step.
-        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], find_unused_parameters=not use_got)
+        # 20 MB of fp32 gradients: 8-MB buckets start their all-reduce while the pre_attn backward is still running
+        # (the default single 25-MB bucket would only fire after the last gradient), bucket views avoid the copy-back.
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], find_unused_parameters=not use_got,
+                                                        bucket_cap_mb=8, gradient_as_bucket_view=True)
     opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
     torch.manual_seed(1000 + rank)   # dropout seeds are drawn from torch's CPU generator: decorrelate the ranks
     crit = InfoNCE(temperature=0.001)
