@@ -1,15 +1,16 @@
-"""Training harness of the pretrain step -- mirrors of the reference's `calculate_losses` and
-`train_loop` (reference madeleine/utils/trainer.py:20-77 and :80-144): same signatures, same per-stain
-mask / gate logic, same summation order [global, local, (intra)] per stain, same sentinel / skip
-behaviour.  Host logic stays Python; the numeric work is in the loss callables handed in.
+"""Host side of the pretrain step: `calculate_losses` and `train_loop` with the reference's signatures and
+behaviour (reference madeleine/utils/trainer.py:20-77 and :80-144) -- per-stain presence gating (a stain takes
+part only when more than one case of the batch has it), the term order [global, local, intra x2] per stain, the
+(-1, False) sentinel for an H&E-only batch, the skip / scheduler / print behaviour of the loop.  The numeric work
+is in the loss callables handed in (madeleine_amd.InfoNCE / GOT, or any callables with the same signatures).
 
-Two host-side differences that do not change results:
-  * row selection uses index_select with indices computed on the CPU labels instead of boolean-mask
-    indexing of device tensors (which forces a device sync per stain);
-  * when the global loss is madeleine_amd.InfoNCE, all stains of the step go through ONE batched launch
-    set (InfoNCE.batched) instead of one call per stain.
+Organisation differs from the reference where it costs device syncs or launches:
+  * rows of a stain are picked with index_select on indices derived from the CPU label matrix (boolean-mask
+    indexing of device tensors forces a sync per stain);
+  * when the global loss is madeleine_amd.InfoNCE, all participating stains go through ONE batched launch set.
 """
 import time
+from typing import Dict, List, NamedTuple, Optional
 
 import numpy as np
 import torch
@@ -22,131 +23,117 @@ HE_POSITION = 0
 WHOLE_VIEW_POSITION = 0
 
 
-def _rows(mask_cpu: torch.Tensor, device) -> torch.Tensor:
-    return mask_cpu.nonzero(as_tuple=True)[0].to(device, non_blocking=True)
+class _Participant(NamedTuple):
+    """A stain that enters the loss of this batch, with the batch rows (cases) that carry it."""
+    column: int            # position in STAINS (= column of modality_labels_withoutHE)
+    name: str
+    rows_cpu: torch.Tensor
 
 
-def _batched_global(loss_fn, stains, active, wsi_embs, symmetric):
-    """All active stains through one InfoNCE.batched call -> dict stain_idx -> scalar loss."""
+def _participants(STAINS, labels_cpu: torch.Tensor) -> List[_Participant]:
+    out = []
+    for column, name in enumerate(STAINS):
+        rows = labels_cpu[:, column].bool().nonzero(as_tuple=True)[0]
+        if rows.numel() > 1:   # trainer.py:28 -- a single case cannot form a contrastive pair
+            out.append(_Participant(column, name, rows))
+    return out
+
+
+def _pair(wsi_embs, part: _Participant, rows, view: int):
+    """(H&E embedding matched to this stain, stain embedding) of view `view` for the participating cases."""
+    he = wsi_embs["HE"][:, view, :, part.column].index_select(0, rows)
+    st = wsi_embs[part.name][:, view, :].index_select(0, rows)
+    return he, st
+
+
+def _global_terms_batched(criterion, parts: List[_Participant], wsi_embs, symmetric) -> Dict[int, torch.Tensor]:
+    """All participating stains in one InfoNCE.batched call: padded [S, k_max, d] problems + live-row counts."""
     he_all = wsi_embs["HE"]
-    dev = he_all.device
-    kmax = max(len(idx) for _, idx in active)
-    d = he_all.shape[2]
-    S = len(active)
-    Q = he_all.new_zeros(S, kmax, d)
-    P = he_all.new_zeros(S, kmax, d)
-    cnts = []
-    for s, (stain_idx, idx_cpu) in enumerate(active):
-        idx = idx_cpu.to(dev, non_blocking=True)
-        k = len(idx_cpu)
-        Q[s, :k] = he_all[:, WHOLE_VIEW_POSITION, :, stain_idx].index_select(0, idx)
-        P[s, :k] = wsi_embs[stains[stain_idx]][:, WHOLE_VIEW_POSITION, :].index_select(0, idx)
-        cnts.append(k)
-    cnt = torch.tensor(cnts, dtype=torch.int32).to(dev, non_blocking=True)
-    losses = loss_fn.batched(Q, P, cnt, symmetric=symmetric)
-    return {stain_idx: losses[s] for s, (stain_idx, _) in enumerate(active)}
+    dev, d = he_all.device, he_all.shape[2]
+    k_max = max(p.rows_cpu.numel() for p in parts)
+    Q = he_all.new_zeros(len(parts), k_max, d)
+    P = he_all.new_zeros(len(parts), k_max, d)
+    for s, part in enumerate(parts):
+        rows = part.rows_cpu.to(dev, non_blocking=True)
+        q, p = _pair(wsi_embs, part, rows, WHOLE_VIEW_POSITION)
+        Q[s, :rows.numel()] = q
+        P[s, :rows.numel()] = p
+    counts = torch.tensor([p.rows_cpu.numel() for p in parts], dtype=torch.int32).to(dev, non_blocking=True)
+    per_problem = criterion.batched(Q, P, counts, symmetric=symmetric)
+    return {part.column: per_problem[s] for s, part in enumerate(parts)}
 
 
 def calculate_losses(STAINS, loss_fn_interMod, loss_fn_interMod_local, loss_fn_intraMod, wsi_embs, token_embs,
                      modality_labels_withoutHE, args):
-    """trainer.py:20-77."""
-    losses = []
-    atleast_two_loss_flag = False
-    labels = modality_labels_withoutHE.detach().cpu()
+    """Sum of the active loss terms over the participating stains; returns (loss, at_least_one_stain_flag)."""
+    parts = _participants(STAINS, modality_labels_withoutHE.detach().cpu())
+    if not parts:
+        return -1, False   # trainer.py:72-75: nothing but H&E in this batch
 
-    active = []
-    for stain_idx, stain in enumerate(STAINS):
-        stain_mask = labels[:, stain_idx].bool()
-        if stain_mask.sum().item() > 1:
-            active.append((stain_idx, stain_mask.nonzero(as_tuple=True)[0]))
+    if loss_fn_interMod and args.global_loss != "info-nce":
+        raise AssertionError("invalid global loss")   # the reference asserts the same (trainer.py:36)
+    precomputed: Optional[Dict[int, torch.Tensor]] = None
+    if isinstance(loss_fn_interMod, _HipInfoNCE) and loss_fn_interMod.reduction == 'mean':
+        precomputed = _global_terms_batched(loss_fn_interMod, parts, wsi_embs, args.symmetric_cl)
 
-    batched = None
-    if loss_fn_interMod and active:
-        if args.global_loss != "info-nce":
-            raise AssertionError("invalid global loss")
-        if isinstance(loss_fn_interMod, _HipInfoNCE) and loss_fn_interMod.reduction == 'mean':
-            batched = _batched_global(loss_fn_interMod, STAINS, active, wsi_embs, args.symmetric_cl)
-
-    for stain_idx, idx_cpu in active:
-        stain = STAINS[stain_idx]
-        dev = wsi_embs["HE"].device
-        idx = idx_cpu.to(dev, non_blocking=True)
-        # Global loss
-        if loss_fn_interMod:
-            if batched is not None:
-                global_loss = batched[stain_idx]
+    dev = wsi_embs["HE"].device
+    terms = []
+    for part in parts:
+        rows = part.rows_cpu.to(dev, non_blocking=True)
+        if loss_fn_interMod:                                     # global: slide-level InfoNCE, whole-bag view
+            if precomputed is not None:
+                terms.append(precomputed[part.column])
             else:
-                HE_for_stain = wsi_embs["HE"][:, WHOLE_VIEW_POSITION, :, stain_idx].index_select(0, idx)
-                stain_ind = wsi_embs[stain][:, WHOLE_VIEW_POSITION, :].index_select(0, idx)
-                global_loss = loss_fn_interMod(query=HE_for_stain, positive_key=stain_ind, symmetric=args.symmetric_cl)
-            losses.append(global_loss)
-        # Local loss
-        if loss_fn_interMod_local:
-            HE_tokens = token_embs["HE"][:, :, :, stain_idx].index_select(0, idx)
-            IHC_tokens = token_embs[stain].squeeze().index_select(0, idx)
-            got_loss = loss_fn_interMod_local(HE_tokens, IHC_tokens, subsample=256)
-            losses.append(got_loss * args.local_loss_weight)
-        # Intra modality loss (views 1 and 2)
-        if loss_fn_intraMod:
-            he1 = wsi_embs["HE"][:, 1, :, stain_idx].index_select(0, idx)
-            st1 = wsi_embs[stain][:, 1, :].index_select(0, idx)
-            he2 = wsi_embs["HE"][:, 2, :, stain_idx].index_select(0, idx)
-            st2 = wsi_embs[stain][:, 2, :].index_select(0, idx)
-            losses.append(loss_fn_intraMod(query=he1, positive_key=he2, symmetric=args.symmetric_cl))
-            losses.append(loss_fn_intraMod(query=st1, positive_key=st2, symmetric=args.symmetric_cl))
-        atleast_two_loss_flag = True
-
-    if len(losses) > 0:
-        loss = sum(losses)
-    else:
-        loss = -1
-        assert loss == -1 and not atleast_two_loss_flag, "Loss should be -1 if there are no losses to calculate"
-    return loss, atleast_two_loss_flag
+                he, st = _pair(wsi_embs, part, rows, WHOLE_VIEW_POSITION)
+                terms.append(loss_fn_interMod(query=he, positive_key=st, symmetric=args.symmetric_cl))
+        if loss_fn_interMod_local:                               # local: token-level GOT, 256 sub-sampled tokens
+            he_tok = token_embs["HE"][:, :, :, part.column].index_select(0, rows)
+            st_tok = token_embs[part.name].squeeze().index_select(0, rows)   # .squeeze() as in trainer.py:43
+            terms.append(loss_fn_interMod_local(he_tok, st_tok, subsample=256) * args.local_loss_weight)
+        if loss_fn_intraMod:                                     # intra: the two half-bag views of each modality
+            he1, st1 = _pair(wsi_embs, part, rows, 1)
+            he2, st2 = _pair(wsi_embs, part, rows, 2)
+            terms.append(loss_fn_intraMod(query=he1, positive_key=he2, symmetric=args.symmetric_cl))
+            terms.append(loss_fn_intraMod(query=st1, positive_key=st2, symmetric=args.symmetric_cl))
+    # stains participate but every loss callable is switched off: the reference trips its consistency assert (trainer.py:75)
+    assert terms, "Loss should be -1 if there are no losses to calculate"
+    return sum(terms), True
 
 
 def train_loop(args, loss_fn_interMod, loss_fn_interMod_local, loss_fn_intraMod, ssl_model, epoch, dataloader, optimizer,
                scheduler_warmup, scheduler):
-    """trainer.py:80-144."""
-    n_views = 3 if loss_fn_intraMod else 1
+    """One epoch (trainer.py:80-144): returns (summed batch losses, smooth rank of the epoch's H&E slide embeddings)."""
+    n_views = 3 if loss_fn_intraMod else 1        # the intra loss needs the two extra half-bag views
+    precision = set_model_precision(args.precision)
+    use_autocast = precision in (torch.bfloat16, torch.float16)   # for fp32/fp64 torch disables autocast anyway
+    in_warmup = epoch <= args.warmup_epochs       # note `<=`, as the reference (trainer.py:128)
     ssl_model.train()
-    torch_precision = set_model_precision(args.precision)
-    autocast_on = torch_precision in (torch.bfloat16, torch.float16)  # fp32/fp64: torch disables autocast anyway
 
-    ep_loss = 0.
-    fb_time = 0.
-    all_embeds = []
-    for b_idx, data in enumerate(dataloader):
-        if epoch == 0 and b_idx == 0:
-            print("Using precision:", torch_precision)
-        s_fb = time.time()
-        modality_labels = data['modality_labels']
-        modality_labels_withoutHE = modality_labels[:, HE_POSITION + 1:]
+    epoch_loss, busy_seconds, he_embeddings = 0.0, 0.0, []
+    for batch_no, data in enumerate(dataloader):
+        if epoch == 0 and batch_no == 0:
+            print("Using precision:", precision)
+        tick = time.time()
+        present = data['modality_labels'][:, HE_POSITION + 1:]
 
         optimizer.zero_grad()
-        with torch.amp.autocast(device_type="cuda", dtype=torch_precision, enabled=autocast_on):
+        with torch.amp.autocast(device_type="cuda", dtype=precision, enabled=use_autocast):
             wsi_embs, token_embs = ssl_model(data, device=DEVICE, n_views=n_views)
-            loss, atleast_two_loss_flag = calculate_losses(args.STAINS, loss_fn_interMod, loss_fn_interMod_local,
-                                                           loss_fn_intraMod, wsi_embs, token_embs,
-                                                           modality_labels_withoutHE, args)
-
-        all_embeds.extend(wsi_embs['HE'][:, WHOLE_VIEW_POSITION, :, 0].detach().to(torch.float32).cpu().numpy())
-
-        if not atleast_two_loss_flag:
+            loss, has_pairs = calculate_losses(args.STAINS, loss_fn_interMod, loss_fn_interMod_local, loss_fn_intraMod,
+                                               wsi_embs, token_embs, present, args)
+        he_embeddings.extend(wsi_embs['HE'][:, WHOLE_VIEW_POSITION, :, 0].detach().float().cpu().numpy())
+        if not has_pairs:
             print("Skipping batch with only HE")
             continue
 
         loss.backward()
         optimizer.step()
-        if epoch <= args.warmup_epochs:
-            scheduler_warmup.step()
-        else:
-            scheduler.step()
+        (scheduler_warmup if in_warmup else scheduler).step()
 
-        if (b_idx % 3) == 0:
-            print(f"Loss for batch: {b_idx} = {loss:.3f}")
-        ep_loss += loss.item()
-        fb_time += time.time() - s_fb
+        if batch_no % 3 == 0:
+            print(f"Loss for batch: {batch_no} = {loss:.3f}")
+        epoch_loss += loss.item()
+        busy_seconds += time.time() - tick
 
-    all_embeds_tensor = torch.Tensor(np.array(all_embeds))
-    rank = smooth_rank_measure(all_embeds_tensor)
-    return ep_loss, rank
+    rank = smooth_rank_measure(torch.Tensor(np.array(he_embeddings)))
+    return epoch_loss, rank
