@@ -130,6 +130,9 @@ def main():
                     help="float32 = the parity path (headline value).  bfloat16 = the reference's `precision: bfloat16` "
                          "runs: forward + losses under torch.autocast, bf16 activation storage + bf16 MFMA in the kernels")
     ap.add_argument("--no-bf16-leg", action="store_true", help="skip the short secondary bf16-mode measurement")
+    ap.add_argument("--skip-absent", action="store_true",
+                    help="SURVEY 8(f) N4: encode the all-zero bag of an absent stain once instead of once per case (c3/c4 "
+                         "mask stains with ACROBAT's presence rates; no effect on c2).  Off by default: the reference encodes them all")
     a = ap.parse_args()
 
     from madeleine_amd import InfoNCE, MADELEINE
@@ -148,6 +151,7 @@ def main():
     torch.manual_seed(42)
     model = MADELEINE(make_cfg(M, Dm), stain_encoding=stain_enc).to(dev)
     model.eval() if a.eval_mode else model.train()
+    model.skip_absent_stains = bool(a.skip_absent)
     net = model
     if world > 1:
         # without the local loss the token_projector takes no part in the graph (as in the reference's global-only
@@ -268,7 +272,8 @@ def main():
                      "synthetic (device-resident randn bags, random-init weights, manual_seed 42)"),
             "config": {"workload": f"{a.config}: {B} slides/GPU x {M} stains x {'ragged U[1024,16384] (mean ' + str(N) + ')' if ragged else N} patches x {Dm}-d, "
                                    f"ABMIL pool + global InfoNCE{' + local GOT' if use_got else ''}, "
-                                   f"{'eval (dropout off)' if a.eval_mode else 'train mode (dropout on)'}, AdamW",
+                                   f"{'eval (dropout off)' if a.eval_mode else 'train mode (dropout on)'}, AdamW"
+                                   f"{', absent-stain zero bags encoded once (N4)' if a.skip_absent else ''}",
                        "global_batch": B * world, "bags_per_sec": round(value * M, 2), "parallelism": f"dp{world}",
                        "final_loss": final_loss},
         }

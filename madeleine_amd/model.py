@@ -231,6 +231,8 @@ class MADELEINE(nn.Module):
         self.config = config
         self.modalities = config.MODALITIES
         self.stain_encoding = stain_encoding
+        # opt-in: encode each distinct all-zero bag of an absent stain once, see _absent_stain_plan
+        self.skip_absent_stains = bool(getattr(config, "skip_absent_stains", False))
         if self.stain_encoding:
             self.stain_encoding_dim = 32
             self.embedding = nn.Embedding(len(self.modalities), self.stain_encoding_dim)
@@ -263,6 +265,34 @@ class MADELEINE(nn.Module):
         """feats [R,N,D], idx LongTensor [R] -> cat([feats, embedding[idx] broadcast over N])."""
         enc = self.embedding(idx.to(feats.device)).unsqueeze(1).expand(-1, feats.shape[1], -1)
         return torch.cat([feats, enc.to(feats.dtype)], dim=-1)
+
+    @staticmethod
+    def _absent_stain_plan(modality_labels, input_key_of_row):
+        """the dataset fills a missing stain with an all-zero bag (wsi_dataset.py:66) that the
+        reference still pushes through the whole encoder (~27 % of ACROBAT's bags) although the losses never read it.
+        All-zero bags with the same stain-encoding index (`input_key_of_row`; one key for all without stain encoding) are
+        IDENTICAL inputs, so one representative per key is encoded and its outputs are shared.  Returns (compact, expand): rows of the flattened [B*M] batch to encode, and for
+        every original row the position of its source in the compact list; (None, None) when nothing is absent.
+        In eval mode every output equals the reference's; in train mode the absent rows share one dropout draw instead of
+        having one each -- in outputs that no loss term reads (trainer.py:27-29 gates on the same labels)."""
+        present = modality_labels.detach().cpu().reshape(-1).bool()
+        if bool(present.all()):
+            return None, None
+        rows = torch.arange(present.numel())
+        compact = rows[present].tolist()
+        position = {r: i for i, r in enumerate(compact)}
+        representative = {}
+        expand = []
+        for r in rows.tolist():
+            if r in position:
+                expand.append(position[r])
+                continue
+            key = int(input_key_of_row[r])
+            if key not in representative:
+                representative[key] = len(compact)
+                compact.append(r)
+            expand.append(representative[key])
+        return torch.tensor(compact, dtype=torch.long), torch.tensor(expand, dtype=torch.long)
 
     @staticmethod
     def _require_single_modality(n_mod):
@@ -325,13 +355,25 @@ class MADELEINE(nn.Module):
         if train:  # Model.py:120-159
             bs, n_mod, n_tokens, d_in = all_wsi_feats.shape
             x = all_wsi_feats.view(bs * n_mod, n_tokens, d_in)
+            # reference quirk kept on purpose (Model.py:125-131): the stain-indicator list is stain-major while the
+            # flattened rows are case-major, so row r gets embedding index r // bs.
+            stain_of_row = torch.arange(bs * n_mod) // bs
+            expand = None
+            if self.skip_absent_stains and 'modality_labels' in data:
+                compact, expand = self._absent_stain_plan(data['modality_labels'],
+                                                          stain_of_row if self.stain_encoding else torch.zeros_like(stain_of_row))
+                if expand is not None:   # encode every present bag + ONE all-zero bag per distinct input among the absent ones
+                    x = x.index_select(0, compact.to(device))
+                    stain_of_row = stain_of_row[compact]
             if self.stain_encoding:
-                # reference quirk kept on purpose (Model.py:125-131): the indicator list is stain-major while
-                # the flattened rows are case-major, so row r gets embedding index r // bs.
-                x = self._cat_stain(x, torch.arange(bs * n_mod) // bs)
+                x = self._cat_stain(x, stain_of_row)
             pooled, E, _ = emb.forward_headmajor(x, n_views=n_views)
-            tok = self._project_tokens(E.view(bs, n_mod, n_tokens, -1))               # [B,M,N,128]
-            slide = self._project_slide(pooled.view(bs * n_mod, -1, pooled.shape[-1]))  # [BM,V,512]
+            tok = self._project_tokens(E)                                             # [rows,N,128]
+            slide = self._project_slide(pooled.view(x.shape[0], -1, pooled.shape[-1]))  # [rows,V,512]
+            if expand is not None:       # absent rows take the outputs of their all-zero representative
+                expand = expand.to(device)
+                tok, slide = tok.index_select(0, expand), slide.index_select(0, expand)
+            tok = tok.view(bs, n_mod, n_tokens, -1)                                   # [B,M,N,128]
             slide = slide.view(bs, n_mod, -1, slide.shape[-1])
             for idx, modality in enumerate(self.modalities):
                 s, t = slide[:, idx], tok[:, idx]

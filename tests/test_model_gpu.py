@@ -363,3 +363,32 @@ def test_device_prefetcher(dev):
     for g, r in zip(got, ref):
         assert g["feats"].is_cuda and torch.equal(g["feats"].cpu(), r["feats"])
         assert torch.equal(g["modality_labels"], r["modality_labels"]) and g["slide_ids"] == r["slide_ids"]
+
+
+@pytest.mark.parametrize("stain_encoding", [False, True])
+def test_skip_absent_stains_matches_full_encode(dev, stain_encoding):
+    """N4: with config.skip_absent_stains the all-zero bags of absent stains are encoded once per distinct input and shared;
+    in eval mode every output, the loss and every parameter gradient equal the full encode (which the reference does)."""
+    from madeleine_amd import InfoNCE, calculate_losses
+    mods = MODS5[:4]
+    B, M, N, D = 5, 4, 96, 64
+    labels = torch.tensor([[1, 1, 0, 1], [1, 0, 0, 1], [1, 1, 1, 1], [1, 1, 0, 0], [1, 0, 1, 1]], dtype=torch.float32)
+    feats = t((B, M, N, D), "skip:feats") * labels[:, :, None, None]          # absent stain -> zero bag (wsi_dataset.py:66)
+    args = SimpleNamespace(global_loss="info-nce", symmetric_cl=True, local_loss_weight=1.0)
+    crit = InfoNCE(temperature=0.1)
+    res = {}
+    for skip in (False, True):
+        model = build(mods, D, "w", dev, stain_encoding=stain_encoding).eval()
+        model.skip_absent_stains = skip
+        embs, toks = model({"feats": feats, "modality_labels": labels}, device=dev, train=True)
+        loss, flag = calculate_losses(mods[1:], crit, None, None, embs, toks, labels[:, 1:], args)
+        assert flag
+        loss.backward()
+        res[skip] = (embs, toks, float(loss.detach()), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+    for k in mods:
+        assert res[True][0][k].shape == res[False][0][k].shape and res[True][1][k].shape == res[False][1][k].shape
+        assert rel_err(res[True][0][k], res[False][0][k]) < 1e-5
+        assert rel_err(res[True][1][k], res[False][1][k]) < 1e-5
+    assert abs(res[True][2] - res[False][2]) < 1e-5 * abs(res[False][2])
+    for k, g in res[False][3].items():
+        assert rel_err(res[True][3][k], g) < 1e-4 or float(g.norm()) < 1e-6, k
