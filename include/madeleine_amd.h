@@ -17,7 +17,12 @@
  *     synchronisation.
  *   - return value: 0 on success; a positive hipError_t if a launch failed; a negative MDL_E_* code
  *     for argument validation.  Nothing throws across the boundary.
- *   - fp32 everywhere ("f32" compute; MFMA contractions use v_mfma_f32_32x32x2_f32, exact fp32).
+ *   - fp32 everywhere ("f32" compute; MFMA contractions use v_mfma_f32_32x32x2_f32, exact fp32) -- except the *_bf16
+ *     entry points at the end of this header (the reference's `precision: bfloat16` mode: bf16 activation storage and
+ *     bf16 MFMA operands, fp32 accumulation / epilogues / parameters).
+ *
+ * Entry points by row of SURVEY.md section 8:  A2 mdl_abmil_gate_*  |  A3 mdl_abmil_pool_*  |  A2+A3 fused backward
+ * mdl_abmil_attnpool_bwd  |  L1 mdl_infonce_*  |  G0-G3 mdl_got_*  |  N1 mdl_linear_*, mdl_ln_gelu_drop_*  |  bf16 mode *_bf16.
  *
  * Internal activation layout ("head-major"): the reference interleaves heads as channel j = e*H + c
  * (rearrange 'b t (e c) -> b t e c', Model.py:396).  Our encoder emits the same numbers with the
