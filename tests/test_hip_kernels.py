@@ -481,3 +481,19 @@ def test_linear_unsupported_geometry_uses_library(dev):
     x, W = t((10, 100), "lin:ux").to(dev), t((128, 100), "lin:uw").to(dev)
     assert not MF.linear_supported(x, W)
     assert rel_err(MF.linear(x, W), x @ W.t()) < 1e-6
+
+
+def test_linear_full_size_vs_library(dev):
+    """Config-2 size (T = 262,144 tokens, 512 -> 2048): forward, dX and dW against the library GEMM on the device."""
+    from madeleine_amd import functional as MF
+    T, N, K = 262144, 2048, 512
+    g = torch.Generator(device=dev).manual_seed(3)
+    x = torch.randn(T, K, device=dev, generator=g).requires_grad_()
+    W = (torch.randn(N, K, device=dev, generator=g) * 0.04).requires_grad_()
+    dy = torch.randn(T, N, device=dev, generator=g)
+    y = MF.linear(x, W)
+    gx, gW = torch.autograd.grad(y, (x, W), dy)
+    yr = torch.nn.functional.linear(x, W)
+    rx, rW = torch.autograd.grad(yr, (x, W), dy)
+    assert rel_err(y[::997], yr[::997]) < 1e-5 and rel_err(gx[::997], rx[::997]) < 1e-5
+    assert rel_err(gW, rW) < 1e-4      # 262,144-term fp32 sums in two different orders
