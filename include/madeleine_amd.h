@@ -51,6 +51,12 @@ extern "C" {
 /* library / build info: returns a static string "madeleine_amd <ver> gfx950" */
 const char* mdl_version(void);
 
+/* ABI revision of this header: bumped whenever an entry point's argument list changes.  A binding compares
+ * mdl_abi_version() with the MDL_ABI_VERSION it was written against BEFORE calling anything else, so that a stale
+ * shared object fails loudly instead of being called with shifted arguments. */
+#define MDL_ABI_VERSION 2
+int mdl_abi_version(void);
+
 /* ------------------------------------------------------------------------------------------------
  * A2 -- gated attention scores.  Replaces BatchedABMIL.forward (madeleine/models/abmil.py:41-68)
  * for all H heads at once (the reference loops H module instances, Model.py:406-409).

@@ -1,5 +1,7 @@
 """Builds libmadeleine_amd.so (gfx950) in-tree with hipcc.  No torch headers, no libtorch linkage:
 the library is a plain C-ABI shared object (include/madeleine_amd.h)."""
+import contextlib
+import fcntl
 import os
 import shutil
 import subprocess
@@ -32,15 +34,39 @@ def hipcc_path():
     for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):
             return cand
-    raise RuntimeError("hipcc not found: cannot build libmadeleine_amd.so")
+    raise HipccMissing("hipcc not found: cannot build libmadeleine_amd.so")
+
+
+class HipccMissing(RuntimeError):
+    pass
+
+
+@contextlib.contextmanager
+def _build_lock(objdir):
+    """Serialises concurrent builders (every rank of a torchrun launch on a fresh clone calls lib() at once): one
+    process compiles, the others wait on the lock and then find everything fresh."""
+    with open(os.path.join(objdir, ".lock"), "w") as f:
+        fcntl.flock(f, fcntl.LOCK_EX)
+        try:
+            yield
+        finally:
+            fcntl.flock(f, fcntl.LOCK_UN)
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile every csrc/*.hip for gfx950 and link the shared library.  Returns its path."""
-    hipcc = hipcc_path()
+    """Compile every csrc/*.hip for gfx950 and link the shared library.  Returns its path.  Multi-process safe: a file
+    lock serialises builders, objects and the library are written to per-process temp names and renamed into place."""
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
+    with _build_lock(objdir):
+        return _build_locked(force, verbose, objdir)
+
+
+def _build_locked(force, verbose, objdir):
     srcs, deps = sources(), _deps()
+    if not force and os.path.exists(LIB) and not _stale(LIB, srcs + deps):
+        return LIB          # another process built it while we waited for the lock
+    hipcc = hipcc_path()
     jobs = []
     for s in srcs:
         o = os.path.join(objdir, os.path.basename(s)[:-4] + ".o")
@@ -49,10 +75,14 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     def cc(job):
         s, o = job
-        cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+        tmp = "%s.%d.tmp" % (o, os.getpid())
+        cmd = [hipcc] + FLAGS + ["-c", s, "-o", tmp]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
+            with contextlib.suppress(OSError):
+                os.remove(tmp)
             raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), r.stderr[-4000:]))
+        os.replace(tmp, o)
         if verbose:
             print("built", os.path.basename(o), file=sys.stderr)
 
@@ -60,11 +90,14 @@ def build(force: bool = False, verbose: bool = False) -> str:
         list(ex.map(cc, jobs))
     objs = [os.path.join(objdir, os.path.basename(s)[:-4] + ".o") for s in srcs]
     if force or jobs or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB + ".tmp"]
+        tmp = "%s.%d.tmp" % (LIB, os.getpid())
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", tmp]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
+            with contextlib.suppress(OSError):
+                os.remove(tmp)
             raise RuntimeError("link failed: %s\n%s" % (" ".join(cmd), r.stderr[-4000:]))
-        os.replace(LIB + ".tmp", LIB)
+        os.replace(tmp, LIB)
     return LIB
 
 

@@ -13,6 +13,7 @@ from . import _build
 
 _LOCK = threading.Lock()
 _LIB = None
+ABI_VERSION = 2   # == MDL_ABI_VERSION of include/madeleine_amd.h this file's SIGNATURES were written against
 
 c_f = ctypes.c_void_p  # float* (device)
 c_p = ctypes.c_void_p
@@ -24,6 +25,7 @@ f32 = ctypes.c_float
 # name -> (restype, argtypes); mirrors include/madeleine_amd.h declaration by declaration
 SIGNATURES = {
     "mdl_version": (ctypes.c_char_p, []),
+    "mdl_abi_version": (i32, []),
     "mdl_abmil_gate_fwd_ws_bytes": (i64, [i64, i32]),
     "mdl_abmil_gate_fwd": (i32, [c_f, i64, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i64, i32, f32, u64, c_p, c_p, c_p, c_p]),
     "mdl_abmil_gate_bwd_ws_bytes": (i64, [i64, i32]),
@@ -84,17 +86,34 @@ def lib():
         if not _build.is_fresh():
             try:
                 _build.build()
-            except Exception as e:  # no hipcc, or compile error
+            except _build.HipccMissing as e:
+                # no compiler on this machine: a prebuilt library may still be used, guarded by the ABI check below
                 if not os.path.exists(path):
                     raise RuntimeError(
                         "madeleine_amd: libmadeleine_amd.so is missing and could not be built (%s). "
                         "There is no fallback path: run `python -m madeleine_amd._build`." % e) from e
+            except Exception as e:
+                # sources newer than the library and the rebuild FAILED: never dlopen the stale object -- its entry points
+                # would be called with this file's (newer) signatures
+                raise RuntimeError("madeleine_amd: libmadeleine_amd.so is stale and the rebuild failed: %s" % e) from e
         try:
             handle = ctypes.CDLL(path)
         except OSError as e:
             raise RuntimeError("madeleine_amd: cannot load %s: %s" % (path, e)) from e
+        try:
+            abi = handle.mdl_abi_version
+        except AttributeError:
+            raise RuntimeError("madeleine_amd: %s predates the ABI-version check; rebuild it "
+                               "(`python -m madeleine_amd._build --force`)" % path) from None
+        abi.restype, abi.argtypes = i32, []
+        if abi() != ABI_VERSION:
+            raise RuntimeError("madeleine_amd: %s implements ABI revision %d, this binding expects %d; rebuild it "
+                               "(`python -m madeleine_amd._build --force`)" % (path, abi(), ABI_VERSION))
         for name, (res, args) in SIGNATURES.items():
-            fn = getattr(handle, name)  # AttributeError here = header/library mismatch
+            try:
+                fn = getattr(handle, name)
+            except AttributeError:
+                raise RuntimeError("madeleine_amd: %s does not export %s (header / library mismatch)" % (path, name)) from None
             fn.restype = res
             fn.argtypes = args
         _LIB = handle

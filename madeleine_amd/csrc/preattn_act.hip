@@ -187,7 +187,7 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_bwd_kernel(const IO* _
                                                                      float* __restrict__ part, int64_t rows, ActDrop drop) {
     constexpr int W = NV * 256 * WPR, RPB = 4 / WPR;
     __shared__ float red[1][4][2];
-    __shared__ float csum[WPR == 1 ? 3 * W : 1];  // WPR == 1: the 4 waves own the same columns -> merged through LDS
+    __shared__ float csum[WPR < 4 ? 3 * W : 1];  // WPR < 4: several waves own the same columns -> merged through LDS
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, slot = wv / WPR, seg = wv % WPR;
     const int col0 = seg * NV * 256 + lane * 4;
     f32x4 g[NV], b[NV], lb[NV], sg[NV], sb[NV], sx[NV];   // sx: column sums of dx = gradient of the Linear's bias
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_bwd_kernel(const IO* _
                     f32x4* pg = reinterpret_cast<f32x4*>(&csum[col0 + i * 256]);
                     f32x4* pb = reinterpret_cast<f32x4*>(&csum[W + col0 + i * 256]);
                     f32x4* px = reinterpret_cast<f32x4*>(&csum[2 * W + col0 + i * 256]);
-                    if (w == 0) {
+                    if (w < WPR) {   // first wave on this column segment
                         *pg = sg[i];
                         *pb = sb[i];
                         *px = sx[i];
@@ -345,7 +345,8 @@ static inline ActDrop make_act_drop(float p, uint64_t seed, const uint8_t* keep)
     d.keep = keep;
     return d;
 }
-static inline int act_rpb(int W) { return W >= 2048 ? 1 : 4; }  // rows per block iteration
+static inline bool act_width_ok(int W) { return W == 256 || W == 512 || W == 1024 || W == 2048 || W == 4096; }
+static inline int act_rpb(int W) { return W >= 2048 ? 1 : (W == 1024 ? 2 : 4); }  // rows per block iteration (= 4 / WPR)
 static inline int act_blocks(int64_t rows, int W) {
     int64_t b = (rows + act_rpb(W) - 1) / act_rpb(W);
     if (b > 2048) b = 2048;  // 256 CUs x 8 blocks; grid-stride over the rest
@@ -359,7 +360,7 @@ using namespace mdl;
 
 extern "C" int64_t mdl_ln_gelu_drop_bwd_ws_bytes(int64_t rows, int W) {
     if (rows < 0) return MDL_E_ARG;
-    if (W != 256 && W != 512 && W != 2048) return MDL_E_UNSUPPORTED;
+    if (!act_width_ok(W)) return MDL_E_UNSUPPORTED;   // 512 * n_heads for n_heads in {1, 2, 4, 8}, and 256
     return (int64_t)act_blocks(rows, W) * 3 * W * 4 + 64;
 }
 
@@ -367,7 +368,9 @@ extern "C" int64_t mdl_ln_gelu_drop_bwd_ws_bytes(int64_t rows, int W) {
     switch (W) {                                                                     \
         case 256: { constexpr int NV = 1, WPR = 1; __VA_ARGS__; } break;             \
         case 512: { constexpr int NV = 2, WPR = 1; __VA_ARGS__; } break;             \
+        case 1024: { constexpr int NV = 2, WPR = 2; __VA_ARGS__; } break;            \
         case 2048: { constexpr int NV = 2, WPR = 4; __VA_ARGS__; } break;            \
+        case 4096: { constexpr int NV = 4, WPR = 4; __VA_ARGS__; } break;            \
         default: return MDL_E_UNSUPPORTED;                                           \
     }
 

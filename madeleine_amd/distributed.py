@@ -7,11 +7,19 @@ GPU:
 
   * cases shard over ranks; encoder, pooling and token projection are rank-local;
   * parameter gradients: PyTorch DDP bucketed all-reduce (mean) on RCCL -- 20 MB fp32;
-  * ONE autograd-aware all-gather per step of the packed slide embeddings [B_l, M, 512] (plus presence
-    labels) forms the full negative set; every rank then evaluates the same global InfoNCE, so the backward
-    of the gather needs NO collective: rank r keeps its own slice of the (replicated) gradient, scaled by W so
-    that DDP's mean over ranks reproduces the single-process global-batch gradient exactly.
+  * ONE autograd-aware all-gather per step of a packed per-rank payload
+        [ slide embeddings B_l*M*V*512 | presence mask B_l*M | local (min,max) of the 3 GOT cost tensors per stain 6*S ]
+     forms the full negative set and the global GOT thresholds; every rank then evaluates
+    the same global InfoNCE, so the backward of the gather needs NO collective: rank r keeps its own slice of the
+    (replicated) gradient, scaled by W so that DDP's mean over ranks reproduces the single-process global-batch
+    gradient exactly.  The only other data-path collective is the [S,6] all-reduce of the threshold gradients in the
+    backward of the GOT node (the thresholds are global extrema: their gradient belongs to the rank that attains them).
   * rank-local loss terms (GOT) are multiplied by W for the same reason.
+  * The presence labels are HOST data the dataloader hands over with the batch; which stains take part and how many
+    tokens GOT uses (n = min(k_global, 256)) must be known on the host before the loss kernels are launched.  They
+    are therefore exchanged host-side (all_gather_labels_async: a gloo CPU group, started at step begin and waited
+    for after the encoder forward has been queued) -- no device synchronisation; without a host group the labels fall
+    back to a device all-gather + one D2H copy.
 
 All collectives work on gloo as well (CPU tests, world_size 2).
 """
@@ -104,21 +112,101 @@ def all_gather_labels(labels: torch.Tensor, device, group=None) -> torch.Tensor:
     return _all_gather_cat(x, group).cpu()
 
 
-def gather_slide_embeddings(wsi_embs: Dict[str, torch.Tensor], modalities: Sequence[str], group=None):
-    """Packs the per-modality slide embeddings [B_l,V,512] into one [B_l, M*V*512] payload, all-gathers it once
-    and returns the global dict in the reference's shapes (HE expanded over M-1)."""
-    if world_size(group) == 1:
-        return wsi_embs
-    M = len(modalities)
+class _Ready:
+    def __init__(self, value):
+        self.value = value
+
+    def wait(self):
+        return self.value
+
+
+class _PendingLabels:
+    def __init__(self, work, out):
+        self.work, self.out = work, out
+
+    def wait(self):
+        self.work.wait()
+        return self.out
+
+
+_HOST_GROUP = {}
+
+
+def host_group():
+    """A gloo (CPU) process group next to the default one, for host-resident control data (presence labels).  Returns
+    None when it cannot be created (the callers then fall back to the device path)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return None
+    if dist.get_backend() == "gloo":
+        return dist.group.WORLD
+    if "g" not in _HOST_GROUP:
+        try:
+            _HOST_GROUP["g"] = dist.new_group(backend="gloo")
+        except Exception:  # no usable interface for gloo: device fallback
+            _HOST_GROUP["g"] = None
+    return _HOST_GROUP["g"]
+
+
+def all_gather_labels_async(labels: torch.Tensor, hgroup=None):
+    """Starts the host-side exchange of the [B_l, M] presence labels; .wait() returns the [W*B_l, M] CPU tensor.  No
+    device work, no device synchronisation (issue at step begin, wait after the encoder forward has been queued)."""
+    if world_size() == 1:
+        return _Ready(labels.detach().cpu().float())
+    if hgroup is None:
+        hgroup = host_group()
+    if hgroup is None:
+        return _Ready(all_gather_labels(labels, torch.device("cuda", torch.cuda.current_device())))
+    x = labels.detach().cpu().to(torch.float32).contiguous()
+    out = x.new_empty((dist.get_world_size(hgroup) * x.shape[0],) + tuple(x.shape[1:]))
+    return _PendingLabels(dist.all_gather_into_tensor(out, x, group=hgroup, async_op=True), out)
+
+
+def _pack_embeddings(wsi_embs, modalities):
     parts = [wsi_embs[m][..., 0] if m == "HE" else wsi_embs[m] for m in modalities]      # each [B_l,V,512]
     Bl, V, D = parts[0].shape
-    payload = torch.stack(parts, dim=1).reshape(Bl, M * V * D)
-    full = all_gather_replicated(payload, group).view(-1, M, V, D)
+    return torch.stack(parts, dim=1).reshape(Bl * len(modalities) * V * D), (Bl, V, D)
+
+
+def _unpack_embeddings(flat_rows, modalities, geom):
+    """flat_rows [W, B_l*M*V*D] (rank-major) -> the global dict in the reference's shapes (HE expanded over M-1)."""
+    Bl, V, D = geom
+    M = len(modalities)
+    full = flat_rows.reshape(-1, M, V, D)
     out = {}
     for i, m in enumerate(modalities):
         e = full[:, i]
         out[m] = e.unsqueeze(3).expand(-1, -1, -1, M - 1) if m == "HE" else e
     return out
+
+
+def gather_packed(wsi_embs: Dict[str, torch.Tensor], modalities: Sequence[str], labels_local: torch.Tensor,
+                  extrema_local: Optional[torch.Tensor], group=None):
+    """THE data-path collective of a step: one autograd-aware all-gather of
+        [ slide embeddings B_l*M*V*512 | presence mask B_l*M | GOT threshold extrema 6*S ]   per rank.
+    Returns (global embedding dict, presence mask [W*B_l, M] on the device, extrema of every rank [W, S, 6] or None).
+    Gradients flow to the embedding part only (own slice x W, no collective in backward)."""
+    W = world_size(group)
+    if W == 1:
+        return wsi_embs, labels_local.to(wsi_embs["HE"].device), None if extrema_local is None else extrema_local.unsqueeze(0)
+    emb, geom = _pack_embeddings(wsi_embs, modalities)
+    dev, dt = emb.device, emb.dtype
+    lab = labels_local.to(device=dev, dtype=dt).reshape(-1)
+    ext = extrema_local.to(dt).reshape(-1) if extrema_local is not None else emb.new_zeros(0)
+    payload = torch.cat([emb, lab, ext]).unsqueeze(0)                               # [1, P]
+    full = all_gather_replicated(payload, group)                                    # [W, P]
+    n_e, n_l = emb.numel(), lab.numel()
+    embs_g = _unpack_embeddings(full[:, :n_e], modalities, geom)
+    labels_g = full[:, n_e:n_e + n_l].detach().reshape(W * labels_local.shape[0], -1)
+    ext_all = full[:, n_e + n_l:].detach().reshape(W, -1, 6) if extrema_local is not None else None
+    return embs_g, labels_g, ext_all
+
+
+def gather_slide_embeddings(wsi_embs: Dict[str, torch.Tensor], modalities: Sequence[str], group=None):
+    """Slide embeddings only (one all-gather of the packed [B_l, M*V*512] payload); see gather_packed."""
+    if world_size(group) == 1:
+        return wsi_embs
+    emb, geom = _pack_embeddings(wsi_embs, modalities)
+    return _unpack_embeddings(all_gather_replicated(emb.unsqueeze(0), group), modalities, geom)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -165,27 +253,35 @@ class _fan_out:
         return False
 
 
-class _GOTMulti(torch.autograd.Function):
-    """S GOT problems (one per stain) in ONE autograd node with global-batch thresholds.
+def _reduce_extrema(ext_all: torch.Tensor) -> torch.Tensor:
+    """[W, S, 6] (min,max | min,max | min,max per problem) of every rank -> the global [S, 6]."""
+    even = (torch.arange(6, device=ext_all.device) % 2 == 0)
+    return torch.where(even, ext_all.amin(dim=0), ext_all.amax(dim=0))
 
-    forward : local extrema of every problem -> one all-gather [S,6] -> min/max over ranks -> forwards
-    backward: reverse sweeps of every problem -> one all-reduce of the extrema gradients [S,6] -> finish
-    Ranks that own no case of a stain pass an empty (k = 0) problem: they still take part in both collectives.
-    With world size 1 this is S independent reference-semantics GOT calls."""
+
+def got_local_extrema(problems, impl=None) -> torch.Tensor:
+    """[S, 6] threshold extrema of this rank's share of every GOT problem (+-inf for a rank that owns no case of it)."""
+    if impl is None:
+        from .functional import HipGotImpl as impl  # noqa: N813
+    inf = float("inf")
+    dev, dt = problems[0][0].device, problems[0][0].dtype
+    return torch.stack([impl.extrema(V.contiguous(), Q.contiguous()) if V.shape[0] > 0 else
+                        torch.tensor([inf, -inf] * 3, device=dev, dtype=dt) for V, Q in problems])
+
+
+class _GOTMulti(torch.autograd.Function):
+    """S GOT problems (one per stain) in ONE autograd node with global-batch thresholds `ext` [S,6].
+
+    forward : forwards of every problem with the given thresholds (side streams)
+    backward: reverse sweeps of every problem -> one all-reduce of the threshold gradients [S,6] -> finish
+    Ranks that own no case of a stain pass an empty (k = 0) problem: they still take part in the collective.
+    With world size 1 and ext = the batch's own extrema this is S independent reference-semantics GOT calls."""
 
     @staticmethod
-    def forward(ctx, impl, group, *tensors):
+    def forward(ctx, impl, group, ext, *tensors):
         S = len(tensors) // 2
         probs = [(tensors[2 * s].contiguous(), tensors[2 * s + 1].contiguous()) for s in range(S)]
         dev = tensors[0].device
-        inf = float("inf")
-        ext = torch.stack([impl.extrema(V, Q) if V.shape[0] > 0 else
-                           torch.tensor([inf, -inf] * 3, device=dev, dtype=tensors[0].dtype) for V, Q in probs])
-        W = world_size(group)
-        if W > 1:
-            allx = _all_gather_cat(ext, group).view(W, ext.shape[0], 6)
-            even = (torch.arange(6, device=dev) % 2 == 0)
-            ext = torch.where(even, allx.amin(dim=0), allx.amax(dim=0))
         outs, states = [], []
         with _fan_out(dev, S) as lanes:   # stains are independent: one HIP stream each (k <= 32 workgroups per problem)
             for s, (V, Q) in enumerate(probs):
@@ -225,60 +321,81 @@ class _GOTMulti(torch.autograd.Function):
                 else:
                     with lanes(s):
                         grads += list(impl.backward_finish(st, dmm[s]))
-        return (None, None) + tuple(grads)
+        return (None, None, None) + tuple(grads)
 
 
-def got_multi(problems, impl=None, group=None) -> torch.Tensor:
-    """problems: list of (V, Q) token tensors [k_s, n_s, d] (already sub-sampled) -> [S, 2] = (WD sum, GWD sum)."""
+def got_multi(problems, impl=None, group=None, extrema=None) -> torch.Tensor:
+    """problems: list of (V, Q) token tensors [k_s, n_s, d] (already sub-sampled) -> [S, 2] = (WD sum, GWD sum).
+    `extrema` [S,6]: the global-batch thresholds (from gather_packed); None -> computed here (one [S,6] all-gather)."""
     if impl is None:
         from .functional import HipGotImpl as impl  # noqa: N813
+    if extrema is None:
+        extrema = got_local_extrema(problems, impl)
+        if world_size(group) > 1:
+            extrema = _reduce_extrema(_all_gather_cat(extrema, group).view(world_size(group), -1, 6))
     flat = []
     for V, Q in problems:
         flat += [V, Q]
-    return _GOTMulti.apply(impl, group, *flat)
+    return _GOTMulti.apply(impl, group, extrema, *flat)
 
 
 _STEP = [0]
 
 
 def calculate_losses_dp(STAINS, loss_fn_interMod, got_impl, wsi_embs, token_embs, modality_labels_withoutHE, args,
-                        labels_global_withoutHE=None, group=None, subsample=256, shared_seed=0, use_local_loss=True):
+                        labels_global_withoutHE=None, group=None, subsample=256, shared_seed=0, use_local_loss=True,
+                        loss_fn_intraMod=None):
     """Data-parallel counterpart of calculate_losses (trainer.py:20-77) with the reference's global-batch semantics.
 
-    wsi_embs / token_embs / modality_labels_withoutHE are this rank's shard.  Returns (loss, flag) where `loss`
-    is the tensor to call .backward() on under DDP (gradient mean over ranks): the replicated global InfoNCE
-    plus W x (this rank's GOT sum); averaged over ranks its gradient equals the single-process global-batch
-    gradient of  sum_stains [InfoNCE + w * GOT]  (SURVEY.md section 8(e))."""
+    wsi_embs / token_embs / modality_labels_withoutHE are this rank's shard; labels_global_withoutHE the [W*B_l, M-1]
+    presence labels of the global batch on the HOST (all_gather_labels_async(...).wait(); gathered here when None).
+    Returns (loss, flag) where `loss` is the tensor to call .backward() on under DDP (gradient mean over ranks): the
+    replicated global InfoNCE (+ intra-modality terms) plus W x (this rank's GOT sum); averaged over ranks its gradient
+    equals the single-process global-batch gradient of  sum_stains [InfoNCE + w * GOT]  (SURVEY.md section 8(e)).
+    One data-path collective in forward (gather_packed) and one [S,6] all-reduce in backward."""
     from .trainer import calculate_losses
     W = world_size(group)
     dev = wsi_embs["HE"].device
     labels_l = modality_labels_withoutHE.detach().cpu()
-    labels_g = labels_global_withoutHE if labels_global_withoutHE is not None else all_gather_labels(labels_l, dev, group)
+    if labels_global_withoutHE is not None:
+        labels_g = labels_global_withoutHE
+    elif W == 1:
+        labels_g = labels_l
+    else:
+        labels_g = all_gather_labels_async(labels_l).wait()
     mods = ["HE"] + list(STAINS)
-    embs_g = gather_slide_embeddings(wsi_embs, mods, group)
-    loss_g, flag = calculate_losses(STAINS, loss_fn_interMod, None, None, embs_g, None, labels_g, args)
-    if not flag or not use_local_loss or got_impl is None:
-        return loss_g, flag
-    _STEP[0] += 1
+
+    # the local (GOT) problems of this step: fixed by the HOST copy of the global labels, identical on every rank
     problems = []
-    for s_idx, stain in enumerate(STAINS):
-        k_g = int(labels_g[:, s_idx].bool().sum().item())
-        if k_g <= 1:
-            continue
-        # reference: randperm(k_global)[:subsample] (loss.py:282) = the first min(k_g, subsample) tokens, any order
-        if k_g <= subsample:
-            tok_idx = torch.arange(k_g)
-        else:
-            gen = torch.Generator().manual_seed(int(shared_seed) * 1000003 + _STEP[0] * 131 + s_idx)
-            tok_idx = torch.randperm(k_g, generator=gen)[:subsample]
-        tok_idx = tok_idx.to(dev)
-        rows = labels_l[:, s_idx].bool().nonzero(as_tuple=True)[0].to(dev)
-        he = token_embs["HE"][:, :, :, s_idx].index_select(0, rows).index_select(1, tok_idx)
-        st = token_embs[stain].index_select(0, rows).index_select(1, tok_idx)
-        problems.append((he if he.dtype == torch.float64 else he.float(), st if st.dtype == torch.float64 else st.float()))
-    if not problems:
+    if use_local_loss and got_impl is not None and any(int(labels_g[:, s].bool().sum()) > 1 for s in range(len(STAINS))):
+        _STEP[0] += 1
+        for s_idx, stain in enumerate(STAINS):
+            k_g = int(labels_g[:, s_idx].bool().sum())
+            if k_g <= 1:
+                continue
+            # reference: randperm(k_global)[:subsample] (loss.py:282) = the first min(k_g, subsample) tokens, any order
+            if k_g <= subsample:
+                tok_idx = torch.arange(k_g)
+            else:
+                gen = torch.Generator().manual_seed(int(shared_seed) * 1000003 + _STEP[0] * 131 + s_idx)
+                tok_idx = torch.randperm(k_g, generator=gen)[:subsample]
+            if int(tok_idx.max()) >= token_embs["HE"].shape[1]:
+                raise ValueError("GOT sub-samples token indices randperm(k)[:%d] with k = %d participating cases, but the bags "
+                                 "carry only %d tokens (reference quirk, loss.py:282)" % (subsample, k_g, token_embs["HE"].shape[1]))
+            tok_idx = tok_idx.to(dev, non_blocking=True)
+            rows = labels_l[:, s_idx].bool().nonzero(as_tuple=True)[0].to(dev, non_blocking=True)
+            he = token_embs["HE"][:, :, :, s_idx].index_select(0, rows).index_select(1, tok_idx)
+            st = token_embs[stain].index_select(0, rows).index_select(1, tok_idx)
+            problems.append((he if he.dtype == torch.float64 else he.float(), st if st.dtype == torch.float64 else st.float()))
+    ext_local = got_local_extrema(problems, got_impl) if problems else None
+
+    # THE collective: slide embeddings + presence mask + GOT extrema in one payload
+    pad = torch.ones(labels_l.shape[0], 1, dtype=labels_l.dtype)                      # H&E column: always present
+    embs_g, _mask_dev, ext_all = gather_packed(wsi_embs, mods, torch.cat([pad, labels_l], dim=1), ext_local, group)
+    loss_g, flag = calculate_losses(STAINS, loss_fn_interMod, None, loss_fn_intraMod, embs_g, None, labels_g, args)
+    if not flag or not problems:
         return loss_g, flag
-    outs = got_multi(problems, got_impl, group)                    # [S,2]
+    outs = got_multi(problems, got_impl, group, extrema=_reduce_extrema(ext_all))     # [S,2]
     local = (outs[:, 1] + outs[:, 0]).sum() * args.local_loss_weight
     loss = (loss_g if torch.is_tensor(loss_g) else 0.0) + float(W) * local
     return loss, flag

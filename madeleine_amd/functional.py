@@ -338,7 +338,7 @@ class LNGeluDropFn(torch.autograd.Function):
                                                               _ptr(rstd), rows, W, float(eps), float(p_drop), int(seed),
                                                               _ptr(keep), _stream())
         if rc == -3:
-            raise NotImplementedError("fused LayerNorm-GELU-Dropout supports widths 256/512/2048 (got %d)" % W)
+            raise NotImplementedError("fused LayerNorm-GELU-Dropout supports widths 256/512/1024/2048/4096 (got %d)" % W)
         _native.check(rc, "mdl_ln_gelu_drop_fwd")
         ctx.save_for_backward(x, gamma, beta, mean, rstd, bias if bias is not None else torch.empty(0))
         ctx.cfg = (float(p_drop), int(seed), keep, bias is not None)

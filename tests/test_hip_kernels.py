@@ -313,17 +313,19 @@ def test_got_vs_golden_and_oracle(dev, k):
     torch.manual_seed(100 + k)                         # same randperm(k) draw as the golden run
     loss = GOT(vd, qd, subsample=256)
     loss.backward()
+    # tolerances = 2x the error measured on MI355X per fixture (tools/parity_report.py, profiles/r02_parity_report.json):
+    # loss <= 1.6e-6, gradient norms <= 1.4e-5, gradient tensors <= 6.2e-5 (k = 7) -- all far inside north_star's 1e-3
     ref = float(g[f"k{k}/loss"])
-    assert abs(float(loss) - ref) < TOL * abs(ref)
-    assert abs(float(vd.grad.norm()) - float(g[f"k{k}/dv_norm"])) < 5e-3 * float(g[f"k{k}/dv_norm"])
-    assert abs(float(qd.grad.norm()) - float(g[f"k{k}/dq_norm"])) < 5e-3 * float(g[f"k{k}/dq_norm"])
+    assert abs(float(loss.detach()) - ref) < 4e-6 * abs(ref)
+    assert abs(float(vd.grad.norm()) - float(g[f"k{k}/dv_norm"])) < 3e-5 * float(g[f"k{k}/dv_norm"])
+    assert abs(float(qd.grad.norm()) - float(g[f"k{k}/dq_norm"])) < 3e-5 * float(g[f"k{k}/dq_norm"])
     assert float(vd.grad[:, k:].abs().max()) == 0.0
     if k <= 7:
-        assert rel_err(vd.grad[:, :k], g[f"k{k}/dv"]) < 5e-3
-        assert rel_err(qd.grad[:, :k], g[f"k{k}/dq"]) < 5e-3
+        assert rel_err(vd.grad[:, :k], g[f"k{k}/dv"]) < 1.3e-4
+        assert rel_err(qd.grad[:, :k], g[f"k{k}/dq"]) < 1.3e-4
     else:
-        assert rel_err(vd.grad[:4, :k, :16], g[f"k{k}/dv"]) < 5e-3
-        assert rel_err(qd.grad[:4, :k, :16], g[f"k{k}/dq"]) < 5e-3
+        assert rel_err(vd.grad[:4, :k, :16], g[f"k{k}/dv"]) < 1.3e-4
+        assert rel_err(qd.grad[:4, :k, :16], g[f"k{k}/dq"]) < 1.3e-4
 
 
 def test_got_pieces_and_fp64_oracle(dev):
@@ -398,7 +400,7 @@ def test_got_external_thresholds_and_limits(dev):
 
 
 # ---------------------------------------------------------------------------------------------- N1 fused LN-GELU-Dropout
-@pytest.mark.parametrize("W,rows", [(512, 300), (2048, 77), (512, 1)])
+@pytest.mark.parametrize("W,rows", [(512, 300), (2048, 77), (512, 1), (1024, 51), (4096, 9), (256, 13)])
 @pytest.mark.parametrize("mode", ["eval", "mask", "mask+bias"])
 def test_ln_gelu_drop_vs_torch(dev, W, rows, mode):
     """mask+bias: the preceding Linear's bias is added inside the kernel and its gradient (column sums of dx) comes out of

@@ -204,8 +204,9 @@ def test_full_step_global_golden(dev):
     loss, flag = calculate_losses(mods[1:], InfoNCE(temperature=0.001), None, None, embs, toks, labels[:, 1:], args)
     model.zero_grad()
     loss.backward()
-    assert flag and abs(float(loss) - float(g["global/loss"])) < TOL * abs(float(g["global/loss"]))
-    grads_match(g, model, prefix="global/", tol=2e-3)
+    # measured on MI355X (profiles/r02_parity_report.json): loss 1.7e-5, gradient norms 2.2e-5, gradient heads 1.5e-4
+    assert flag and abs(float(loss.detach()) - float(g["global/loss"])) < 4e-5 * abs(float(g["global/loss"]))
+    grads_match(g, model, prefix="global/", tol=3e-4)
 
 
 def test_state_dict_roundtrip_with_module_prefix(dev, tmp_path):
@@ -236,7 +237,8 @@ def test_calculate_losses_full_golden(dev):
     args = SimpleNamespace(global_loss="info-nce", symmetric_cl=True, local_loss_weight=0.7)
     torch.manual_seed(5)
     loss, flag = calculate_losses(stains, InfoNCE(temperature=0.001), GOT, None, wsi, tok, labels[:, 1:], args)
-    assert flag and abs(float(loss) - float(g["full/loss"])) < 2e-3 * abs(float(g["full/loss"]))
+    # measured on MI355X: 4.0e-7 (profiles/r02_parity_report.json)
+    assert flag and abs(float(loss.detach()) - float(g["full/loss"])) < 1e-6 * abs(float(g["full/loss"]))
 
 
 def test_full_step_with_got_golden(dev):
@@ -254,8 +256,9 @@ def test_full_step_with_got_golden(dev):
     loss, flag = calculate_losses(mods[1:], InfoNCE(temperature=0.001), GOT, None, embs, toks, labels[:, 1:], args)
     model.zero_grad()
     loss.backward()
-    assert flag and abs(float(loss) - float(g["loss"])) < 2e-3 * abs(float(g["loss"]))
-    grads_match(g, model, tol=1e-2)
+    # measured on MI355X (profiles/r02_parity_report.json): loss 1.6e-5, gradient norms 2.2e-5, gradient heads 1.5e-4
+    assert flag and abs(float(loss.detach()) - float(g["loss"])) < 4e-5 * abs(float(g["loss"]))
+    grads_match(g, model, tol=3e-4)
 
 
 def test_forward_ragged_matches_per_bag_dense(dev):
