@@ -10,6 +10,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <type_traits>
 #include <vector>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -42,16 +44,22 @@ struct Smem {
     float B[2][BK][BN];
 };
 
-template <int PIPE>
+template <int PIPE, int EPI, int PRIO>
 __device__ __forceinline__ void nn_body(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, float* __restrict__ C,
                                         int64_t ldc, int64_t T, int Nc, int Kc, int n_tiles, Smem& sm) {
-    const int tid = threadIdx.x, lane = tid & 63, wm = (tid >> 6) >> 1, wn = (tid >> 6) & 1;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: SGPR addressing downstream
+    const int wm = wave >> 1, wn = wave & 1;
     const int ncol = Nc / BN;
     const int lid = xcd_remap(blockIdx.x, n_tiles);
     const int nt = lid % ncol;
     const int64_t t0 = (int64_t)(lid / ncol) * BM;
     const int n0 = nt * BN;
+    if constexpr (PRIO == 1) {   // de-synchronise the co-resident workgroups: static issue priority from the tile index
+        const int pr = lid % 3;
+        if (pr == 1) __builtin_amdgcn_s_setprio(1);
+        else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+    }
     const float* srcA[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -211,30 +219,83 @@ __device__ __forceinline__ void nn_body(const float* __restrict__ A, int64_t lda
 #undef SB
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the two redundant tail fetches
     }
+    if constexpr (EPI == 0) {
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+        for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int64_t t = t0 + wm * 64 + rt * 32 + acc_row(r, lane);
-            if (t < T) {
-                float* __restrict__ o = C + t * ldc + n0 + l32;
+            for (int r = 0; r < 16; ++r) {
+                const int64_t t = t0 + wm * 64 + rt * 32 + acc_row(r, lane);
+                if (t < T) {
+                    float* __restrict__ o = C + t * ldc + n0 + l32;
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) o[colb[ct]] = acc[rt][ct][r];
+                    for (int ct = 0; ct < 4; ++ct) o[colb[ct]] = acc[rt][ct][r];
+                }
             }
+    } else if constexpr (EPI == 1) {
+        // wave-private LDS transpose: 4 passes of a 32 x 64 sub-tile (8 KiB per wave), then 16-B row-contiguous stores
+        // (16 lanes = 256 B of one row): 32 store instructions per wave instead of 128
+        __syncthreads();   // every wave is done with the staging buffers
+        float* tile = reinterpret_cast<float*>(&sm) + wave * (32 * 64);
+        const int rl = lane >> 4, c4 = lane & 15;
+        const uint32_t ldc32 = (uint32_t)ldc;
+        const uint32_t voff = (rl * ldc32 + c4 * 4) * 4;          // byte offset of this lane inside a 32-row block
+        const bool full = t0 + BM <= T;                             // block-uniform
+        auto run = [&](auto full_c) {
+            constexpr bool FULL = decltype(full_c)::value;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const int64_t tb = t0 + wm * 64 + rt * 32;
+                const int nvalid = FULL ? 32 : (int)((T - tb) < 0 ? 0 : ((T - tb) > 32 ? 32 : (T - tb)));
+#pragma unroll
+                for (int cp = 0; cp < 2; ++cp) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+#pragma unroll
+                        for (int c2 = 0; c2 < 2; ++c2) tile[acc_row(r, lane) * 64 + c2 * 32 + l32] = acc[rt][cp * 2 + c2][r];
+                    char* cb = reinterpret_cast<char*>(C + tb * ldc + n0 + wn * 128 + cp * 64);   // uniform base of the pass
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {   // 4 reads in flight, then their 4 stores
+                        f32x4 v[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const f32x4*>(&tile[((h * 4 + j) * 4 + rl) * 64 + c4 * 4]);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (FULL || (h * 4 + j) * 4 + rl < nvalid)
+                                *reinterpret_cast<f32x4*>(cb + (voff + (uint32_t)(h * 4 + j) * 16u * ldc32)) = v[j];
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+        };
+        if (full) run(std::true_type{});
+        else run(std::false_type{});
+    } else {
+        if (T < 0) {   // never true at run time: keeps the accumulators alive without an epilogue
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) C[(int64_t)r * ldc + colb[ct] + l32 + rt] = acc[rt][ct][r];
         }
+    }
 }
 
-#define KERNEL(NAME, PIPE, ...)                                                                                             \
+#define KERNEL(NAME, PIPE, EPI, PRIO, ...)                                                                                             \
     __global__ __launch_bounds__(__VA_ARGS__) void NAME(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, \
                                                         float* __restrict__ C, int64_t ldc, int64_t T, int Nc, int Kc,       \
                                                         int n_tiles) {                                                      \
         __shared__ __attribute__((aligned(16))) Smem sm;                                                                    \
-        nn_body<PIPE>(A, lda, B, C, ldc, T, Nc, Kc, n_tiles, sm);                                                            \
+        nn_body<PIPE, EPI, PRIO>(A, lda, B, C, ldc, T, Nc, Kc, n_tiles, sm);                                                            \
     }
-KERNEL(k_base_v, 0, 256, 2)
-KERNEL(k_base_a, 0, 256)
-KERNEL(k_pipe_v, 1, 256, 2)
-KERNEL(k_pipe_a, 1, 256)
+KERNEL(k_base_v, 0, 0, 0, 256, 2)
+KERNEL(k_pipe_v, 1, 0, 0, 256, 2)
+KERNEL(k_pipe_a, 1, 0, 0, 256)
+KERNEL(k_pipe_prio, 1, 0, 1, 256)
+KERNEL(k_pipe_lds, 1, 1, 0, 256)
+KERNEL(k_pipe_lds_prio, 1, 1, 1, 256)
+KERNEL(k_pipe_noepi, 1, 2, 0, 256)
+KERNEL(k_base_noepi, 0, 2, 0, 256, 2)
 
 // register-only MFMA rate with the accumulators forced into arch VGPRs / AGPRs (3 waves per SIMD like the engine)
 __global__ __launch_bounds__(256, 2) void peak_v(float* out, int iters) {
@@ -282,11 +343,14 @@ int main(int argc, char** argv) {
     hipEventCreate(&e0);
     hipEventCreate(&e1);
     struct V { const char* name; kern_t k; };
-    const V vs[] = {{"base_vgpr", k_base_v}, {"base_agpr", k_base_a}, {"pipe_vgpr", k_pipe_v}, {"pipe_agpr", k_pipe_a}};
+    const V vs[] = {{"base_vgpr", k_base_v}, {"pipe_vgpr", k_pipe_v}, {"pipe_agpr", k_pipe_a}, {"pipe_prio", k_pipe_prio},
+                    {"pipe_lds", k_pipe_lds}, {"pipe_lds_prio", k_pipe_lds_prio}, {"pipe_noepi", k_pipe_noepi},
+                    {"base_noepi", k_base_noepi}};
     const int nv = sizeof(vs) / sizeof(vs[0]);
     const int64_t Ts[2] = {T, 1000};   // full size (timing) and a ragged small problem (tails)
     // correctness first: rows 777.. of the big problem and the whole ragged problem against fp64 on the host
     for (int v = 0; v < nv; ++v) {
+        if (strstr(vs[v].name, "noepi")) continue;
         for (int which = 0; which < 2; ++which) {
             const int64_t Tc = Ts[which];
             const int tiles = (int)(((Tc + BM - 1) / BM) * (N / BN));
@@ -322,19 +386,5 @@ int main(int argc, char** argv) {
     for (int v = 0; v < nv; ++v)
         printf("%-10s mean %.3f ms (%.1f TF)  best %.3f ms (%.1f TF)\n", vs[v].name, sum[v] / (rounds - 1),
                2.0 * T * N * K / (sum[v] / (rounds - 1)) / 1e9, best[v], 2.0 * T * N * K / best[v] / 1e9);
-    float* out;
-    hipMalloc(&out, 256 * 3 * 256 * 4);
-    for (int which = 0; which < 2; ++which)
-        for (int rep = 0; rep < 3; ++rep) {
-            const int iters = 40000;
-            hipEventRecord(e0);
-            if (which) hipLaunchKernelGGL(peak_a, dim3(768), dim3(256), 0, 0, out, iters);
-            else hipLaunchKernelGGL(peak_v, dim3(768), dim3(256), 0, 0, out, iters);
-            hipEventRecord(e1);
-            hipEventSynchronize(e1);
-            float ms;
-            hipEventElapsedTime(&ms, e0, e1);
-            printf("peak %s rep %d: %.2f ms %.1f TF\n", which ? "agpr" : "vgpr", rep, ms, 768.0 * 4 * iters * 8 * 4096.0 / ms / 1e9);
-        }
     return 0;
 }
