@@ -12,45 +12,15 @@
 //   dW      : [dWa;dWb]^T = X^T dz                                    GEMM [512,T] x [T,128a|128b], split over T
 //
 // One block tile shape for the three GEMMs: 128 x 256 outputs, BK = 16, 256 threads = 4 waves (2 x 2), each wave
-// 64 x 128 = 2 x 4 MFMA 32x32 accumulators (128 registers).  Every operand reaches LDS by LDS-DMA
-// (global_load_lds_dwordx4: no staging VGPRs, no ds_write pass), two LDS stages of 24 KiB, the next chunk's DMA is
-// issued before the current chunk's 64 MFMAs, one barrier per chunk; ~160 VGPRs => 3 workgroups per CU.
-#include "gate_common.hpp"
+// 64 x 128 = 2 x 4 MFMA 32x32 accumulators (128 AGPRs).  Every operand reaches LDS by LDS-DMA
+// (global_load_lds_dwordx4: no staging VGPRs, no ds_write pass), two LDS stages of 24 KiB; the main loop is the
+// software-pipelined one of tile_engine.hpp (fragment requests one step ahead, the chunk barrier before the last step, the
+// next DMA between that step's MFMAs), 3 workgroups per CU.
+#include "tile_engine.hpp"
 
 namespace mdl {
 
 constexpr int GBM = 128, GBN = 256, GBK = 16;
-
-// MFMA over one staged K-chunk.  colb[ct] = first column (within the 256-wide B tile) of this wave's ct-th
-// 32-column accumulator tile; rows wm*64 + rt*32.
-template <int LDA, int LDB>
-__device__ __forceinline__ void mma_chunk(const float (*__restrict__ As)[LDA], const float (*__restrict__ Bs)[LDB],
-                                          f32x16 (&acc)[2][4], int wm, const int (&colb)[4], int lane) {
-    const int l32 = lane & 31, kh = lane >> 5;
-#pragma unroll
-    for (int kk = 0; kk < GBK / 2; ++kk) {
-        const int k = kk * 2 + kh;
-        const float a0 = As[k][wm * 64 + l32];
-        const float a1 = As[k][wm * 64 + 32 + l32];
-        float b[4];
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) b[ct] = Bs[k][colb[ct] + l32];
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-            acc[0][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[ct], acc[0][ct], 0, 0, 0);
-            acc[1][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[ct], acc[1][ct], 0, 0, 0);
-        }
-    }
-}
-
-__device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][4]) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-}
 
 // ================================================================================================
 // forward
@@ -78,128 +48,116 @@ __global__ __launch_bounds__(256) void gate_wt_kernel(const float* __restrict__ 
     for (int i = 0; i < 4; ++i) WT[((int64_t)c * HID + kb + ty + i * 8) * 1024 + jb + tx] = tile[tx][ty + i * 8];
 }
 
-__global__ __launch_bounds__(256, 2) void gate_fwd_kernel(const float* __restrict__ E, int64_t ldE,
-                                                          const float* __restrict__ WT, const float* __restrict__ ba,
-                                                          const float* __restrict__ bb, const float* __restrict__ wc,
-                                                          float* __restrict__ part, float* __restrict__ act_a,
-                                                          float* __restrict__ act_b, int64_t T, int H, int n_ttiles,
-                                                          DropCfg drop) {
-    __shared__ __attribute__((aligned(16))) struct {
-        float A[2][GBM * GBK];  // 8 KiB per stage
-        float B[2][GBK][GBN];   // 16 KiB per stage
-    } sm;
-    const int tid = threadIdx.x, lane = tid & 63, wm = (tid >> 6) >> 1, wn = (tid >> 6) & 1;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform (LDS-DMA destination base)
+// DM: dropout mode 0 = off, 1 = counter-hash RNG, 2 = explicit uint8 masks (one code path per instantiation: the
+// three-way runtime choice per element cost 12 arch VGPRs, i.e. the third wave per SIMD).  SAVE: store the activations.
+template <int DM>
+__device__ __forceinline__ void fwd_keep2(const DropCfg& d, int64_t idx, bool& ka, bool& kb) {
+    if (DM == 0) {
+        ka = kb = true;
+    } else if (DM == 2) {
+        ka = d.ka[idx] != 0;
+        kb = d.kb[idx] != 0;
+    } else {
+        const uint32_t h = rng_u32(d.key, (uint64_t)idx);
+        ka = (h & 0xFFFFu) >= d.thr;
+        kb = (h >> 16) >= d.thr;
+    }
+}
+
+template <int DM, bool SAVE>
+__global__ __launch_bounds__(256) void gate_fwd_kernel(const float* __restrict__ E, int64_t ldE,
+                                                       const float* __restrict__ WT, const float* __restrict__ ba,
+                                                       const float* __restrict__ bb, const float* __restrict__ wc,
+                                                       float* __restrict__ part, float* __restrict__ act_a,
+                                                       float* __restrict__ act_b, int64_t T, int H, int n_ttiles,
+                                                       DropCfg drop) {
+    __shared__ __attribute__((aligned(16))) TileSmem sm;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform (LDS-DMA bases, SGPR addressing)
+    const int wm = wave >> 1, wn = wave & 1;
     const XcdHead xh = xcd_head(blockIdx.x, H);
     const int jt = xh.li % GATE_JT, c = xh.c, tt = (xh.li / GATE_JT) * xh.nshare + xh.share;
     if (tt >= n_ttiles) return;  // block-uniform
     const int64_t t0 = (int64_t)tt * GBM;
     const int j0 = jt * 128;
 
-    // LDS-DMA sources.  A: instruction q of wave w fills slots [(2w+q)*64, +64); slot s = (row = s>>2, kq' = s&3) holds
-    // global chunk kq = kq' ^ ((row>>2)&3) of that row; rows past T re-read row T-1 (discarded in the epilogue).
-    const float* srcA[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int sl = (wave * 2 + q) * 64 + lane, row = sl >> 2, kq = (sl & 3) ^ ((row >> 2) & 3);
-        int64_t t = t0 + row;
-        if (t > T - 1) t = T - 1;
-        srcA[q] = E + t * ldE + (int64_t)c * HID + kq * 4;
-    }
-    // B: row k of WT, lanes 0-31 -> a columns j0.., lanes 32-63 -> b columns 512 + j0..
-    const float* __restrict__ srcB = WT + (int64_t)c * HID * 1024 + j0 + (lane & 31) * 4 + (lane >> 5) * HID;
-    auto issue = [&](int st, int k0) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) glds16(srcA[q] + k0, &sm.A[st][(wave * 2 + q) * 256]);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) glds16(srcB + (int64_t)(k0 + wave * 4 + q) * 1024, &sm.B[st][wave * 4 + q][0]);
-    };
-
-    const int l32 = lane & 31, kh = lane >> 5;
+    // A: E rows of head c (swizzled row image).  B: row k of WT, lanes 0-31 -> a columns j0.., lanes 32-63 -> b columns 512 + j0..
+    const char* baseA = reinterpret_cast<const char*>(E + t0 * ldE + (int64_t)c * HID);
+    const char* baseB = reinterpret_cast<const char*>(WT + ((int64_t)c * HID + wave * 4) * 1024 + j0);
+    uint32_t voA[2];
+    rows_voff(voA, T - t0, ldE, wave, lane);
+    const uint32_t voB = ((lane & 31) * 4 + (lane >> 5) * HID) * 4;
+    constexpr int64_t rowB = 1024 * 4;
+    const int l32 = lane & 31;
     const int colb[4] = {wn * 64, wn * 64 + 32, 128 + wn * 64, 128 + wn * 64 + 32};  // a, a, b, b
-    int offA[2];
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-        const int r = wm * 64 + rt * 32 + l32;
-        offA[rt] = r * GBK + ((kh ^ ((r >> 2) & 3)) << 2);
-    }
 
     f32x16 acc[2][4];
-    zero_acc(acc);
-    constexpr int NCH = HID / GBK;  // 32 chunks
-    issue(0, 0);
-    __syncthreads();
-    for (int ch = 0; ch < NCH; ++ch) {
-        const int st = ch & 1;
-        if (ch + 1 < NCH) issue(st ^ 1, (ch + 1) * GBK);  // lands in the stage last read before the previous barrier
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            f32x4 fa[2];
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt) fa[rt] = *reinterpret_cast<const f32x4*>(&sm.A[st][offA[rt] ^ (g << 3)]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float fb[4];
-#pragma unroll
-                for (int ct = 0; ct < 4; ++ct) fb[ct] = sm.B[st][8 * g + 4 * kh + e][colb[ct] + l32];
-#pragma unroll
-                for (int m = 0; m < 8; ++m) {
-                    const int rt = m & 1, ct = m >> 1;
-                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[rt][e], fb[ct], acc[rt][ct], 0, 0, 0);
-                }
-            }
-        }
-        __syncthreads();  // drains the LDS-DMA of chunk ch+1 (vmcnt) and fences this chunk's reads
-    }
+    tile_zero(acc);
+    tile_loop_nn(acc, sm, HID / GBK, wm, colb, lane, [&](int st, int f, int piece) {
+        if (piece == 0) rows_issue(baseA + (int64_t)f * (GBK * 4), voA, sm.A[st], wave);
+        else krows_issue2(baseB + ((int64_t)f * GBK + (piece - 1) * 2) * rowB, rowB, voB, sm.B[st], wave, (piece - 1) * 2);
+    });
 
-    // ---- epilogue: activations, dropout, wc-weighted row reduction (one 32-row tile at a time: 16 live partials) ----
-    float* sred = &sm.A[0][0];  // [2 (wn)][128 rows]; all MFMA reads finished at the loop's last barrier
-    float bav[2], bbv[2], wcv[2];
+    // ---- epilogue: 4 passes (rt, ct) of a 32-row x (32 a | 32 b)-column block through a wave-private LDS tile.
+    // (1) accumulator layout: a = tanh(za + ba), b = sigmoid(zb + bb) -> tile (accumulators are read one at a time:
+    //     the arch-VGPR budget of 3 waves per SIMD is 40);  (2) transposed layout, lane = (row = lane>>3, 4 columns):
+    //     dropout, wc-weighted partial sum reduced over the row's 8 lanes, and 16-B stores of the activations.
+    float* tile = reinterpret_cast<float*>(&sm) + wave * (32 * 64);
+    float* sred = reinterpret_cast<float*>(&sm) + 4 * (32 * 64) + wn * GBM + wm * 64;   // [2 (wn)][128 rows]
+    const int g8 = lane & 7, r8 = lane >> 3;
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-        const int j = j0 + wn * 64 + ct * 32 + l32;
-        bav[ct] = ba[c * HID + j];
-        bbv[ct] = bb[c * HID + j];
-        wcv[ct] = wc[c * HID + j];
-    }
+    for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-        float ps[16];
+        for (int ct = 0; ct < 2; ++ct) {
+            const int jc = j0 + wn * 64 + ct * 32;                 // first gate column of this pass
+            const float bav = ba[c * HID + jc + l32], bbv = bb[c * HID + jc + l32];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int64_t t = t0 + wm * 64 + rt * 32 + acc_row(r, lane);
-            float sum = 0.f;
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) {
-                const float a = fast_tanh(acc[rt][ct][r] + bav[ct]);
-                const float b = fast_sigmoid(acc[rt][2 + ct][r] + bbv[ct]);
-                if (t < T) {
-                    const int64_t idx = (t * H + c) * HID + j0 + wn * 64 + ct * 32 + l32;
-                    if (act_a) {
-                        act_a[idx] = a;
-                        act_b[idx] = b;
-                    }
-                    bool keep_a, keep_b;
-                    drop_keep2(drop, idx, keep_a, keep_b);
-                    const float ad = keep_a ? a * drop.inv : 0.f;
-                    const float bd = keep_b ? b * drop.inv : 0.f;
-                    sum += ad * bd * wcv[ct];
-                }
+            for (int r = 0; r < 16; ++r) {
+                float za, zb;
+                asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(za) : "a"(acc[rt][ct][r]));
+                asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(zb) : "a"(acc[rt][2 + ct][r]));
+                tile[acc_row(r, lane) * 64 + l32] = fast_tanh(za + bav);
+                tile[acc_row(r, lane) * 64 + 32 + l32] = fast_sigmoid(zb + bbv);
+                if ((r & 3) == 3) TILE_SB();
             }
-            ps[r] = sum;
-        }
+            const f32x4 wc4 = *reinterpret_cast<const f32x4*>(wc + c * HID + jc + g8 * 4);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float v = ps[r];
+            for (int i = 0; i < 4; ++i) {
+                const int row = i * 8 + r8;
+                const f32x4 a4 = *reinterpret_cast<const f32x4*>(&tile[row * 64 + g8 * 4]);
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(&tile[row * 64 + 32 + g8 * 4]);
+                float sum = 0.f;
+                if (t0 + wm * 64 + rt * 32 + row < T) {
+                    // element index = uniform 64-bit base of the pass + 32-bit lane part
+                    const int64_t idx = ((t0 + wm * 64 + rt * 32) * H + c) * HID + jc + (uint32_t)(row * H * HID + g8 * 4);
+                    if (SAVE) {
+                        *reinterpret_cast<f32x4*>(act_a + idx) = a4;
+                        *reinterpret_cast<f32x4*>(act_b + idx) = b4;
+                    }
 #pragma unroll
-            for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-            if (l32 == 0) sred[wn * GBM + wm * 64 + rt * 32 + acc_row(r, lane)] = v;
+                    for (int e = 0; e < 4; ++e) {
+                        bool keep_a, keep_b;
+                        fwd_keep2<DM>(drop, idx + e, keep_a, keep_b);
+                        const float ad = keep_a ? a4[e] * drop.inv : 0.f;
+                        const float bd = keep_b ? b4[e] * drop.inv : 0.f;
+                        sum += ad * bd * wc4[e];
+                    }
+                }
+                sum += __shfl_xor(sum, 1, 64);
+                sum += __shfl_xor(sum, 2, 64);
+                sum += __shfl_xor(sum, 4, 64);
+                if (g8 == 0) {
+                    if (ct == 0) sred[rt * 32 + row] = sum;
+                    else sred[rt * 32 + row] += sum;
+                }
+                TILE_SB();   // one row group at a time: keeps the epilogue inside the 40 arch VGPRs of 3 waves per SIMD
+            }
         }
-    }
     __syncthreads();
     if (tid < GBM) {
         const int64_t t = t0 + tid;
-        if (t < T) part[(t * H + c) * GATE_JT + jt] = sred[tid] + sred[GBM + tid];
+        const float* sr = reinterpret_cast<const float*>(&sm) + 4 * (32 * 64);
+        if (t < T) part[(t * H + c) * GATE_JT + jt] = sr[tid] + sr[GBM + tid];
     }
 }
 
@@ -224,113 +182,70 @@ __global__ void gate_finalize_kernel(const float* __restrict__ part, const float
 // A = dz rows (K-contiguous): swizzled row image like the forward; B = 16 weight rows x 256 columns per chunk (K-major
 // in global memory already): one 1-KiB row per wave instruction.  k order within a chunk: (8g+e | 8g+4+e) per half-wave.
 // ================================================================================================
-__global__ __launch_bounds__(256, 2) void gate_bwd_dx_kernel(const float* __restrict__ dz, const float* __restrict__ Wa,
-                                                             const float* __restrict__ Wb, float* __restrict__ dE,
-                                                             int64_t ldE, int accumulate, int64_t T, int H, PoolTerm pt) {
-    __shared__ __attribute__((aligned(16))) struct {
-        float A[2][GBM * GBK];
-        float B[2][GBK][GBN];
-    } sm;
-    const int tid = threadIdx.x, lane = tid & 63, wm = (tid >> 6) >> 1, wn = (tid >> 6) & 1;
+__global__ __launch_bounds__(256) void gate_bwd_dx_kernel(const float* __restrict__ dz, const float* __restrict__ Wa,
+                                                          const float* __restrict__ Wb, float* __restrict__ dE,
+                                                          int64_t ldE, int accumulate, int64_t T, int H, PoolTerm pt) {
+    __shared__ __attribute__((aligned(16))) TileSmem sm;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
     const XcdHead xh = xcd_head(blockIdx.x, H);
     const int nt = xh.li % 2, c = xh.c, tt = (xh.li / 2) * xh.nshare + xh.share;
     const int64_t t0 = (int64_t)tt * GBM;
     if (t0 >= T) return;  // block-uniform
     const int n0 = nt * GBN;
 
-    const float* srcA[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int sl = (wave * 2 + q) * 64 + lane, row = sl >> 2, kq = (sl & 3) ^ ((row >> 2) & 3);
-        int64_t t = t0 + row;
-        if (t > T - 1) t = T - 1;
-        srcA[q] = dz + (t * H + c) * 1024 + kq * 4;
-    }
-    const float* __restrict__ Wac = Wa + (int64_t)c * HID * HID + n0 + lane * 4;  // + j*512
-    const float* __restrict__ Wbc = Wb + (int64_t)c * HID * HID + n0 + lane * 4;
-    auto issue = [&](int st, int k0) {  // k0 in [0,1024): first 512 = Wa rows, then Wb rows (a chunk never straddles)
-#pragma unroll
-        for (int q = 0; q < 2; ++q) glds16(srcA[q] + k0, &sm.A[st][(wave * 2 + q) * 256]);
-        const float* wsrc = (k0 < HID) ? (Wac + (int64_t)k0 * HID) : (Wbc + (int64_t)(k0 - HID) * HID);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) glds16(wsrc + (int64_t)(wave * 4 + q) * HID, &sm.B[st][wave * 4 + q][0]);
-    };
-
-    const int l32 = lane & 31, kh = lane >> 5;
+    const char* baseA = reinterpret_cast<const char*>(dz + (t0 * H + c) * 1024);
+    uint32_t voA[2];
+    rows_voff(voA, T - t0, (int64_t)H * 1024, wave, lane);
+    // B: weight rows j (K-major in memory already): chunks 0..31 = Wa rows, 32..63 = Wb rows (a chunk never straddles)
+    const char* baseWa = reinterpret_cast<const char*>(Wa + ((int64_t)c * HID + wave * 4) * HID + n0);
+    const char* baseWb = reinterpret_cast<const char*>(Wb + ((int64_t)c * HID + wave * 4) * HID + n0);
+    const uint32_t voB = lane * 16;
+    constexpr int64_t rowB = HID * 4;
     const int colb[4] = {wn * 128, wn * 128 + 32, wn * 128 + 64, wn * 128 + 96};
-    int offA[2];
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-        const int r = wm * 64 + rt * 32 + l32;
-        offA[rt] = r * GBK + ((kh ^ ((r >> 2) & 3)) << 2);
-    }
     f32x16 acc[2][4];
-    zero_acc(acc);
-    constexpr int NCH = 2 * HID / GBK;  // 64 chunks
-    issue(0, 0);
-    __syncthreads();
-    for (int ch = 0; ch < NCH; ++ch) {
-        const int st = ch & 1;
-        if (ch + 1 < NCH) issue(st ^ 1, (ch + 1) * GBK);
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            f32x4 fa[2];
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt) fa[rt] = *reinterpret_cast<const f32x4*>(&sm.A[st][offA[rt] ^ (g << 3)]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float fb[4];
-#pragma unroll
-                for (int ct = 0; ct < 4; ++ct) fb[ct] = sm.B[st][8 * g + 4 * kh + e][colb[ct] + l32];
-#pragma unroll
-                for (int m = 0; m < 8; ++m) {
-                    const int rt = m & 1, ct = m >> 1;
-                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[rt][e], fb[ct], acc[rt][ct], 0, 0, 0);
-                }
-            }
+    tile_zero(acc);
+    tile_loop_nn(acc, sm, 2 * HID / GBK, wm, colb, lane, [&](int st, int f, int piece) {
+        if (piece == 0) {
+            rows_issue(baseA + (int64_t)f * (GBK * 4), voA, sm.A[st], wave);
+        } else {
+            const char* w = (f < HID / GBK) ? baseWa + (int64_t)f * GBK * rowB : baseWb + (int64_t)(f - HID / GBK) * GBK * rowB;
+            krows_issue2(w + (piece - 1) * 2 * rowB, rowB, voB, sm.B[st], wave, (piece - 1) * 2);
         }
-        __syncthreads();
-    }
+    });
 
+    char* ob = reinterpret_cast<char*>(dE + t0 * ldE + (int64_t)c * HID + n0);
+    const uint32_t ld4 = (uint32_t)ldE * 4u;
+    auto emit = [&](int row_u, int rl, int lane_col, const f32x4& v, int) {
+        f32x4* o = reinterpret_cast<f32x4*>(ob + (int64_t)row_u * ld4 + ((uint32_t)rl * ld4 + (uint32_t)lane_col * 4u));
+        f32x4 r = v;
+        if (pt.scores) {  // fused A3 term: + w[t,c] * d_pooled[bag(t), c, :]  (cache-resident row, no dE re-read)
+            int bag;
+            const float w = pool_term_weight(pt, t0 + row_u + rl, c, H, bag);
+            const f32x4 dp = *reinterpret_cast<const f32x4*>(pt.d_pooled + ((int64_t)bag * H + c) * HID + n0 + lane_col);
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int64_t t = t0 + wm * 64 + rt * 32 + acc_row(r, lane);
-            if (t < T) {
-                float* __restrict__ o = dE + t * ldE + (int64_t)c * HID + n0 + l32;
-                if (pt.scores) {  // fused A3 term: + w[t,c] * d_pooled[bag(t), c, :]  (cache-resident row, no dE re-read)
-                    int bag;
-                    const float w = pool_term_weight(pt, t, c, H, bag);
-                    const float* __restrict__ dp = pt.d_pooled + ((int64_t)bag * H + c) * HID + n0 + l32;
-#pragma unroll
-                    for (int ct = 0; ct < 4; ++ct) o[colb[ct]] = fmaf(w, dp[colb[ct]], acc[rt][ct][r]);
-                } else {
-#pragma unroll
-                    for (int ct = 0; ct < 4; ++ct) {
-                        float v = acc[rt][ct][r];
-                        if (accumulate) v += o[colb[ct]];
-                        o[colb[ct]] = v;
-                    }
-                }
-            }
+            for (int i = 0; i < 4; ++i) r[i] = fmaf(w, dp[i], v[i]);
+        } else if (accumulate) {
+            r += *o;
         }
+        *o = r;
+    };
+    if (t0 + GBM <= T) tile_epilogue_rows<true, 2>(acc, sm, wave, wm, colb, lane, GBM, emit);
+    else tile_epilogue_rows<false, 2>(acc, sm, wave, wm, colb, lane, (int)(T - t0), emit);
 }
 
 // ================================================================================================
 // backward, stage 3: dW^T tile  C[k', n] = sum_t X[t, k'] dz[t, n]   (n < 128: dza column j0+n ; else dzb column j0+n-128)
 // over the token range of this split; both operands are K-major in global memory -> LDS-DMA, natural images.
 // ================================================================================================
-__global__ __launch_bounds__(256, 2) void gate_bwd_dw_kernel(const float* __restrict__ E, int64_t ldE,
-                                                             const float* __restrict__ dz, float* __restrict__ slabW,
-                                                             int64_t T, int H, int64_t tok_per_split, int n_splits) {
-    __shared__ __attribute__((aligned(16))) struct {
-        float A[2][GBK][GBM];
-        float B[2][GBK][GBN];
-    } sm;
-    const int tid = threadIdx.x, lane = tid & 63, wm = (tid >> 6) >> 1, wn = (tid >> 6) & 1;
+__global__ __launch_bounds__(256) void gate_bwd_dw_kernel(const float* __restrict__ E, int64_t ldE,
+                                                          const float* __restrict__ dz, float* __restrict__ slabW,
+                                                          int64_t T, int H, int64_t tok_per_split, int n_splits) {
+    __shared__ __attribute__((aligned(16))) TileSmem sm;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
     const XcdHead xh = xcd_head(blockIdx.x, H);
     const int kt = xh.li % 4, jt = (xh.li / 4) % GATE_JT, c = xh.c, sp = (xh.li / (4 * GATE_JT)) * xh.nshare + xh.share;
     if (sp >= n_splits) return;  // block-uniform
@@ -340,36 +255,35 @@ __global__ __launch_bounds__(256, 2) void gate_bwd_dw_kernel(const float* __rest
     if (te > T) te = T;
 
     // A: two 512-B rows of X per wave instruction (rows past T re-read row T-1: their dz rows are the zero pad)
-    // B: one row per wave instruction: lanes 0-31 -> dza segment, lanes 32-63 -> dzb segment
-    const float* __restrict__ Xg = E + (int64_t)c * HID + k0 + (lane & 31) * 4;
-    const float* __restrict__ Zg = dz + (int64_t)c * 1024 + j0 + (lane & 31) * 4 + (lane >> 5) * HID;
-    auto issue = [&](int st, int64_t tb) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int r0 = (wave * 2 + q) * 2;
-            int64_t t = tb + r0 + (lane >> 5);
-            if (t > T - 1) t = T - 1;
-            glds16(Xg + t * ldE, &sm.A[st][r0][0]);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int r = wave * 4 + q;
-            glds16(Zg + (tb + r) * (int64_t)H * 1024, &sm.B[st][r][0]);  // tb + r <= T + GBK - 1: inside the zero pad
-        }
-    };
+    // B: one row per wave instruction: lanes 0-31 -> dza segment, lanes 32-63 -> dzb segment (rows < T + GBK: zero pad)
+    const char* Xb = reinterpret_cast<const char*>(E + (int64_t)c * HID + k0);
+    const char* Zb = reinterpret_cast<const char*>(dz + (int64_t)c * 1024 + j0);
+    const uint32_t ldE4 = (uint32_t)ldE * 4u;
+    const uint32_t colA = (lane & 31) * 16;
+    const uint32_t voB = ((lane & 31) * 4 + (lane >> 5) * HID) * 4;
+    const int64_t rowZ = (int64_t)H * 1024 * 4;
+    float (*As)[TBK][TBM] = reinterpret_cast<float (*)[TBK][TBM]>(&sm.A[0][0]);
 
     f32x16 acc[2][4];
-    zero_acc(acc);
+    tile_zero(acc);
     const int colb[4] = {wn * 128, wn * 128 + 32, wn * 128 + 64, wn * 128 + 96};
     const int64_t nch = (te > ts) ? (te - ts + GBK - 1) / GBK : 0;
-    if (nch > 0) issue(0, ts);
-    __syncthreads();
-    for (int64_t ch = 0; ch < nch; ++ch) {
-        const int st = (int)(ch & 1);
-        if (ch + 1 < nch) issue(st ^ 1, ts + (ch + 1) * GBK);
-        mma_chunk<GBM, GBN>(sm.A[st], sm.B[st], acc, wm, colb, lane);
-        __syncthreads();
-    }
+    tile_loop_tn(acc, sm, nch, wm, colb, lane, [&](int st, int64_t f, int piece) {
+        const int64_t tb = ts + f * GBK;
+        if (piece == 0) {
+            const int64_t left = T - 1 - tb;   // >= 0
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int r0 = (wave * 2 + q) * 2;
+                uint32_t r = r0 + (lane >> 5);
+                if (left < GBK) r = r < (uint32_t)left ? r : (uint32_t)left;   // uniform branch: only the chunk at the end of E
+                glds16_s(r * ldE4 + colA, Xb + tb * (int64_t)ldE4, lds_addr_of(&As[st][r0][0]));
+            }
+        } else {
+            const char* z = Zb + (tb + wave * 4 + (piece - 1) * 2) * rowZ;
+            krows_issue2(z, rowZ, voB, sm.B[st], wave, (piece - 1) * 2);
+        }
+    });
 
     // slabW [split][head][k' 512][1024: a-cols 0..511 | b-cols 512..1023]
     float* __restrict__ so = slabW + (((int64_t)sp * H + c) * HID) * 1024;
@@ -509,8 +423,20 @@ extern "C" int mdl_abmil_gate_fwd(const float* E, int64_t ldE, const float* Wa, 
     float* part = WT + (int64_t)H * HID * 1024;
     hipLaunchKernelGGL(gate_wt_kernel, dim3(16, 32, H), dim3(256), 0, s, Wa, Wb, WT);
     MDL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gate_fwd_kernel, dim3((unsigned)grid), dim3(256), 0, s, E, ldE, (const float*)WT, ba, bb, wc, part, act_a,
-                       act_b, T, H, (int)n_tt, d);
+    const int dm = !d.on ? 0 : (d.ka ? 2 : 1);
+#define MDL_GATE_FWD(DM, SAVE)                                                                                                  \
+    hipLaunchKernelGGL((gate_fwd_kernel<DM, SAVE>), dim3((unsigned)grid), dim3(256), 0, s, E, ldE, (const float*)WT, ba, bb, wc, part, \
+                       act_a, act_b, T, H, (int)n_tt, d)
+    if (act_a) {
+        if (dm == 0) MDL_GATE_FWD(0, true);
+        else if (dm == 1) MDL_GATE_FWD(1, true);
+        else MDL_GATE_FWD(2, true);
+    } else {
+        if (dm == 0) MDL_GATE_FWD(0, false);
+        else if (dm == 1) MDL_GATE_FWD(1, false);
+        else MDL_GATE_FWD(2, false);
+    }
+#undef MDL_GATE_FWD
     MDL_LAUNCH_CHECK();
     const int64_t n = T * H;
     hipLaunchKernelGGL(gate_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)part, bc, scores,

@@ -7,20 +7,11 @@
 //     dX      : dX[t, k] = sum_n dY[t, n] W[n, k]     = lin_nn(A = dY, B = W   [N][K] as stored)
 //     dW      : dW[n, k] = sum_t dY[t, n] X[t, k]     = lin_tn(A = X, B = dY), split over tokens, slabs reduced + transposed
 // Shapes: N % 256 == 0 (lin_nn output width / lin_tn slab width), contraction length % 16 == 0, row strides % 4 == 0.
-#include "gate_common.hpp"
+#include "tile_engine.hpp"
 
 namespace mdl {
 
 constexpr int LBM = 128, LBN = 256, LBK = 16;
-
-__device__ __forceinline__ void lin_zero(f32x16 (&acc)[2][4]) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-}
 
 // out[c][r] = in[r][c]   (32 x 32 LDS tiles; R, C multiples of 32)
 __global__ __launch_bounds__(256) void lin_transpose_kernel(const float* __restrict__ in, int R, int C, float* __restrict__ out) {
@@ -35,98 +26,54 @@ __global__ __launch_bounds__(256) void lin_transpose_kernel(const float* __restr
 
 // C[t, n] = sum_k A[t, k] B[k][n];  A [T, Kc] rows (stride lda), B [Kc][Nc] row-major, C [T, Nc] (stride ldc).
 // A lands as the XOR-swizzled row image (ds_read_b128 fragments, k-pair permutation), B as one 1-KiB row per wave
-// instruction (conflict-free ds_read_b32) -- exactly the gate forward's staging.  Consecutive workgroups of an XCD share
-// the token tile (xcd_remap), so A is fetched from HBM once per XCD.
-__global__ __launch_bounds__(256, 2) void lin_nn_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
-                                                        float* __restrict__ C, int64_t ldc, int64_t T, int Nc, int Kc,
-                                                        int n_tiles) {
-    __shared__ __attribute__((aligned(16))) struct {
-        float A[2][LBM * LBK];
-        float B[2][LBK][LBN];
-    } sm;
-    const int tid = threadIdx.x, lane = tid & 63, wm = (tid >> 6) >> 1, wn = (tid >> 6) & 1;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+// instruction (conflict-free ds_read_b32) -- exactly the gate forward's staging (tile_engine.hpp).  Consecutive workgroups
+// of an XCD share the token tile (xcd_remap), so A is fetched from HBM once per XCD.
+__global__ __launch_bounds__(256) void lin_nn_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
+                                                     float* __restrict__ C, int64_t ldc, int64_t T, int Nc, int Kc,
+                                                     int n_tiles) {
+    __shared__ __attribute__((aligned(16))) TileSmem sm;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: SGPR addressing downstream
+    const int wm = wave >> 1, wn = wave & 1;
     const int ncol = Nc / LBN;
     const int lid = xcd_remap(blockIdx.x, n_tiles);
     const int nt = lid % ncol;
     const int64_t t0 = (int64_t)(lid / ncol) * LBM;
     const int n0 = nt * LBN;
 
-    const float* srcA[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int sl = (wave * 2 + q) * 64 + lane, row = sl >> 2, kq = (sl & 3) ^ ((row >> 2) & 3);
-        int64_t t = t0 + row;
-        if (t > T - 1) t = T - 1;  // rows past T re-read row T-1 (discarded in the epilogue)
-        srcA[q] = A + t * lda + kq * 4;
-    }
-    const float* __restrict__ srcB = B + n0 + lane * 4;
-    auto issue = [&](int st, int k0) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) glds16(srcA[q] + k0, &sm.A[st][(wave * 2 + q) * 256]);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) glds16(srcB + (int64_t)(k0 + wave * 4 + q) * Nc, &sm.B[st][wave * 4 + q][0]);
-    };
-    const int l32 = lane & 31, kh = lane >> 5;
+    const char* baseA = reinterpret_cast<const char*>(A + t0 * lda);
+    const char* baseB = reinterpret_cast<const char*>(B + n0 + (int64_t)(wave * 4) * Nc);
+    uint32_t voA[2];
+    rows_voff(voA, T - t0, lda, wave, lane);
+    const uint32_t voB = lane * 16;
+    const int64_t rowB = (int64_t)Nc * 4;
     const int colb[4] = {wn * 128, wn * 128 + 32, wn * 128 + 64, wn * 128 + 96};
-    int offA[2];
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-        const int r = wm * 64 + rt * 32 + l32;
-        offA[rt] = r * LBK + ((kh ^ ((r >> 2) & 3)) << 2);
-    }
     f32x16 acc[2][4];
-    lin_zero(acc);
-    const int nch = Kc / LBK;
-    issue(0, 0);
-    __syncthreads();
-    for (int ch = 0; ch < nch; ++ch) {
-        const int st = ch & 1;
-        if (ch + 1 < nch) issue(st ^ 1, (ch + 1) * LBK);
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            f32x4 fa[2];
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt) fa[rt] = *reinterpret_cast<const f32x4*>(&sm.A[st][offA[rt] ^ (g << 3)]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float fb[4];
-#pragma unroll
-                for (int ct = 0; ct < 4; ++ct) fb[ct] = sm.B[st][8 * g + 4 * kh + e][colb[ct] + l32];
-#pragma unroll
-                for (int m = 0; m < 8; ++m) {
-                    const int rt = m & 1, ct = m >> 1;
-                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[rt][e], fb[ct], acc[rt][ct], 0, 0, 0);
-                }
-            }
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int64_t t = t0 + wm * 64 + rt * 32 + acc_row(r, lane);
-            if (t < T) {
-                float* __restrict__ o = C + t * ldc + n0 + l32;
-#pragma unroll
-                for (int ct = 0; ct < 4; ++ct) o[colb[ct]] = acc[rt][ct][r];
-            }
-        }
+    tile_zero(acc);
+    tile_loop_nn(acc, sm, Kc / LBK, wm, colb, lane, [&](int st, int f, int piece) {
+        if (piece == 0) rows_issue(baseA + (int64_t)f * (LBK * 4), voA, sm.A[st], wave);
+        else krows_issue2(baseB + ((int64_t)f * LBK + (piece - 1) * 2) * rowB, rowB, voB, sm.B[st], wave, (piece - 1) * 2);
+    });
+    char* cb = reinterpret_cast<char*>(C + t0 * ldc + n0);
+    const uint32_t ldc4 = (uint32_t)ldc * 4u;
+    auto emit = [&](int row_u, int rl, int lane_col, const f32x4& v, int) {
+        *reinterpret_cast<f32x4*>(cb + (int64_t)row_u * ldc4 + ((uint32_t)rl * ldc4 + (uint32_t)lane_col * 4u)) = v;
+    };
+    if (t0 + LBM <= T) tile_epilogue_rows<true>(acc, sm, wave, wm, colb, lane, LBM, emit);
+    else tile_epilogue_rows<false>(acc, sm, wave, wm, colb, lane, (int)(T - t0), emit);
 }
 
 // slab[sp][k][n] = sum_{t in split sp} X[t, k] dY[t, n];  both operands are K(= t)-major in memory: natural LDS images.
-// Rows t >= T read from `zrow` (zeros); columns k >= Kx of the last k-tile read column 0 (discarded).
-__global__ __launch_bounds__(256, 2) void lin_tn_kernel(const float* __restrict__ X, int64_t ldx, int Kx,
-                                                        const float* __restrict__ dY, int64_t ldy, int Ny,
-                                                        float* __restrict__ slab, const float* __restrict__ zrow, int64_t T,
-                                                        int64_t tok_per_split, int n_splits, int n_tiles) {
-    __shared__ __attribute__((aligned(16))) struct {
-        float A[2][LBK][LBM];
-        float B[2][LBK][LBN];
-    } sm;
-    const int tid = threadIdx.x, lane = tid & 63, wm = (tid >> 6) >> 1, wn = (tid >> 6) & 1;
+// dY rows t >= T read from `zrow` (zeros); X rows t >= T re-read row T-1 (their products with the zero rows vanish);
+// columns k >= Kx of the last k-tile read column 0 (discarded).
+__global__ __launch_bounds__(256) void lin_tn_kernel(const float* __restrict__ X, int64_t ldx, int Kx,
+                                                     const float* __restrict__ dY, int64_t ldy, int Ny,
+                                                     float* __restrict__ slab, const float* __restrict__ zrow, int64_t T,
+                                                     int64_t tok_per_split, int n_splits, int n_tiles) {
+    __shared__ __attribute__((aligned(16))) TileSmem sm;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
     const int nkt = (Kx + LBM - 1) / LBM, nnt = Ny / LBN;
     const int lid = xcd_remap(blockIdx.x, n_tiles);
     const int kt = lid % nkt, ntile = (lid / nkt) % nnt, sp = lid / (nkt * nnt);
@@ -135,50 +82,40 @@ __global__ __launch_bounds__(256, 2) void lin_tn_kernel(const float* __restrict_
     int64_t te = ts + tok_per_split;
     if (te > T) te = T;
 
-    // A: two 512-B row segments of X per wave instruction; B: one 1-KiB row segment of dY per wave instruction
+    // A: two 512-B row segments of X per wave instruction (lanes 0-31 row r, lanes 32-63 row r+1); B: one 1-KiB row of dY
     const int ka = k0 + (lane & 31) * 4;
-    const int64_t offXa = (ka < Kx) ? ka : 0;
-    const int64_t offYb = n0 + lane * 4;
-    auto issue = [&](int st, int64_t tb) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int r0 = (wave * 2 + q) * 2;
-            const int64_t t = tb + r0 + (lane >> 5);
-            glds16(t < T ? X + t * ldx + offXa : zrow + (lane & 31) * 4, &sm.A[st][r0][0]);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int64_t t = tb + wave * 4 + q;
-            glds16(t < T ? dY + t * ldy + offYb : zrow + lane * 4, &sm.B[st][wave * 4 + q][0]);
-        }
-    };
+    const uint32_t colA = (uint32_t)((ka < Kx) ? ka : 0) * 4u;
+    const uint32_t ldx4 = (uint32_t)ldx * 4u;
+    const char* Xb = reinterpret_cast<const char*>(X);
+    const char* Yb = reinterpret_cast<const char*>(dY + n0);
+    const char* Zb = reinterpret_cast<const char*>(zrow);
+    const uint32_t voB = lane * 16;
+    float (*As)[TBK][TBM] = reinterpret_cast<float (*)[TBK][TBM]>(&sm.A[0][0]);
     f32x16 acc[2][4];
-    lin_zero(acc);
+    tile_zero(acc);
     const int colb[4] = {wn * 128, wn * 128 + 32, wn * 128 + 64, wn * 128 + 96};
-    const int l32 = lane & 31, kh = lane >> 5;
     const int64_t nch = (te > ts) ? (te - ts + LBK - 1) / LBK : 0;
-    if (nch > 0) issue(0, ts);
-    __syncthreads();
-    for (int64_t ch = 0; ch < nch; ++ch) {
-        const int st = (int)(ch & 1);
-        if (ch + 1 < nch) issue(st ^ 1, ts + (ch + 1) * LBK);
+    tile_loop_tn(acc, sm, nch, wm, colb, lane, [&](int st, int64_t f, int piece) {
+        const int64_t tb = ts + f * LBK;
+        if (piece == 0) {
+            const int64_t left = T - 1 - tb;   // >= 0: last valid row relative to this chunk
 #pragma unroll
-        for (int kk = 0; kk < LBK / 2; ++kk) {
-            const int k = kk * 2 + kh;
-            const float a0 = sm.A[st][k][wm * 64 + l32];
-            const float a1 = sm.A[st][k][wm * 64 + 32 + l32];
-            float b[4];
+            for (int q = 0; q < 2; ++q) {
+                const int r0 = (wave * 2 + q) * 2;
+                uint32_t r = r0 + (lane >> 5);
+                if (left < 2 * 8) r = r < (uint32_t)left ? r : (uint32_t)left;   // uniform branch: only the chunk at the end of X
+                glds16_s(r * ldx4 + colA, Xb + tb * (int64_t)ldx4, lds_addr_of(&As[st][r0][0]));
+            }
+        } else {
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) b[ct] = sm.B[st][k][colb[ct] + l32];
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) {
-                acc[0][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[ct], acc[0][ct], 0, 0, 0);
-                acc[1][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[ct], acc[1][ct], 0, 0, 0);
+            for (int q = (piece - 1) * 2; q < (piece - 1) * 2 + 2; ++q) {
+                const int64_t t = tb + wave * 4 + q;
+                glds16_s(voB, t < T ? Yb + t * ldy * 4 : Zb, lds_addr_of(&sm.B[st][wave * 4 + q][0]));
             }
         }
-        __syncthreads();
-    }
+    });
     float* __restrict__ so = slab + (int64_t)sp * Kx * Ny;
+    const int l32 = lane & 31;
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll

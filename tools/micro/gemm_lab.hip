@@ -281,6 +281,13 @@ __device__ __forceinline__ void nn_body(const float* __restrict__ A, int64_t lda
     }
 }
 
+#define KERNEL2(NAME, PIPE, EPI, PRIO, PADKB)                                                                              \
+    __global__ __launch_bounds__(256) void NAME(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,        \
+                                                float* __restrict__ C, int64_t ldc, int64_t T, int Nc, int Kc, int n_tiles) { \
+        __shared__ __attribute__((aligned(16))) struct { Smem s; float pad[PADKB * 256]; } smx;                               \
+        if (T < 0) smx.pad[threadIdx.x] = 1.f;  /* keeps the padding allocated: fewer workgroups per CU */                    \
+        nn_body<PIPE, EPI, PRIO>(A, lda, B, C, ldc, T, Nc, Kc, n_tiles, smx.s);                                                \
+    }
 #define KERNEL(NAME, PIPE, EPI, PRIO, ...)                                                                                             \
     __global__ __launch_bounds__(__VA_ARGS__) void NAME(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, \
                                                         float* __restrict__ C, int64_t ldc, int64_t T, int Nc, int Kc,       \
@@ -295,6 +302,8 @@ KERNEL(k_pipe_prio, 1, 0, 1, 256)
 KERNEL(k_pipe_lds, 1, 1, 0, 256)
 KERNEL(k_pipe_lds_prio, 1, 1, 1, 256)
 KERNEL(k_pipe_noepi, 1, 2, 0, 256)
+KERNEL2(k_pipe_lds_2wg, 1, 1, 0, 24)   /* 72 KiB: 2 workgroups per CU */
+KERNEL2(k_pipe_lds_1wg, 1, 1, 0, 48)   /* 96 KiB: 1 workgroup per CU */
 KERNEL(k_base_noepi, 0, 2, 0, 256, 2)
 
 // register-only MFMA rate with the accumulators forced into arch VGPRs / AGPRs (3 waves per SIMD like the engine)
@@ -345,6 +354,7 @@ int main(int argc, char** argv) {
     struct V { const char* name; kern_t k; };
     const V vs[] = {{"base_vgpr", k_base_v}, {"pipe_vgpr", k_pipe_v}, {"pipe_agpr", k_pipe_a}, {"pipe_prio", k_pipe_prio},
                     {"pipe_lds", k_pipe_lds}, {"pipe_lds_prio", k_pipe_lds_prio}, {"pipe_noepi", k_pipe_noepi},
+                    {"pipe_lds_2wg", k_pipe_lds_2wg}, {"pipe_lds_1wg", k_pipe_lds_1wg},
                     {"base_noepi", k_base_noepi}};
     const int nv = sizeof(vs) / sizeof(vs[0]);
     const int64_t Ts[2] = {T, 1000};   // full size (timing) and a ragged small problem (tails)
