@@ -196,19 +196,22 @@ def main():
                 i += 1
         host_iter = iter(DevicePrefetcher(host_batches(), dev, depth=2))
 
+    hgroup = D.host_group()   # gloo group for host-resident control data (None on one rank / when gloo is unavailable)
+
     def step(bf16=(a.precision == "bfloat16")):
         nonlocal data
         if host_iter is not None:
             data = next(host_iter)
         opt.zero_grad(set_to_none=True)
-        # presence labels of the global batch first (tiny collective, issued while the GPU queue is empty)
-        lab_g = D.all_gather_labels(labels[:, 1:], dev)
+        # presence labels of the global batch: host-side exchange started now, waited for after the encoder forward has
+        # been queued (no device work, no device synchronisation)
+        pending = D.all_gather_labels_async(labels[:, 1:], hgroup)
         with torch.autocast(device_type="cuda", dtype=torch.bfloat16, enabled=bf16):   # as trainer.py:101-103
             embs, toks = net(data, device=dev)
-            # one all-gather of the packed slide embeddings -> replicated global InfoNCE; rank-local GOT with
-            # global-batch thresholds (one [S,6] all-gather fwd, one all-reduce bwd); DDP all-reduces the grads.
+            # ONE data-path collective: all-gather of [slide embeddings | presence mask | GOT extrema] -> replicated global
+            # InfoNCE + rank-local GOT with global-batch thresholds ([S,6] all-reduce in backward); DDP all-reduces the grads.
             loss, flag = D.calculate_losses_dp(mods[1:], crit, got_impl, embs, toks, labels[:, 1:], largs,
-                                               labels_global_withoutHE=lab_g, use_local_loss=use_got)
+                                               labels_global_withoutHE=pending.wait(), use_local_loss=use_got)
         loss.backward()
         opt.step()
         return loss
@@ -275,7 +278,10 @@ def main():
                                    f"{'eval (dropout off)' if a.eval_mode else 'train mode (dropout on)'}, AdamW"
                                    f"{', absent-stain zero bags encoded once (N4)' if a.skip_absent else ''}",
                        "global_batch": B * world, "bags_per_sec": round(value * M, 2), "parallelism": f"dp{world}",
-                       "final_loss": final_loss},
+                       "final_loss": final_loss,
+                       "collective_backend": (torch.distributed.get_backend() if world > 1 else "none"),
+                       "ranks_seen": (torch.distributed.get_world_size() if world > 1 else 1),
+                       "host_label_exchange": ("gloo" if hgroup is not None else ("device" if world > 1 else "none"))},
         }
         if "pool_fwd" in prof:
             ms, n = prof["pool_fwd"]

@@ -44,7 +44,13 @@ class BatchedABMIL(nn.Module):
                 % (self.input_dim, self.hidden_dim, self.n_classes))
 
     def dropout_p(self) -> float:
-        return GATE_DROPOUT_P if (self.use_dropout and self.training) else 0.0
+        """Rate of the two nn.Dropout modules of the gate (abmil.py:33-35: 0.25 each) while training, else 0."""
+        if not (self.use_dropout and self.training):
+            return 0.0
+        pa, pb = float(self.attention_a[2].p), float(self.attention_b[2].p)
+        if pa != pb:
+            raise NotImplementedError("madeleine_amd.BatchedABMIL: the gate kernels take one dropout rate for both branches")
+        return pa
 
     def forward(self, x, return_raw_attention=False):
         """x [B, N, 512] -> activated attention [B, N, 1] (and the raw scores when asked)."""

@@ -105,9 +105,11 @@ class ABMILEmbedder(nn.Module):
             lin_bias = lin_bias[perm]
         p, seed, keep = 0.0, 0, None
         if self.training:
-            p = PRE_DROPOUT_P
+            p = float(self.pre_attn[4 * blk + 3].p)   # the nn.Dropout module of this block (0.1 unless the user changed it)
             inj = self._injected_keep
-            if inj is not None:
+            if p == 0.0:
+                pass
+            elif inj is not None:
                 keep = inj["pre"][blk]
                 if perm is not None:
                     keep = keep[..., perm]

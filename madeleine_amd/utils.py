@@ -1,8 +1,29 @@
-"""Host-side glue the training harness needs (mirrors of reference madeleine/utils/utils.py:124-201)."""
+"""Host-side glue the training harness needs (mirrors of reference madeleine/utils/utils.py:27-66 and :124-201)."""
 import random
 
 import numpy as np
 import torch
+
+DEVICE = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+
+
+def run_inference(ssl_model, val_dataloader, config=None, torch_precision=None):
+    """Slide-embedding extraction loop (utils.py:27-66): eval mode, no gradients, one full bag per batch through
+    `ssl_model.encode_he` under the configured precision; returns ({"embeds": [n,512] fp32 array, "slide_ids": [...]},
+    smooth rank of the embeddings).  The dataloader yields (feats [1,N,D], slide_ids) like the reference's SimpleDataset
+    (wsi_dataset.py:102-124).  Forward-only use of the HIP path: nothing is saved for backward."""
+    ssl_model.eval()
+    precision = torch_precision if torch_precision is not None else set_model_precision(config.precision)
+    reduced = precision in (torch.bfloat16, torch.float16)      # for fp32 / fp64 torch disables autocast
+    embeds, slide_ids = [], []
+    with torch.no_grad():
+        for feats, ids in val_dataloader:
+            with torch.amp.autocast(device_type="cuda", dtype=precision, enabled=reduced):
+                wsi_embed = ssl_model.encode_he(feats, device=DEVICE)
+            embeds.extend(wsi_embed.float().cpu().numpy())
+            slide_ids.append(ids[0])
+    embeds = np.array(embeds)
+    return {"embeds": embeds, "slide_ids": slide_ids}, smooth_rank_measure(torch.Tensor(embeds))
 
 
 def set_model_precision(precision):

@@ -344,10 +344,75 @@ def gen_full_step():
     np.savez_compressed(os.path.join(OUT, "full_step.npz"), **out)
 
 
+# ------------------------------------------------------------------ H2: a train_loop trajectory (trainer.py:80-144)
+SGD_LR = 30.0   # gradients are O(1e-4) at this scale: a large rate makes the three steps visible in the losses
+TRAIN_LOOP_LABELS = [[[1, 1, 1], [1, 1, 0], [1, 1, 1], [1, 0, 1]],
+                     [[1, 0, 0], [1, 0, 0], [1, 0, 0], [1, 0, 0]],      # H&E only: the loop must skip this batch
+                     [[1, 1, 1], [1, 1, 1], [1, 0, 1], [1, 1, 1]],
+                     [[1, 1, 0], [1, 1, 1], [1, 1, 1], [1, 1, 1]]]
+
+
+def train_loop_batches(B, M, N, D):
+    return [{"feats": t((B, M, N, D), f"tl:feats{i}"), "modality_labels": torch.tensor(lab, dtype=torch.float32),
+             "slide_ids": [f"s{i}_{j}" for j in range(B)]} for i, lab in enumerate(TRAIN_LOOP_LABELS)]
+
+
+def gen_train_loop():
+    """Three optimiser steps (one of four batches is H&E-only and skipped) of the reference's train_loop in train mode.
+    The trajectory is pinned by making every nn.Dropout the identity (p = 0 on the modules; train mode stays on) and,
+    for the parameter trajectory, by a plain SGD optimiser: AdamW's first steps are sign(g)-like, so an element whose
+    gradient is rounding noise moves by +-lr on either side and no implementation can reproduce it -- with AdamW only
+    the per-step losses are recorded."""
+    B, M, N, D = 4, 3, 40, 64
+    mods = MODS5[:M]
+    args = SimpleNamespace(STAINS=mods[1:], precision="float32", warmup_epochs=1, global_loss="info-nce", symmetric_cl=True,
+                           local_loss_weight=0.5)
+    out = {"shape": np.array([B, M, N, D])}
+    orig_cl = ref_trainer.calculate_losses
+    for opt_name in ("sgd", "adamw"):
+        model, _ = build(mods, D, tag="wtl")
+        for m in model.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        opt = torch.optim.SGD(model.parameters(), lr=SGD_LR) if opt_name == "sgd" else torch.optim.AdamW(model.parameters(), lr=1e-3)
+        warm = torch.optim.lr_scheduler.LinearLR(opt, start_factor=1e-5, total_iters=4)
+        cos = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=10, eta_min=1e-8)
+        step_losses = []
+
+        def logged(*a, **k):
+            loss, flag = orig_cl(*a, **k)
+            if flag:
+                step_losses.append(float(loss))
+            return loss, flag
+        ref_trainer.calculate_losses = logged
+        try:
+            torch.manual_seed(0)
+            ep_loss, rank = ref_trainer.train_loop(args, ref_loss.InfoNCE(temperature=0.1), ref_loss.GOT, None, model, 5,
+                                                   train_loop_batches(B, M, N, D), opt, warm, cos)
+        finally:
+            ref_trainer.calculate_losses = orig_cl
+        assert len(step_losses) == 3 and cos.last_epoch == 3 and warm.last_epoch == 0
+        out[f"{opt_name}/step_losses"] = np.array(step_losses, dtype=np.float64)
+        out[f"{opt_name}/ep_loss"] = np.float64(ep_loss)
+        out[f"{opt_name}/rank"] = np.float64(rank)
+        if opt_name == "sgd":
+            for k, v in model.state_dict().items():
+                out[f"sgd/pnorm/{k}"] = npy(v.norm())
+                out[f"sgd/phead/{k}"] = npy(v.flatten()[:16])
+            ref0 = {k: torch.from_numpy(v) for k, v in recipe.state_dict_recipe({k: tuple(v.shape) for k, v in model.state_dict().items()}, "wtl").items()}
+            for k, v in model.state_dict().items():
+                out[f"sgd/dnorm/{k}"] = npy((v - ref0[k]).norm())        # how far the three steps moved the tensor
+                out[f"sgd/dhead/{k}"] = npy((v - ref0[k]).flatten()[:16])
+    np.savez_compressed(os.path.join(OUT, "train_loop.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    only = sys.argv[1:]
     for fn in (gen_encoder, gen_stain_encoding, gen_train_dropout, gen_infonce, gen_got,
-               gen_calculate_losses, gen_full_step):
+               gen_calculate_losses, gen_full_step, gen_train_loop):
+        if only and fn.__name__ not in only:
+            continue
         fn()
         print("ok", fn.__name__)
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))

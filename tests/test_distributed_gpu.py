@@ -1,0 +1,115 @@
+"""Two-rank data-parallel step on the GPU with the real HIP kernels ("make the multi-GPU path provably
+ready"): encoder + calculate_losses_dp (one packed all-gather: slide embeddings | presence mask | GOT extrema; [S,6]
+all-reduce in backward) + the gradient mean DDP performs, against the single-process global-batch HIP result -- the
+semantics nn.DataParallel gives the reference (setup_components.py:185-187).
+
+  backend "nccl" : RCCL over xGMI, one rank per GPU -- needs >= 2 GPUs (skipped on a 1-GPU box);
+  backend "gloo" : both ranks share cuda:0 and the collectives are host-staged (distributed._host_staged) -- the same
+                   host logic, packing, autograd nodes and kernels, runnable on one GPU.
+Tolerance: the two sides run the same kernels on different batch partitions, so sums are re-associated: 1e-4 relative on the
+loss and on every parameter gradient (GOT's fixed point amplifies summation-order noise, cf. tests/test_distributed_cpu.py
+where the fp64 oracle pins the decomposition itself to 1e-9)."""
+import os
+import socket
+from types import SimpleNamespace
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests._util import MODS5, t
+
+pytestmark = pytest.mark.gpu
+
+B, M, N, D = 8, 4, 300, 64
+LABELS = torch.tensor([[1, 1, 1, 0], [1, 1, 0, 1], [1, 0, 1, 1], [1, 1, 1, 1],
+                       [1, 1, 1, 0], [1, 0, 1, 1], [1, 1, 1, 1], [1, 0, 0, 1]], dtype=torch.float32)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _build_model(dev):
+    from tests.test_model_gpu import build
+    return build(MODS5[:M], D, "wdp", dev).eval()   # eval: dropout off, gradients still flow (parity mode)
+
+
+def _step(model, feats, labels_local, dev, use_got, labels_global=None):
+    from madeleine_amd import InfoNCE
+    from madeleine_amd import distributed as DP
+    from madeleine_amd import functional as MF
+    mods = MODS5[:M]
+    args = SimpleNamespace(global_loss="info-nce", symmetric_cl=True, local_loss_weight=0.7)
+    embs, toks = model({"feats": feats}, device=dev, train=True)
+    loss, flag = DP.calculate_losses_dp(mods[1:], InfoNCE(temperature=0.01), MF.HipGotImpl if use_got else None, embs, toks,
+                                        labels_local[:, 1:], args, labels_global_withoutHE=labels_global, use_local_loss=use_got)
+    model.zero_grad()
+    loss.backward()
+    return loss.detach(), flag
+
+
+def _single(dev, use_got):
+    model = _build_model(dev)
+    loss, flag = _step(model, t((B, M, N, D), "dpg:feats"), LABELS, dev, use_got)
+    assert flag
+    return float(loss), {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters() if p.grad is not None}
+
+
+def _worker(rank, world, port, backend, use_got, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = torch.device("cuda", rank if backend == "nccl" else 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    try:
+        from madeleine_amd import distributed as DP
+        model = _build_model(dev)
+        Bl = B // world
+        sl = slice(rank * Bl, (rank + 1) * Bl)
+        pending = DP.all_gather_labels_async(LABELS[sl, 1:])          # host-side label exchange (gloo group)
+        loss, flag = _step(model, t((B, M, N, D), "dpg:feats")[sl], LABELS[sl], dev, use_got, labels_global=None)
+        lab_g = pending.wait()
+        assert torch.equal(lab_g, LABELS[:, 1:])
+        grads = {}
+        for k, p in model.named_parameters():                          # what DDP does: mean over ranks
+            if p.grad is None:
+                continue
+            g = p.grad.detach().clone()
+            g = DP._all_reduce_sum(g) / world
+            grads[k] = g.cpu()
+        # loss value of the global batch: replicated global part + sum over ranks of the local parts (undo the W scaling)
+        loss_nogot, _ = _step(model, t((B, M, N, D), "dpg:feats")[sl], LABELS[sl], dev, False, labels_global=lab_g)
+        local = ((loss - loss_nogot) / world).reshape(1).clone()
+        local = DP._all_reduce_sum(local)
+        if rank == 0:
+            ret["loss"] = float(loss_nogot + local[0])
+            ret["grads"] = {k: v.numpy() for k, v in grads.items()}
+            ret["flag"] = bool(flag)
+            ret["backend"] = dist.get_backend()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("use_got", [False, True])
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_two_ranks_equal_global_batch(backend, use_got):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("RCCL needs one GPU per rank (this box has %d)" % torch.cuda.device_count())
+    ref_loss, ref_grads = _single(torch.device("cuda:0"), use_got)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), backend, use_got, ret), nprocs=2, join=True)
+    assert ret["flag"] and ret["backend"] == backend
+    assert abs(ret["loss"] - ref_loss) < 1e-4 * abs(ref_loss), (ret["loss"], ref_loss)
+    top = max(float(g.norm()) for g in ref_grads.values())
+    assert set(ret["grads"]) == set(ref_grads)
+    for k, g in ref_grads.items():
+        got = torch.from_numpy(ret["grads"][k])
+        err = float((got - g).norm())
+        assert err <= 1e-4 * float(g.norm()) + 1e-6 * top, (k, err, float(g.norm()))

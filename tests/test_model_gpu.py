@@ -395,3 +395,93 @@ def test_skip_absent_stains_matches_full_encode(dev, stain_encoding):
     assert abs(res[True][2] - res[False][2]) < 1e-5 * abs(res[False][2])
     for k, g in res[False][3].items():
         assert rel_err(res[True][3][k], g) < 1e-4 or float(g.norm()) < 1e-6, k
+
+
+def test_inference_full_bag_vs_oracle_and_run_inference(dev):
+    """N3: forward-only extraction path.  encode_he on ONE full bag of 30,000 patches (batch 1, as
+    utils.py:52-56 feeds it) against the oracle, and the run_inference mirror (utils.py:27-66) over a SimpleDataset-style
+    loader: eval mode, no gradients, embeddings fp32 on the host, slide ids, smooth rank."""
+    import madeleine_amd.utils as U
+    from madeleine_amd import run_inference
+    U.DEVICE = dev
+    mods = MODS5[:2]
+    N, D = 30000, 512
+    model = build(mods, D, "w", dev).train()                      # run_inference must switch to eval itself
+    bag = t((1, N, D), "inf:bag")
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        out = R.abmil_embed(bag, sd)
+        ref = torch.nn.functional.linear(out["slide"].reshape(1, -1), sd["projector.weight"], sd["projector.bias"])
+    loader = [(bag, ["slide_a"]), (t((1, 777, D), "inf:bag2"), ["slide_b"]), (t((1, 4096, D), "inf:bag3"), ["slide_c"])]
+    res, rank = run_inference(model, loader, config=SimpleNamespace(precision="float32"))
+    assert not model.training
+    assert res["slide_ids"] == ["slide_a", "slide_b", "slide_c"]
+    assert res["embeds"].shape == (3, 512) and res["embeds"].dtype == np.float32
+    assert rel_err(res["embeds"][0], ref[0]) < TOL and max_rel(res["embeds"][0], ref[0]) < 5 * TOL
+    assert rank > 0
+    with torch.no_grad():
+        direct = model.encode_he(bag, dev)
+    assert torch.equal(direct.cpu()[0], torch.from_numpy(res["embeds"][0]))
+    # the reference's bf16 extraction (extract_slide_embeddings.py:49 passes torch_precision): same loop under autocast
+    res16, _ = run_inference(model, loader[1:], torch_precision=torch.bfloat16)
+    assert rel_err(res16["embeds"], res["embeds"][1:]) < 3e-2
+
+
+def test_train_loop_trajectory_golden(dev, capsys):
+    """H2 pinned: three optimiser steps of train_loop (trainer.py:80-144) -- four batches, the H&E-only one skipped, cosine
+    branch of the scheduler switch, InfoNCE + local GOT -- against the trajectory captured from the imported reference
+    (oracle/gen_golden.py:gen_train_loop): per-step losses, epoch loss, smooth rank, and with SGD how far every parameter
+    tensor moved.  Train mode with every nn.Dropout set to p = 0 on both sides (the only way to pin the RNG-free path)."""
+    import madeleine_amd.trainer as TR
+    from madeleine_amd import GOT, InfoNCE, train_loop
+    from oracle.recipe import state_dict_recipe
+    g = golden("train_loop")
+    TR.DEVICE = dev
+    B, M, N, D = (int(x) for x in g["shape"])
+    mods = MODS5[:M]
+    labels = [[[1, 1, 1], [1, 1, 0], [1, 1, 1], [1, 0, 1]], [[1, 0, 0]] * 4,
+              [[1, 1, 1], [1, 1, 1], [1, 0, 1], [1, 1, 1]], [[1, 1, 0], [1, 1, 1], [1, 1, 1], [1, 1, 1]]]
+    args = SimpleNamespace(STAINS=mods[1:], precision="float32", warmup_epochs=1, global_loss="info-nce", symmetric_cl=True,
+                           local_loss_weight=0.5)
+    orig_cl = TR.calculate_losses
+    for opt_name in ("sgd", "adamw"):
+        model = build(mods, D, "wtl", dev)
+        for m in model.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        batches = [{"feats": t((B, M, N, D), f"tl:feats{i}"), "modality_labels": torch.tensor(lab, dtype=torch.float32),
+                    "slide_ids": [f"s{i}_{j}" for j in range(B)]} for i, lab in enumerate(labels)]
+        opt = torch.optim.SGD(model.parameters(), lr=30.0) if opt_name == "sgd" else torch.optim.AdamW(model.parameters(), lr=1e-3)
+        warm = torch.optim.lr_scheduler.LinearLR(opt, start_factor=1e-5, total_iters=4)
+        cos = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=10, eta_min=1e-8)
+        step_losses = []
+
+        def logged(*a, **k):
+            loss, flag = orig_cl(*a, **k)
+            if flag:
+                step_losses.append(float(loss.detach()))
+            return loss, flag
+        TR.calculate_losses = logged
+        try:
+            torch.manual_seed(0)
+            ep_loss, rank = train_loop(args, InfoNCE(temperature=0.1), GOT, None, model, 5, batches, opt, warm, cos)
+        finally:
+            TR.calculate_losses = orig_cl
+        assert "Skipping batch with only HE" in capsys.readouterr().out
+        assert model.training and cos.last_epoch == 3 and warm.last_epoch == 0
+        ref = g[f"{opt_name}/step_losses"]
+        assert len(step_losses) == 3
+        for a, b in zip(step_losses, ref):
+            assert abs(a - b) < 2e-5 * abs(b), (opt_name, step_losses, ref)       # parameter updates show at 4e-4
+        assert abs(ep_loss - float(g[f"{opt_name}/ep_loss"])) < 2e-5 * float(g[f"{opt_name}/ep_loss"])
+        assert abs(rank - float(g[f"{opt_name}/rank"])) <= 0.011                   # rounded to 2 decimals
+        if opt_name == "sgd":
+            shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+            start = {k: torch.from_numpy(v) for k, v in state_dict_recipe(shapes, "wtl").items()}
+            top = max(float(g[f"sgd/dnorm/{k}"]) for k in shapes)
+            for k, v in model.state_dict().items():
+                d = v.detach().cpu() - start[k]
+                ref_n = float(g[f"sgd/dnorm/{k}"])
+                assert abs(float(d.norm()) - ref_n) <= 1e-3 * ref_n + 1e-5 * top, k
+                head = torch.from_numpy(g[f"sgd/dhead/{k}"])
+                assert float((d.flatten()[:16] - head).norm()) <= 2e-3 * float(head.norm()) + 1e-5 * top, k
