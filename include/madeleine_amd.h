@@ -54,7 +54,7 @@ const char* mdl_version(void);
 /* ABI revision of this header: bumped whenever an entry point's argument list changes.  A binding compares
  * mdl_abi_version() with the MDL_ABI_VERSION it was written against BEFORE calling anything else, so that a stale
  * shared object fails loudly instead of being called with shifted arguments. */
-#define MDL_ABI_VERSION 2
+#define MDL_ABI_VERSION 3
 int mdl_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -177,19 +177,24 @@ int mdl_infonce_bwd(const float* d_loss, const int32_t* cnt, float* dQ, float* d
                     float temperature, int symmetric, void* ws, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * N1 -- the Linear layers of the pre-attention MLP (madeleine/models/Model.py:351, :355, :359)
- * as exact-fp32 contractions on the matrix cores, bias-free (the bias and its gradient are handled by
- * mdl_ln_gelu_drop_*).  X [T,K] (row stride ldx), W [N,K] contiguous (torch's Linear.weight), Y [T,N] (row stride ldy).
- * Supported: N % 256 == 0, K % 32 == 0 (returns MDL_E_UNSUPPORTED otherwise; the host wrapper then uses the library GEMM).
- *   mdl_linear_fwd : Y = X W^T
- *   mdl_linear_bwd : dW [N,K] = dY^T X  (always);  dX [T,K] = dY W  when dX != NULL (needs K % 256 == 0)
+ * N1 -- every Linear of the encoder as an exact-fp32 contraction in hand-written kernels: the three
+ * Linears of the pre-attention MLP (madeleine/models/Model.py:351, :355, :359; bias = NULL there: the bias and its gradient
+ * are handled by mdl_ln_gelu_drop_*), the token_projector Linear(2048, 128) (Model.py:140) and the slide projector
+ * Linear(2048, 512) on the pooled embeddings (Model.py:145).
+ * X [T,K] (row stride ldx), W [N,K] contiguous (torch's Linear.weight), bias [N] or NULL, Y [T,N] (row stride ldy).
+ * Supported (MDL_E_UNSUPPORTED otherwise):
+ *   T > 256 : K % 32 == 0 and N % 128 == 0 -- matrix-core tile engine (128 x 256 tile for N % 256 == 0, the 256 x 128 "tall"
+ *             geometry otherwise); the backward additionally needs K % 256 == 0 when dX != NULL or N % 256 != 0;
+ *   T <= 256: any K, N % 4 == 0 -- LDS-tiled fp32 FMA kernel (the slide projector's 64 rows).
+ *   mdl_linear_fwd : Y = X W^T (+ bias)
+ *   mdl_linear_bwd : dW [N,K] = dY^T X  (always);  dX [T,K] = dY W  when dX != NULL;  dbias [N] = column sums of dY when != NULL
  */
 int64_t mdl_linear_fwd_ws_bytes(int64_t T, int N, int K);
-int mdl_linear_fwd(const float* X, int64_t ldx, const float* W, float* Y, int64_t ldy, int64_t T, int N, int K, void* ws,
-                   void* stream);
+int mdl_linear_fwd(const float* X, int64_t ldx, const float* W, const float* bias, float* Y, int64_t ldy, int64_t T, int N, int K,
+                   void* ws, void* stream);
 int64_t mdl_linear_bwd_ws_bytes(int64_t T, int N, int K);
 int mdl_linear_bwd(const float* X, int64_t ldx, const float* W, const float* dY, int64_t ldy, float* dX, int64_t lddx,
-                   float* dW, int64_t T, int N, int K, void* ws, void* stream);
+                   float* dW, float* dbias, int64_t T, int N, int K, void* ws, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * G0-G3 -- Graph Optimal Transport.  Replaces GOT (madeleine/utils/loss.py:278-302) =

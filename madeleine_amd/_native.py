@@ -13,7 +13,7 @@ from . import _build
 
 _LOCK = threading.Lock()
 _LIB = None
-ABI_VERSION = 2   # == MDL_ABI_VERSION of include/madeleine_amd.h this file's SIGNATURES were written against
+ABI_VERSION = 3   # == MDL_ABI_VERSION of include/madeleine_amd.h this file's SIGNATURES were written against
 
 c_f = ctypes.c_void_p  # float* (device)
 c_p = ctypes.c_void_p
@@ -41,9 +41,9 @@ SIGNATURES = {
     "mdl_ln_gelu_drop_bwd_ws_bytes": (i64, [i64, i32]),
     "mdl_ln_gelu_drop_bwd": (i32, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i64, i32, f32, u64, c_p, c_p, c_p]),
     "mdl_linear_fwd_ws_bytes": (i64, [i64, i32, i32]),
-    "mdl_linear_fwd": (i32, [c_f, i64, c_f, c_f, i64, i64, i32, i32, c_p, c_p]),
+    "mdl_linear_fwd": (i32, [c_f, i64, c_f, c_f, c_f, i64, i64, i32, i32, c_p, c_p]),
     "mdl_linear_bwd_ws_bytes": (i64, [i64, i32, i32]),
-    "mdl_linear_bwd": (i32, [c_f, i64, c_f, c_f, i64, c_f, i64, c_f, i64, i32, i32, c_p, c_p]),
+    "mdl_linear_bwd": (i32, [c_f, i64, c_f, c_f, i64, c_f, i64, c_f, c_f, i64, i32, i32, c_p, c_p]),
     "mdl_infonce_ws_bytes": (i64, [i32, i32, i32]),
     "mdl_infonce_fwd": (i32, [c_f, c_f, c_p, c_f, i32, i32, i32, f32, i32, c_p, c_p]),
     "mdl_infonce_bwd": (i32, [c_f, c_p, c_f, c_f, i32, i32, i32, f32, i32, c_p, c_p]),

@@ -88,9 +88,11 @@ __device__ __forceinline__ void krows_issue2(const char* row_base, int64_t row_s
 // this wave's two LDS-DMA instructions of piece 0..2 for K-chunk `chunk` into stage `stage` (piece 0: the A rows;
 // pieces 1, 2: B rows 4w+0..1 / 4w+2..3 by convention).  On return every DMA has landed and all waves have passed a barrier
 // after their last fragment read: the staging memory is free.
-template <class Dma>
-__device__ __forceinline__ void tile_loop_nn(f32x16 (&acc)[2][4], TileSmem& sm, int nch, int wm, const int (&colb)[4], int lane,
-                                             Dma&& dma) {
+// Generic form: the A stages start at Ab (a_stage floats apart, rows of 16 k), the B stages at Bb (rows of NB floats); the
+// "tall" geometry (256 rows x 128 columns per workgroup, the 4 waves stacked in M: wm = wave) uses a_stage = 4096, NB = 128.
+template <int NB, class Dma>
+__device__ __forceinline__ void tile_loop_nn_g(f32x16 (&acc)[2][4], float* Ab, int a_stage, float* Bb, int nch, int wm,
+                                               const int (&colb)[4], int lane, Dma&& dma) {
     const int l32 = lane & 31, kh = lane >> 5;
     int offA[2];
 #pragma unroll
@@ -102,12 +104,12 @@ __device__ __forceinline__ void tile_loop_nn(f32x16 (&acc)[2][4], TileSmem& sm, 
     float fb0[4], fb1[4];   // B fragments of even / odd steps
     auto ldA = [&](f32x4 (&fa)[2], int st, int g) {
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt) fa[rt] = *reinterpret_cast<const f32x4*>(&sm.A[st][offA[rt] ^ (g << 3)]);
+        for (int rt = 0; rt < 2; ++rt) fa[rt] = *reinterpret_cast<const f32x4*>(&Ab[st * a_stage + (offA[rt] ^ (g << 3))]);
     };
     auto ldB = [&](float (&fb)[4], int st, int s) {   // step s = 4 g + e
         const int g = s >> 2, e = s & 3;
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) fb[ct] = sm.B[st][8 * g + 4 * kh + e][colb[ct] + l32];
+        for (int ct = 0; ct < 4; ++ct) fb[ct] = Bb[(st * TBK + 8 * g + 4 * kh + e) * NB + colb[ct] + l32];
     };
     auto mma1 = [&](const f32x4 (&fa)[2], int e, const float (&fb)[4], int m) {
         const int rt = m & 1, ct = m >> 1;
@@ -168,6 +170,12 @@ __device__ __forceinline__ void tile_loop_nn(f32x16 (&acc)[2][4], TileSmem& sm, 
     }
     TILE_DMA_WAIT();   // the redundant tail fetches
     __syncthreads();   // every wave is done with the staging buffers
+}
+
+template <class Dma>
+__device__ __forceinline__ void tile_loop_nn(f32x16 (&acc)[2][4], TileSmem& sm, int nch, int wm, const int (&colb)[4], int lane,
+                                             Dma&& dma) {
+    tile_loop_nn_g<TBN>(acc, &sm.A[0][0], TBM * TBK, &sm.B[0][0][0], nch, wm, colb, lane, static_cast<Dma&&>(dma));
 }
 
 // ---- TN main loop -------------------------------------------------------------------------------------------------

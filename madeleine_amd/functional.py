@@ -374,21 +374,25 @@ def ln_gelu_drop(x, gamma, beta, eps=1e-5, p_drop=0.0, seed=0, keep=None, bias=N
 # N1: bias-free Linear of the pre-attention MLP on the fp32 matrix cores
 # --------------------------------------------------------------------------------------------------
 class LinearFn(torch.autograd.Function):
-    """Y = X W^T (Model.py:351, :355, :359 without the bias, which ln_gelu_drop adds); X [T,K], W [N,K]."""
+    """Y = X W^T (+ bias) (Model.py:351, :355, :359 without the bias, which ln_gelu_drop adds; Model.py:140 token_projector and
+    Model.py:145 projector with their bias); X [T,K], W [N,K]."""
 
     @staticmethod
-    def forward(ctx, x, W):
+    def forward(ctx, x, W, bias):
         _require(x, "x")
         _require(W, "weight")
+        if bias is not None:
+            _require(bias, "bias")
         lib = _native.lib()
         T, K = x.shape
         N = W.shape[0]
         y = torch.empty(T, N, device=x.device, dtype=torch.float32)
         ws = _ws(lib.mdl_linear_fwd_ws_bytes(T, N, K), x.device)
         with _timed("linear_fwd"):
-            rc = lib.mdl_linear_fwd(_ptr(x), x.stride(0), _ptr(W), _ptr(y), N, T, N, K, _ptr(ws), _stream())
+            rc = lib.mdl_linear_fwd(_ptr(x), x.stride(0), _ptr(W), _ptr(bias), _ptr(y), N, T, N, K, _ptr(ws), _stream())
         _native.check(rc, "mdl_linear_fwd")
         ctx.save_for_backward(x, W)
+        ctx.has_bias = bias is not None
         return y
 
     @staticmethod
@@ -400,27 +404,33 @@ class LinearFn(torch.autograd.Function):
         dy = dy.float().contiguous()
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dW = torch.empty_like(W)
+        db = torch.empty(N, device=x.device, dtype=torch.float32) if ctx.has_bias else None
         ws = _ws(lib.mdl_linear_bwd_ws_bytes(T, N, K), x.device)
         with _timed("linear_bwd"):
-            rc = lib.mdl_linear_bwd(_ptr(x), x.stride(0), _ptr(W), _ptr(dy), N, _ptr(dx), K, _ptr(dW), T, N, K, _ptr(ws),
+            rc = lib.mdl_linear_bwd(_ptr(x), x.stride(0), _ptr(W), _ptr(dy), N, _ptr(dx), K, _ptr(dW), _ptr(db), T, N, K, _ptr(ws),
                                     _stream())
         _native.check(rc, "mdl_linear_bwd")
-        return dx, dW
+        return dx, dW, db
 
 
 def linear_supported(x, W) -> bool:
-    """Geometries of mdl_linear_*: N % 256 == 0, K % 32 == 0, and K % 256 == 0 when the input needs a gradient."""
+    """Geometries of mdl_linear_* (include/madeleine_amd.h): at most 256 rows -> any K, N % 4 == 0; otherwise N % 128 == 0,
+    K % 32 == 0, and K % 256 == 0 when the input needs a gradient or N is not a multiple of 256."""
     N, K = W.shape
-    return (x.dtype == torch.float32 and W.dtype == torch.float32 and N % 256 == 0 and K % 32 == 0 and
-            (K % 256 == 0 or not x.requires_grad))
+    if x.dtype != torch.float32 or W.dtype != torch.float32:
+        return False
+    T = x.numel() // max(1, x.shape[-1])
+    if T <= 256:
+        return N % 4 == 0
+    return N % 128 == 0 and K % 32 == 0 and (K % 256 == 0 or not (x.requires_grad or N % 256))
 
 
-def linear(x, W):
-    """Bias-free Linear over the last axis through the HIP kernels; other geometries / dtypes use the library GEMM."""
+def linear(x, W, bias=None):
+    """Linear over the last axis through the HIP kernels; other geometries / dtypes use the library GEMM."""
     if not linear_supported(x, W):
-        return torch.nn.functional.linear(x, W)
+        return torch.nn.functional.linear(x, W, bias)
     lead = x.shape[:-1]
-    y = LinearFn.apply(x.reshape(-1, x.shape[-1]).contiguous(), W.contiguous())
+    y = LinearFn.apply(x.reshape(-1, x.shape[-1]).contiguous(), W.contiguous(), None if bias is None else bias.contiguous())
     return y.view(*lead, W.shape[0])
 
 

@@ -5,8 +5,9 @@ Same constructor / forward / encode_he contracts, same sub-module names and ther
 state_dict keys and shapes (reference and HuggingFace checkpoints load unchanged, with or without a
 `module.` prefix).  What differs is where the work happens:
 
-  * pre_attn (3 x Linear+LayerNorm+GELU+Dropout) and the two projector Linears stay torch ops on
-    hipBLASLt (host plumbing; SURVEY.md section 8(f) row N1 tracks fusing them);
+  * pre_attn (3 x Linear + fused LayerNorm-GELU-Dropout), token_projector and projector run in the hand-written
+    fp32 matrix-core Linear kernels (functional.linear / ln_gelu_drop) -- in the bf16
+    mode (torch.autocast(bfloat16)) the Linears are bf16 library GEMMs as under autocast;
   * gated attention scores + softmax-over-patches + weighted pooling, forward and backward, are the
     hand-written HIP kernels behind madeleine_amd.functional.attn_pool.
 
@@ -256,11 +257,17 @@ class MADELEINE(nn.Module):
 
     # ------------------------------------------------------------------ helpers
     def _project_slide(self, pooled_hm):
+        """projector Linear(2048, 512) (Model.py:145) on the head-major pooled embeddings (columns permuted to match)."""
         perm = self.wsi_embedders._perm
+        if pooled_hm.dtype == torch.float32 and not bf16_mode():
+            return MF.linear(pooled_hm, self.projector.weight[:, perm], self.projector.bias)
         return F.linear(pooled_hm, self.projector.weight[:, perm], self.projector.bias)
 
     def _project_tokens(self, E_hm):
+        """token_projector Linear(2048, 128) (Model.py:140) on the head-major token embeddings."""
         perm = self.wsi_embedders._perm
+        if E_hm.dtype == torch.float32 and not bf16_mode():
+            return MF.linear(E_hm, self.token_projector.weight[:, perm], self.token_projector.bias)
         return F.linear(E_hm, self.token_projector.weight[:, perm], self.token_projector.bias)
 
     def _cat_stain(self, feats, idx):

@@ -478,9 +478,32 @@ def test_linear_vs_torch(dev, T, N, K, need_dx):
         assert rel_err(xd.grad, x64.grad) < 1e-6
 
 
+@pytest.mark.parametrize("T,N,K,need_dx", [(1000, 128, 2048, True), (300, 384, 256, True), (64, 512, 2048, True), (192, 512, 2048, True),
+                                           (7, 12, 100, True), (700, 128, 512, False)])
+def test_linear_bias_tall_and_small_paths(dev, T, N, K, need_dx):
+    """token_projector-like (N = 128 (mod 256): tall 256 x 128 tile, role-swapped dW), projector-like (T <= 256 rows: fp32 FMA
+    kernel) and the bias / dbias path, against torch in fp64."""
+    from madeleine_amd import functional as MF
+    x = t((T, K), f"linb:x{T}{K}")
+    W = 0.05 * t((N, K), f"linb:w{N}{K}")
+    b = 0.3 * t((N,), f"linb:b{N}")
+    dy = t((T, N), f"linb:dy{T}{N}")
+    x64, W64, b64 = x.double().requires_grad_(), W.double().requires_grad_(), b.double().requires_grad_()
+    (x64 @ W64.t() + b64).backward(dy.double())
+    xd = x.to(dev).requires_grad_(need_dx)
+    Wd, bd = W.to(dev).requires_grad_(), b.to(dev).requires_grad_()
+    assert MF.linear_supported(xd, Wd)
+    y = MF.linear(xd, Wd, bd)
+    y.backward(dy.to(dev))
+    assert rel_err(y, (x64 @ W64.t() + b64).detach()) < 1e-6
+    assert rel_err(Wd.grad, W64.grad) < 1e-6 and rel_err(bd.grad, b64.grad) < 1e-6
+    if need_dx:
+        assert rel_err(xd.grad, x64.grad) < 1e-6
+
+
 def test_linear_unsupported_geometry_uses_library(dev):
     from madeleine_amd import functional as MF
-    x, W = t((10, 100), "lin:ux").to(dev), t((128, 100), "lin:uw").to(dev)
+    x, W = t((300, 100), "lin:ux").to(dev), t((130, 100), "lin:uw").to(dev)
     assert not MF.linear_supported(x, W)
     assert rel_err(MF.linear(x, W), x @ W.t()) < 1e-6
 
