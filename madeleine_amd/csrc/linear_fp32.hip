@@ -237,21 +237,27 @@ __global__ __launch_bounds__(256) void lin_colsum_final_kernel(const float* __re
 }
 
 // Small-M products (M <= 256 rows): C[m, n] = sum_k A[m sam + k sak] B[n sbn + k sbk] (+ bias[n]), 64 x 64 tile, 16-deep
-// chunks through LDS, 4 x 4 outputs per thread, plain fp32 FMAs in k order.
+// chunks through LDS, 4 x 4 outputs per thread, plain fp32 FMAs.  The K range is split over blockIdx.z (the projector's
+// 64 x 512 x 2048 product would otherwise be 8 workgroups of 128 dependent global->LDS round trips); partials go to
+// part[z][M][N] and lin_small_reduce_kernel adds them in z order (deterministic) together with the bias.
 __global__ __launch_bounds__(256) void lin_small_kernel(const float* __restrict__ A, int64_t sam, int64_t sak,
                                                         const float* __restrict__ B, int64_t sbn, int64_t sbk,
-                                                        float* __restrict__ C, int64_t ldc, int M, int N, int K,
-                                                        const float* __restrict__ bias) {
+                                                        float* __restrict__ part, int M, int N, int K, int k_per_split) {
     __shared__ float As[16][65], Bs[16][65];
     const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64, tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int kb = blockIdx.z * k_per_split;
+    int ke = kb + k_per_split;
+    if (ke > K) ke = K;
     float acc[4][4] = {};
-    for (int k0 = 0; k0 < K; k0 += 16) {
+    for (int k0 = kb; k0 < ke; k0 += 16) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int e = tid + i * 256, r = e >> 4, kk = e & 15;   // r: row of the tile, kk: k within the chunk
-            const bool kin = k0 + kk < K;
-            As[kk][r] = (kin && m0 + r < M) ? A[(int64_t)(m0 + r) * sam + (int64_t)(k0 + kk) * sak] : 0.f;
-            Bs[kk][r] = (kin && n0 + r < N) ? B[(int64_t)(n0 + r) * sbn + (int64_t)(k0 + kk) * sbk] : 0.f;
+            const int e = tid + i * 256;
+            // consecutive threads walk the unit-stride axis of each operand (coalesced either way)
+            const int ra = (sak == 1) ? (e >> 4) : (e & 63), ka = (sak == 1) ? (e & 15) : (e >> 6);
+            const int rb = (sbk == 1) ? (e >> 4) : (e & 63), kq = (sbk == 1) ? (e & 15) : (e >> 6);
+            As[ka][ra] = (k0 + ka < ke && m0 + ra < M) ? A[(int64_t)(m0 + ra) * sam + (int64_t)(k0 + ka) * sak] : 0.f;
+            Bs[kq][rb] = (k0 + kq < ke && n0 + rb < N) ? B[(int64_t)(n0 + rb) * sbn + (int64_t)(k0 + kq) * sbk] : 0.f;
         }
         __syncthreads();
 #pragma unroll
@@ -269,6 +275,7 @@ __global__ __launch_bounds__(256) void lin_small_kernel(const float* __restrict_
         }
         __syncthreads();
     }
+    float* __restrict__ out = part + (int64_t)blockIdx.z * M * N;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + ty * 4 + i;
@@ -276,10 +283,24 @@ __global__ __launch_bounds__(256) void lin_small_kernel(const float* __restrict_
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = n0 + tx * 4 + j;
-            if (n < N) C[(int64_t)m * ldc + n] = acc[i][j] + (bias ? bias[n] : 0.f);
+            if (n < N) out[(int64_t)m * N + n] = acc[i][j];
         }
     }
 }
+__global__ __launch_bounds__(256) void lin_small_reduce_kernel(const float* __restrict__ part, int SK, float* __restrict__ C,
+                                                               int64_t ldc, int M, int N, const float* __restrict__ bias) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)M * N) return;
+    const int m = (int)(i / N), n = (int)(i % N);
+    float v = bias ? bias[n] : 0.f;
+    for (int z = 0; z < SK; ++z) v += part[(int64_t)z * M * N + i];
+    C[(int64_t)m * ldc + n] = v;
+}
+static inline int lin_small_splits(int K) {
+    int sk = K / 128;
+    return sk < 1 ? 1 : (sk > 16 ? 16 : sk);
+}
+static inline int64_t lin_small_ws(int M, int N, int K) { return (int64_t)lin_small_splits(K) * M * N * 4; }
 
 constexpr int LIN_SMALL_T = 256;   // at most this many rows: lin_small_kernel
 constexpr int LIN_COLSUM_BLOCKS = 512;
@@ -307,10 +328,15 @@ static inline int lin_splits_any(int64_t T, int N, int K) {
 }
 
 static int lin_small_launch(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbn, int64_t sbk, float* C, int64_t ldc,
-                            int M, int N, int K, const float* bias, hipStream_t s) {
+                            int M, int N, int K, const float* bias, float* part, hipStream_t s) {
     if (M <= 0 || N <= 0) return MDL_OK;
-    hipLaunchKernelGGL(lin_small_kernel, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, s, A, sam, sak, B, sbn, sbk, C, ldc, M, N, K,
-                       bias);
+    const int SK = lin_small_splits(K);
+    const int kps = ((K + SK - 1) / SK + 15) / 16 * 16;
+    hipLaunchKernelGGL(lin_small_kernel, dim3((N + 63) / 64, (M + 63) / 64, SK), dim3(256), 0, s, A, sam, sak, B, sbn, sbk, part, M, N, K,
+                       kps);
+    MDL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(lin_small_reduce_kernel, dim3((unsigned)(((int64_t)M * N + 255) / 256)), dim3(256), 0, s, (const float*)part, SK, C,
+                       ldc, M, N, bias);
     MDL_LAUNCH_CHECK();
     return MDL_OK;
 }
@@ -318,6 +344,7 @@ static int lin_small_launch(const float* A, int64_t sam, int64_t sak, const floa
 extern "C" int64_t mdl_linear_fwd_ws_bytes(int64_t T, int N, int K) {
     const int rc = lin_check(T, N, K);
     if (rc) return rc;
+    if (T <= LIN_SMALL_T) return lin_small_ws((int)T, N, K) + 64;   // split-K partials
     return (int64_t)N * K * 4 + 64;  // W^T [K][N]
 }
 
@@ -330,7 +357,7 @@ extern "C" int mdl_linear_fwd(const float* X, int64_t ldx, const float* W, const
         return MDL_E_ALIGN;
     if (T == 0) return MDL_OK;
     hipStream_t s = (hipStream_t)stream;
-    if (T <= LIN_SMALL_T) return lin_small_launch(X, ldx, 1, W, K, 1, Y, ldy, (int)T, N, K, bias, s);
+    if (T <= LIN_SMALL_T) return lin_small_launch(X, ldx, 1, W, K, 1, Y, ldy, (int)T, N, K, bias, (float*)ws, s);
     float* WT = (float*)ws;
     hipLaunchKernelGGL(lin_transpose_kernel, dim3(K / 32, N / 32), dim3(256), 0, s, W, N, K, WT);
     MDL_LAUNCH_CHECK();
@@ -352,7 +379,10 @@ extern "C" int mdl_linear_fwd(const float* X, int64_t ldx, const float* W, const
 extern "C" int64_t mdl_linear_bwd_ws_bytes(int64_t T, int N, int K) {
     const int rc = lin_check(T, N, K);
     if (rc) return rc;
-    if (T <= LIN_SMALL_T) return 64;
+    if (T <= LIN_SMALL_T) {   // split-K partials of dX (T x K, contraction N) and dW (N x K, contraction T), used one after the other
+        const int64_t a = lin_small_ws((int)T, K, N), b = lin_small_ws(N, K, (int)T);
+        return (a > b ? a : b) + 64;
+    }
     const int S = lin_splits_any(T, N, K);
     // slabs | zero row | column-sum partials
     return up16b((int64_t)S * K * N * 4) + up16b((int64_t)(N > K ? N : K) * 4 + 1024) + up16b((int64_t)LIN_COLSUM_BLOCKS * N * 4) + 64;
@@ -371,9 +401,9 @@ extern "C" int mdl_linear_bwd(const float* X, int64_t ldx, const float* W, const
     hipStream_t s = (hipStream_t)stream;
     if (T <= LIN_SMALL_T) {
         int r = MDL_OK;
-        if (dX) r = lin_small_launch(dY, ldy, 1, W, 1, K, dX, lddx, (int)T, K, N, nullptr, s);        // dX[t,k] = sum_n dY[t,n] W[n,k]
+        if (dX) r = lin_small_launch(dY, ldy, 1, W, 1, K, dX, lddx, (int)T, K, N, nullptr, (float*)ws, s);   // dX[t,k] = sum_n dY[t,n] W[n,k]
         if (r) return r;
-        r = lin_small_launch(dY, 1, ldy, X, 1, ldx, dW, K, N, K, (int)T, nullptr, s);                  // dW[n,k] = sum_t dY[t,n] X[t,k]
+        r = lin_small_launch(dY, 1, ldy, X, 1, ldx, dW, K, N, K, (int)T, nullptr, (float*)ws, s);             // dW[n,k] = sum_t dY[t,n] X[t,k]
         if (r) return r;
         if (dbias) {
             hipLaunchKernelGGL(lin_colsum_part_kernel, dim3(1), dim3(256), 0, s, dY, ldy, T, N, dbias, (int64_t)(T > 0 ? T : 1));
