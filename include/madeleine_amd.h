@@ -54,7 +54,7 @@ const char* mdl_version(void);
 /* ABI revision of this header: bumped whenever an entry point's argument list changes.  A binding compares
  * mdl_abi_version() with the MDL_ABI_VERSION it was written against BEFORE calling anything else, so that a stale
  * shared object fails loudly instead of being called with shifted arguments. */
-#define MDL_ABI_VERSION 3
+#define MDL_ABI_VERSION 4
 int mdl_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -123,6 +123,18 @@ int mdl_abmil_pool_bwd(const float* E, int64_t ldE, const float* scores, const f
                        const float* stat_m, const float* stat_l, const float* d_pooled, float* dE,
                        int accumulate, float* d_scores, int accumulate_scores, int64_t n_bags, int64_t N,
                        const int64_t* cu_seqlens, int64_t max_len, int H, void* stream);
+
+/* Views: the intra-modality path pools two random half-bags per bag with the raw scores
+ * re-softmaxed over the subset (Model.py:419-440).  A view is a DENSE bag of N tokens restricted to the index list
+ * token_idx int32 [n_idx] (the same list for every bag: logical token i of bag b is row b*N + token_idx[i]); the kernels
+ * gather the 8-KiB token rows in place -- no index_select copies of E.  ws: mdl_abmil_pool_ws_bytes(n_bags, n_idx, H).
+ * The backward ACCUMULATES into dE (rows of the view) and/or d_scores; either may be NULL: d_scores == NULL is a dE-only pass
+ * that does not read E (dE[t,c,:] += w[t,c] d_pooled[b,c,:]). */
+int mdl_abmil_pool_view_fwd(const float* E, int64_t ldE, const float* scores, float* pooled, float* stat_m, float* stat_l,
+                            int64_t n_bags, int64_t N, const int32_t* token_idx, int64_t n_idx, int H, void* ws, void* stream);
+int mdl_abmil_pool_view_bwd(const float* E, int64_t ldE, const float* scores, const float* pooled, const float* stat_m,
+                            const float* stat_l, const float* d_pooled, float* dE, float* d_scores, int64_t n_bags, int64_t N,
+                            const int32_t* token_idx, int64_t n_idx, int H, void* stream);
 
 /* Fused backward of A2 + A3 ("abmil_attnpool_bwd").  Call sequence:
  *   1. mdl_abmil_pool_bwd(..., dE = NULL, ...)   -> d_scores only (one read of E; dE may be NULL in that call)
@@ -254,6 +266,11 @@ int mdl_abmil_pool_bwd_bf16(const uint16_t* E, int64_t ldE, const float* scores,
                             const float* stat_l, const float* d_pooled, uint16_t* dE, int accumulate, float* d_scores,
                             int accumulate_scores, int64_t n_bags, int64_t N, const int64_t* cu_seqlens, int64_t max_len,
                             int H, void* stream);
+int mdl_abmil_pool_view_fwd_bf16(const uint16_t* E, int64_t ldE, const float* scores, float* pooled, float* stat_m, float* stat_l,
+                                 int64_t n_bags, int64_t N, const int32_t* token_idx, int64_t n_idx, int H, void* ws, void* stream);
+int mdl_abmil_pool_view_bwd_bf16(const uint16_t* E, int64_t ldE, const float* scores, const float* pooled, const float* stat_m,
+                                 const float* stat_l, const float* d_pooled, uint16_t* dE, float* d_scores, int64_t n_bags,
+                                 int64_t N, const int32_t* token_idx, int64_t n_idx, int H, void* stream);
 int64_t mdl_abmil_gate_fwd_bf16_ws_bytes(int64_t T, int H);
 int mdl_abmil_gate_fwd_bf16(const uint16_t* E, int64_t ldE, const float* Wa, const float* ba, const float* Wb,
                             const float* bb, const float* wc, const float* bc, float* scores, uint16_t* act_a,

@@ -22,9 +22,14 @@ constexpr int POOL_BWD_TOKENS = 128;  // tokens per backward workgroup (4 waves)
 struct BagSpan {
     int64_t start, len;
 };
-__device__ __forceinline__ BagSpan bag_span(int b, int64_t N, const int64_t* cu) {
+// A "view" (intra-modality half-bag views, reference Model.py:419-440) is a dense bag restricted to the token index list
+// idx[0..n_idx): logical token i of bag b is the physical row b*N + idx[i]; the same list for every bag.
+__device__ __forceinline__ BagSpan bag_span(int b, int64_t N, const int64_t* cu, int64_t n_idx = -1) {
     BagSpan s;
-    if (cu) {
+    if (n_idx >= 0) {
+        s.start = (int64_t)b * N;
+        s.len = n_idx;
+    } else if (cu) {
         s.start = cu[b];
         s.len = cu[b + 1] - s.start;
     } else {
@@ -35,28 +40,32 @@ __device__ __forceinline__ BagSpan bag_span(int b, int64_t N, const int64_t* cu)
 }
 
 // blockDim.x == H*128: thread f owns channels [4f, 4f+4) (head f/128).
-template <int H, class TE>
+template <int H, class TE, bool IDX = false>
 __global__ __launch_bounds__(H * 128) void pool_partial_kernel(const TE* __restrict__ E, int64_t ldE,
                                                                const float* __restrict__ scores,
                                                                float* __restrict__ part_acc,
                                                                float* __restrict__ part_m,
                                                                float* __restrict__ part_l, int64_t N,
-                                                               const int64_t* __restrict__ cu, int max_chunks) {
+                                                               const int64_t* __restrict__ cu, int max_chunks,
+                                                               const int32_t* __restrict__ idx = nullptr, int64_t n_idx = -1) {
     constexpr int NT = H * 128;
     constexpr int NW = NT / 64;
     __shared__ float p_s[POOL_CHUNK * H];  // exp(s - m_chunk), [t][c]
     __shared__ float red_s[NW * H];
     __shared__ float stat_s[2 * H];
+    __shared__ int32_t tok_s[IDX ? POOL_CHUNK : 1];   // physical token of each logical token of the chunk (views)
 
     const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
-    const BagSpan sp = bag_span(b, N, cu);
+    const BagSpan sp = bag_span(b, N, cu, IDX ? n_idx : -1);
     const int64_t t0 = (int64_t)chunk * POOL_CHUNK;
     if (t0 >= sp.len) return;  // block-uniform
     const int nt = (int)((sp.len - t0 < POOL_CHUNK) ? (sp.len - t0) : POOL_CHUNK);
 
     // ---- chunk softmax statistics: thread tid holds score (t = tid / H, c = tid % H) ----------
     const int st = tid / H, sc = tid % H;
-    const float s = (st < nt) ? scores[(sp.start + t0 + st) * H + sc] : -INFINITY;
+    const int64_t prow = (st < nt) ? (IDX ? (int64_t)idx[t0 + st] : t0 + st) : 0;
+    if (IDX && sc == 0 && st < nt) tok_s[st] = (int32_t)prow;
+    const float s = (st < nt) ? scores[(sp.start + prow) * H + sc] : -INFINITY;
     float mx = s;
 #pragma unroll
     for (int o = 32; o >= H; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
@@ -85,14 +94,14 @@ __global__ __launch_bounds__(H * 128) void pool_partial_kernel(const TE* __restr
 
     // ---- weighted accumulation: thread owns one float4 column, loops over the chunk's tokens -----
     const int ca = tid / 128;
-    const TE* __restrict__ Ep = E + (sp.start + t0) * ldE + (int64_t)tid * 4;
+    const TE* __restrict__ Ep = E + (sp.start + (IDX ? 0 : t0)) * ldE + (int64_t)tid * 4;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     constexpr int U = 8;
     int t = 0;
     for (; t + U <= nt; t += U) {
         f32x4 x[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) x[u] = ld4_nt(Ep + (int64_t)(t + u) * ldE);
+        for (int u = 0; u < U; ++u) x[u] = ld4_nt(Ep + (int64_t)(IDX ? tok_s[t + u] : t + u) * ldE);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const float w = p_s[(t + u) * H + ca];
@@ -100,7 +109,7 @@ __global__ __launch_bounds__(H * 128) void pool_partial_kernel(const TE* __restr
         }
     }
     for (; t < nt; ++t) {
-        const f32x4 x = ld4(Ep + (int64_t)t * ldE);
+        const f32x4 x = ld4(Ep + (int64_t)(IDX ? tok_s[t] : t) * ldE);
         acc += p_s[t * H + ca] * x;
     }
     *reinterpret_cast<f32x4*>(part_acc + ((int64_t)b * max_chunks + chunk) * (H * HID) + (int64_t)tid * 4) = acc;
@@ -112,9 +121,10 @@ __global__ __launch_bounds__(H * 128) void pool_combine_kernel(const float* __re
                                                                const float* __restrict__ part_l,
                                                                float* __restrict__ pooled, float* __restrict__ stat_m,
                                                                float* __restrict__ stat_l, int64_t N,
-                                                               const int64_t* __restrict__ cu, int max_chunks) {
+                                                               const int64_t* __restrict__ cu, int max_chunks,
+                                                               int64_t n_idx = -1) {
     const int b = blockIdx.x, tid = threadIdx.x, ca = tid / 128;
-    const BagSpan sp = bag_span(b, N, cu);
+    const BagSpan sp = bag_span(b, N, cu, n_idx);
     const int nchunks = (int)((sp.len + POOL_CHUNK - 1) / POOL_CHUNK);
     f32x4 out = {0.f, 0.f, 0.f, 0.f};
     float M = 0.f, L = 1.f;
@@ -141,7 +151,8 @@ __global__ __launch_bounds__(H * 128) void pool_combine_kernel(const float* __re
 }
 
 // One wave per token row.  Lane L, slot i in [0,2H): channels [i*256 + 4L, +4), head i/2.
-template <int H, class TE>
+// IDX (views): d_scores == nullptr -> dE-only pass (no read of E: dE[t] += w[t,c] d_pooled[b,c,:]); both outputs accumulate.
+template <int H, class TE, bool IDX = false>
 __global__ __launch_bounds__(256) void pool_bwd_kernel(const TE* __restrict__ E, int64_t ldE,
                                                        const float* __restrict__ scores,
                                                        const float* __restrict__ pooled,
@@ -150,9 +161,10 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const TE* __restrict__ E,
                                                        const float* __restrict__ d_pooled, TE* __restrict__ dE,
                                                        int accumulate, float* __restrict__ d_scores,
                                                        int accumulate_scores, int64_t N,
-                                                       const int64_t* __restrict__ cu) {
+                                                       const int64_t* __restrict__ cu,
+                                                       const int32_t* __restrict__ idx = nullptr, int64_t n_idx = -1) {
     const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const BagSpan sp = bag_span(b, N, cu);
+    const BagSpan sp = bag_span(b, N, cu, IDX ? n_idx : -1);
     const int64_t t0 = (int64_t)chunk * POOL_BWD_TOKENS;
     if (t0 >= sp.len) return;
     const int nt = (int)((sp.len - t0 < POOL_BWD_TOKENS) ? (sp.len - t0) : POOL_BWD_TOKENS);
@@ -176,18 +188,20 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const TE* __restrict__ E,
     }
 
     for (int t = wave; t < nt; t += 4) {
-        const int64_t row = sp.start + t0 + t;
-        const TE* __restrict__ er = E + row * ldE + lane * 4;
-        f32x4 x[2 * H];
-#pragma unroll
-        for (int i = 0; i < 2 * H; ++i) x[i] = ld4_nt(er + i * 256);
+        const int64_t row = sp.start + (IDX ? (int64_t)idx[t0 + t] : t0 + t);
         float w[H], dw[H];
 #pragma unroll
         for (int c = 0; c < H; ++c) w[c] = expf(scores[row * H + c] - m[c]) * rl[c];
+        if (!IDX || d_scores) {
+            const TE* __restrict__ er = E + row * ldE + lane * 4;
+            f32x4 x[2 * H];
 #pragma unroll
-        for (int c = 0; c < H; ++c) {
-            const f32x4 a = x[2 * c] * dp[2 * c] + x[2 * c + 1] * dp[2 * c + 1];
-            dw[c] = wave_sum(a.x + a.y + a.z + a.w);
+            for (int i = 0; i < 2 * H; ++i) x[i] = ld4_nt(er + i * 256);
+#pragma unroll
+            for (int c = 0; c < H; ++c) {
+                const f32x4 a = x[2 * c] * dp[2 * c] + x[2 * c + 1] * dp[2 * c + 1];
+                dw[c] = wave_sum(a.x + a.y + a.z + a.w);
+            }
         }
         if (dE) {  // dE == nullptr: scores-only pass (the dE term is folded into the gate's dX epilogue, mdl_abmil_attnpool_bwd)
             TE* __restrict__ gr = dE + row * ldE + lane * 4;
@@ -198,6 +212,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const TE* __restrict__ E,
                 st4(gr + i * 256, g);
             }
         }
+        if (IDX && !d_scores) continue;
         float ds = 0.f;
 #pragma unroll
         for (int c = 0; c < H; ++c)
@@ -280,6 +295,76 @@ static int pool_bwd_launch(const TE* E, int64_t ldE, const float* scores, const 
         MDL_LAUNCH_CHECK();
     });
     return MDL_OK;
+}
+
+template <class TE>
+static int pool_view_fwd_launch(const TE* E, int64_t ldE, const float* scores, float* pooled, float* stat_m, float* stat_l,
+                                int64_t n_bags, int64_t N, const int32_t* token_idx, int64_t n_idx, int H, void* ws, void* stream) {
+    if (!E || !scores || !pooled || !stat_m || !stat_l || !ws || !token_idx) return MDL_E_ARG;
+    if (n_bags < 0 || N < 0 || n_idx < 0 || n_idx > N || ldE < (int64_t)H * HID || (ldE & 3)) return MDL_E_ARG;
+    if (!host_aligned16(E) || !host_aligned16(pooled) || !host_aligned16(ws)) return MDL_E_ALIGN;
+    if (n_bags == 0) return MDL_OK;
+    if (n_bags > 65535) return MDL_E_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const int mc = (int)pool_max_chunks(n_idx);
+    float* part_acc = (float*)ws;
+    const int64_t st = ((n_bags * (int64_t)mc * H * 4 + 15) / 16) * 16;
+    float* part_m = (float*)((char*)ws + n_bags * (int64_t)mc * H * HID * 4);
+    float* part_l = (float*)((char*)part_m + st);
+    MDL_DISPATCH_H(H, {
+        if (mc > 0) {
+            hipLaunchKernelGGL((pool_partial_kernel<HH, TE, true>), dim3(mc, (unsigned)n_bags), dim3(HH * 128), 0, s, E, ldE, scores,
+                               part_acc, part_m, part_l, N, (const int64_t*)nullptr, mc, token_idx, n_idx);
+            MDL_LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL((pool_combine_kernel<HH>), dim3((unsigned)n_bags), dim3(HH * 128), 0, s, part_acc, part_m, part_l,
+                           pooled, stat_m, stat_l, N, (const int64_t*)nullptr, mc, n_idx);
+        MDL_LAUNCH_CHECK();
+    });
+    return MDL_OK;
+}
+
+template <class TE>
+static int pool_view_bwd_launch(const TE* E, int64_t ldE, const float* scores, const float* pooled, const float* stat_m,
+                                const float* stat_l, const float* d_pooled, TE* dE, float* d_scores, int64_t n_bags, int64_t N,
+                                const int32_t* token_idx, int64_t n_idx, int H, void* stream) {
+    if (!E || !scores || !pooled || !stat_m || !stat_l || !d_pooled || !token_idx || (!dE && !d_scores)) return MDL_E_ARG;
+    if (n_bags < 0 || N < 0 || n_idx < 0 || n_idx > N || ldE < (int64_t)H * HID || (ldE & 3)) return MDL_E_ARG;
+    if (!host_aligned16(E) || !host_aligned16(dE) || !host_aligned16(pooled) || !host_aligned16(d_pooled)) return MDL_E_ALIGN;
+    if (n_bags == 0 || n_idx == 0) return MDL_OK;
+    if (n_bags > 65535) return MDL_E_UNSUPPORTED;
+    const int nc = (int)((n_idx + POOL_BWD_TOKENS - 1) / POOL_BWD_TOKENS);
+    MDL_DISPATCH_H(H, {
+        hipLaunchKernelGGL((pool_bwd_kernel<HH, TE, true>), dim3(nc, (unsigned)n_bags), dim3(256), 0, (hipStream_t)stream, E, ldE,
+                           scores, pooled, stat_m, stat_l, d_pooled, dE, 1, d_scores, 1, N, (const int64_t*)nullptr, token_idx, n_idx);
+        MDL_LAUNCH_CHECK();
+    });
+    return MDL_OK;
+}
+
+extern "C" int mdl_abmil_pool_view_fwd(const float* E, int64_t ldE, const float* scores, float* pooled, float* stat_m, float* stat_l,
+                                       int64_t n_bags, int64_t N, const int32_t* token_idx, int64_t n_idx, int H, void* ws,
+                                       void* stream) {
+    return pool_view_fwd_launch<float>(E, ldE, scores, pooled, stat_m, stat_l, n_bags, N, token_idx, n_idx, H, ws, stream);
+}
+extern "C" int mdl_abmil_pool_view_bwd(const float* E, int64_t ldE, const float* scores, const float* pooled, const float* stat_m,
+                                       const float* stat_l, const float* d_pooled, float* dE, float* d_scores, int64_t n_bags,
+                                       int64_t N, const int32_t* token_idx, int64_t n_idx, int H, void* stream) {
+    return pool_view_bwd_launch<float>(E, ldE, scores, pooled, stat_m, stat_l, d_pooled, dE, d_scores, n_bags, N, token_idx, n_idx, H,
+                                       stream);
+}
+extern "C" int mdl_abmil_pool_view_fwd_bf16(const uint16_t* E, int64_t ldE, const float* scores, float* pooled, float* stat_m,
+                                            float* stat_l, int64_t n_bags, int64_t N, const int32_t* token_idx, int64_t n_idx, int H,
+                                            void* ws, void* stream) {
+    return pool_view_fwd_launch<bf16_t>((const bf16_t*)E, ldE, scores, pooled, stat_m, stat_l, n_bags, N, token_idx, n_idx, H, ws,
+                                        stream);
+}
+extern "C" int mdl_abmil_pool_view_bwd_bf16(const uint16_t* E, int64_t ldE, const float* scores, const float* pooled,
+                                            const float* stat_m, const float* stat_l, const float* d_pooled, uint16_t* dE,
+                                            float* d_scores, int64_t n_bags, int64_t N, const int32_t* token_idx, int64_t n_idx, int H,
+                                            void* stream) {
+    return pool_view_bwd_launch<bf16_t>((const bf16_t*)E, ldE, scores, pooled, stat_m, stat_l, d_pooled, (bf16_t*)dE, d_scores, n_bags,
+                                        N, token_idx, n_idx, H, stream);
 }
 
 extern "C" int mdl_abmil_pool_fwd(const float* E, int64_t ldE, const float* scores, float* pooled, float* stat_m,

@@ -181,6 +181,33 @@ def pool_bwd_raw(E2d, scores, pooled, stat_m, stat_l, d_pooled, dE, accumulate, 
     _native.check(rc, "mdl_abmil_pool_bwd")
 
 
+def pool_view_fwd_raw(E2d, scores, n_bags, N, token_idx):
+    lib = _native.lib()
+    H = scores.shape[-1]
+    dev = E2d.device
+    n_idx = token_idx.numel()
+    pooled = torch.empty(n_bags, H * HID, device=dev, dtype=torch.float32)
+    stat_m = torch.empty(n_bags, H, device=dev, dtype=torch.float32)
+    stat_l = torch.empty(n_bags, H, device=dev, dtype=torch.float32)
+    ws = _ws(lib.mdl_abmil_pool_ws_bytes(n_bags, n_idx, H), dev)
+    with _timed("pool_view_fwd"):
+        rc = getattr(lib, "mdl_abmil_pool_view_fwd" + _sfx(E2d))(_ptr(E2d), E2d.stride(0), _ptr(scores), _ptr(pooled), _ptr(stat_m),
+                                                                _ptr(stat_l), n_bags, N, _ptr(token_idx), n_idx, H, _ptr(ws), _stream())
+    _native.check(rc, "mdl_abmil_pool_view_fwd")
+    return pooled, stat_m, stat_l
+
+
+def pool_view_bwd_raw(E2d, scores, pooled, stat_m, stat_l, d_pooled, dE, d_scores, n_bags, N, token_idx):
+    """Accumulates the view's contribution into dE and / or d_scores (either may be None)."""
+    lib = _native.lib()
+    H = scores.shape[-1]
+    with _timed("pool_view_bwd"):
+        rc = getattr(lib, "mdl_abmil_pool_view_bwd" + _sfx(E2d))(_ptr(E2d), E2d.stride(0), _ptr(scores), _ptr(pooled), _ptr(stat_m),
+                                                                _ptr(stat_l), _ptr(d_pooled), _ptr(dE), _ptr(d_scores), n_bags, N,
+                                                                _ptr(token_idx), token_idx.numel(), H, _stream())
+    _native.check(rc, "mdl_abmil_pool_view_bwd")
+
+
 def _bag_geometry(E, cu_seqlens, max_len):
     """E is [n_bags,N,C] (dense) or [T,C] with cu_seqlens int64 [n_bags+1] (ragged)."""
     if cu_seqlens is None:
@@ -258,27 +285,38 @@ class SoftmaxPoolFn(torch.autograd.Function):
 # w * d_pooled is added in the gate backward's dX epilogue -- dE is written exactly once.
 # --------------------------------------------------------------------------------------------------
 class AttnPoolFn(torch.autograd.Function):
-    """(pooled [n_bags,H*512], raw scores [T,H]) = multi-head gated-ABMIL pooling (Model.py:406-417)."""
+    """(pooled [n_bags,(1+V,)H*512], raw scores [T,H]) = multi-head gated-ABMIL pooling (Model.py:406-417) and, with
+    `views` = V int32 token-index lists (dense bags only), the V re-softmaxed sub-bag poolings of Model.py:419-440."""
 
     @staticmethod
-    def forward(ctx, E, Wa, ba, Wb, bb, wc, bc, p_drop, seed, keep_a, keep_b, cu_seqlens, max_len):
+    def forward(ctx, E, Wa, ba, Wb, bb, wc, bc, p_drop, seed, keep_a, keep_b, cu_seqlens, max_len, *views):
         _require_act(E, "E")
         for t, n in ((Wa, "Wa"), (ba, "ba"), (Wb, "Wb"), (bb, "bb"), (wc, "wc"), (bc, "bc")):
             _require(t, n)
         n_bags, N, max_len, E2d = _bag_geometry(E, cu_seqlens, max_len)
+        if views and cu_seqlens is not None:
+            raise NotImplementedError("token-index views are defined on dense bags (the reference's n_views path stacks equal-N bags)")
+        for v in views:
+            _require(v, "view token indices", torch.int32)
         need = any(ctx.needs_input_grad[:7])
         scores, act_a, act_b = gate_fwd_raw(E2d, Wa, ba, Wb, bb, wc, bc, p_drop, seed, keep_a, keep_b, need)
         pooled, m, l = pool_fwd_raw(E2d, scores, n_bags, N, cu_seqlens, max_len)
+        vstate = [pool_view_fwd_raw(E2d, scores, n_bags, N, v) for v in views]
         if need:
+            flat = [t for st in vstate for t in st]
             ctx.save_for_backward(E2d, Wa, Wb, wc, act_a, act_b, scores, pooled, m, l,
-                                  cu_seqlens if cu_seqlens is not None else torch.empty(0))
-            ctx.cfg = (p_drop, seed, keep_a, keep_b, n_bags, N, max_len, cu_seqlens is not None, E.shape)
+                                  cu_seqlens if cu_seqlens is not None else torch.empty(0), *views, *flat)
+            ctx.cfg = (p_drop, seed, keep_a, keep_b, n_bags, N, max_len, cu_seqlens is not None, E.shape, len(views))
+        if views:
+            pooled = torch.stack([pooled] + [st[0] for st in vstate], dim=1)
         return pooled, scores
 
     @staticmethod
     def backward(ctx, d_pooled, d_scores_in):
-        E2d, Wa, Wb, wc, act_a, act_b, scores, pooled, m, l, cu = ctx.saved_tensors
-        p_drop, seed, keep_a, keep_b, n_bags, N, max_len, ragged, e_shape = ctx.cfg
+        p_drop, seed, keep_a, keep_b, n_bags, N, max_len, ragged, e_shape, V = ctx.cfg
+        saved = ctx.saved_tensors
+        E2d, Wa, Wb, wc, act_a, act_b, scores, pooled, m, l, cu = saved[:11]
+        views, vflat = saved[11:11 + V], saved[11 + V:]
         cu = cu if ragged else None
         dE = torch.empty_like(E2d)
         if d_scores_in is not None:
@@ -288,20 +326,27 @@ class AttnPoolFn(torch.autograd.Function):
             ds = torch.empty_like(scores)
             acc_s = 0
         if d_pooled is None:
-            d_pooled = torch.zeros_like(pooled)
+            d_pooled = torch.zeros(n_bags, 1 + V, pooled.shape[-1], device=pooled.device) if V else torch.zeros_like(pooled)
         d_pooled = d_pooled.float().contiguous()
+        d_main = d_pooled[:, 0].contiguous() if V else d_pooled
         # scores-only pooling backward (one read of E), then the gate backward whose dX epilogue adds the pooling term
-        pool_bwd_raw(E2d, scores, pooled, m, l, d_pooled, None, 0, ds, acc_s, n_bags, N, cu, max_len)
+        pool_bwd_raw(E2d, scores, pooled, m, l, d_main, None, 0, ds, acc_s, n_bags, N, cu, max_len)
+        for i in range(V):   # the views' score gradients must be in ds before the gate backward consumes it
+            vp, vm, vl = vflat[3 * i:3 * i + 3]
+            pool_view_bwd_raw(E2d, scores, vp, vm, vl, d_pooled[:, 1 + i].contiguous(), None, ds, n_bags, N, views[i])
         row_bag = None
         if ragged:   # bag index of every packed token row, on the device (no sync)
             row_bag = torch.searchsorted(cu[1:].contiguous(), torch.arange(E2d.shape[0], device=E2d.device), right=True).to(torch.int32)
         dWa, dWb, dba, dbb, dwc, dbc = attnpool_bwd_raw(E2d, Wa, Wb, wc, act_a, act_b, ds, dE, p_drop, seed, keep_a, keep_b,
-                                                        scores, m, l, d_pooled, row_bag, N if not ragged else 0)
-        return dE.view(e_shape), dWa, dba, dWb, dbb, dwc, dbc, None, None, None, None, None, None
+                                                        scores, m, l, d_main, row_bag, N if not ragged else 0)
+        for i in range(V):   # ... and their dE terms are added once dE has been written (no read of E)
+            vp, vm, vl = vflat[3 * i:3 * i + 3]
+            pool_view_bwd_raw(E2d, scores, vp, vm, vl, d_pooled[:, 1 + i].contiguous(), dE, None, n_bags, N, views[i])
+        return (dE.view(e_shape), dWa, dba, dWb, dbb, dwc, dbc, None, None, None, None, None, None) + (None,) * V
 
 
-def attn_pool(E, Wa, ba, Wb, bb, wc, bc, p_drop=0.0, seed=0, keep_a=None, keep_b=None, cu_seqlens=None, max_len=None):
-    return AttnPoolFn.apply(E, Wa, ba, Wb, bb, wc, bc, float(p_drop), int(seed), keep_a, keep_b, cu_seqlens, max_len)
+def attn_pool(E, Wa, ba, Wb, bb, wc, bc, p_drop=0.0, seed=0, keep_a=None, keep_b=None, cu_seqlens=None, max_len=None, views=()):
+    return AttnPoolFn.apply(E, Wa, ba, Wb, bb, wc, bc, float(p_drop), int(seed), keep_a, keep_b, cu_seqlens, max_len, *views)
 
 
 def gate_scores(E2d, Wa, ba, Wb, bb, wc, bc, p_drop=0.0, seed=0, keep_a=None, keep_b=None):

@@ -155,14 +155,15 @@ class ABMILEmbedder(nn.Module):
                 kb.reshape(T, self.n_heads, MF.HID).to(torch.uint8).contiguous()
         return p, MF.new_dropout_seed(), None, None
 
-    def pool_headmajor(self, E_hm: torch.Tensor):
-        """E_hm [BM,N,H*512] -> (pooled_hm [BM,H*512], raw scores [BM,N,H]) through the fused HIP path."""
+    def pool_headmajor(self, E_hm: torch.Tensor, views=()):
+        """E_hm [BM,N,H*512] -> (pooled_hm [BM,(1+V,)H*512], raw scores [BM,N,H]) through the fused HIP path; `views` = V int32
+        token-index lists pooled in the same autograd node (no index_select copies of E)."""
         for h in self.attn:
             h._check_geometry()
         BM, N, _ = E_hm.shape
         wa, ba, wb, bb, wc, bc = self.gate_params_stacked()
         p, seed, ka, kb = self._gate_dropout((BM, N))
-        pooled, scores = MF.attn_pool(E_hm, wa, ba, wb, bb, wc, bc, p, seed, ka, kb)
+        pooled, scores = MF.attn_pool(E_hm, wa, ba, wb, bb, wc, bc, p, seed, ka, kb, views=views)
         return pooled, scores.view(BM, N, self.n_heads)
 
     def pool_headmajor_ragged(self, E_hm: torch.Tensor, cu_seqlens: torch.Tensor, max_len: int):
@@ -195,6 +196,15 @@ class ABMILEmbedder(nn.Module):
             raise NotImplementedError('Agg type not supported. Options are "regular".')
         E = self.embed_tokens_headmajor(bags)
         act = self.attn[0].activation
+        if act == 'softmax' and n_views != 1:
+            # intra-modality views (Model.py:419-440): two random halves of the token axis (numpy RNG, as the reference),
+            # raw scores re-softmaxed per subset -- pooled by index list inside the fused A2+A3 node
+            all_indices = np.arange(E.shape[1])
+            np.random.shuffle(all_indices)
+            mid = len(all_indices) // 2
+            views = tuple(torch.as_tensor(idx, dtype=torch.int32).to(E.device) for idx in (all_indices[:mid], all_indices[mid:]))
+            pooled, scores = self.pool_headmajor(E, views)
+            return pooled, E, scores
         if act == 'softmax':
             pooled, scores = self.pool_headmajor(E)
         else:

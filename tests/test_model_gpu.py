@@ -485,3 +485,38 @@ def test_train_loop_trajectory_golden(dev, capsys):
                 assert abs(float(d.norm()) - ref_n) <= 1e-3 * ref_n + 1e-5 * top, k
                 head = torch.from_numpy(g[f"sgd/dhead/{k}"])
                 assert float((d.flatten()[:16] - head).norm()) <= 2e-3 * float(head.norm()) + 1e-5 * top, k
+
+
+def test_three_views_gradients_vs_oracle(dev):
+    """N2: the intra-modality branch (n_views = 3, Model.py:419-440) pooled by token-index lists inside the fused A2+A3 node --
+    embeddings of the three views and EVERY parameter gradient (the view terms reach the gate through the re-softmaxed raw
+    scores and the encoder through E) against the oracle given the same numpy split; odd token count, N > one 128-token chunk."""
+    B, M, N, D = 2, 2, 301, 64
+    mods = MODS5[:M]
+    model = build(mods, D, "w3v", dev).eval()
+    feats = t((B, M, N, D), "v3:feats")
+    w = [t((B, 3, 512), f"v3:w{i}") for i in range(M)]
+    np.random.seed(21)
+    embs, _ = model({"feats": feats}, device=dev, train=True, n_views=3)
+    obj = sum((embs[k] * (w[i].to(dev) if k != "HE" else w[i].to(dev).unsqueeze(3))).sum() for i, k in enumerate(mods))
+    model.zero_grad()
+    obj.backward()
+    # the oracle with the very same split
+    np.random.seed(21)
+    idx = np.arange(N)
+    np.random.shuffle(idx)
+    views = [torch.as_tensor(idx[:N // 2]), torch.as_tensor(idx[N // 2:])]
+    sd = {k: v.detach().cpu().clone().requires_grad_() for k, v in model.state_dict().items()}
+    ref_e, _ = R.madeleine_forward_train(feats, sd, mods, view_indices=views)
+    ref_obj = sum((ref_e[k] * (w[i] if k != "HE" else w[i].unsqueeze(3))).sum() for i, k in enumerate(mods))
+    ref_obj.backward()
+    for k in mods:
+        assert tuple(embs[k].shape) == tuple(ref_e[k].shape) and rel_err(embs[k], ref_e[k]) < 1e-4, k
+    assert abs(float(obj.detach()) - float(ref_obj.detach())) < 1e-4 * abs(float(ref_obj.detach()))
+    top = max(float(v.grad.norm()) for v in sd.values() if v.grad is not None)
+    for k, p in model.named_parameters():
+        ref_g = sd[k].grad
+        if ref_g is None:
+            assert p.grad is None or float(p.grad.norm()) == 0.0, k
+            continue
+        assert float((p.grad.cpu() - ref_g).norm()) <= TOL * float(ref_g.norm()) + 1e-5 * top, k
