@@ -54,7 +54,7 @@ const char* mdl_version(void);
 /* ABI revision of this header: bumped whenever an entry point's argument list changes.  A binding compares
  * mdl_abi_version() with the MDL_ABI_VERSION it was written against BEFORE calling anything else, so that a stale
  * shared object fails loudly instead of being called with shifted arguments. */
-#define MDL_ABI_VERSION 4
+#define MDL_ABI_VERSION 5
 int mdl_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -182,10 +182,13 @@ int mdl_ln_gelu_drop_bwd(const float* x, const float* bias, const float* gamma, 
  * ws: mdl_infonce_ws_bytes(S,Kmax,D): normalised rows, inverse norms, logits, LSEs (kept for bwd).
  */
 int64_t mdl_infonce_ws_bytes(int S, int Kmax, int D);
-int mdl_infonce_fwd(const float* Q, const float* P, const int32_t* cnt, float* loss, int S, int Kmax,
+/* row_loss (NULL, or [S,Kmax]): the per-sample losses of reduction='none' (loss.py:58 -> F.cross_entropy(..., reduction); symmetric:
+ * 0.5 CE_i + 0.5 CE'_i); rows >= cnt[s] are zeroed. */
+int mdl_infonce_fwd(const float* Q, const float* P, const int32_t* cnt, float* loss, float* row_loss, int S, int Kmax,
                     int D, float temperature, int symmetric, void* ws, void* stream);
-/* d_loss [S] incoming; dQ,dP [S,Kmax,D] (rows >= cnt[s] are zeroed).  ws must be the forward's. */
-int mdl_infonce_bwd(const float* d_loss, const int32_t* cnt, float* dQ, float* dP, int S, int Kmax, int D,
+/* d_loss [S] incoming gradient of the mean losses -- or, when d_row_loss [S,Kmax] != NULL, the gradients of the per-sample
+ * losses (d_loss is then ignored and may be NULL); dQ,dP [S,Kmax,D] (rows >= cnt[s] are zeroed).  ws must be the forward's. */
+int mdl_infonce_bwd(const float* d_loss, const float* d_row_loss, const int32_t* cnt, float* dQ, float* dP, int S, int Kmax, int D,
                     float temperature, int symmetric, void* ws, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

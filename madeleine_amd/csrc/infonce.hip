@@ -113,7 +113,8 @@ __global__ __launch_bounds__(64) void nce_lse_kernel(const float* __restrict__ Z
 __global__ __launch_bounds__(256) void nce_loss_kernel(const float* __restrict__ Z, const float* __restrict__ m0,
                                                        const float* __restrict__ l0, const float* __restrict__ m1,
                                                        const float* __restrict__ l1, const int32_t* __restrict__ cnt,
-                                                       float* __restrict__ loss, int Kp, int symmetric) {
+                                                       float* __restrict__ loss, float* __restrict__ row_loss, int Kmax, int Kp,
+                                                       int symmetric) {
     __shared__ float red[4];
     const int s = blockIdx.x, tid = threadIdx.x, k = cnt[s];
     float v = 0.f;
@@ -121,20 +122,25 @@ __global__ __launch_bounds__(256) void nce_loss_kernel(const float* __restrict__
         const float d = Z[((int64_t)s * Kp + i) * Kp + i];
         const int64_t o = (int64_t)s * Kp + i;
         const float r0 = l0[o] - (d - m0[o]);  // -log_softmax(z)[i] = log sum exp(z - max) - (z_ii - max)
-        v += symmetric ? 0.5f * r0 + 0.5f * (l1[o] - (d - m1[o])) : r0;
+        const float r = symmetric ? 0.5f * r0 + 0.5f * (l1[o] - (d - m1[o])) : r0;
+        if (row_loss) row_loss[(int64_t)s * Kmax + i] = r;   // reduction='none' (loss.py:58: F.cross_entropy(..., reduction))
+        v += r;
     }
+    if (row_loss)
+        for (int i = k + tid; i < Kmax; i += 256) row_loss[(int64_t)s * Kmax + i] = 0.f;
     v = wave_sum(v);
     if ((tid & 63) == 0) red[tid >> 6] = v;
     __syncthreads();
     if (tid == 0) loss[s] = (k > 0) ? (red[0] + red[1] + red[2] + red[3]) / (float)k : 0.f;
 }
 
-// coef = dL/d(cosine_ij) = g/(k T) (w0 softmax_row + w1 softmax_col - (w0+w1) delta_ij); zero outside [0,k)^2
+// coef = dL/d(cosine_ij) = 1/T (w0 g_i softmax_row + w1 g_j softmax_col - (w0 g_i + w1 g_j) delta_ij); zero outside [0,k)^2.
+// g_i = d_loss / k (mean reduction) or, with d_row != NULL, the upstream gradient of row i's own loss (reduction 'none').
 __global__ void nce_coef_kernel(const float* __restrict__ Z, const float* __restrict__ m0, const float* __restrict__ l0,
                                 const float* __restrict__ m1, const float* __restrict__ l1,
                                 const int32_t* __restrict__ cnt,
-                                const float* __restrict__ d_loss, float* __restrict__ coef, int Kp, float inv_T,
-                                int symmetric) {
+                                const float* __restrict__ d_loss, const float* __restrict__ d_row, int Kmax,
+                                float* __restrict__ coef, int Kp, float inv_T, int symmetric) {
     const int s = blockIdx.y;
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (int64_t)Kp * Kp) return;
@@ -142,11 +148,14 @@ __global__ void nce_coef_kernel(const float* __restrict__ Z, const float* __rest
     float c = 0.f;
     if (i < k && j < k) {
         const float z = Z[(int64_t)s * Kp * Kp + e];
+        // (softmax - delta) FIRST: for a saturated softmax (T = 0.001) p_ii -> 1 and the subtraction is exact (Sterbenz); scaling by
+        // the loss weights afterwards keeps the cancellation out of the rounding of the products
+        const float dlt = (i == j) ? 1.f : 0.f;
+        const float a = expf((z - m0[(int64_t)s * Kp + i]) - l0[(int64_t)s * Kp + i]) - dlt;
+        const float b = symmetric ? expf((z - m1[(int64_t)s * Kp + j]) - l1[(int64_t)s * Kp + j]) - dlt : 0.f;
         const float w0 = symmetric ? 0.5f : 1.f, w1 = symmetric ? 0.5f : 0.f;
-        float v = w0 * expf((z - m0[(int64_t)s * Kp + i]) - l0[(int64_t)s * Kp + i]);
-        if (symmetric) v += w1 * expf((z - m1[(int64_t)s * Kp + j]) - l1[(int64_t)s * Kp + j]);
-        if (i == j) v -= (w0 + w1);
-        c = v * d_loss[s] * inv_T / (float)k;
+        if (d_row) c = (w0 * d_row[(int64_t)s * Kmax + i] * a + w1 * d_row[(int64_t)s * Kmax + j] * b) * inv_T;
+        else c = (w0 * a + w1 * b) * d_loss[s] * inv_T / (float)k;
     }
     coef[(int64_t)s * Kp * Kp + e] = c;
 }
@@ -210,8 +219,8 @@ extern "C" int64_t mdl_infonce_ws_bytes(int S, int Kmax, int D) {
     return (4 * rows * D + 6 * rows + 2 * rows * Kp) * 4 + 64;
 }
 
-extern "C" int mdl_infonce_fwd(const float* Q, const float* P, const int32_t* cnt, float* loss, int S, int Kmax, int D,
-                               float temperature, int symmetric, void* ws, void* stream) {
+extern "C" int mdl_infonce_fwd(const float* Q, const float* P, const int32_t* cnt, float* loss, float* row_loss, int S, int Kmax,
+                               int D, float temperature, int symmetric, void* ws, void* stream) {
     if (!Q || !P || !cnt || !loss || !ws) return MDL_E_ARG;
     if (S < 0 || Kmax < 0 || D < 8 || (D % 32) || !(temperature > 0.f)) return MDL_E_ARG;
     if (!host_aligned16(ws)) return MDL_E_ALIGN;
@@ -229,14 +238,14 @@ extern "C" int mdl_infonce_fwd(const float* Q, const float* P, const int32_t* cn
         hipLaunchKernelGGL(nce_lse_kernel, dim3(S * Kp, symmetric ? 2 : 1), dim3(64), 0, st, w.Z, cnt, w.m0, w.l0, w.m1, w.l1, Kp);
         MDL_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(nce_loss_kernel, dim3(S), dim3(256), 0, st, w.Z, w.m0, w.l0, w.m1, w.l1, cnt, loss, Kp, symmetric);
+    hipLaunchKernelGGL(nce_loss_kernel, dim3(S), dim3(256), 0, st, w.Z, w.m0, w.l0, w.m1, w.l1, cnt, loss, row_loss, Kmax, Kp, symmetric);
     MDL_LAUNCH_CHECK();
     return MDL_OK;
 }
 
-extern "C" int mdl_infonce_bwd(const float* d_loss, const int32_t* cnt, float* dQ, float* dP, int S, int Kmax, int D,
-                               float temperature, int symmetric, void* ws, void* stream) {
-    if (!d_loss || !cnt || !dQ || !dP || !ws) return MDL_E_ARG;
+extern "C" int mdl_infonce_bwd(const float* d_loss, const float* d_row_loss, const int32_t* cnt, float* dQ, float* dP, int S, int Kmax,
+                               int D, float temperature, int symmetric, void* ws, void* stream) {
+    if ((!d_loss && !d_row_loss) || !cnt || !dQ || !dP || !ws) return MDL_E_ARG;
     if (S < 0 || Kmax < 0 || D < 8 || (D % 32) || !(temperature > 0.f)) return MDL_E_ARG;
     if (!host_aligned16(ws)) return MDL_E_ALIGN;
     if (S == 0 || Kmax == 0) return MDL_OK;
@@ -244,7 +253,7 @@ extern "C" int mdl_infonce_bwd(const float* d_loss, const int32_t* cnt, float* d
     const NceWs w = nce_ws(ws, S, Kmax, D);
     const int Kp = w.Kp;
     hipLaunchKernelGGL(nce_coef_kernel, dim3((Kp * Kp + 255) / 256, S), dim3(256), 0, st, w.Z, w.m0, w.l0, w.m1, w.l1, cnt,
-                       d_loss, w.coef, Kp, 1.f / temperature, symmetric);
+                       d_loss, d_row_loss, Kmax, w.coef, Kp, 1.f / temperature, symmetric);
     MDL_LAUNCH_CHECK();
     hipLaunchKernelGGL(nce_grad_kernel, dim3(D / 32, Kp / 32, S * 2), dim3(64), 0, st, w.coef, w.Qn, w.Pn, w.dQn, w.dPn, Kp, D,
                        S);

@@ -483,39 +483,58 @@ def linear(x, W, bias=None):
 # L1: InfoNCE (batched over problems)
 # --------------------------------------------------------------------------------------------------
 class InfoNCEFn(torch.autograd.Function):
-    """loss[S] for S padded problems Q,P [S,Kmax,D] with cnt[S] live rows each (loss.py:111-127)."""
+    """(loss [S], row_loss [S,Kmax]) for S padded problems Q,P [S,Kmax,D] with cnt[S] live rows each (loss.py:111-127);
+    row_loss = the per-sample losses (reduction 'none').  Use ONE of the two outputs downstream."""
 
     @staticmethod
-    def forward(ctx, Q, P, cnt, temperature, symmetric):
+    def forward(ctx, Q, P, cnt, temperature, symmetric, per_row):
         _require(Q, "query")
         _require(P, "positive_key")
         _require(cnt, "cnt", torch.int32)
         lib = _native.lib()
         S, Kmax, D = Q.shape
         loss = torch.empty(S, device=Q.device, dtype=torch.float32)
+        rows = torch.empty(S, Kmax, device=Q.device, dtype=torch.float32) if per_row else None
         ws = _ws(lib.mdl_infonce_ws_bytes(S, Kmax, D), Q.device)
-        rc = lib.mdl_infonce_fwd(_ptr(Q), _ptr(P), _ptr(cnt), _ptr(loss), S, Kmax, D, float(temperature), int(symmetric),
+        rc = lib.mdl_infonce_fwd(_ptr(Q), _ptr(P), _ptr(cnt), _ptr(loss), _ptr(rows), S, Kmax, D, float(temperature), int(symmetric),
                                  _ptr(ws), _stream())
         _native.check(rc, "mdl_infonce_fwd")
         ctx.save_for_backward(cnt, ws)
-        ctx.cfg = (S, Kmax, D, float(temperature), int(symmetric))
-        return loss
+        ctx.cfg = (S, Kmax, D, float(temperature), int(symmetric), bool(per_row))
+        if not per_row:
+            rows = loss.new_empty(0)
+            ctx.mark_non_differentiable(rows)
+        return loss, rows
 
     @staticmethod
-    def backward(ctx, d_loss):
+    def backward(ctx, d_loss, d_rows):
         cnt, ws = ctx.saved_tensors
-        S, Kmax, D, temperature, symmetric = ctx.cfg
+        S, Kmax, D, temperature, symmetric, per_row = ctx.cfg
         lib = _native.lib()
-        dQ = torch.empty(S, Kmax, D, device=d_loss.device, dtype=torch.float32)
+        dev = cnt.device
+        dQ = torch.empty(S, Kmax, D, device=dev, dtype=torch.float32)
         dP = torch.empty_like(dQ)
-        rc = lib.mdl_infonce_bwd(_ptr(d_loss.contiguous()), _ptr(cnt), _ptr(dQ), _ptr(dP), S, Kmax, D, temperature,
-                                 symmetric, _ptr(ws), _stream())
+        if per_row:
+            # loss [S] = mean of the rows: fold an upstream gradient on it into the per-row gradients
+            g = d_rows.float().contiguous() if d_rows is not None else torch.zeros(S, Kmax, device=dev)
+            if d_loss is not None:
+                g = g + d_loss.float().unsqueeze(1) / cnt.clamp_min(1).unsqueeze(1).float()
+            rc = lib.mdl_infonce_bwd(None, _ptr(g.contiguous()), _ptr(cnt), _ptr(dQ), _ptr(dP), S, Kmax, D, temperature, symmetric,
+                                     _ptr(ws), _stream())
+        else:
+            rc = lib.mdl_infonce_bwd(_ptr(d_loss.float().contiguous()), None, _ptr(cnt), _ptr(dQ), _ptr(dP), S, Kmax, D, temperature,
+                                     symmetric, _ptr(ws), _stream())
         _native.check(rc, "mdl_infonce_bwd")
-        return dQ, dP, None, None, None
+        return dQ, dP, None, None, None, None
 
 
 def info_nce_batched(Q, P, cnt, temperature, symmetric):
-    return InfoNCEFn.apply(Q, P, cnt, float(temperature), bool(symmetric))
+    return InfoNCEFn.apply(Q, P, cnt, float(temperature), bool(symmetric), False)[0]
+
+
+def info_nce_rows(Q, P, cnt, temperature, symmetric):
+    """Per-sample losses [S, Kmax] (reduction 'none'); rows >= cnt[s] are zero."""
+    return InfoNCEFn.apply(Q, P, cnt, float(temperature), bool(symmetric), True)[1]
 
 
 # --------------------------------------------------------------------------------------------------

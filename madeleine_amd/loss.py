@@ -39,14 +39,17 @@ def info_nce(query, positive_key, negative_keys=None, temperature=0.1, reduction
         # In the reference this branch builds logits and then falls off the end of the function, returning None
         # (loss.py:93-110): it is not a usable code path, so it is not reproduced.
         raise NotImplementedError("explicit negative_keys: the reference branch (loss.py:93-110) never returns a loss")
-    if reduction not in ('mean', 'sum'):
-        raise NotImplementedError("madeleine_amd.InfoNCE supports reduction 'mean' (reference default) and 'sum'")
+    if reduction not in ('mean', 'sum', 'none'):
+        raise ValueError("reduction must be 'mean', 'sum' or 'none' (F.cross_entropy's values, loss.py:124)")
     k, d = query.shape
-    if d % 32:
-        raise NotImplementedError("madeleine_amd.InfoNCE: embedding width must be a multiple of 32 (got %d)" % d)
+    q, p = query.float().contiguous(), positive_key.float().contiguous()
+    if d % 32:   # the similarity kernel works on 32-wide feature blocks: zero columns change neither norms nor cosines
+        pad = 32 - d % 32
+        q, p = torch.nn.functional.pad(q, (0, pad)), torch.nn.functional.pad(p, (0, pad))
     cnt = torch.full((1,), k, dtype=torch.int32, device=query.device)
-    loss = MF.info_nce_batched(query.float().contiguous().unsqueeze(0), positive_key.float().contiguous().unsqueeze(0),
-                               cnt, temperature, symmetric)[0]
+    if reduction == 'none':
+        return MF.info_nce_rows(q.unsqueeze(0), p.unsqueeze(0), cnt, temperature, symmetric)[0]
+    loss = MF.info_nce_batched(q.unsqueeze(0), p.unsqueeze(0), cnt, temperature, symmetric)[0]
     return loss * k if reduction == 'sum' else loss
 
 

@@ -328,7 +328,7 @@ class MADELEINE(nn.Module):
         pooled, _, _ = self.wsi_embedders.forward_headmajor(feats)
         return self._project_slide(pooled)
 
-    def forward_ragged(self, bags, device, n_loss_tokens=256):
+    def forward_ragged(self, bags, device, n_loss_tokens=None):
         """Variable-length bags (BASELINE config 5) -- NEW functionality: the reference can only torch.stack equal-N
         bags (wsi_dataset.py:89-92).  `bags` is a list over cases of lists over modalities of [N_bm, D] tensors.
         Semantics = the train branch applied to each bag on its own (incl. the stain-encoding row quirk r // B of
@@ -336,10 +336,15 @@ class MADELEINE(nn.Module):
         Returns the reference-shaped dicts, with token embeddings restricted to the first `n_loss_tokens` tokens of
         every bag -- all the local loss ever reads (GOT sub-samples randperm(k)[:256])."""
         bs, n_mod = len(bags), len(bags[0])
+        if n_loss_tokens is None:
+            # GOT draws token indices randperm(k)[:256] with k = the number of participating CASES (reference quirk, loss.py:282,
+            # SURVEY.md section 8(a) G0): indices reach k - 1, so a batch of more than 256 cases needs that many tokens kept
+            n_loss_tokens = max(256, bs)
         flat = [bags[b][m] for b in range(bs) for m in range(n_mod)]          # case-major rows, like .view(bs*n_mod,...)
         lens = [int(x.shape[0]) for x in flat]
         if min(lens) < n_loss_tokens:
-            raise ValueError("every bag needs at least n_loss_tokens=%d tokens (shortest has %d)" % (n_loss_tokens, min(lens)))
+            raise ValueError("every bag needs at least n_loss_tokens=%d tokens (shortest has %d): the local loss reads token "
+                             "indices up to min(batch, 256) - 1 of every bag" % (n_loss_tokens, min(lens)))
         cu = torch.zeros(len(flat) + 1, dtype=torch.int64)
         cu[1:] = torch.cumsum(torch.tensor(lens, dtype=torch.int64), 0)
         x = torch.cat([f.to(device) for f in flat], dim=0)                     # packed [T, D]

@@ -255,6 +255,35 @@ def test_infonce_golden_and_batched(dev):
         assert float(Qd.grad[s, k:].abs().max() if k < 33 else 0.0) == 0.0
 
 
+@pytest.mark.parametrize("sym", [False, True])
+def test_infonce_reduction_none_sum_and_odd_width(dev, sym):
+    """reduction 'none' / 'sum' (F.cross_entropy's other values, loss.py:58,124) and an embedding width that is not a multiple of
+    32: per-sample losses and their gradients under a non-uniform upstream weight, against the oracle formula."""
+    import torch.nn.functional as F
+    from madeleine_amd import InfoNCE
+    k, d, T = 19, 100, 0.07
+    q0, p0 = t((k, d), "ncen:q"), t((k, d), "ncen:p")
+    p0 = p0 + 0.2 * q0
+    w = t((k,), "ncen:w").abs() + 0.1
+    q, p = q0.double().requires_grad_(), p0.double().requires_grad_()
+    logits = F.normalize(q, dim=-1) @ F.normalize(p, dim=-1).t() / T
+    lab = torch.arange(k)
+    ref = F.cross_entropy(logits, lab, reduction="none")
+    if sym:
+        ref = 0.5 * ref + 0.5 * F.cross_entropy(logits.t(), lab, reduction="none")
+    (ref * w.double()).sum().backward()
+    qd, pd = q0.to(dev).requires_grad_(), p0.to(dev).requires_grad_()
+    out = InfoNCE(temperature=T, reduction="none")(qd, pd, symmetric=sym)
+    assert tuple(out.shape) == (k,)
+    (out * w.to(dev)).sum().backward()
+    assert rel_err(out, ref) < 1e-5
+    assert rel_err(qd.grad, q.grad) < 1e-4 and rel_err(pd.grad, p.grad) < 1e-4
+    s = InfoNCE(temperature=T, reduction="sum")(q0.to(dev), p0.to(dev), symmetric=sym)
+    assert abs(float(s) - float(ref.sum())) < 1e-5 * float(ref.sum())
+    with pytest.raises(ValueError):
+        InfoNCE(reduction="median")(q0.to(dev), p0.to(dev))
+
+
 def test_infonce_errors(dev):
     from madeleine_amd import InfoNCE
     crit = InfoNCE()

@@ -135,3 +135,34 @@ def test_dataset_collate_contract():
     assert len(item["feats"]) == 5 and item["feats"][0].shape == (8, 16) and item["modality_labels"][0] == 1
     for m, lab in enumerate(item["modality_labels"]):
         assert (float(item["feats"][m].abs().sum()) == 0.0) == (lab == 0)
+
+
+def test_h5_feature_files_without_h5py(tmp_path):
+    """N4: `load_features` (wsi_dataset.py:14-19) reads the chunked / resizable `features` datasets save_hdf5 writes
+    (conch_patch_embedder.py:16-66) through the ctypes binding of the system's libhdf5, and SlideDataset + collate produce the
+    reference's batch contract from real .h5 files (present stain -> file, absent stain -> zero bag, fixed-N resample)."""
+    import numpy as np
+    import pandas as pd
+    from madeleine_amd import h5io
+    from madeleine_amd.data import SlideDataset, collate, load_features
+    rng = np.random.default_rng(0)
+    D = 32
+    feats = {("c0", "HE"): rng.standard_normal((50, 1, D)).astype(np.float32),      # [N,1,D]: squeezed by the loader
+             ("c0", "ER"): rng.standard_normal((7, D)).astype(np.float32),           # shorter than `sample`: randint resample
+             ("c1", "HE"): rng.standard_normal((40, D)).astype(np.float32)}
+    for (cid, m), a in feats.items():
+        h5io.write_datasets(str(tmp_path / f"{cid}_{m}.h5"), {"features": a, "coords": np.zeros((a.shape[0], 2), np.float32)})
+    got = load_features(str(tmp_path / "c0_HE.h5"))
+    assert got.dtype == torch.float32 and tuple(got.shape) == (50, D)
+    assert torch.equal(got, torch.from_numpy(feats[("c0", "HE")].squeeze()))
+    with pytest.raises(KeyError):
+        h5io.read_dataset(str(tmp_path / "c0_HE.h5"), "nope")
+    df = pd.DataFrame({"slide_id": ["c0", "c1"], "HE": [1, 1], "ER": [1, 0], "split": ["train", "train"]})
+    ds = SlideDataset("toy", None, str(tmp_path), ["HE", "ER"], embedding_size=D, sample=16, train=True, dataframe=df)
+    torch.manual_seed(0)
+    batch = collate([ds[0], ds[1]])
+    assert tuple(batch["feats"].shape) == (2, 2, 16, D) and batch["slide_ids"] == ["c0", "c1"]
+    assert torch.equal(batch["modality_labels"], torch.tensor([[1.0, 1.0], [1.0, 0.0]]))
+    assert float(batch["feats"][1, 1].abs().max()) == 0.0                             # absent stain -> zero bag
+    rows = {tuple(r.tolist()) for r in torch.from_numpy(feats[("c0", "ER")])}
+    assert all(tuple(r.tolist()) in rows for r in batch["feats"][0, 1])               # resampled rows come from the file

@@ -368,6 +368,20 @@ def test_device_prefetcher(dev):
         assert torch.equal(g["modality_labels"], r["modality_labels"]) and g["slide_ids"] == r["slide_ids"]
 
 
+def test_device_prefetcher_drops_absent_bags(dev):
+    """N4: with drop_absent only the present bags cross PCIe; the device batch equals the collate()d one bit for bit."""
+    from torch.utils.data import DataLoader
+    from madeleine_amd.data import DevicePrefetcher, SyntheticSlideDataset, collate
+    ds = SyntheticSlideDataset(9, MODS5[:4], 48, 32, seed=5)
+    ref = list(DataLoader(ds, batch_size=4, shuffle=False, collate_fn=collate, num_workers=0))
+    assert any(float(r["modality_labels"].min()) == 0.0 for r in ref)                # some stains really are absent
+    got = list(DevicePrefetcher(DataLoader(ds, batch_size=4, shuffle=False, collate_fn=collate, num_workers=0), dev, depth=2,
+                                drop_absent=True))
+    assert len(got) == len(ref)
+    for g, r in zip(got, ref):
+        assert g["feats"].is_cuda and torch.equal(g["feats"].cpu(), r["feats"])
+
+
 @pytest.mark.parametrize("stain_encoding", [False, True])
 def test_skip_absent_stains_matches_full_encode(dev, stain_encoding):
     """N4: with config.skip_absent_stains the all-zero bags of absent stains are encoded once per distinct input and shared;
