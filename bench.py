@@ -83,6 +83,47 @@ def pool_traffic_from_profiles(tokens_c2=64 * 4096):
     return int((2.0 * f + w) * 1024)
 
 
+def measure_pool_traffic(timeout_s=150):
+    """HBM bytes per launch of the A3 forward MEASURED IN THIS RUN: two short rocprofv3 passes (`--pmc FETCH_SIZE`, `--pmc
+    WRITE_SIZE`; separate passes, kernel-trace only -- MI355X_MICROARCH.md, HBM section) over tools/prof_kernels.py --only pool
+    (config-2 geometry), read back from the rocpd database.  FETCH_SIZE is in KiB and on gfx950 counts half of a wide coalesced
+    read stream -> x2.  Returns (bytes, provenance) or (None, reason)."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="mdl_pmc_", dir="/tmp")
+        try:
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run([exe, "--pmc", counter, "--kernel-trace", "-d", d, "--", sys.executable,
+                                os.path.join(ROOT, "tools", "prof_kernels.py"), "--iters", "2", "--only", "pool"],
+                               cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            dbs = glob.glob(os.path.join(d, "*", "*.db"))
+            if r.returncode != 0 or not dbs:
+                return None, "rocprofv3 --pmc %s failed (rc %d)" % (counter, r.returncode)
+            c = sqlite3.connect(dbs[0])
+            rows = c.execute("""select s.kernel_name, avg(e.value) from rocpd_pmc_event e join rocpd_info_pmc p on e.pmc_id = p.id
+                                join rocpd_kernel_dispatch d on d.event_id = e.event_id
+                                join rocpd_info_kernel_symbol s on d.kernel_id = s.id
+                                where p.name = ? group by s.kernel_name""", (counter,)).fetchall()
+            tot = sum(v for k, v in rows if ("pool_partial_kernel" in k or "pool_combine_kernel" in k))
+            if tot <= 0:
+                return None, "no %s samples for the pool kernels" % counter
+            vals[counter] = tot
+        except Exception as e:  # timeout, sqlite schema, ...
+            return None, "%s: %s" % (type(e).__name__, e)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), \
+        "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (2 passes) over tools/prof_kernels.py --only pool; 2 x FETCH + WRITE"
+
+
 def cpu_baseline(B_sample, M, N, D, use_got, steps=2):
     """Times the CPU oracle's full step (fwd + losses + bwd + AdamW, train-mode dropout) on B_sample slides."""
     from oracle import restatement as R
@@ -114,6 +155,79 @@ def cpu_baseline(B_sample, M, N, D, use_got, steps=2):
                       f"train-mode dropout, median of {steps} after 1 warm-up; {med:.2f} s/step"}
 
 
+def secondary_c3_leg(dev, D, MF, InfoNCE, MADELEINE, steps=5, warmup=2):
+    """BASELINE configs[2] as a short secondary measurement beside the headline: 32 slides x 5 stains (ACROBAT presence rates,
+    absent stain = all-zero bag) x 4096 x 512, global InfoNCE + local GOT (IPOT Wasserstein + Gromov-Wasserstein, n = k <= 32
+    tokens), AdamW, train mode.  The headline workload (c2) has no GOT: this leg is where the GOT kernels are timed."""
+    B, M, N, Dm, _, _ = CONFIGS["c3"]
+    mods = MODS5[:M]
+    torch.manual_seed(42)
+    model = MADELEINE(make_cfg(M, Dm)).to(dev).train()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
+    gen = torch.Generator(device=dev).manual_seed(1234)
+    feats = torch.randn(B, M, N, Dm, device=dev, generator=gen)
+    rates = torch.tensor([1.0, 0.46, 0.73, 0.73, 0.73])
+    labels = (torch.rand(B, M, generator=torch.Generator().manual_seed(77)) < rates).float()
+    labels[:, 0] = 1
+    feats = feats * labels.to(dev)[:, :, None, None]
+    data = {"feats": feats, "modality_labels": labels}
+    crit = InfoNCE(temperature=0.001)
+    largs = SimpleNamespace(global_loss="info-nce", symmetric_cl=True, local_loss_weight=1.0)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        embs, toks = model(data, device=dev)
+        loss, _ = D.calculate_losses_dp(mods[1:], crit, MF.HipGotImpl, embs, toks, labels[:, 1:], largs)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    MF.TIMER = MF.KernelTimer()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    prof = MF.TIMER.report()
+    MF.TIMER = None
+    k = [int(labels[:, s].sum()) for s in range(1, M)]
+    return {"value": round(B * steps / el, 3), "unit": "slides/s", "ms_per_step": round(1e3 * el / steps, 3), "steps": steps,
+            "workload": f"c3: {B} slides x {M} stains (cases per stain {k}) x {N} x {Dm}, InfoNCE + GOT, train mode, AdamW",
+            "final_loss": float(loss.detach()),
+            "kernel_ms": {n: round(v[0], 4) for n, v in prof.items()}, "kernel_calls_per_step": {n: v[1] // steps for n, v in prof.items()}}
+
+
+def secondary_inference_leg(dev, MF, MADELEINE, n_patches=30000, bags=20):
+    """slide-embedding extraction as utils.run_inference drives it -- one full bag per call
+    (batch 1, no gradients, nothing saved for backward) through encode_he."""
+    torch.manual_seed(42)
+    model = MADELEINE(make_cfg(2, 512)).to(dev).eval()
+    gen = torch.Generator(device=dev).manual_seed(99)
+    bag = torch.randn(1, n_patches, 512, device=dev, generator=gen)
+    with torch.no_grad():
+        for _ in range(3):
+            model.encode_he(bag, dev)
+        torch.cuda.synchronize()
+        MF.TIMER = MF.KernelTimer()
+        t0 = time.perf_counter()
+        for _ in range(bags):
+            model.encode_he(bag, dev)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+    prof = MF.TIMER.report()
+    MF.TIMER = None
+    out = {"value": round(bags / el, 2), "unit": "bags/s", "ms_per_bag": round(1e3 * el / bags, 3), "patches_per_bag": n_patches,
+           "patches_per_sec": round(bags * n_patches / el), "workload": "encode_he, batch 1, fp32, no_grad",
+           "kernel_ms": {n: round(v[0], 4) for n, v in prof.items()}}
+    if "pool_fwd" in prof:
+        alg = n_patches * (4 * 512 * 4 + 4 * 4) + 4 * 512 * 4
+        out["pool_fwd_GBs"] = round(alg / (prof["pool_fwd"][0] * 1e-3) / 1e9, 1)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -130,6 +244,8 @@ def main():
                     help="float32 = the parity path (headline value).  bfloat16 = the reference's `precision: bfloat16` "
                          "runs: forward + losses under torch.autocast, bf16 activation storage + bf16 MFMA in the kernels")
     ap.add_argument("--no-bf16-leg", action="store_true", help="skip the short secondary bf16-mode measurement")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 PMC passes behind roofline.traffic")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the secondary c3 (5 stains + GOT) and inference legs")
     ap.add_argument("--skip-absent", action="store_true",
                     help="SURVEY 8(f) N4: encode the all-zero bag of an absent stain once instead of once per case (c3/c4 "
                          "mask stains with ACROBAT's presence rates; no effect on c2).  Off by default: the reference encodes them all")
@@ -255,6 +371,16 @@ def main():
     if host_iter is not None:
         host_iter.close()   # stops and joins the stager thread
 
+    c3_leg = infer_leg = None
+    if a.config == "c2" and a.precision == "float32" and world == 1 and not a.no_extra_legs and host_iter is None:
+        # free the c2 working set first (the c3 step keeps ~60 GiB live)
+        feats = data = None
+        torch.cuda.empty_cache()
+        c3_leg = secondary_c3_leg(dev, D, MF, InfoNCE, MADELEINE)
+        torch.cuda.empty_cache()
+        infer_leg = secondary_inference_leg(dev, MF, MADELEINE)
+        torch.cuda.empty_cache()
+
     tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -288,10 +414,17 @@ def main():
             esz = 4 if a.precision == "float32" else 2
             alg = tokens * (H * 512 * esz + H * 4) + B * M * H * 512 * 4
             ach = alg / (ms * 1e-3) / 1e9
+            traffic, traffic_src = None, "not collected (only for c2 at N=1)"
+            if a.config == "c2" and world == 1 and a.precision == "float32":
+                if not a.no_pmc:
+                    traffic, traffic_src = measure_pool_traffic()
+                if traffic is None:
+                    why = traffic_src
+                    traffic = pool_traffic_from_profiles()
+                    traffic_src = "committed PMC passes profiles/*_pool_pmc_{fetch,write}.txt (in-run collection: %s)" % why
             out["roofline"] = {"kernel": "abmil_pool_fwd (pool_partial + pool_combine)", "bound": "hbm",
                                "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(ach / HBM_PEAK_GBS, 4),
-                               "traffic": pool_traffic_from_profiles() if (a.config == "c2" and world == 1) else None,
+                               "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                                "algorithmic_bytes_per_launch": alg, "avg_ms": round(ms, 4), "launches": n}
         if "gate_fwd" in prof and "gate_bwd" in prof:
             msf, _ = prof["gate_fwd"]
@@ -309,6 +442,10 @@ def main():
         out["kernel_ms"] = {k: round(v[0], 4) for k, v in prof.items()}
         if bf16_leg is not None:
             out["bf16_mode"] = bf16_leg
+        if c3_leg is not None:
+            out["c3_mode"] = c3_leg
+        if infer_leg is not None:
+            out["inference_mode"] = infer_leg
         if world == 1 and not a.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(min(a.cpu_sample, B), M, N, Dm, use_got)
