@@ -148,6 +148,23 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const uint16_t* __r
 // ================================================================================================
 // forward
 // ================================================================================================
+// DM: dropout mode 0 = off, 1 = counter-hash RNG, 2 = explicit uint8 masks; SAVE: store the activations (one code path per
+// instantiation keeps the unrolled epilogue inside the register budget).
+template <int DM>
+__device__ __forceinline__ void fwd_keep2_bf16(const DropCfg& d, int64_t idx, bool& ka, bool& kb) {
+    if (DM == 0) {
+        ka = kb = true;
+    } else if (DM == 2) {
+        ka = d.ka[idx] != 0;
+        kb = d.kb[idx] != 0;
+    } else {
+        const uint32_t h = rng_u32(d.key, (uint64_t)idx);
+        ka = (h & 0xFFFFu) >= d.thr;
+        kb = (h >> 16) >= d.thr;
+    }
+}
+
+template <int DM, bool SAVE>
 __global__ __launch_bounds__(256, 2) void gate_fwd_bf16_kernel(const bf16_t* __restrict__ E, int64_t ldE,
                                                                const bf16_t* __restrict__ WK, const float* __restrict__ ba,
                                                                const float* __restrict__ bb, const float* __restrict__ wc,
@@ -194,56 +211,67 @@ __global__ __launch_bounds__(256, 2) void gate_fwd_bf16_kernel(const bf16_t* __r
     zero_acc8(acc);
     nt_mainloop(sm, acc, HID / BBK, issue, offA, offB);
 
-    // ---- epilogue: activations (rounded to bf16 like the stored copies the backward re-reads), dropout, wc row sums ----
+    // ---- epilogue: 4 passes (rt, ct) of a 32-row x (32 a | 32 b)-column block through a wave-private LDS tile.
+    // (1) accumulator layout: a = tanh(za + ba), b = sigmoid(zb + bb), rounded to bf16 like the stored copies the backward
+    //     re-reads -> tile;  (2) transposed layout, lane = (row = lane >> 2, 8 columns): 16-B stores of the activations (the
+    //     accumulator layout gives 2-byte stores 64 B apart), dropout, wc-weighted partial sum reduced over the row's 4 lanes.
     const int l32 = lane & 31;
-    float* sred = reinterpret_cast<float*>(&sm.A[0][0]);  // [2 (wn)][128 rows]
-    float bav[2], bbv[2], wcv[2];
+    float* tile = reinterpret_cast<float*>(&sm) + wave * (32 * 64);
+    float* sred = reinterpret_cast<float*>(&sm) + 4 * (32 * 64) + wn * BBM + wm * 64;   // [2 (wn)][128 rows]
+    const int g4 = lane & 3, r16 = lane >> 2;
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-        const int j = j0 + wn * 64 + ct * 32 + l32;
-        bav[ct] = ba[c * HID + j];
-        bbv[ct] = bb[c * HID + j];
-        wcv[ct] = wc[c * HID + j];
-    }
+    for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-        float ps[16];
+        for (int ct = 0; ct < 2; ++ct) {
+            const int jc = j0 + wn * 64 + ct * 32;                 // first gate column of this pass
+            const float bav = ba[c * HID + jc + l32], bbv = bb[c * HID + jc + l32];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int64_t t = t0 + wm * 64 + rt * 32 + acc_row(r, lane);
-            float sum = 0.f;
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) {
-                const bf16_t ah = (bf16_t)fast_tanh(acc[rt][ct][r] + bav[ct]);
-                const bf16_t bh = (bf16_t)fast_sigmoid(acc[rt][2 + ct][r] + bbv[ct]);
-                const float a = (float)ah, b = (float)bh;
-                if (t < T) {
-                    const int64_t idx = (t * H + c) * HID + j0 + wn * 64 + ct * 32 + l32;
-                    if (act_a) {
-                        act_a[idx] = ah;
-                        act_b[idx] = bh;
-                    }
-                    bool keep_a, keep_b;
-                    drop_keep2(drop, idx, keep_a, keep_b);
-                    const float ad = keep_a ? a * drop.inv : 0.f;
-                    const float bd = keep_b ? b * drop.inv : 0.f;
-                    sum += ad * bd * wcv[ct];
-                }
+            for (int r = 0; r < 16; ++r) {
+                tile[acc_row(r, lane) * 64 + l32] = (float)(bf16_t)fast_tanh(acc[rt][ct][r] + bav);
+                tile[acc_row(r, lane) * 64 + 32 + l32] = (float)(bf16_t)fast_sigmoid(acc[rt][2 + ct][r] + bbv);
+                if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
-            ps[r] = sum;
-        }
+            const f32x4 wlo = *reinterpret_cast<const f32x4*>(wc + c * HID + jc + g4 * 8);
+            const f32x4 whi = *reinterpret_cast<const f32x4*>(wc + c * HID + jc + g4 * 8 + 4);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float v = ps[r];
+            for (int i = 0; i < 2; ++i) {
+                const int row = i * 16 + r16;
+                const f32x4 alo = *reinterpret_cast<const f32x4*>(&tile[row * 64 + g4 * 8]);
+                const f32x4 ahi = *reinterpret_cast<const f32x4*>(&tile[row * 64 + g4 * 8 + 4]);
+                const f32x4 blo = *reinterpret_cast<const f32x4*>(&tile[row * 64 + 32 + g4 * 8]);
+                const f32x4 bhi = *reinterpret_cast<const f32x4*>(&tile[row * 64 + 32 + g4 * 8 + 4]);
+                float sum = 0.f;
+                if (t0 + wm * 64 + rt * 32 + row < T) {
+                    const int64_t idx = ((t0 + wm * 64 + rt * 32) * H + c) * HID + jc + (uint32_t)(row * H * HID + g4 * 8);
+                    if (SAVE) {
+                        st8_bf16(act_a + idx, alo, ahi);
+                        st8_bf16(act_b + idx, blo, bhi);
+                    }
 #pragma unroll
-            for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-            if (l32 == 0) sred[wn * BBM + wm * 64 + rt * 32 + acc_row(r, lane)] = v;
+                    for (int e = 0; e < 8; ++e) {
+                        bool keep_a, keep_b;
+                        fwd_keep2_bf16<DM>(drop, idx + e, keep_a, keep_b);
+                        const float a = e < 4 ? alo[e & 3] : ahi[e & 3], b = e < 4 ? blo[e & 3] : bhi[e & 3];
+                        const float w = e < 4 ? wlo[e & 3] : whi[e & 3];
+                        const float ad = keep_a ? a * drop.inv : 0.f;
+                        const float bd = keep_b ? b * drop.inv : 0.f;
+                        sum += ad * bd * w;
+                    }
+                }
+                sum += __shfl_xor(sum, 1, 64);
+                sum += __shfl_xor(sum, 2, 64);
+                if (g4 == 0) {
+                    if (ct == 0) sred[rt * 32 + row] = sum;
+                    else sred[rt * 32 + row] += sum;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-    }
     __syncthreads();
     if (tid < BBM) {
         const int64_t t = t0 + tid;
-        if (t < T) part[(t * H + c) * GATE_JT + jt] = sred[tid] + sred[BBM + tid];
+        const float* sr = reinterpret_cast<const float*>(&sm) + 4 * (32 * 64);
+        if (t < T) part[(t * H + c) * GATE_JT + jt] = sr[tid] + sr[BBM + tid];
     }
 }
 
@@ -292,30 +320,34 @@ __global__ __launch_bounds__(256, 2) void gate_dx_bf16_kernel(const bf16_t* __re
     zero_acc8(acc);
     nt_mainloop(sm, acc, 1024 / BBK, issue, offA, offB);
 
-    const int l32 = lane & 31;
+    // dE (bf16) leaves through the LDS transpose: 8 columns = one 16-B store per lane, 128 contiguous bytes per row
+    float* tile = reinterpret_cast<float*>(&sm) + wave * (32 * 64);
+    bf16_t* ob = dE + t0 * ldE + (int64_t)c * HID + n0;
+    auto emit = [&](int row_u, int rl, int lane_col, const f32x4& lo, const f32x4& hi, int) {
+        bf16_t* o = ob + (int64_t)row_u * ldE + ((uint32_t)rl * (uint32_t)ldE + (uint32_t)lane_col);
+        f32x4 a = lo, b = hi;
+        if (pt.scores) {  // fused A3 term: + w[t,c] * d_pooled[bag(t), c, :]
+            int bag;
+            const float w = pool_term_weight(pt, t0 + row_u + rl, c, H, bag);
+            const float* __restrict__ dp = pt.d_pooled + ((int64_t)bag * H + c) * HID + n0 + lane_col;
+            const f32x4 d0 = *reinterpret_cast<const f32x4*>(dp), d1 = *reinterpret_cast<const f32x4*>(dp + 4);
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+            for (int i = 0; i < 4; ++i) {
+                a[i] = fmaf(w, d0[i], lo[i]);
+                b[i] = fmaf(w, d1[i], hi[i]);
+            }
+        } else if (accumulate) {
+            const bf16x8 old = *reinterpret_cast<const bf16x8*>(o);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int64_t t = t0 + wm * 64 + rt * 32 + acc_row(r, lane);
-            if (t < T) {
-                bf16_t* __restrict__ o = dE + t * ldE + (int64_t)c * HID + n0 + l32;
-                if (pt.scores) {  // fused A3 term: + w[t,c] * d_pooled[bag(t), c, :]
-                    int bag;
-                    const float w = pool_term_weight(pt, t, c, H, bag);
-                    const float* __restrict__ dp = pt.d_pooled + ((int64_t)bag * H + c) * HID + n0 + l32;
-#pragma unroll
-                    for (int ct = 0; ct < 4; ++ct) o[colb[ct]] = (bf16_t)fmaf(w, dp[colb[ct]], acc[rt][ct][r]);
-                } else {
-#pragma unroll
-                    for (int ct = 0; ct < 4; ++ct) {
-                        float v = acc[rt][ct][r];
-                        if (accumulate) v += (float)o[colb[ct]];
-                        o[colb[ct]] = (bf16_t)v;
-                    }
-                }
+            for (int i = 0; i < 4; ++i) {
+                a[i] += (float)old[i];
+                b[i] += (float)old[4 + i];
             }
         }
+        st8_bf16(o, a, b);
+    };
+    if (t0 + BBM <= T) epilogue_rows8<true>(acc, tile, wm, colb, lane, BBM, emit);
+    else epilogue_rows8<false>(acc, tile, wm, colb, lane, (int)(T - t0), emit);
 }
 
 // ================================================================================================
@@ -432,8 +464,20 @@ extern "C" int mdl_abmil_gate_fwd_bf16(const uint16_t* E, int64_t ldE, const flo
     float* part = (float*)((char*)ws + (int64_t)H * 1024 * HID * 2);
     hipLaunchKernelGGL(gate_wk_bf16_kernel, dim3((unsigned)((int64_t)H * 1024 * HID / 4 / 256)), dim3(256), 0, s, Wa, Wb, WK, H);
     MDL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gate_fwd_bf16_kernel, dim3((unsigned)grid), dim3(256), 0, s, (const bf16_t*)E, ldE, (const bf16_t*)WK, ba, bb,
-                       wc, part, (bf16_t*)act_a, (bf16_t*)act_b, T, H, (int)n_tt, d);
+    const int dm = !d.on ? 0 : (d.ka ? 2 : 1);
+#define MDL_GATE_FWD16(DM, SAVE)                                                                                                   \
+    hipLaunchKernelGGL((gate_fwd_bf16_kernel<DM, SAVE>), dim3((unsigned)grid), dim3(256), 0, s, (const bf16_t*)E, ldE, (const bf16_t*)WK, \
+                       ba, bb, wc, part, (bf16_t*)act_a, (bf16_t*)act_b, T, H, (int)n_tt, d)
+    if (act_a) {
+        if (dm == 0) MDL_GATE_FWD16(0, true);
+        else if (dm == 1) MDL_GATE_FWD16(1, true);
+        else MDL_GATE_FWD16(2, true);
+    } else {
+        if (dm == 0) MDL_GATE_FWD16(0, false);
+        else if (dm == 1) MDL_GATE_FWD16(1, false);
+        else MDL_GATE_FWD16(2, false);
+    }
+#undef MDL_GATE_FWD16
     MDL_LAUNCH_CHECK();
     return gate_launch_finalize(part, bc, scores, T * H, H, s);
 }

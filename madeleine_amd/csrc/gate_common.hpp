@@ -176,6 +176,45 @@ __device__ __forceinline__ float pool_term_weight(const PoolTerm& pt, int64_t t,
     return expf(pt.scores[t * H + c] - pt.stat_m[(int64_t)bag * H + c]) * (1.f / pt.stat_l[(int64_t)bag * H + c]);
 }
 
+// Epilogue through LDS for 2-byte outputs (bf16 mode): the 32x32 MFMA layout gives a lane one COLUMN of 16 rows, i.e. 2-byte
+// stores 64 B apart; a wave-private [32][64] fp32 transpose tile turns the wave's 64 x 128 sub-tile into row-contiguous groups
+// of 8 columns per lane: emit(row_u, rl, lane_col, lo, hi, cp) gets columns lane_col .. +7 (tile coordinates through colb) of
+// tile row row_u + rl (row_u wave-uniform, rl = lane >> 3) as two float4 -> one 16-B store of 8 bf16; 8 lanes cover 128
+// contiguous bytes of a row.  `tile` = 2048 floats private to the wave, in staging memory that is free (main loop done).
+template <bool FULL, class Emit>
+__device__ __forceinline__ void epilogue_rows8(const f32x16 (&acc)[2][4], float* tile, int wm, const int (&colb)[4], int lane,
+                                               int rows_valid, Emit&& emit) {
+    const int l32 = lane & 31, rl = lane >> 3, g = lane & 7;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int cp = 0; cp < 2; ++cp) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) tile[acc_row(r, lane) * 64 + c2 * 32 + l32] = acc[rt][cp * 2 + c2][r];
+            const int lane_col = ((g >> 2) ? colb[cp * 2 + 1] : colb[cp * 2]) + (g & 3) * 8;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(&tile[(i * 8 + rl) * 64 + g * 8]);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(&tile[(i * 8 + rl) * 64 + g * 8 + 4]);
+                const int row_u = wm * 64 + rt * 32 + i * 8;
+                if (FULL || row_u + rl < rows_valid) emit(row_u, rl, lane_col, lo, hi, cp);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+}
+__device__ __forceinline__ void st8_bf16(bf16_t* p, const f32x4& lo, const f32x4& hi) {   // p 16-B aligned
+    typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
+    bf16x8v o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        o[i] = (bf16_t)lo[i];
+        o[4 + i] = (bf16_t)hi[i];
+    }
+    *reinterpret_cast<bf16x8v*>(p) = o;
+}
+
 // launchers of the reduction / finalize kernels defined in abmil_gate.hip (shared with the bf16 path)
 int gate_launch_finalize(const float* part, const float* bc, float* scores, int64_t n, int H, hipStream_t s);
 int gate_launch_reduce_w(const float* slabW, float* dWa, float* dWb, int H, int S, hipStream_t s);

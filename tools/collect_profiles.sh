@@ -1,8 +1,10 @@
 #!/bin/bash
-# Runs on the GPU box (gpurun): rocprofv3 passes over bench.py / tools/prof_kernels.py, summarised to text under
-# gpurun_out/prof_txt/ (the rocpd .db files are too big to travel back).  Usage: bash tools/collect_profiles.sh <tag>
+# Runs on the GPU box (gpurun): rocprofv3 passes over bench.py / tools/prof_kernels.py / tools/bench_got.py, summarised to text
+# under gpurun_out/prof_txt/ (the rocpd .db files are too big to travel back).  Usage: bash tools/collect_profiles.sh <tag> [what]
+# PMC passes use --kernel-trace only (gpurun refuses --pmc combined with other trace domains).
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
+WHAT=${2:-all}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof_txt
 mkdir -p $OUT
@@ -14,11 +16,24 @@ run() {  # name, summary-top-n, rocprof args..., -- command
     { echo "# $TAG $name: rocprofv3 $*" | sed "s#$R/##g"; python $R/tools/rocpd_summary.py /tmp/prof_$name/*/*.db $top; } > $OUT/${TAG}_$name.txt 2>&1
     rm -rf /tmp/prof_$name
 }
-run bench_c2_kernel_stats 40 --kernel-trace --stats -d /tmp/prof_bench_c2_kernel_stats -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-bf16-leg
-run bench_c2_bf16_kernel_stats 45 --kernel-trace --stats -d /tmp/prof_bench_c2_bf16_kernel_stats -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-bf16-leg --precision bfloat16
+B="--no-cpu-baseline --no-bf16-leg --no-pmc --no-extra-legs"
+if [ $WHAT = all ] || [ $WHAT = bench ]; then
+run bench_c2_kernel_stats 40 --kernel-trace --stats -d /tmp/prof_bench_c2_kernel_stats -- python $R/bench.py --steps 3 --warmup 1 $B
+run bench_c2_bf16_kernel_stats 45 --kernel-trace --stats -d /tmp/prof_bench_c2_bf16_kernel_stats -- python $R/bench.py --steps 3 --warmup 1 $B --precision bfloat16
+run bench_c3_kernel_stats 50 --kernel-trace --stats -d /tmp/prof_bench_c3_kernel_stats -- python $R/bench.py --config c3 --steps 3 --warmup 1 $B
+fi
+if [ $WHAT = all ] || [ $WHAT = kernels ]; then
 run kernels_c2_stats 25 --kernel-trace --stats -d /tmp/prof_kernels_c2_stats -- python $R/tools/prof_kernels.py --iters 5
 run pool_pmc_fetch 8 --pmc FETCH_SIZE --kernel-trace -d /tmp/prof_pool_pmc_fetch -- python $R/tools/prof_kernels.py --iters 2 --only pool
 run pool_pmc_write 8 --pmc WRITE_SIZE --kernel-trace -d /tmp/prof_pool_pmc_write -- python $R/tools/prof_kernels.py --iters 2 --only pool
 run gate_pmc_sq 40 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES --kernel-trace -d /tmp/prof_gate_pmc_sq -- python $R/tools/prof_kernels.py --iters 1 --only gate
 run gate_pmc_tcc 40 --pmc TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE --kernel-trace -d /tmp/prof_gate_pmc_tcc -- python $R/tools/prof_kernels.py --iters 1 --only gate
+fi
+if [ $WHAT = all ] || [ $WHAT = got ]; then
+# GOT kernels alone (tools/bench_got.py: k = 32 cases, n = 32 .. 256 tokens, fwd + bwd): durations, then SQ / memory counters
+run got_kernel_stats 40 --kernel-trace --stats -d /tmp/prof_got_kernel_stats -- python $R/tools/bench_got.py
+run got_pmc_sq 40 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES --kernel-trace -d /tmp/prof_got_pmc_sq -- python $R/tools/bench_got.py
+run got_pmc_fetch 40 --pmc FETCH_SIZE TCC_HIT_sum --kernel-trace -d /tmp/prof_got_pmc_fetch -- python $R/tools/bench_got.py
+run got_pmc_write 40 --pmc WRITE_SIZE --kernel-trace -d /tmp/prof_got_pmc_write -- python $R/tools/bench_got.py
+fi
 ls -la $OUT

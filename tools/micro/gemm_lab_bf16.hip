@@ -1,0 +1,344 @@
+// gemm_lab_bf16.hip -- standalone A/B of the bf16 "NT" tile engine:  C[m, n] (fp32) = sum_k A[m][k] B[n][k], bf16 operands,
+// v_mfma_f32_32x32x16_bf16.  Gate-forward shape: M = 262144 tokens, N = 1024 ([Wa;Wb] rows of one head), K = 512.
+//   v0  the round-1 engine shape: 128 x 256 tile, BK = 32, 4 waves, barrier + DMA issue block per 16 MFMAs
+//   v1  256 x 256 tile, BK = 64, 8 waves (2 x 4, 128 x 64 per wave), 2 LDS stages of 64 KiB, software-pipelined like the
+//       fp32 engine (tile_engine.hpp): fragments of k-step s+1 requested after the first MFMA of step s, the chunk barrier
+//       before the last k-step, the next chunk's 8 LDS-DMA pieces between that step's MFMAs, saddr-form DMA.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 gemm_lab_bf16.hip -o gemm_lab_bf16
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void glds16_s(uint32_t voff, const void* sbase, uint32_t lds_addr) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_addr)
+                 : "memory");
+}
+__device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+}
+__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+#define DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define SB() __builtin_amdgcn_sched_barrier(0)
+
+// ------------------------------------------------------------------------------------------------------------------
+// v1: 256 x 256 x 64
+// LDS image of one operand stage: [256 rows][64 k] bf16 = 128 B per row, 16-B chunk c of row r stored at chunk position
+// c ^ ((r >> 1) & 7): with the 128-B row stride a ds_read_b128 lane group (16 lanes, rows r..) then touches 16 distinct
+// 16-B slots of the 256-B bank row -> conflict-free.
+constexpr int PM = 256, PN = 256, PK = 64;
+constexpr int STAGE_BYTES = PM * PK * 2;   // 32 KiB per operand per stage
+struct SmemP {
+    char A[2][STAGE_BYTES];
+    char B[2][STAGE_BYTES];
+};
+
+template <int EPI>
+__device__ __forceinline__ void nt256_body(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
+                                           float* __restrict__ C, int64_t ldc, int64_t M, int N, int K, SmemP& sm) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;   // 2 x 4: rows wm*128 + rt*32 (rt < 4), columns wn*64 + ct*32 (ct < 2)
+    const int ncol = N / PN;
+    const int nt = blockIdx.x % ncol;
+    const int64_t m0 = (int64_t)(blockIdx.x / ncol) * PM;
+    const int n0 = nt * PN;
+    const int l32 = lane & 31, kh = lane >> 5;
+
+    // DMA: one instruction = 8 rows x 128 B; wave w issues row blocks 4w .. 4w+3 of each operand (256 rows = 32 blocks)
+    const char* baseA = reinterpret_cast<const char*>(A + m0 * lda);
+    const char* baseB = reinterpret_cast<const char*>(B + (int64_t)n0 * ldb);
+    uint32_t voA[4], voB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        int64_t ra = row;
+        if (m0 + ra > M - 1) ra = M - 1 - m0;
+        voA[i] = (uint32_t)(ra * lda * 2 + c * 16);
+        voB[i] = (uint32_t)((int64_t)row * ldb * 2 + c * 16);
+    }
+    auto dma = [&](int st, int f, int piece) {   // piece 0..7: 0-3 = A row blocks, 4-7 = B row blocks
+        const int i = piece & 3;
+        if (piece < 4) glds16_s(voA[i], baseA + (int64_t)f * (PK * 2), lds_addr_of(&sm.A[st][(wave * 4 + i) * 1024]));
+        else glds16_s(voB[i], baseB + (int64_t)f * (PK * 2), lds_addr_of(&sm.B[st][(wave * 4 + i) * 1024]));
+    };
+    // fragment addresses (stage 0, k-step 0); k-step ks: ^ (ks << 5); stage: + st * STAGE_BYTES
+    uint32_t offA[4], offB[2];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+        const int r = wm * 128 + rt * 32 + l32;
+        offA[rt] = r * 128 + ((kh ^ ((r >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        const int r = wn * 64 + ct * 32 + l32;
+        offB[ct] = r * 128 + ((kh ^ ((r >> 1) & 7)) << 4);
+    }
+    bf16x8 fa0[4], fb0[2], fa1[4], fb1[2];
+    auto ld = [&](bf16x8 (&fa)[4], bf16x8 (&fb)[2], int st, int ks) {
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) fa[rt] = *reinterpret_cast<const bf16x8*>(&sm.A[st][offA[rt] ^ (ks << 5)]);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) fb[ct] = *reinterpret_cast<const bf16x8*>(&sm.B[st][offB[ct] ^ (ks << 5)]);
+    };
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    auto mma1 = [&](const bf16x8 (&fa)[4], const bf16x8 (&fb)[2], int m) {
+        const int rt = m >> 1, ct = m & 1;
+        acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[rt], fb[ct], acc[rt][ct], 0, 0, 0);
+    };
+#define KSTEP(FA, FB, LOADS)                                                    \
+    mma1(FA, FB, 0);                                                            \
+    SB();                                                                       \
+    LOADS;                                                                      \
+    SB();                                                                       \
+    _Pragma("unroll") for (int m = 1; m < 8; ++m) mma1(FA, FB, m);              \
+    SB();
+    const int nch = K / PK;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) dma(0, 0, p);
+    DMA_WAIT();
+    __syncthreads();
+    {
+        const int f = nch > 1 ? 1 : 0;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) dma(1, f, p);
+    }
+    ld(fa0, fb0, 0, 0);
+    for (int ch = 0; ch < nch; ++ch) {
+        const int st = ch & 1;
+        KSTEP(fa0, fb0, ld(fa1, fb1, st, 1))
+        KSTEP(fa1, fb1, ld(fa0, fb0, st, 2))
+        KSTEP(fa0, fb0, ld(fa1, fb1, st, 3))
+        DMA_WAIT();
+        __syncthreads();
+        ld(fa0, fb0, st ^ 1, 0);
+        SB();
+        const int f = (ch + 2 < nch) ? ch + 2 : nch - 1;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            mma1(fa1, fb1, m);
+            SB();
+            dma(st, f, m);
+            SB();
+        }
+    }
+    DMA_WAIT();
+    __syncthreads();
+    // epilogue: plain (lab): row-per-lane dword stores; EPI = 1: none (main-loop rate)
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t m = m0 + wm * 128 + rt * 32 + acc_row(r, lane);
+            if (EPI == 1 ? (M < 0) : (m < M)) {
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) C[m * ldc + n0 + wn * 64 + ct * 32 + l32] = acc[rt][ct][r];
+            }
+        }
+}
+__global__ __launch_bounds__(512) void nt256(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
+                                             float* __restrict__ C, int64_t ldc, int64_t M, int N, int K) {
+    __shared__ __attribute__((aligned(16))) SmemP sm;
+    nt256_body<0>(A, lda, B, ldb, C, ldc, M, N, K, sm);
+}
+__global__ __launch_bounds__(512) void nt256_noepi(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
+                                                   float* __restrict__ C, int64_t ldc, int64_t M, int N, int K) {
+    __shared__ __attribute__((aligned(16))) SmemP sm;
+    nt256_body<1>(A, lda, B, ldb, C, ldc, M, N, K, sm);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// v0: the round-1 engine shape (128 x 256 x 32, 4 waves, 2 LDS stages of 24 KiB, compiler-ordered loop)
+constexpr int BBM = 128, BBN = 256, BBK = 32;
+struct __attribute__((aligned(16))) SmemNT {
+    bf16_t A[2][BBM * BBK];
+    bf16_t B[2][BBN * BBK];
+};
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+template <int EPI>
+__device__ __forceinline__ void nt128_body(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
+                                           float* __restrict__ C, int64_t ldc, int64_t M, int N, int K, SmemNT& sm) {
+    const int tid = threadIdx.x, lane = tid & 63, wm = (tid >> 6) >> 1, wn = (tid >> 6) & 1;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ncol = N / BBN;
+    const int nt = blockIdx.x % ncol;
+    const int64_t m0 = (int64_t)(blockIdx.x / ncol) * BBM;
+    const int n0 = nt * BBN;
+    const bf16_t* srcA[2];
+    const bf16_t* srcB[4];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int sl = (wave * 2 + q) * 64 + lane, row = sl >> 2, kq = (sl & 3) ^ ((row >> 2) & 3);
+        int64_t t = m0 + row;
+        if (t > M - 1) t = M - 1;
+        srcA[q] = A + t * lda + kq * 8;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int sl = (wave * 4 + q) * 64 + lane, row = sl >> 2, kq = (sl & 3) ^ ((row >> 2) & 3);
+        srcB[q] = B + (int64_t)(n0 + row) * ldb + kq * 8;
+    }
+    auto issue = [&](int st, int ch) {
+        const int k0 = ch * BBK;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) glds16(srcA[q] + k0, &sm.A[st][(wave * 2 + q) * 512]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) glds16(srcB[q] + k0, &sm.B[st][(wave * 4 + q) * 512]);
+    };
+    const int l32 = lane & 31, kh = lane >> 5;
+    int offA[2], offB[4];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const int r = wm * 64 + rt * 32 + l32;
+        offA[rt] = r * 64 + ((kh ^ ((r >> 2) & 3)) << 4);
+    }
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        const int r = wn * 128 + ct * 32 + l32;
+        offB[ct] = r * 64 + ((kh ^ ((r >> 2) & 3)) << 4);
+    }
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int nch = K / BBK;
+    issue(0, 0);
+    __syncthreads();
+    for (int ch = 0; ch < nch; ++ch) {
+        const int st = ch & 1;
+        if (ch + 1 < nch) issue(st ^ 1, ch + 1);
+        const char* Ab = reinterpret_cast<const char*>(sm.A[st]);
+        const char* Bb = reinterpret_cast<const char*>(sm.B[st]);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            bf16x8 fa[2], fb[4];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) fa[rt] = *reinterpret_cast<const bf16x8*>(Ab + (offA[rt] ^ (g << 5)));
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) fb[ct] = *reinterpret_cast<const bf16x8*>(Bb + (offB[ct] ^ (g << 5)));
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const int rt = m & 1, ct = m >> 1;
+                acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[rt], fb[ct], acc[rt][ct], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t m = m0 + wm * 64 + rt * 32 + acc_row(r, lane);
+            if (EPI == 1 ? (M < 0) : (m < M)) {
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) C[m * ldc + n0 + wn * 128 + ct * 32 + l32] = acc[rt][ct][r];
+            }
+        }
+}
+__global__ __launch_bounds__(256, 2) void nt128(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
+                                                float* __restrict__ C, int64_t ldc, int64_t M, int N, int K) {
+    __shared__ SmemNT sm;
+    nt128_body<0>(A, lda, B, ldb, C, ldc, M, N, K, sm);
+}
+__global__ __launch_bounds__(256, 2) void nt128_noepi(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
+                                                      float* __restrict__ C, int64_t ldc, int64_t M, int N, int K) {
+    __shared__ SmemNT sm;
+    nt128_body<1>(A, lda, B, ldb, C, ldc, M, N, K, sm);
+}
+
+typedef void (*kern_t)(const bf16_t*, int64_t, const bf16_t*, int64_t, float*, int64_t, int64_t, int, int);
+static uint16_t f2bf(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    u += 0x7fff + ((u >> 16) & 1);
+    return (uint16_t)(u >> 16);
+}
+static float bf2f(uint16_t h) {
+    uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+int main(int argc, char** argv) {
+    const int rounds = argc > 1 ? atoi(argv[1]) : 6;
+    const int64_t M = 262144;
+    const int N = 1024, K = 512;
+    uint16_t *A, *B;
+    float* C;
+    hipMalloc(&A, M * K * 2);
+    hipMalloc(&B, (size_t)N * K * 2);
+    hipMalloc(&C, M * N * 4);
+    std::vector<uint16_t> hA(1024 * K), hB((size_t)N * K);
+    srand(1);
+    for (auto& v : hA) v = f2bf((rand() % 2001 - 1000) * 1e-3f);
+    for (auto& v : hB) v = f2bf((rand() % 2001 - 1000) * 1e-3f);
+    for (int64_t r = 0; r < M; r += 1024) hipMemcpy(A + r * K, hA.data(), hA.size() * 2, hipMemcpyHostToDevice);
+    hipMemcpy(B, hB.data(), hB.size() * 2, hipMemcpyHostToDevice);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    struct V { const char* name; kern_t k; int bm, bn, threads; };
+    const V vs[] = {{"nt128x256x32", nt128, BBM, BBN, 256}, {"nt256x256x64_pipe", nt256, PM, PN, 512},
+                    {"nt128_noepi", nt128_noepi, BBM, BBN, 256}, {"nt256_noepi", nt256_noepi, PM, PN, 512}};
+    const int nv = 4;
+    for (int v = 0; v < 2; ++v)
+        for (int which = 0; which < 2; ++which) {
+            const int64_t Mc = which ? 1000 : M;
+            const int tiles = (int)(((Mc + vs[v].bm - 1) / vs[v].bm) * (N / vs[v].bn));
+            hipMemset(C, 0xff, (size_t)Mc * N * 4);
+            hipLaunchKernelGGL(vs[v].k, dim3(tiles), dim3(vs[v].threads), 0, 0, (const bf16_t*)A, (int64_t)K, (const bf16_t*)B, (int64_t)K, C,
+                               (int64_t)N, Mc, N, K);
+            hipDeviceSynchronize();
+            const int64_t r0 = which ? 0 : 777;
+            const int nr = which ? 1000 : 8;
+            std::vector<float> hC((size_t)nr * N);
+            hipMemcpy(hC.data(), C + r0 * N, hC.size() * 4, hipMemcpyDeviceToHost);
+            double maxerr = 0;
+            for (int r = 0; r < nr; r += (which ? 37 : 1))
+                for (int n = 0; n < N; n += 13) {
+                    double s = 0;
+                    for (int k = 0; k < K; ++k) s += (double)bf2f(hA[(size_t)((r0 + r) % 1024) * K + k]) * bf2f(hB[(size_t)n * K + k]);
+                    maxerr = fmax(maxerr, fabs(s - hC[(size_t)r * N + n]));
+                }
+            printf("check %-18s M=%-7lld max abs err vs fp64 %.3e %s\n", vs[v].name, (long long)Mc, maxerr, maxerr < 1e-3 ? "OK" : "FAIL");
+        }
+    std::vector<double> best(nv, 1e9), sum(nv, 0);
+    for (int rd = 0; rd < rounds; ++rd)
+        for (int v = 0; v < nv; ++v) {
+            const int tiles = (int)((M / vs[v].bm) * (N / vs[v].bn));
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(vs[v].k, dim3(tiles), dim3(vs[v].threads), 0, 0, (const bf16_t*)A, (int64_t)K, (const bf16_t*)B, (int64_t)K, C,
+                               (int64_t)N, M, N, K);
+            hipEventRecord(e1);
+            hipEventSynchronize(e1);
+            float ms;
+            hipEventElapsedTime(&ms, e0, e1);
+            if (rd > 0) { sum[v] += ms; if (ms < best[v]) best[v] = ms; }
+        }
+    for (int v = 0; v < nv; ++v)
+        printf("%-18s mean %.3f ms (%.0f TF)  best %.3f ms (%.0f TF)\n", vs[v].name, sum[v] / (rounds - 1),
+               2.0 * M * N * K / (sum[v] / (rounds - 1)) / 1e9, best[v], 2.0 * M * N * K / best[v] / 1e9);
+    return 0;
+}
