@@ -7,9 +7,9 @@
 //     C[m, n] = sum_k A[m][k] B[n][k]      tile 128 x 256, BK = 32 bf16 (64 B per tile row), 4 waves (2 x 2) x (2 x 4) MFMA tiles
 //   forward : A = E rows (tokens)            B = [Wa;Wb] rows (bf16 copy, K = 512)        fused activation / dropout / wc epilogue
 //   dX      : A = dz rows (tokens, K = 1024) B = [Wa;Wb]^T rows (bf16 transposed copy)    dE (bf16) (+)= C
-//   dW      : A = E^T rows (channels)        B = dz^T rows (K = tokens, split over K)     fp32 slabs, reduced by gate_reduce_w
-// E^T and dz^T are bf16 transposed copies made once per backward (HBM-bound passes, ~1 ms at config 2): the MFMA
-// operand registers hold 8 CONSECUTIVE k per lane, which a token-major tensor cannot feed without a transpose.
+//   dW      : "TN" instead: A = E rows, B = dz rows, both token-major (K-major); the fragments (8 CONSECUTIVE k per lane) are
+//             gathered from the K-major LDS image by ds_read_b64_tr_b16 -- no transposed copies (round 1 made E^T and dz^T
+//             per backward: 1.3 ms of HBM-bound passes at config 2).  fp32 slabs over token splits, reduced by gate_reduce_w.
 // Operands reach LDS by LDS-DMA (global_load_lds_dwordx4) into the same XOR-swizzled 64-B row image the fp32 kernels
 // use (16-B chunk kq of row r is stored at slot kq ^ ((r >> 2) & 3)), read back with conflict-free ds_read_b128.
 #include "gate_common.hpp"
@@ -114,35 +114,6 @@ __global__ __launch_bounds__(256) void gate_wn_bf16_kernel(const float* __restri
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 4; ++i) WN[((int64_t)c * HID + kb + ty + i * 8) * 1024 + jb + tx] = (bf16_t)tile[tx][ty + i * 8];
-}
-
-// out[c][r] = in[r][c] (bf16), r < R; columns R <= r < ld_out are zero-filled.  64 x 64 tiles; grid (ld_out/64, C/64).
-__global__ __launch_bounds__(256) void transpose_bf16_kernel(const uint16_t* __restrict__ in, int64_t R, int64_t ld_in,
-                                                             uint16_t* __restrict__ out, int64_t ld_out) {
-    __shared__ uint16_t tile[64][72];
-    const int64_t r0 = (int64_t)blockIdx.x * 64;
-    const int c0 = blockIdx.y * 64;
-    const int tid = threadIdx.x, row = tid >> 2, seg = (tid & 3) * 16;
-    {
-        const int64_t r = r0 + row;
-        u32x4 v0 = {0u, 0u, 0u, 0u}, v1 = v0;
-        if (r < R) {
-            const u32x4* src = reinterpret_cast<const u32x4*>(in + r * ld_in + c0 + seg);
-            v0 = __builtin_nontemporal_load(src);
-            v1 = __builtin_nontemporal_load(src + 1);
-        }
-        *reinterpret_cast<u32x4*>(&tile[row][seg]) = v0;
-        *reinterpret_cast<u32x4*>(&tile[row][seg + 8]) = v1;
-    }
-    __syncthreads();
-    {
-        uint32_t w[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) w[i] = (uint32_t)tile[seg + 2 * i][row] | ((uint32_t)tile[seg + 2 * i + 1][row] << 16);
-        u32x4* dst = reinterpret_cast<u32x4*>(out + (int64_t)(c0 + row) * ld_out + r0 + seg);
-        dst[0] = u32x4{w[0], w[1], w[2], w[3]};
-        dst[1] = u32x4{w[4], w[5], w[6], w[7]};
-    }
 }
 
 // ================================================================================================
@@ -351,47 +322,175 @@ __global__ __launch_bounds__(256, 2) void gate_dx_bf16_kernel(const bf16_t* __re
 }
 
 // ================================================================================================
-// dW: slabW[sp][c][k'][n] = sum_{t in split sp} ET[c*512 + k'][t] dzT[c*1024 + n][t]
+// dW: slabW[sp][c][k'][n] = sum_{t in split sp} E[t, c, k'] dz[t, c, n]        ("TN": both operands token-major = K-major)
+// Round 2: no transposed copies of E and dz any more.  The MFMA fragments (8 consecutive k = tokens per lane) are gathered
+// from the K-major LDS image by ds_read_b64_tr_b16.  Measured semantics (tools/micro/tr_probe.hip): within a 16-lane group
+// every lane r supplies the address of 4 consecutive bf16 D[r][0..3] and lane l receives D[4j + (l >> 2)][l & 3], j = 0..3;
+// with lane r pointing at tile[k0 + (r >> 2)][i0 + 4 (r & 3)] lane l gets tile[k0 + j][i0 + l] -- 4 consecutive tokens of
+// "its" row.  LDS stage: A image [32 t][128 k'] (8 KiB) + B image [32 t][256 n] (16 KiB), 64-B unit u of token row t stored
+// at unit u ^ (t & 3) (source-side swizzle of the LDS-DMA), two stages, fragments of k-step s+1 requested behind the first
+// MFMA of step s (inline-asm reads: the s_waitcnt lgkmcnt is placed by hand).
 // ================================================================================================
-__global__ __launch_bounds__(256, 2) void gate_dw_bf16_kernel(const bf16_t* __restrict__ ET, const bf16_t* __restrict__ dzT,
-                                                              int64_t ldT, float* __restrict__ slabW, int H,
-                                                              int64_t tok_per_split, int n_splits) {
-    __shared__ SmemNT sm;
-    const int tid = threadIdx.x, lane = tid & 63, wm = (tid >> 6) >> 1, wn = (tid >> 6) & 1;
+constexpr int TNK = 32;
+struct __attribute__((aligned(16))) SmemTN {
+    bf16_t A[2][TNK * 128];
+    bf16_t B[2][TNK * 256];
+};
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+template <int OFF>
+__device__ __forceinline__ u32x2 ds_tr16(uint32_t lds_byte_addr) {
+    u32x2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(lds_byte_addr), "i"(OFF));
+    return v;
+}
+__device__ __forceinline__ void glds16_s(uint32_t voff, const void* sbase, uint32_t lds_addr) {   // LDS-DMA, saddr form
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_addr)
+                 : "memory");
+}
+__device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+}
+struct TnFrag {
+    u32x2 a[2][2], b[4][2];   // [row / column tile][k half]
+};
+template <int KS>   // k-step 0 / 1 of the staged chunk
+__device__ __forceinline__ void tn_load(TnFrag& f, const uint32_t (&aA)[2], const uint32_t (&aB)[4]) {
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        f.a[rt][0] = ds_tr16<KS * 4096>(aA[rt]);
+        f.a[rt][1] = ds_tr16<KS * 4096 + 1024>(aA[rt]);
+    }
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        f.b[ct][0] = ds_tr16<KS * 8192>(aB[ct]);
+        f.b[ct][1] = ds_tr16<KS * 8192 + 2048>(aB[ct]);
+    }
+}
+__device__ __forceinline__ void tn_mma(f32x16 (&acc)[2][4], const TnFrag& f, int m) {
+    const int rt = m & 1, ct = m >> 1;
+    const u32x4 av = {f.a[rt][0].x, f.a[rt][0].y, f.a[rt][1].x, f.a[rt][1].y};
+    const u32x4 bv = {f.b[ct][0].x, f.b[ct][0].y, f.b[ct][1].x, f.b[ct][1].y};
+    acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc[rt][ct], 0,
+                                                          0, 0);
+}
+
+// Generic TN tile loop: acc[rt][ct] += sum over nch chunks of 32 k of A[k][wm*64 + rt*32 ..] B[k][wn*128 + ct*32 ..].
+// dma(stage, chunk, piece): piece 0..5 = this wave's LDS-DMA instructions (0,1: A k-rows 4(2w+p)..+3; 2..5: B k-rows 2(4w+p-2), +1).
+template <class Dma>
+__device__ __forceinline__ void tn_mainloop(SmemTN& sm, f32x16 (&acc)[2][4], int64_t nch, int wm, int wn, int lane, Dma&& dma) {
+    const int g = lane >> 4, r = lane & 15;
+    // lane r of group g points at token row (g >> 1) * 8 + (r >> 2) (+ 16 KS + 4 h through the immediate offset), columns
+    // tile0 + (g & 1) * 16 + (r & 3) * 4; the 64-B unit XOR depends on (token & 3) = (r >> 2) only
+    uint32_t a0[2], b0[4];
+    const int kb = (g >> 1) * 8 + (r >> 2);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+        a0[rt] = lds_addr_of(&sm.A[0][0]) + kb * 256 + (((wm * 64 + rt * 32 + (g & 1) * 16 + (r & 3) * 4) * 2) ^ ((kb & 3) << 6));
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+        b0[ct] = lds_addr_of(&sm.B[0][0]) + kb * 512 + (((wn * 128 + ct * 32 + (g & 1) * 16 + (r & 3) * 4) * 2) ^ ((kb & 3) << 6));
+    if (nch <= 0) return;
+#pragma unroll
+    for (int p = 0; p < 6; ++p) dma(0, (int64_t)0, p);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    {
+        const int64_t f = nch > 1 ? 1 : 0;
+#pragma unroll
+        for (int p = 0; p < 6; ++p) dma(1, f, p);
+    }
+    TnFrag f0, f1;
+    tn_load<0>(f0, a0, b0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    for (int64_t ch = 0; ch < nch; ++ch) {
+        const int st = (int)(ch & 1);
+        uint32_t aA[2], aB[4], nA[2], nB[4];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            aA[rt] = a0[rt] + st * (TNK * 128 * 2);
+            nA[rt] = a0[rt] + (st ^ 1) * (TNK * 128 * 2);
+        }
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            aB[ct] = b0[ct] + st * (TNK * 256 * 2);
+            nB[ct] = b0[ct] + (st ^ 1) * (TNK * 256 * 2);
+        }
+        // k-step 0: its first MFMA, then the requests of k-step 1, then the other 7 MFMAs
+        tn_mma(acc, f0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        tn_load<1>(f1, aA, aB);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 1; m < 8; ++m) tn_mma(acc, f0, m);
+        __builtin_amdgcn_sched_barrier(0);
+        // k-step 1 (last of the chunk): all reads of this stage are requested -> wait for them and for this wave's DMA of the next
+        // chunk, barrier, then the next chunk's first fragments and the DMA of chunk ch+2 ride between the MFMAs
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        tn_load<0>(f0, nA, nB);
+        __builtin_amdgcn_sched_barrier(0);
+        const int64_t f = (ch + 2 < nch) ? ch + 2 : nch - 1;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            tn_mma(acc, f1, m);
+            __builtin_amdgcn_sched_barrier(0);
+            if (m < 6) dma(st, f, m);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);   // no MFMA of the next iteration above the wait (inline-asm reads are not tracked)
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256, 2) void gate_dw_bf16_kernel(const bf16_t* __restrict__ E, int64_t ldE, const bf16_t* __restrict__ dz,
+                                                              float* __restrict__ slabW, int64_t T, int H, int64_t tok_per_split,
+                                                              int n_splits) {
+    __shared__ SmemTN sm;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
     const XcdHead xh = xcd_head(blockIdx.x, H);
     const int kt = xh.li % 4, ntile = (xh.li / 4) % 4, c = xh.c, sp = (xh.li / 16) * xh.nshare + xh.share;
     if (sp >= n_splits) return;  // block-uniform
-    const int k0 = kt * BBM, n0 = ntile * BBN;
-    const int64_t ts = (int64_t)sp * tok_per_split;  // [ts, ts + tok_per_split) lies inside the zero-padded ldT
+    const int k0 = kt * 128, n0 = ntile * 256;
+    const int64_t ts = (int64_t)sp * tok_per_split;
+    int64_t te = ts + tok_per_split;
+    if (te > T) te = T;
+    const int64_t nch = (te > ts) ? (te - ts + TNK - 1) / TNK : 0;
 
-    const bf16_t* srcA[2];
-    const bf16_t* srcB[4];
+    const char* baseA = reinterpret_cast<const char*>(E + ts * ldE + (int64_t)c * HID + k0);
+    const char* baseB = reinterpret_cast<const char*>(dz + (ts * H + c) * 1024 + n0);
+    const uint32_t ldA2 = (uint32_t)ldE * 2u, ldB2 = (uint32_t)H * 1024u * 2u;
+    uint32_t cA, cB, kA[2], kB[4];   // 16-B chunk (swizzled) and token row of this lane in each DMA piece
+    cA = lane & 15;
+    cB = lane & 31;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        int row, kq;
-        nt_slot(wave * 2 + q, lane, row, kq);
-        srcA[q] = ET + ((int64_t)c * HID + k0 + row) * ldT + ts + kq * 8;
-    }
+    for (int q = 0; q < 2; ++q) kA[q] = (wave * 2 + q) * 4 + (lane >> 4);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        int row, kq;
-        nt_slot(wave * 4 + q, lane, row, kq);
-        srcB[q] = dzT + ((int64_t)c * 1024 + n0 + row) * ldT + ts + kq * 8;
-    }
-    auto issue = [&](int st, int64_t ch) {
-        const int64_t o = ch * BBK;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) glds16(srcA[q] + o, &sm.A[st][(wave * 2 + q) * 512]);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) glds16(srcB[q] + o, &sm.B[st][(wave * 4 + q) * 512]);
+    for (int q = 0; q < 4; ++q) kB[q] = (wave * 4 + q) * 2 + (lane >> 5);
+    auto dma = [&](int st, int64_t f, int piece) {
+        if (piece < 2) {   // E rows past T-1 re-read row T-1: their dz rows are the zero pad
+            uint32_t k = kA[piece];
+            const int64_t left = T - 1 - (ts + f * TNK);
+            if (left < TNK) k = k < (uint32_t)left ? k : (uint32_t)left;   // uniform branch: only the chunk at the end of E
+            const uint32_t vo = k * ldA2 + ((cA ^ ((kA[piece] & 3) << 2)) << 4);
+            glds16_s(vo, baseA + f * TNK * (int64_t)ldA2, lds_addr_of(&sm.A[st][(wave * 2 + piece) * 512]));
+        } else {
+            const int q = piece - 2;
+            const uint32_t vo = kB[q] * ldB2 + ((cB ^ ((kB[q] & 3) << 2)) << 4);
+            glds16_s(vo, baseB + f * TNK * (int64_t)ldB2, lds_addr_of(&sm.B[st][(wave * 4 + q) * 512]));
+        }
     };
-    const int colb[4] = {wn * 128, wn * 128 + 32, wn * 128 + 64, wn * 128 + 96};
-    int offA[2], offB[4];
-    nt_offsets(wm, colb, lane, offA, offB);
     f32x16 acc[2][4];
     zero_acc8(acc);
-    nt_mainloop(sm, acc, tok_per_split / BBK, issue, offA, offB);
+    tn_mainloop(sm, acc, nch, wm, wn, lane, dma);
 
     // slabW [split][head][k' 512][1024: a-cols 0..511 | b-cols 512..1023]
     float* __restrict__ so = slabW + (((int64_t)sp * H + c) * HID) * 1024;
@@ -402,7 +501,7 @@ __global__ __launch_bounds__(256, 2) void gate_dw_bf16_kernel(const bf16_t* __re
         for (int r = 0; r < 16; ++r) {
             const int kr = k0 + wm * 64 + rt * 32 + acc_row(r, lane);
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) so[(int64_t)kr * 1024 + n0 + colb[ct] + l32] = acc[rt][ct][r];
+            for (int ct = 0; ct < 4; ++ct) so[(int64_t)kr * 1024 + n0 + wn * 128 + ct * 32 + l32] = acc[rt][ct][r];
         }
 }
 
@@ -412,21 +511,19 @@ static inline int64_t up16(int64_t b) { return (b + 15) & ~(int64_t)15; }
 struct BwdWs {
     int S;
     int64_t tps, Tpad, nblk;
-    int64_t oWN, odz, odzT, oET, oslabW, oslabV, total;  // byte offsets
+    int64_t oWN, odz, oslabW, oslabV, total;  // byte offsets
 };
 static inline BwdWs bwd_ws(int64_t T, int H) {
     BwdWs w;
     w.S = gate_splits(T, H);
     int64_t tps = (T + w.S - 1) / w.S;
-    w.tps = ((tps + 63) / 64) * 64;  // a multiple of the 64-row transpose tile (and of BBK)
-    if (w.tps < 64) w.tps = 64;
+    w.tps = ((tps + TNK - 1) / TNK) * TNK;  // whole 32-token chunks: a chunk never straddles two splits
+    if (w.tps < TNK) w.tps = TNK;
     w.Tpad = w.tps * w.S;
     w.nblk = (T + DZ_ROWS - 1) / DZ_ROWS;
     int64_t o = 0;
     w.oWN = o; o += up16((int64_t)H * HID * 1024 * 2);
-    w.odz = o; o += up16(T * H * 1024 * 2);
-    w.odzT = o; o += up16((int64_t)H * 1024 * w.Tpad * 2);
-    w.oET = o; o += up16((int64_t)H * HID * w.Tpad * 2);
+    w.odz = o; o += up16((T + TNK) * H * 1024 * 2);   // + TNK zero rows: K-tail of the dW contraction
     w.oslabW = o; o += up16((int64_t)w.S * H * HID * 1024 * 4);
     w.oslabV = o; o += up16(w.nblk * H * 4 * HID * 4);
     w.total = o + 64;
@@ -497,7 +594,6 @@ static int gate_bwd_bf16_impl(const uint16_t* E, int64_t ldE, const float* Wa, c
     if ((keep_a == nullptr) != (keep_b == nullptr)) return MDL_E_ARG;
     if (T < 0 || H < 1 || H > MDL_MAX_HEADS || ldE < (int64_t)H * HID || (ldE & 7)) return MDL_E_ARG;
     if (H != 1 && H != 2 && H != 4 && H != 8) return MDL_E_UNSUPPORTED;
-    if (ldE != (int64_t)H * HID) return MDL_E_UNSUPPORTED;  // the E^T pass transposes the whole [T, H*512] matrix
     if (!(p_drop >= 0.f && p_drop < 1.f)) return MDL_E_ARG;
     if (!host_aligned16(E) || !host_aligned16(dE) || !host_aligned16(Wa) || !host_aligned16(Wb) || !host_aligned16(act_a) ||
         !host_aligned16(act_b) || !host_aligned16(wc) || !host_aligned16(ws))
@@ -508,11 +604,13 @@ static int gate_bwd_bf16_impl(const uint16_t* E, int64_t ldE, const float* Wa, c
     char* base = (char*)ws;
     bf16_t* WN = (bf16_t*)(base + L.oWN);
     bf16_t* dz = (bf16_t*)(base + L.odz);
-    bf16_t* dzT = (bf16_t*)(base + L.odzT);
-    bf16_t* ET = (bf16_t*)(base + L.oET);
     float* slabW = (float*)(base + L.oslabW);
     float* slabV = (float*)(base + L.oslabV);
-    if (L.nblk > 0x7fffffff || L.Tpad / 64 > 0x7fffffff) return MDL_E_UNSUPPORTED;
+    if (L.nblk > 0x7fffffff) return MDL_E_UNSUPPORTED;
+    {   // zero pad rows of dz (K-tail of the dW contraction)
+        const hipError_t e = hipMemsetAsync(dz + T * H * 1024, 0, (size_t)TNK * H * 1024 * 2, s);
+        if (e != hipSuccess) return (int)e;
+    }
     if (T > 0) {
         hipLaunchKernelGGL(gate_wn_bf16_kernel, dim3(16, 32, H), dim3(256), 0, s, Wa, Wb, WN);
         MDL_LAUNCH_CHECK();
@@ -526,15 +624,8 @@ static int gate_bwd_bf16_impl(const uint16_t* E, int64_t ldE, const float* Wa, c
                            (bf16_t*)dE, ldE, accumulate, T, H, pt);
         MDL_LAUNCH_CHECK();
     }
-    // transposed copies for the token contraction (zero-filled up to Tpad), then dW over S splits of the tokens
-    hipLaunchKernelGGL(transpose_bf16_kernel, dim3((unsigned)(L.Tpad / 64), (unsigned)(H * 1024 / 64)), dim3(256), 0, s,
-                       (const uint16_t*)dz, T, (int64_t)H * 1024, (uint16_t*)dzT, L.Tpad);
-    MDL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(transpose_bf16_kernel, dim3((unsigned)(L.Tpad / 64), (unsigned)(H * HID / 64)), dim3(256), 0, s, E, T, ldE,
-                       (uint16_t*)ET, L.Tpad);
-    MDL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gate_dw_bf16_kernel, dim3((unsigned)xcd_head_grid(L.S, 16, H)), dim3(256), 0, s, (const bf16_t*)ET,
-                       (const bf16_t*)dzT, L.Tpad, slabW, H, L.tps, L.S);
+    hipLaunchKernelGGL(gate_dw_bf16_kernel, dim3((unsigned)xcd_head_grid(L.S, 16, H)), dim3(256), 0, s, (const bf16_t*)E, ldE,
+                       (const bf16_t*)dz, slabW, T, H, L.tps, L.S);
     MDL_LAUNCH_CHECK();
     int rc = gate_launch_reduce_w(slabW, dWa, dWb, H, L.S, s);
     if (rc) return rc;

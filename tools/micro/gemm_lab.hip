@@ -16,6 +16,7 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BM = 128, BN = 256, BK = 16;
+constexpr int STAGGER_SLEEPS = 16;   // x 8128 cycles: one third of a 393k-cycle tile generation
 
 __device__ __forceinline__ void glds16(const void* g, void* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
@@ -55,6 +56,12 @@ __device__ __forceinline__ void nn_body(const float* __restrict__ A, int64_t lda
     const int nt = lid % ncol;
     const int64_t t0 = (int64_t)(lid / ncol) * BM;
     const int n0 = nt * BN;
+    if constexpr (PRIO >= 2) {   // de-synchronise the co-resident workgroups: the first generation starts staggered
+        if (blockIdx.x < 768) {
+            const int ph = (PRIO == 2) ? (int)(blockIdx.x % 3) : (int)((blockIdx.x / 8) % 3);
+            for (int i = 0; i < ph * STAGGER_SLEEPS; ++i) __builtin_amdgcn_s_sleep(127);   // 127 x 64 cycles each
+        }
+    }
     if constexpr (PRIO == 1) {   // de-synchronise the co-resident workgroups: static issue priority from the tile index
         const int pr = lid % 3;
         if (pr == 1) __builtin_amdgcn_s_setprio(1);
@@ -302,6 +309,9 @@ KERNEL(k_pipe_prio, 1, 0, 1, 256)
 KERNEL(k_pipe_lds, 1, 1, 0, 256)
 KERNEL(k_pipe_lds_prio, 1, 1, 1, 256)
 KERNEL(k_pipe_noepi, 1, 2, 0, 256)
+KERNEL(k_pipe_lds_stag, 1, 1, 2, 256)
+KERNEL(k_pipe_lds_stag8, 1, 1, 3, 256)
+KERNEL(k_pipe_dir_stag, 1, 0, 2, 256)
 KERNEL2(k_pipe_lds_2wg, 1, 1, 0, 24)   /* 72 KiB: 2 workgroups per CU */
 KERNEL2(k_pipe_lds_1wg, 1, 1, 0, 48)   /* 96 KiB: 1 workgroup per CU */
 KERNEL(k_base_noepi, 0, 2, 0, 256, 2)
@@ -354,7 +364,8 @@ int main(int argc, char** argv) {
     struct V { const char* name; kern_t k; };
     const V vs[] = {{"base_vgpr", k_base_v}, {"pipe_vgpr", k_pipe_v}, {"pipe_agpr", k_pipe_a}, {"pipe_prio", k_pipe_prio},
                     {"pipe_lds", k_pipe_lds}, {"pipe_lds_prio", k_pipe_lds_prio}, {"pipe_noepi", k_pipe_noepi},
-                    {"pipe_lds_2wg", k_pipe_lds_2wg}, {"pipe_lds_1wg", k_pipe_lds_1wg},
+                    {"pipe_lds_2wg", k_pipe_lds_2wg}, {"pipe_lds_1wg", k_pipe_lds_1wg}, {"pipe_lds_stag", k_pipe_lds_stag},
+                    {"pipe_lds_stag8", k_pipe_lds_stag8}, {"pipe_dir_stag", k_pipe_dir_stag},
                     {"base_noepi", k_base_noepi}};
     const int nv = sizeof(vs) / sizeof(vs[0]);
     const int64_t Ts[2] = {T, 1000};   // full size (timing) and a ragged small problem (tails)

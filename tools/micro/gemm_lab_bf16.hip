@@ -267,6 +267,265 @@ __global__ __launch_bounds__(256, 2) void nt128_noepi(const bf16_t* __restrict__
     nt128_body<1>(A, lda, B, ldb, C, ldc, M, N, K, sm);
 }
 
+// v2: 128 x 256 x 32, 4 waves, the round-1 LDS image, but the in-wave pipeline of the fp32 engine (2 k-steps per chunk: the
+// barrier sits before the second one, whose 8 MFMAs carry the next fragment requests and the 6 DMA pieces) and saddr-form DMA.
+template <int EPI>
+__device__ __forceinline__ void nt128p_body(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
+                                            float* __restrict__ C, int64_t ldc, int64_t M, int N, int K, SmemNT& sm) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ncol = N / BBN;
+    const int nt = blockIdx.x % ncol;
+    const int64_t m0 = (int64_t)(blockIdx.x / ncol) * BBM;
+    const int n0 = nt * BBN;
+    const char* baseA = reinterpret_cast<const char*>(A + m0 * lda);
+    const char* baseB = reinterpret_cast<const char*>(B + (int64_t)n0 * ldb);
+    uint32_t voA[2], voB[4];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int sl = (wave * 2 + q) * 64 + lane, row = sl >> 2, kq = (sl & 3) ^ ((row >> 2) & 3);
+        int64_t r = row;
+        if (m0 + r > M - 1) r = M - 1 - m0;
+        voA[q] = (uint32_t)(r * lda * 2 + kq * 16);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int sl = (wave * 4 + q) * 64 + lane, row = sl >> 2, kq = (sl & 3) ^ ((row >> 2) & 3);
+        voB[q] = (uint32_t)((int64_t)row * ldb * 2 + kq * 16);
+    }
+    auto dma = [&](int st, int f, int piece) {   // 0,1: A; 2..5: B
+        if (piece < 2) glds16_s(voA[piece], baseA + (int64_t)f * (BBK * 2), lds_addr_of(&sm.A[st][(wave * 2 + piece) * 512]));
+        else glds16_s(voB[piece - 2], baseB + (int64_t)f * (BBK * 2), lds_addr_of(&sm.B[st][(wave * 4 + piece - 2) * 512]));
+    };
+    const int l32 = lane & 31, kh = lane >> 5;
+    int offA[2], offB[4];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const int r = wm * 64 + rt * 32 + l32;
+        offA[rt] = r * 64 + ((kh ^ ((r >> 2) & 3)) << 4);
+    }
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        const int r = wn * 128 + ct * 32 + l32;
+        offB[ct] = r * 64 + ((kh ^ ((r >> 2) & 3)) << 4);
+    }
+    bf16x8 fa0[2], fb0[4], fa1[2], fb1[4];
+    auto ld = [&](bf16x8 (&fa)[2], bf16x8 (&fb)[4], int st, int g) {
+        const char* Ab = reinterpret_cast<const char*>(sm.A[st]);
+        const char* Bb = reinterpret_cast<const char*>(sm.B[st]);
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) fa[rt] = *reinterpret_cast<const bf16x8*>(Ab + (offA[rt] ^ (g << 5)));
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) fb[ct] = *reinterpret_cast<const bf16x8*>(Bb + (offB[ct] ^ (g << 5)));
+    };
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    auto mma1 = [&](const bf16x8 (&fa)[2], const bf16x8 (&fb)[4], int m) {
+        const int rt = m & 1, ct = m >> 1;
+        acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[rt], fb[ct], acc[rt][ct], 0, 0, 0);
+    };
+    const int nch = K / BBK;
+#pragma unroll
+    for (int p = 0; p < 6; ++p) dma(0, 0, p);
+    DMA_WAIT();
+    __syncthreads();
+    {
+        const int f = nch > 1 ? 1 : 0;
+#pragma unroll
+        for (int p = 0; p < 6; ++p) dma(1, f, p);
+    }
+    ld(fa0, fb0, 0, 0);
+    for (int ch = 0; ch < nch; ++ch) {
+        const int st = ch & 1;
+        mma1(fa0, fb0, 0);
+        SB();
+        ld(fa1, fb1, st, 1);
+        SB();
+#pragma unroll
+        for (int m = 1; m < 8; ++m) mma1(fa0, fb0, m);
+        SB();
+        DMA_WAIT();
+        __syncthreads();
+        ld(fa0, fb0, st ^ 1, 0);
+        SB();
+        const int f = (ch + 2 < nch) ? ch + 2 : nch - 1;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            mma1(fa1, fb1, m);
+            SB();
+            if (m < 6) dma(st, f, m);
+            SB();
+        }
+    }
+    DMA_WAIT();
+    __syncthreads();
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t m = m0 + wm * 64 + rt * 32 + acc_row(r, lane);
+            if (EPI == 1 ? (M < 0) : (m < M)) {
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) C[m * ldc + n0 + wn * 128 + ct * 32 + l32] = acc[rt][ct][r];
+            }
+        }
+}
+__global__ __launch_bounds__(256) void nt128p(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
+                                              float* __restrict__ C, int64_t ldc, int64_t M, int N, int K) {
+    __shared__ SmemNT sm;
+    nt128p_body<0>(A, lda, B, ldb, C, ldc, M, N, K, sm);
+}
+__global__ __launch_bounds__(256) void nt128p_noepi(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
+                                                    float* __restrict__ C, int64_t ldc, int64_t M, int N, int K) {
+    __shared__ SmemNT sm;
+    nt128p_body<1>(A, lda, B, ldb, C, ldc, M, N, K, sm);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// TN: C[i, n] = sum_k A[k][i] B[k][n] with BOTH operands K-major in memory (token-major activations: the dW products) --
+// no transposed copies: the MFMA fragments (8 consecutive k per lane) are gathered from the K-major LDS image by
+// ds_read_b64_tr_b16.  Measured semantics (tools/micro/tr_probe.hip): within a 16-lane group every lane r supplies the
+// address of 4 consecutive bf16 D[r][0..3]; lane l receives D[4j + (l >> 2)][l & 3], j = 0..3.  With lane r pointing at
+// tile[k0 + (r >> 2)][i0 + 4 (r & 3)] lane l gets tile[k0 + j][i0 + l]: 4 consecutive k of "its" row.
+// LDS image: [32 k][W] bf16 (W = 128 for A, 256 for B); 64-B unit u of k-row k is stored at unit u ^ (k & 3) (source-side
+// swizzle of the LDS-DMA) so that the 4 k-rows of a read hit 4 different bank windows.
+constexpr int TK = 32;
+struct __attribute__((aligned(16))) SmemTN {
+    bf16_t A[2][TK * 128];   // 8 KiB per stage
+    bf16_t B[2][TK * 256];   // 16 KiB per stage
+};
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32x2 ds_tr16(uint32_t lds_byte_addr) {
+    u32x2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(lds_byte_addr));
+    return v;
+}
+template <int EPI, int SWZ>
+__device__ __forceinline__ void tn128_body(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
+                                           float* __restrict__ C, int64_t ldc, int64_t Kt, int Mi, int N, int64_t k_per_split,
+                                           SmemTN& sm) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nit = Mi / 128, nnt = N / 256;
+    const int it = blockIdx.x % nit, nt = (blockIdx.x / nit) % nnt, sp = blockIdx.x / (nit * nnt);
+    const int i0 = it * 128, n0 = nt * 256;
+    const int64_t ks = (int64_t)sp * k_per_split;
+    int64_t ke = ks + k_per_split;
+    if (ke > Kt) ke = Kt;
+    const int nch = (int)((ke - ks + TK - 1) / TK);
+    // DMA: A: instruction q of wave w = k-rows 4(2w+q) .. +3, 256 B each (16 lanes per row); B: instruction q = k-rows 2(4w+q), +1
+    const char* baseA = reinterpret_cast<const char*>(A + ks * lda + i0);
+    const char* baseB = reinterpret_cast<const char*>(B + ks * ldb + n0);
+    uint32_t voA[2], voB[4];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int kr = (wave * 2 + q) * 4 + (lane >> 4), c = lane & 15;          // 16-B chunk c' of k-row kr
+        const int src = SWZ ? (c ^ ((kr & 3) << 2)) : c;
+        voA[q] = (uint32_t)((int64_t)kr * lda * 2 + src * 16);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int kr = (wave * 4 + q) * 2 + (lane >> 5), c = lane & 31;
+        const int src = SWZ ? (c ^ ((kr & 3) << 2)) : c;
+        voB[q] = (uint32_t)((int64_t)kr * ldb * 2 + src * 16);
+    }
+    auto dma = [&](int st, int f, int piece) {
+        if (piece < 2) glds16_s(voA[piece], baseA + (int64_t)f * TK * lda * 2, lds_addr_of(&sm.A[st][(wave * 2 + piece) * 512]));
+        else glds16_s(voB[piece - 2], baseB + (int64_t)f * TK * ldb * 2, lds_addr_of(&sm.B[st][(wave * 4 + piece - 2) * 512]));
+    };
+    // fragment addresses: lane = 16 g + r; rows/cols of its group: col block (g & 1) * 16, k half g >> 1
+    const int g = lane >> 4, r = lane & 15;
+    const uint32_t ldsA = lds_addr_of(&sm.A[0][0]), ldsB = lds_addr_of(&sm.B[0][0]);
+    auto addrA = [&](int st, int rt, int ks16, int h) {   // rows wm*64 + rt*32 .. ; k = ks16*16 + (g>>1)*8 + h*4 + (r>>2)
+        const int k = ks16 * 16 + (g >> 1) * 8 + h * 4 + (r >> 2);
+        int col = wm * 64 + rt * 32 + (g & 1) * 16 + (r & 3) * 4;           // element index within the 128-wide row
+        int byte = col * 2;
+        if (SWZ) byte ^= (k & 3) << 6;
+        return ldsA + st * (TK * 128 * 2) + k * 256 + byte;
+    };
+    auto addrB = [&](int st, int ct, int ks16, int h) {
+        const int k = ks16 * 16 + (g >> 1) * 8 + h * 4 + (r >> 2);
+        int col = wn * 128 + ct * 32 + (g & 1) * 16 + (r & 3) * 4;
+        int byte = col * 2;
+        if (SWZ) byte ^= (k & 3) << 6;
+        return ldsB + st * (TK * 256 * 2) + k * 512 + byte;
+    };
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    if (nch > 0) {
+#pragma unroll
+        for (int p = 0; p < 6; ++p) dma(0, 0, p);
+    }
+    DMA_WAIT();
+    __syncthreads();
+    for (int ch = 0; ch < nch; ++ch) {
+        const int st = ch & 1;
+        if (ch + 1 < nch) {
+#pragma unroll
+            for (int p = 0; p < 6; ++p) dma(st ^ 1, ch + 1, p);
+        }
+#pragma unroll
+        for (int ks16 = 0; ks16 < 2; ++ks16) {
+            u32x2 a[2][2], b[4][2];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) a[rt][h] = ds_tr16(addrA(st, rt, ks16, h));
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) b[ct][h] = ds_tr16(addrB(st, ct, ks16, h));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            SB();
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const int rt = m & 1, ct = m >> 1;
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 av = {a[rt][0].x, a[rt][0].y, a[rt][1].x, a[rt][1].y};
+                const u32x4 bv = {b[ct][0].x, b[ct][0].y, b[ct][1].x, b[ct][1].y};
+                acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv),
+                                                                      acc[rt][ct], 0, 0, 0);
+            }
+        }
+        DMA_WAIT();
+        __syncthreads();
+    }
+    const int l32 = lane & 31;
+    float* __restrict__ so = C + (int64_t)sp * Mi * ldc;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int i = i0 + wm * 64 + rt * 32 + acc_row(e, lane);
+            if (EPI == 1 ? (Kt < 0) : true) {
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) so[(int64_t)i * ldc + n0 + wn * 128 + ct * 32 + l32] = acc[rt][ct][e];
+            }
+        }
+}
+__global__ __launch_bounds__(256, 2) void tn128(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, float* C, int64_t ldc,
+                                                int64_t Kt, int Mi, int N, int64_t kps) {
+    __shared__ SmemTN sm;
+    tn128_body<0, 1>(A, lda, B, ldb, C, ldc, Kt, Mi, N, kps, sm);
+}
+__global__ __launch_bounds__(256, 2) void tn128_noswz(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, float* C, int64_t ldc,
+                                                      int64_t Kt, int Mi, int N, int64_t kps) {
+    __shared__ SmemTN sm;
+    tn128_body<0, 0>(A, lda, B, ldb, C, ldc, Kt, Mi, N, kps, sm);
+}
+
 typedef void (*kern_t)(const bf16_t*, int64_t, const bf16_t*, int64_t, float*, int64_t, int64_t, int, int);
 static uint16_t f2bf(float f) {
     uint32_t u;
@@ -301,9 +560,11 @@ int main(int argc, char** argv) {
     hipEventCreate(&e1);
     struct V { const char* name; kern_t k; int bm, bn, threads; };
     const V vs[] = {{"nt128x256x32", nt128, BBM, BBN, 256}, {"nt256x256x64_pipe", nt256, PM, PN, 512},
-                    {"nt128_noepi", nt128_noepi, BBM, BBN, 256}, {"nt256_noepi", nt256_noepi, PM, PN, 512}};
-    const int nv = 4;
-    for (int v = 0; v < 2; ++v)
+                    {"nt128_pipe", nt128p, BBM, BBN, 256},
+                    {"nt128_noepi", nt128_noepi, BBM, BBN, 256}, {"nt256_noepi", nt256_noepi, PM, PN, 512},
+                    {"nt128_pipe_noepi", nt128p_noepi, BBM, BBN, 256}};
+    const int nv = 6;
+    for (int v = 0; v < 3; ++v)
         for (int which = 0; which < 2; ++which) {
             const int64_t Mc = which ? 1000 : M;
             const int tiles = (int)(((Mc + vs[v].bm - 1) / vs[v].bm) * (N / vs[v].bn));
@@ -340,5 +601,57 @@ int main(int argc, char** argv) {
     for (int v = 0; v < nv; ++v)
         printf("%-18s mean %.3f ms (%.0f TF)  best %.3f ms (%.0f TF)\n", vs[v].name, sum[v] / (rounds - 1),
                2.0 * M * N * K / (sum[v] / (rounds - 1)) / 1e9, best[v], 2.0 * M * N * K / best[v] / 1e9);
+    // ---- TN: the gate dW shape of one head: C[512, 1024] = A[Kt, 512]^T B[Kt, 1024], Kt = 262144 tokens in 72 splits ----
+    {
+        const int64_t Kt = 262144;
+        const int Mi = 512, Nn = 1024, S = 72;
+        const int64_t kps = ((Kt + S - 1) / S + TK - 1) / TK * TK;
+        uint16_t *At, *Bt;
+        float* Ct;
+        hipMalloc(&At, Kt * Mi * 2);
+        hipMalloc(&Bt, Kt * Nn * 2);
+        hipMalloc(&Ct, (size_t)S * Mi * Nn * 4);
+        std::vector<uint16_t> hAt(4096 * Mi), hBt((size_t)4096 * Nn);
+        for (auto& v : hAt) v = f2bf((rand() % 2001 - 1000) * 1e-3f);
+        for (auto& v : hBt) v = f2bf((rand() % 2001 - 1000) * 1e-3f);
+        for (int64_t r = 0; r < Kt; r += 4096) {
+            hipMemcpy(At + r * Mi, hAt.data(), hAt.size() * 2, hipMemcpyHostToDevice);
+            hipMemcpy(Bt + r * Nn, hBt.data(), hBt.size() * 2, hipMemcpyHostToDevice);
+        }
+        typedef void (*tn_t)(const bf16_t*, int64_t, const bf16_t*, int64_t, float*, int64_t, int64_t, int, int, int64_t);
+        struct TV { const char* name; tn_t k; };
+        const TV tv[] = {{"tn128_swz", tn128}, {"tn128_noswz", tn128_noswz}};
+        const int grid = (Mi / 128) * (Nn / 256) * S;
+        for (int v = 0; v < 2; ++v) {
+            // correctness on a small K (one split of 96 tokens incl. a partial... K multiple of 32 here)
+            hipMemset(Ct, 0xff, (size_t)Mi * Nn * 4);
+            hipLaunchKernelGGL(tv[v].k, dim3((Mi / 128) * (Nn / 256)), dim3(256), 0, 0, (const bf16_t*)At, (int64_t)Mi, (const bf16_t*)Bt,
+                               (int64_t)Nn, Ct, (int64_t)Nn, (int64_t)96, Mi, Nn, (int64_t)96);
+            hipDeviceSynchronize();
+            std::vector<float> hC((size_t)Mi * Nn);
+            hipMemcpy(hC.data(), Ct, hC.size() * 4, hipMemcpyDeviceToHost);
+            double maxerr = 0;
+            for (int i = 0; i < Mi; i += 7)
+                for (int n = 0; n < Nn; n += 11) {
+                    double s2 = 0;
+                    for (int k = 0; k < 96; ++k) s2 += (double)bf2f(hAt[(size_t)k * Mi + i]) * bf2f(hBt[(size_t)k * Nn + n]);
+                    maxerr = fmax(maxerr, fabs(s2 - hC[(size_t)i * Nn + n]));
+                }
+            printf("check %-12s K=96 max abs err vs fp64 %.3e %s\n", tv[v].name, maxerr, maxerr < 1e-3 ? "OK" : "FAIL");
+            double sum2 = 0, best2 = 1e9;
+            for (int rd = 0; rd < rounds; ++rd) {
+                hipEventRecord(e0);
+                hipLaunchKernelGGL(tv[v].k, dim3(grid), dim3(256), 0, 0, (const bf16_t*)At, (int64_t)Mi, (const bf16_t*)Bt, (int64_t)Nn, Ct,
+                                   (int64_t)Nn, Kt, Mi, Nn, kps);
+                hipEventRecord(e1);
+                hipEventSynchronize(e1);
+                float ms;
+                hipEventElapsedTime(&ms, e0, e1);
+                if (rd > 0) { sum2 += ms; if (ms < best2) best2 = ms; }
+            }
+            printf("%-18s mean %.3f ms (%.0f TF)  best %.3f ms (%.0f TF)\n", tv[v].name, sum2 / (rounds - 1),
+                   2.0 * Kt * Mi * Nn / (sum2 / (rounds - 1)) / 1e9, best2, 2.0 * Kt * Mi * Nn / best2 / 1e9);
+        }
+    }
     return 0;
 }
