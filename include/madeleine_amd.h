@@ -54,7 +54,7 @@ const char* mdl_version(void);
 /* ABI revision of this header: bumped whenever an entry point's argument list changes.  A binding compares
  * mdl_abi_version() with the MDL_ABI_VERSION it was written against BEFORE calling anything else, so that a stale
  * shared object fails loudly instead of being called with shifted arguments. */
-#define MDL_ABI_VERSION 5
+#define MDL_ABI_VERSION 6
 int mdl_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -274,6 +274,19 @@ int mdl_abmil_pool_view_fwd_bf16(const uint16_t* E, int64_t ldE, const float* sc
 int mdl_abmil_pool_view_bwd_bf16(const uint16_t* E, int64_t ldE, const float* scores, const float* pooled, const float* stat_m,
                                  const float* stat_l, const float* d_pooled, uint16_t* dE, float* d_scores, int64_t n_bags,
                                  int64_t N, const int32_t* token_idx, int64_t n_idx, int H, void* stream);
+/* N1 Linears in the bf16 mode (madeleine/models/Model.py:351, :355, :359 pre-attention MLP, :140 token_projector under
+ * `precision: bfloat16`, trainer.py:101-103): X, Y, dY, dX bf16; W [N,K], bias [N], dW, dbias fp32.  v_mfma_f32_32x32x16_bf16 with
+ * fp32 accumulation; dW through the ds_read_b64_tr_b16 "TN" engine (no transposed copies of X / dY).
+ * Supported (mdl_linear_bf16_supported; MDL_E_UNSUPPORTED otherwise): forward N % 128 == 0, K % 32 == 0; backward additionally
+ * K % 256 == 0.  Leading dimensions multiples of 8.  Same argument meaning as mdl_linear_fwd / mdl_linear_bwd. */
+int mdl_linear_bf16_supported(int64_t N, int64_t K, int backward);
+int64_t mdl_linear_fwd_bf16_ws_bytes(int64_t T, int64_t N, int64_t K);
+int mdl_linear_fwd_bf16(const uint16_t* X, int64_t ldx, const float* W, const float* bias, uint16_t* Y, int64_t ldy, int64_t T,
+                        int64_t N, int64_t K, void* ws, void* stream);
+int64_t mdl_linear_bwd_bf16_ws_bytes(int64_t T, int64_t N, int64_t K);
+int mdl_linear_bwd_bf16(const uint16_t* X, int64_t ldx, const float* W, const uint16_t* dY, int64_t lddy, uint16_t* dX, int64_t lddx,
+                        float* dW, float* dbias, int64_t T, int64_t N, int64_t K, void* ws, void* stream);
+
 int64_t mdl_abmil_gate_fwd_bf16_ws_bytes(int64_t T, int H);
 int mdl_abmil_gate_fwd_bf16(const uint16_t* E, int64_t ldE, const float* Wa, const float* ba, const float* Wb,
                             const float* bb, const float* wc, const float* bc, float* scores, uint16_t* act_a,

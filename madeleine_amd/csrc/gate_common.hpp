@@ -58,6 +58,18 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// LDS-DMA, saddr form.  M0 = LDS destination of the wave (wave-uniform); restored because hipcc owns M0.
+__device__ __forceinline__ void glds16_s(uint32_t voff, const void* sbase, uint32_t lds_addr) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_addr)
+                 : "memory");
+}
+__device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+}
+
 __device__ __forceinline__ void gate_dz(const DropCfg& d, float ds, float wcv, float a, float b, int64_t idx, float& dza,
                                         float& dzb, float& pab) {
     bool keep_a, keep_b;
@@ -181,14 +193,14 @@ __device__ __forceinline__ float pool_term_weight(const PoolTerm& pt, int64_t t,
 // of 8 columns per lane: emit(row_u, rl, lane_col, lo, hi, cp) gets columns lane_col .. +7 (tile coordinates through colb) of
 // tile row row_u + rl (row_u wave-uniform, rl = lane >> 3) as two float4 -> one 16-B store of 8 bf16; 8 lanes cover 128
 // contiguous bytes of a row.  `tile` = 2048 floats private to the wave, in staging memory that is free (main loop done).
-template <bool FULL, class Emit>
-__device__ __forceinline__ void epilogue_rows8(const f32x16 (&acc)[2][4], float* tile, int wm, const int (&colb)[4], int lane,
+template <bool FULL, int NCT, class Emit>
+__device__ __forceinline__ void epilogue_rows8(const f32x16 (&acc)[2][NCT], float* tile, int wm, const int (&colb)[NCT], int lane,
                                                int rows_valid, Emit&& emit) {
     const int l32 = lane & 31, rl = lane >> 3, g = lane & 7;
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-        for (int cp = 0; cp < 2; ++cp) {
+        for (int cp = 0; cp < NCT / 2; ++cp) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
 #pragma unroll

@@ -35,17 +35,6 @@ struct TileSmem {
     float B[2][TBK][TBN];    // K-major rows
 };
 
-// LDS-DMA, saddr form.  M0 = LDS destination of the wave (wave-uniform); restored because hipcc owns M0.
-__device__ __forceinline__ void glds16_s(uint32_t voff, const void* sbase, uint32_t lds_addr) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(sbase), "s"(lds_addr)
-                 : "memory");
-}
-__device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
-    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
-}
 #define TILE_DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #define TILE_SB() __builtin_amdgcn_sched_barrier(0)
 

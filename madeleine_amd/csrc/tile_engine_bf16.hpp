@@ -1,0 +1,207 @@
+// tile_engine_bf16.hpp -- the two bf16 tile loops (v_mfma_f32_32x32x16_bf16, fp32 accumulate) shared by the bf16 gate kernels
+// (abmil_gate_bf16.hip) and the bf16 Linear kernels (linear_bf16.hip).  Workgroup = 4 waves (2 x 2), tile 128 x 256, each wave
+// 64 x 128 = 2 x 4 MFMA tiles (128 accumulator registers); the NT loop also comes 128 x 128 (NCT = 2 column tiles per wave).
+//   NT: C[m][n] = sum_k A[m][k] B[n][k]  both operands K-contiguous rows; LDS image = XOR-swizzled 64-B rows, ds_read_b128.
+//   TN: C[m][n] = sum_k A[k][m] B[k][n]  both operands K-major; fragments gathered by ds_read_b64_tr_b16.
+#pragma once
+#include "gate_common.hpp"
+
+namespace mdl {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+// ================================================================================================
+// NT
+// ================================================================================================
+constexpr int BBM = 128, BBN = 256, BBK = 32;
+
+struct __attribute__((aligned(16))) SmemNT {
+    bf16_t A[2][BBM * BBK];  // 8 KiB per stage
+    bf16_t B[2][BBN * BBK];  // 16 KiB per stage
+};
+
+template <int NCT>
+__device__ __forceinline__ void zero_acc8(f32x16 (&acc)[2][NCT]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NCT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+}
+
+// byte offsets (within one stage) of the 16-B fragments this lane reads for k-step g = 0; g = 1 is `^ 32`
+template <int NCT>
+__device__ __forceinline__ void nt_offsets(int wm, const int (&colb)[NCT], int lane, int (&offA)[2], int (&offB)[NCT]) {
+    const int l32 = lane & 31, kh = lane >> 5;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const int r = wm * 64 + rt * 32 + l32;
+        offA[rt] = r * 64 + ((kh ^ ((r >> 2) & 3)) << 4);
+    }
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+        const int r = colb[ct] + l32;
+        offB[ct] = r * 64 + ((kh ^ ((r >> 2) & 3)) << 4);
+    }
+}
+
+// the 16 MFMAs of one staged chunk (two k-steps of 16)
+template <int NCT>
+__device__ __forceinline__ void nt_mma_chunk(const SmemNT& sm, int st, f32x16 (&acc)[2][NCT], const int (&offA)[2],
+                                             const int (&offB)[NCT]) {
+    const char* Ab = reinterpret_cast<const char*>(sm.A[st]);
+    const char* Bb = reinterpret_cast<const char*>(sm.B[st]);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        bf16x8 fa[2], fb[NCT];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) fa[rt] = *reinterpret_cast<const bf16x8*>(Ab + (offA[rt] ^ (g << 5)));
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) fb[ct] = *reinterpret_cast<const bf16x8*>(Bb + (offB[ct] ^ (g << 5)));
+#pragma unroll
+        for (int m = 0; m < 2 * NCT; ++m) {
+            const int rt = m & 1, ct = m >> 1;
+            acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[rt], fb[ct], acc[rt][ct], 0, 0, 0);
+        }
+    }
+}
+
+// LDS-DMA slot geometry: instruction q of wave w deposits slots [(nq*w + q)*64, +64); slot s = (row s>>2, stored chunk s&3)
+// holds the global chunk (s&3) ^ ((row>>2)&3) of that row.
+__device__ __forceinline__ void nt_slot(int instr, int lane, int& row, int& kq) {
+    const int sl = instr * 64 + lane;
+    row = sl >> 2;
+    kq = (sl & 3) ^ ((row >> 2) & 3);
+}
+
+template <int NCT, class Issue>
+__device__ __forceinline__ void nt_mainloop(SmemNT& sm, f32x16 (&acc)[2][NCT], int64_t nch, Issue&& issue, const int (&offA)[2],
+                                            const int (&offB)[NCT]) {
+    if (nch > 0) issue(0, (int64_t)0);
+    __syncthreads();
+    for (int64_t ch = 0; ch < nch; ++ch) {
+        const int st = (int)(ch & 1);
+        if (ch + 1 < nch) issue(st ^ 1, ch + 1);  // lands in the stage last read before the previous barrier
+        nt_mma_chunk(sm, st, acc, offA, offB);
+        __syncthreads();  // drains the LDS-DMA of chunk ch+1 (vmcnt) and fences this chunk's reads
+    }
+}
+
+// ================================================================================================
+// TN.  Measured semantics of ds_read_b64_tr_b16 (tools/micro/tr_probe.hip): within a 16-lane group every lane r supplies the
+// address of 4 consecutive bf16 D[r][0..3] and lane l receives D[4j + (l >> 2)][l & 3], j = 0..3; with lane r pointing at
+// tile[k0 + (r >> 2)][i0 + 4 (r & 3)] lane l gets tile[k0 + j][i0 + l] -- 4 consecutive k of "its" row/column.  LDS stage:
+// A image [32 k][128 m] (8 KiB) + B image [32 k][256 n] (16 KiB), 64-B unit u of k-row t stored at unit u ^ (t & 3)
+// (source-side swizzle of the LDS-DMA), two stages, fragments of k-step s+1 requested behind the first MFMA of step s
+// (inline-asm reads: the s_waitcnt lgkmcnt is placed by hand).
+// ================================================================================================
+constexpr int TNK = 32;
+struct __attribute__((aligned(16))) SmemTN {
+    bf16_t A[2][TNK * 128];
+    bf16_t B[2][TNK * 256];
+};
+template <int OFF>
+__device__ __forceinline__ u32x2 ds_tr16(uint32_t lds_byte_addr) {
+    u32x2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(lds_byte_addr), "i"(OFF));
+    return v;
+}
+struct TnFrag {
+    u32x2 a[2][2], b[4][2];   // [row / column tile][k half]
+};
+template <int KS>   // k-step 0 / 1 of the staged chunk
+__device__ __forceinline__ void tn_load(TnFrag& f, const uint32_t (&aA)[2], const uint32_t (&aB)[4]) {
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        f.a[rt][0] = ds_tr16<KS * 4096>(aA[rt]);
+        f.a[rt][1] = ds_tr16<KS * 4096 + 1024>(aA[rt]);
+    }
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        f.b[ct][0] = ds_tr16<KS * 8192>(aB[ct]);
+        f.b[ct][1] = ds_tr16<KS * 8192 + 2048>(aB[ct]);
+    }
+}
+__device__ __forceinline__ void tn_mma(f32x16 (&acc)[2][4], const TnFrag& f, int m) {
+    const int rt = m & 1, ct = m >> 1;
+    const u32x4 av = {f.a[rt][0].x, f.a[rt][0].y, f.a[rt][1].x, f.a[rt][1].y};
+    const u32x4 bv = {f.b[ct][0].x, f.b[ct][0].y, f.b[ct][1].x, f.b[ct][1].y};
+    acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc[rt][ct], 0,
+                                                          0, 0);
+}
+
+// Generic TN tile loop: acc[rt][ct] += sum over nch chunks of 32 k of A[k][wm*64 + rt*32 ..] B[k][wn*128 + ct*32 ..].
+// dma(stage, chunk, piece): piece 0..5 = this wave's LDS-DMA instructions (0,1: A k-rows 4(2w+p)..+3; 2..5: B k-rows 2(4w+p-2), +1).
+template <class Dma>
+__device__ __forceinline__ void tn_mainloop(SmemTN& sm, f32x16 (&acc)[2][4], int64_t nch, int wm, int wn, int lane, Dma&& dma) {
+    const int g = lane >> 4, r = lane & 15;
+    // lane r of group g points at token row (g >> 1) * 8 + (r >> 2) (+ 16 KS + 4 h through the immediate offset), columns
+    // tile0 + (g & 1) * 16 + (r & 3) * 4; the 64-B unit XOR depends on (token & 3) = (r >> 2) only
+    uint32_t a0[2], b0[4];
+    const int kb = (g >> 1) * 8 + (r >> 2);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+        a0[rt] = lds_addr_of(&sm.A[0][0]) + kb * 256 + (((wm * 64 + rt * 32 + (g & 1) * 16 + (r & 3) * 4) * 2) ^ ((kb & 3) << 6));
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+        b0[ct] = lds_addr_of(&sm.B[0][0]) + kb * 512 + (((wn * 128 + ct * 32 + (g & 1) * 16 + (r & 3) * 4) * 2) ^ ((kb & 3) << 6));
+    if (nch <= 0) return;
+#pragma unroll
+    for (int p = 0; p < 6; ++p) dma(0, (int64_t)0, p);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    {
+        const int64_t f = nch > 1 ? 1 : 0;
+#pragma unroll
+        for (int p = 0; p < 6; ++p) dma(1, f, p);
+    }
+    TnFrag f0, f1;
+    tn_load<0>(f0, a0, b0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    for (int64_t ch = 0; ch < nch; ++ch) {
+        const int st = (int)(ch & 1);
+        uint32_t aA[2], aB[4], nA[2], nB[4];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            aA[rt] = a0[rt] + st * (TNK * 128 * 2);
+            nA[rt] = a0[rt] + (st ^ 1) * (TNK * 128 * 2);
+        }
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            aB[ct] = b0[ct] + st * (TNK * 256 * 2);
+            nB[ct] = b0[ct] + (st ^ 1) * (TNK * 256 * 2);
+        }
+        // k-step 0: its first MFMA, then the requests of k-step 1, then the other 7 MFMAs
+        tn_mma(acc, f0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        tn_load<1>(f1, aA, aB);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 1; m < 8; ++m) tn_mma(acc, f0, m);
+        __builtin_amdgcn_sched_barrier(0);
+        // k-step 1 (last of the chunk): all reads of this stage are requested -> wait for them and for this wave's DMA of the next
+        // chunk, barrier, then the next chunk's first fragments and the DMA of chunk ch+2 ride between the MFMAs
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        tn_load<0>(f0, nA, nB);
+        __builtin_amdgcn_sched_barrier(0);
+        const int64_t f = (ch + 2 < nch) ? ch + 2 : nch - 1;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            tn_mma(acc, f1, m);
+            __builtin_amdgcn_sched_barrier(0);
+            if (m < 6) dma(st, f, m);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);   // no MFMA of the next iteration above the wait (inline-asm reads are not tracked)
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
+}  // namespace mdl

@@ -458,24 +458,72 @@ class LinearFn(torch.autograd.Function):
         return dx, dW, db
 
 
+class LinearBf16Fn(torch.autograd.Function):
+    """bf16 mode of LinearFn: x, y and their gradients bf16; W, bias and their gradients fp32 (mdl_linear_*_bf16)."""
+
+    @staticmethod
+    def forward(ctx, x, W, bias):
+        _require(x, "x", torch.bfloat16)
+        _require(W, "weight")
+        if bias is not None:
+            _require(bias, "bias")
+        lib = _native.lib()
+        T, K = x.shape
+        N = W.shape[0]
+        y = torch.empty(T, N, device=x.device, dtype=torch.bfloat16)
+        ws = _ws(lib.mdl_linear_fwd_bf16_ws_bytes(T, N, K), x.device)
+        with _timed("linear_fwd"):
+            rc = lib.mdl_linear_fwd_bf16(_ptr(x), x.stride(0), _ptr(W), _ptr(bias), _ptr(y), N, T, N, K, _ptr(ws), _stream())
+        _native.check(rc, "mdl_linear_fwd_bf16")
+        ctx.save_for_backward(x, W)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        lib = _native.lib()
+        T, K = x.shape
+        N = W.shape[0]
+        dy = dy.to(torch.bfloat16).contiguous()
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dW = torch.empty_like(W)
+        db = torch.empty(N, device=x.device, dtype=torch.float32) if ctx.has_bias else None
+        ws = _ws(lib.mdl_linear_bwd_bf16_ws_bytes(T, N, K), x.device)
+        with _timed("linear_bwd"):
+            rc = lib.mdl_linear_bwd_bf16(_ptr(x), x.stride(0), _ptr(W), _ptr(dy), N, _ptr(dx), K, _ptr(dW), _ptr(db), T, N, K,
+                                         _ptr(ws), _stream())
+        _native.check(rc, "mdl_linear_bwd_bf16")
+        return dx, dW, db
+
+
 def linear_supported(x, W) -> bool:
-    """Geometries of mdl_linear_* (include/madeleine_amd.h): at most 256 rows -> any K, N % 4 == 0; otherwise N % 128 == 0,
-    K % 32 == 0, and K % 256 == 0 when the input needs a gradient or N is not a multiple of 256."""
+    """Geometries of mdl_linear_* (include/madeleine_amd.h).  fp32: at most 256 rows -> any K, N % 4 == 0; otherwise
+    N % 128 == 0, K % 32 == 0, and K % 256 == 0 when the input needs a gradient or N is not a multiple of 256.
+    bf16 activations (fp32 weight): more than 256 rows, N % 128 == 0, K % 256 == 0 (mdl_linear_*_bf16)."""
     N, K = W.shape
-    if x.dtype != torch.float32 or W.dtype != torch.float32:
+    if W.dtype != torch.float32 or not x.is_cuda:
         return False
     T = x.numel() // max(1, x.shape[-1])
+    if x.dtype == torch.bfloat16:
+        return T > 256 and bool(_native.lib().mdl_linear_bf16_supported(N, K, 1))
+    if x.dtype != torch.float32:
+        return False
     if T <= 256:
         return N % 4 == 0
     return N % 128 == 0 and K % 32 == 0 and (K % 256 == 0 or not (x.requires_grad or N % 256))
 
 
 def linear(x, W, bias=None):
-    """Linear over the last axis through the HIP kernels; other geometries / dtypes use the library GEMM."""
+    """Linear over the last axis through the HIP kernels (fp32, or bf16 activations with fp32 parameters); other geometries /
+    dtypes use the library GEMM."""
     if not linear_supported(x, W):
+        if x.dtype != W.dtype:
+            return torch.nn.functional.linear(x, W.to(x.dtype), None if bias is None else bias.to(x.dtype))
         return torch.nn.functional.linear(x, W, bias)
     lead = x.shape[:-1]
-    y = LinearFn.apply(x.reshape(-1, x.shape[-1]).contiguous(), W.contiguous(), None if bias is None else bias.contiguous())
+    fn = LinearBf16Fn if x.dtype == torch.bfloat16 else LinearFn
+    y = fn.apply(x.reshape(-1, x.shape[-1]).contiguous(), W.contiguous(), None if bias is None else bias.contiguous())
     return y.view(*lead, W.shape[0])
 
 

@@ -130,9 +130,9 @@ class ABMILEmbedder(nn.Module):
         if bf16_mode():
             with torch.autocast(device_type="cuda", enabled=False):
                 bf = torch.bfloat16
-                x = self._act(F.linear(bags.to(bf), pa[0].weight.to(bf)), pa[1], 0, None, pa[0].bias)
-                x = self._act(F.linear(x, pa[4].weight.to(bf)), pa[5], 1, None, pa[4].bias)
-                return self._act(F.linear(x, pa[8].weight[perm].to(bf)), pa[9], 2, perm, pa[8].bias)
+                x = self._act(MF.linear(bags.to(bf), pa[0].weight), pa[1], 0, None, pa[0].bias)
+                x = self._act(MF.linear(x, pa[4].weight), pa[5], 1, None, pa[4].bias)
+                return self._act(MF.linear(x, pa[8].weight[perm]), pa[9], 2, perm, pa[8].bias)
         x = self._act(MF.linear(bags.float(), pa[0].weight), pa[1], 0, None, pa[0].bias)
         x = self._act(MF.linear(x, pa[4].weight), pa[5], 1, None, pa[4].bias)
         return self._act(MF.linear(x, pa[8].weight[perm]), pa[9], 2, perm, pa[8].bias)
@@ -269,16 +269,14 @@ class MADELEINE(nn.Module):
     def _project_slide(self, pooled_hm):
         """projector Linear(2048, 512) (Model.py:145) on the head-major pooled embeddings (columns permuted to match)."""
         perm = self.wsi_embedders._perm
-        if pooled_hm.dtype == torch.float32 and not bf16_mode():
+        with torch.autocast(device_type="cuda", enabled=False):   # fp32 pooled embeddings: the fp32 kernel in both modes
             return MF.linear(pooled_hm, self.projector.weight[:, perm], self.projector.bias)
-        return F.linear(pooled_hm, self.projector.weight[:, perm], self.projector.bias)
 
     def _project_tokens(self, E_hm):
         """token_projector Linear(2048, 128) (Model.py:140) on the head-major token embeddings."""
         perm = self.wsi_embedders._perm
-        if E_hm.dtype == torch.float32 and not bf16_mode():
+        with torch.autocast(device_type="cuda", enabled=False):
             return MF.linear(E_hm, self.token_projector.weight[:, perm], self.token_projector.bias)
-        return F.linear(E_hm, self.token_projector.weight[:, perm], self.token_projector.bias)
 
     def _cat_stain(self, feats, idx):
         """feats [R,N,D], idx LongTensor [R] -> cat([feats, embedding[idx] broadcast over N])."""

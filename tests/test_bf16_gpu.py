@@ -48,6 +48,36 @@ def test_ln_gelu_drop_bf16_vs_fp32_kernel(dev, W, rows):
     assert rel_err(outs["bf16"][2], outs["f32"][2]) < 1e-5 and rel_err(outs["bf16"][3], outs["f32"][3]) < 1e-5
 
 
+@pytest.mark.parametrize("T,N,K,bias", [(1000, 512, 512, False), (4133, 256, 512, True), (257, 2048, 256, True),
+                                         (20000, 512, 1024, False), (1500, 128, 2048, True), (700, 384, 256, False)])
+def test_linear_bf16_vs_fp32_math(dev, T, N, K, bias):
+    """mdl_linear_*_bf16 (hand-written bf16 MFMA Linears) against fp32 matmuls of the same bf16-representable operands.  The
+    products of bf16 values are exact in fp32 and accumulation is fp32, so Y / dX differ from the reference by the output
+    rounding to bf16 only (one ulp = 2^-8 relative per element); dW / dbias are fp32 sums of identical terms: 1e-5.  T covers
+    ragged row tails (not a multiple of the 128-row tile nor of the 32-token chunk of the dW contraction)."""
+    from madeleine_amd import functional as MF
+    x = _bf(t((T, K), f"bf:lin:x{T}")).to(dev)
+    W = _bf(t((N, K), f"bf:lin:w{N}{K}") / K ** 0.5).to(dev).requires_grad_()
+    b = (0.1 * t((N,), f"bf:lin:b{N}")).to(dev).requires_grad_() if bias else None
+    dy = _bf(t((T, N), f"bf:lin:dy{T}")).to(dev)
+    xb = x.to(BF).requires_grad_()
+    assert MF.linear_supported(xb, W)
+    y = MF.linear(xb, W, b)
+    assert y.dtype == BF
+    y.backward(dy.to(BF))
+    got = (y.detach().float(), xb.grad.float(), W.grad.clone(), None if b is None else b.grad.clone())
+    W.grad = None
+    xr = x.clone().requires_grad_()
+    yr = xr @ W.t() + (0 if b is None else b.detach())
+    yr.backward(dy)
+    assert (got[0] - yr.detach()).abs().max() <= EPS_BF16 * yr.detach().abs().max()
+    assert rel_err(got[0], yr.detach()) < EPS_BF16
+    assert rel_err(got[1], xr.grad) < EPS_BF16
+    assert rel_err(got[2], W.grad) < 1e-5
+    if bias:
+        assert rel_err(got[3], dy.sum(0)) < 1e-5
+
+
 def test_pool_bf16_vs_fp32_kernel(dev):
     from madeleine_amd import functional as MF
     BM, N, H = 3, 333, 4
