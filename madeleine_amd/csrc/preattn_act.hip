@@ -52,21 +52,23 @@ struct ActDrop {
 // Keep decisions of the 4 consecutive elements [idx4, idx4 + 4) of a row (idx4 % 4 == 0): ONE counter hash per element
 // PAIR -- the even element takes the low 16 bits, the odd one the high 16 bits -- and 32-bit index arithmetic inside a
 // row (a row never straddles a 2^32 boundary because W divides 2^32).  row_key = key ^ (hi32(row * W) * golden).
-__device__ __forceinline__ void act_keep4(const ActDrop& d, uint32_t row_key, uint32_t lo4, int64_t idx4, bool (&k)[4]) {
+// Output: the dropout MULTIPLIER of each element (1/(1-p) or 0) -- booleans crossing the mode branch were materialised as
+// packed bytes and unpacked again (~3 extra VALU instructions per element in kernels that are VALU-bound).
+__device__ __forceinline__ void act_keep4(const ActDrop& d, uint32_t row_key, uint32_t lo4, int64_t idx4, float (&k)[4]) {
     if (!d.on) {
-        k[0] = k[1] = k[2] = k[3] = true;
+        k[0] = k[1] = k[2] = k[3] = 1.f;
     } else if (d.keep) {
         const uint32_t m = *reinterpret_cast<const uint32_t*>(d.keep + idx4);
-        k[0] = (m & 0xFFu) != 0;
-        k[1] = (m & 0xFF00u) != 0;
-        k[2] = (m & 0xFF0000u) != 0;
-        k[3] = (m >> 24) != 0;
+        k[0] = (m & 0xFFu) ? d.inv : 0.f;
+        k[1] = (m & 0xFF00u) ? d.inv : 0.f;
+        k[2] = (m & 0xFF0000u) ? d.inv : 0.f;
+        k[3] = (m >> 24) ? d.inv : 0.f;
     } else {
         const uint32_t h0 = mix32(lo4 ^ row_key), h1 = mix32((lo4 + 2u) ^ row_key);
-        k[0] = (h0 & 0xFFFFu) >= d.thr;
-        k[1] = (h0 >> 16) >= d.thr;
-        k[2] = (h1 & 0xFFFFu) >= d.thr;
-        k[3] = (h1 >> 16) >= d.thr;
+        k[0] = (h0 & 0xFFFFu) >= d.thr ? d.inv : 0.f;
+        k[1] = (h0 >> 16) >= d.thr ? d.inv : 0.f;
+        k[2] = (h1 & 0xFFFFu) >= d.thr ? d.inv : 0.f;
+        k[3] = (h1 >> 16) >= d.thr ? d.inv : 0.f;
     }
 }
 __device__ __forceinline__ uint32_t act_row_key(const ActDrop& d, int64_t row_base) {
@@ -158,13 +160,12 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_fwd_kernel(const IO* _
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 f32x4 o;
-                bool kp[4];
+                float kp[4];
                 act_keep4(drop, rkey, (uint32_t)rb + (uint32_t)(col0 + i * 256), rb + col0 + i * 256, kp);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float t = (v[i][e] - mean) * rstd * g[i][e] + b[i][e];
-                    const float a = gelu_f(t);
-                    o[e] = kp[e] ? a * drop.inv : 0.f;
+                    o[e] = gelu_f(t) * kp[e];
                 }
                 st4(yr + i * 256, o);
             }
@@ -240,14 +241,13 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_bwd_kernel(const IO* _
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const f32x4 xv = xc[i] + lb[i], gv = gc[i];
-            bool kp[4];
+            float kp[4];
             act_keep4(drop, rkey, (uint32_t)rb + (uint32_t)(col0 + i * 256), rb + col0 + i * 256, kp);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float h = (xv[e] - mean) * rstd;
                 const float t = h * g[i][e] + b[i][e];
-                const float k = (live && kp[e]) ? drop.inv : 0.f;
-                const float dt = gv[e] * k * gelu_grad_f(t);  // d/d(LN output)
+                const float dt = gv[e] * kp[e] * gelu_grad_f(t);  // d/d(LN output); rows past the end carry gv = 0
                 sg[i][e] += dt * h;
                 sb[i][e] += dt;
                 const float dh = dt * g[i][e];

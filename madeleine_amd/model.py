@@ -32,6 +32,22 @@ HE_POSITION = 0
 PRE_DROPOUT_P = 0.1  # Model.py:354,358,362
 
 
+class _PermuteFn(torch.autograd.Function):
+    """w.index_select(dim, perm) for a BIJECTIVE perm: the backward is the gather by the inverse permutation (one kernel)
+    instead of autograd's index_put_(accumulate=True), which sorts the indices (~10 small launches per use and step)."""
+
+    @staticmethod
+    def forward(ctx, w, perm, inv, dim):
+        ctx.save_for_backward(inv)
+        ctx.dim = dim
+        return w.index_select(dim, perm)
+
+    @staticmethod
+    def backward(ctx, g):
+        (inv,) = ctx.saved_tensors
+        return g.index_select(ctx.dim, inv), None, None, None
+
+
 def bf16_mode() -> bool:
     """True inside torch.autocast(device_type='cuda', dtype=torch.bfloat16): selects the kernels' bf16 mode."""
     return torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16
@@ -72,6 +88,7 @@ class ABMILEmbedder(nn.Module):
         # perm[j'] = j with j' = c*hid + e (head-major) and j = e*H + c (reference order)
         jp = torch.arange(hid * H)
         self.register_buffer("_perm", (jp % hid) * H + (jp // hid), persistent=False)
+        self.register_buffer("_inv_perm", torch.argsort(self._perm), persistent=False)
         self._injected_keep = None  # dict(pre=[3 masks, reference layout], gate=[(ka,kb) per head]) for parity tests
 
     def _build_pre_attention_params(self, params):
@@ -98,12 +115,16 @@ class ABMILEmbedder(nn.Module):
             raise NotImplementedError('Attention model not implemented -- Options are ABMIL')
 
     # ------------------------------------------------------------------ internals (head-major)
+    def permuted(self, w, dim):
+        """Parameter `w` with axis `dim` (length H*512) in head-major order."""
+        return _PermuteFn.apply(w, self._perm, self._inv_perm, dim)
+
     def _act(self, x, ln, blk, perm=None, lin_bias=None):
         """(+ bias of the preceding Linear) -> LayerNorm -> GELU -> Dropout(.1) of block `blk` in ONE fused HIP pass each
         way (functional.ln_gelu_drop); the Linear itself runs bias-free."""
-        g, b = (ln.weight, ln.bias) if perm is None else (ln.weight[perm], ln.bias[perm])
+        g, b = (ln.weight, ln.bias) if perm is None else (self.permuted(ln.weight, 0), self.permuted(ln.bias, 0))
         if lin_bias is not None and perm is not None:
-            lin_bias = lin_bias[perm]
+            lin_bias = self.permuted(lin_bias, 0)
         p, seed, keep = 0.0, 0, None
         if self.training:
             p = float(self.pre_attn[4 * blk + 3].p)   # the nn.Dropout module of this block (0.1 unless the user changed it)
@@ -132,10 +153,10 @@ class ABMILEmbedder(nn.Module):
                 bf = torch.bfloat16
                 x = self._act(MF.linear(bags.to(bf), pa[0].weight), pa[1], 0, None, pa[0].bias)
                 x = self._act(MF.linear(x, pa[4].weight), pa[5], 1, None, pa[4].bias)
-                return self._act(MF.linear(x, pa[8].weight[perm]), pa[9], 2, perm, pa[8].bias)
+                return self._act(MF.linear(x, self.permuted(pa[8].weight, 0)), pa[9], 2, perm, pa[8].bias)
         x = self._act(MF.linear(bags.float(), pa[0].weight), pa[1], 0, None, pa[0].bias)
         x = self._act(MF.linear(x, pa[4].weight), pa[5], 1, None, pa[4].bias)
-        return self._act(MF.linear(x, pa[8].weight[perm]), pa[9], 2, perm, pa[8].bias)
+        return self._act(MF.linear(x, self.permuted(pa[8].weight, 0)), pa[9], 2, perm, pa[8].bias)
 
     def gate_params_stacked(self):
         ps = [h.gate_params() for h in self.attn]
@@ -268,15 +289,13 @@ class MADELEINE(nn.Module):
     # ------------------------------------------------------------------ helpers
     def _project_slide(self, pooled_hm):
         """projector Linear(2048, 512) (Model.py:145) on the head-major pooled embeddings (columns permuted to match)."""
-        perm = self.wsi_embedders._perm
         with torch.autocast(device_type="cuda", enabled=False):   # fp32 pooled embeddings: the fp32 kernel in both modes
-            return MF.linear(pooled_hm, self.projector.weight[:, perm], self.projector.bias)
+            return MF.linear(pooled_hm, self.wsi_embedders.permuted(self.projector.weight, 1), self.projector.bias)
 
     def _project_tokens(self, E_hm):
         """token_projector Linear(2048, 128) (Model.py:140) on the head-major token embeddings."""
-        perm = self.wsi_embedders._perm
         with torch.autocast(device_type="cuda", enabled=False):
-            return MF.linear(E_hm, self.token_projector.weight[:, perm], self.token_projector.bias)
+            return MF.linear(E_hm, self.wsi_embedders.permuted(self.token_projector.weight, 1), self.token_projector.bias)
 
     def _cat_stain(self, feats, idx):
         """feats [R,N,D], idx LongTensor [R] -> cat([feats, embedding[idx] broadcast over N])."""
