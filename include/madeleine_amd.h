@@ -277,8 +277,8 @@ int mdl_abmil_pool_view_bwd_bf16(const uint16_t* E, int64_t ldE, const float* sc
 /* N1 Linears in the bf16 mode (madeleine/models/Model.py:351, :355, :359 pre-attention MLP, :140 token_projector under
  * `precision: bfloat16`, trainer.py:101-103): X, Y, dY, dX bf16; W [N,K], bias [N], dW, dbias fp32.  v_mfma_f32_32x32x16_bf16 with
  * fp32 accumulation; dW through the ds_read_b64_tr_b16 "TN" engine (no transposed copies of X / dY).
- * Supported (mdl_linear_bf16_supported; MDL_E_UNSUPPORTED otherwise): forward N % 128 == 0, K % 32 == 0; backward additionally
- * K % 256 == 0.  Leading dimensions multiples of 8.  Same argument meaning as mdl_linear_fwd / mdl_linear_bwd. */
+ * Supported (mdl_linear_bf16_supported; MDL_E_UNSUPPORTED otherwise): N % 128 == 0 and K % 32 == 0 (forward and
+ * backward).  Leading dimensions multiples of 8.  Same argument meaning as mdl_linear_fwd / mdl_linear_bwd. */
 int mdl_linear_bf16_supported(int64_t N, int64_t K, int backward);
 int64_t mdl_linear_fwd_bf16_ws_bytes(int64_t T, int64_t N, int64_t K);
 int mdl_linear_fwd_bf16(const uint16_t* X, int64_t ldx, const float* W, const float* bias, uint16_t* Y, int64_t ldy, int64_t T,

@@ -6,8 +6,8 @@
 //   dX      : dX[t, k] = sum_n dY[t, n] W[n, k]                   NT engine, B = bf16 copy of W^T
 //   dW      : dW[n, k] = sum_t dY[t, n] X[t, k]                   TN engine (ds_read_b64_tr_b16), fp32 slabs over token splits
 //   dbias   : column sums of dY (fp32)
-// Geometry: forward N % 128 == 0 (128 x 256 tile when N % 256 == 0, else 128 x 128), K % 32 == 0; backward additionally K % 256 == 0 (dX
-// tile width, dW B-tile);
+// Geometry: N % 128 == 0 (forward: 128 x 256 tile when N % 256 == 0, else 128 x 128), K % 32 == 0 (ragged last 256-column tile of dX /
+// dW: clamped operand fetches, masked stores);
 // leading dimensions multiples of 8 elements, 16-B aligned bases.  T is free (row tails are clamped / zero-filled).
 #include "tile_engine_bf16.hpp"
 
@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void linb_w_transpose_kernel(const float* __re
 template <int NCT>   // 32-column tiles per wave: 4 -> 128 x 256 tile, 2 -> 128 x 128 (the token projector's 128 outputs)
 __global__ __launch_bounds__(256, 2) void linb_nt_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B,
                                                          const float* __restrict__ bias, bf16_t* __restrict__ C, int64_t ldc,
-                                                         int64_t T, int Kc, int n_ct, int n_tiles) {
+                                                         int64_t T, int Kc, int ncols, int n_ct, int n_tiles) {
     __shared__ SmemNT sm;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -60,7 +60,9 @@ __global__ __launch_bounds__(256, 2) void linb_nt_kernel(const bf16_t* __restric
     for (int q = 0; q < NCT; ++q) {
         int row, kq;
         nt_slot(wave * NCT + q, lane, row, kq);
-        srcB[q] = B + (int64_t)(n0 + row) * Kc + kq * 8;
+        int nr = n0 + row;
+        if (nr > ncols - 1) nr = ncols - 1;   // ragged last column tile: duplicate rows, their outputs are not stored
+        srcB[q] = B + (int64_t)nr * Kc + kq * 8;
     }
     auto issue = [&](int st, int64_t ch) {
         const int k0 = (int)ch * BBK;
@@ -81,6 +83,7 @@ __global__ __launch_bounds__(256, 2) void linb_nt_kernel(const bf16_t* __restric
     float* tile = reinterpret_cast<float*>(&sm) + wave * (32 * 64);
     bf16_t* ob = C + t0 * ldc + n0;
     auto emit = [&](int row_u, int rl, int lane_col, const f32x4& lo, const f32x4& hi, int) {
+        if (n0 + lane_col >= ncols) return;   // ncols % 8 == 0: an 8-column group is entirely in or out
         bf16_t* o = ob + (int64_t)row_u * ldc + ((uint32_t)rl * (uint32_t)ldc + (uint32_t)lane_col);
         f32x4 a = lo, b = hi;
         if (bias) {
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void linb_tn_kernel(const bf16_t* __restric
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int lid = xcd_remap(blockIdx.x, n_tiles);
-    const int n_kt = K / 256, n_nt = N / 128;
+    const int n_kt = (K + 255) / 256, n_nt = N / 128;
     const int kt = lid % n_kt, ntile = (lid / n_kt) % n_nt, sp = lid / (n_kt * n_nt);
     if (sp >= n_splits) return;
     const int n0 = ntile * 128, k0 = kt * 256;
@@ -140,7 +143,9 @@ __global__ __launch_bounds__(256, 2) void linb_tn_kernel(const bf16_t* __restric
         } else {
             const int q = piece - 2;
             uint32_t k = kB[q];
-            const uint32_t cs = (cB ^ ((k & 3) << 2)) << 4;
+            uint32_t cg = cB ^ ((k & 3) << 2);        // 16-B chunk of the X row this lane fetches (source-side swizzle)
+            if (k0 + (int)cg * 8 >= K) cg = 0;        // ragged last column tile: re-read chunk 0, those columns are not stored
+            const uint32_t cs = cg << 4;
             if (left < TNK - 1) k = ((int64_t)k <= left) ? k : (uint32_t)(left > 0 ? left : 0);
             glds16_s(k * ldB2 + cs, uptr(baseB + f * TNK * (int64_t)ldB2), lds_addr_of(&sm.B[st][(wave * 4 + q) * 512]));
         }
@@ -157,7 +162,10 @@ __global__ __launch_bounds__(256, 2) void linb_tn_kernel(const bf16_t* __restric
         for (int r = 0; r < 16; ++r) {
             const int nr = n0 + wm * 64 + rt * 32 + acc_row(r, lane);
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) so[(int64_t)nr * K + k0 + wn * 128 + ct * 32 + l32] = acc[rt][ct][r];
+            for (int ct = 0; ct < 4; ++ct) {
+                const int kc = k0 + wn * 128 + ct * 32 + l32;
+                if (kc < K) so[(int64_t)nr * K + kc] = acc[rt][ct][r];
+            }
         }
 }
 
@@ -210,7 +218,7 @@ struct LinbWs {
 };
 static inline LinbWs linb_ws(int64_t T, int N, int K) {
     LinbWs w;
-    const int tiles = (N / 128) * (K / 256);
+    const int tiles = (N / 128) * ((K + 255) / 256);
     w.S = splits_for(T, tiles > 0 ? tiles : 1);
     int64_t tps = (T + w.S - 1) / w.S;
     w.tps = ((tps + TNK - 1) / TNK) * TNK;
@@ -227,7 +235,7 @@ static inline LinbWs linb_ws(int64_t T, int N, int K) {
     return w;
 }
 static inline bool linb_geom_fwd(int64_t N, int64_t K) { return N > 0 && K > 0 && N % 128 == 0 && K % BBK == 0 && N <= (1 << 20) && K <= (1 << 20); }
-static inline bool linb_geom_bwd(int64_t N, int64_t K) { return linb_geom_fwd(N, K) && K % BBN == 0; }
+static inline bool linb_geom_bwd(int64_t N, int64_t K) { return linb_geom_fwd(N, K); }
 
 }  // namespace mdl
 
@@ -259,10 +267,10 @@ extern "C" int mdl_linear_fwd_bf16(const uint16_t* X, int64_t ldx, const float* 
     if (tiles > 0x7fffffff) return MDL_E_UNSUPPORTED;
     if (wide)
         hipLaunchKernelGGL(linb_nt_kernel<4>, dim3((unsigned)tiles), dim3(256), 0, s, (const bf16_t*)X, ldx, (const bf16_t*)Wb, bias,
-                           (bf16_t*)Y, ldy, T, (int)K, n_ct, (int)tiles);
+                           (bf16_t*)Y, ldy, T, (int)K, (int)N, n_ct, (int)tiles);
     else
         hipLaunchKernelGGL(linb_nt_kernel<2>, dim3((unsigned)tiles), dim3(256), 0, s, (const bf16_t*)X, ldx, (const bf16_t*)Wb, bias,
-                           (bf16_t*)Y, ldy, T, (int)K, n_ct, (int)tiles);
+                           (bf16_t*)Y, ldy, T, (int)K, (int)N, n_ct, (int)tiles);
     MDL_LAUNCH_CHECK();
     return MDL_OK;
 }
@@ -302,15 +310,15 @@ extern "C" int mdl_linear_bwd_bf16(const uint16_t* X, int64_t ldx, const float* 
     if (dX) {   // dX = dY W: NT with B = W^T rows [K][N]
         hipLaunchKernelGGL(linb_w_transpose_kernel, dim3((unsigned)(K / 32), (unsigned)(N / 32)), dim3(256), 0, s, W, WT, (int)N, (int)K);
         MDL_LAUNCH_CHECK();
-        const int n_ct = (int)(K / BBN);
+        const int n_ct = (int)((K + BBN - 1) / BBN);
         const int64_t tiles = ((T + BBM - 1) / BBM) * n_ct;
         if (tiles > 0x7fffffff) return MDL_E_UNSUPPORTED;
         hipLaunchKernelGGL(linb_nt_kernel<4>, dim3((unsigned)tiles), dim3(256), 0, s, (const bf16_t*)dY, lddy, (const bf16_t*)WT,
-                           (const float*)nullptr, (bf16_t*)dX, lddx, T, (int)N, n_ct, (int)tiles);
+                           (const float*)nullptr, (bf16_t*)dX, lddx, T, (int)N, (int)K, n_ct, (int)tiles);
         MDL_LAUNCH_CHECK();
     }
     {
-        const int64_t tiles = (int64_t)L.S * (N / 128) * (K / 256);
+        const int64_t tiles = (int64_t)L.S * (N / 128) * ((K + 255) / 256);
         if (tiles > 0x7fffffff) return MDL_E_UNSUPPORTED;
         hipLaunchKernelGGL(linb_tn_kernel, dim3((unsigned)tiles), dim3(256), 0, s, (const bf16_t*)dY, lddy, (const bf16_t*)X, ldx,
                            (const bf16_t*)zrow, slab, T, (int)N, (int)K, L.tps, L.S, (int)tiles);

@@ -500,7 +500,7 @@ class LinearBf16Fn(torch.autograd.Function):
 def linear_supported(x, W) -> bool:
     """Geometries of mdl_linear_* (include/madeleine_amd.h).  fp32: at most 256 rows -> any K, N % 4 == 0; otherwise
     N % 128 == 0, K % 32 == 0, and K % 256 == 0 when the input needs a gradient or N is not a multiple of 256.
-    bf16 activations (fp32 weight): more than 256 rows, N % 128 == 0, K % 256 == 0 (mdl_linear_*_bf16)."""
+    bf16 activations (fp32 weight): more than 256 rows, N % 128 == 0, K % 32 == 0 (mdl_linear_*_bf16)."""
     N, K = W.shape
     if W.dtype != torch.float32 or not x.is_cuda:
         return False
