@@ -388,6 +388,127 @@ __global__ __launch_bounds__(256) void nt128p_noepi(const bf16_t* __restrict__ A
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// v3: 128 x 256 x 32, 4 waves, NS-stage LDS ring (NS x 24 KiB): the LDS-DMA of chunk ch + NS - 1 is issued when chunk ch starts,
+// so NS - 1 chunks (not one) cover the global->LDS latency.  With v_mfma_f32_32x32x16_bf16 a 32-deep chunk is only 16 x 32 =
+// 512 MFMA cycles (~0.2 us) of work per wave: one chunk of lookahead (v0) leaves every chunk waiting ~1 us for its operands.
+template <int NS>
+struct __attribute__((aligned(16))) SmemNTS {
+    bf16_t A[NS][BBM * BBK];
+    bf16_t B[NS][BBN * BBK];
+};
+template <int EPI, int NS>
+__device__ __forceinline__ void nt128s_body(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
+                                            float* __restrict__ C, int64_t ldc, int64_t M, int N, int K, SmemNTS<NS>& sm) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ncol = N / BBN;
+    const int nt = blockIdx.x % ncol;
+    const int64_t m0 = (int64_t)(blockIdx.x / ncol) * BBM;
+    const int n0 = nt * BBN;
+    const char* baseA = reinterpret_cast<const char*>(A + m0 * lda);
+    const char* baseB = reinterpret_cast<const char*>(B + (int64_t)n0 * ldb);
+    uint32_t voA[2], voB[4];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int sl = (wave * 2 + q) * 64 + lane, row = sl >> 2, kq = (sl & 3) ^ ((row >> 2) & 3);
+        int64_t r = row;
+        if (m0 + r > M - 1) r = M - 1 - m0;
+        voA[q] = (uint32_t)(r * lda * 2 + kq * 16);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int sl = (wave * 4 + q) * 64 + lane, row = sl >> 2, kq = (sl & 3) ^ ((row >> 2) & 3);
+        voB[q] = (uint32_t)((int64_t)row * ldb * 2 + kq * 16);
+    }
+    const uint32_t ldsA = lds_addr_of(&sm.A[0][0]) + wave * 2 * 1024, ldsB = lds_addr_of(&sm.B[0][0]) + wave * 4 * 1024;
+    auto issue = [&](int st, int f) {
+        const char* a = baseA + (int64_t)f * (BBK * 2);
+        const char* b = baseB + (int64_t)f * (BBK * 2);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) glds16_s(voA[q], a, ldsA + st * (BBM * BBK * 2) + q * 1024);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) glds16_s(voB[q], b, ldsB + st * (BBN * BBK * 2) + q * 1024);
+    };
+    const int l32 = lane & 31, kh = lane >> 5;
+    int offA[2], offB[4];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const int r = wm * 64 + rt * 32 + l32;
+        offA[rt] = r * 64 + ((kh ^ ((r >> 2) & 3)) << 4);
+    }
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        const int r = wn * 128 + ct * 32 + l32;
+        offB[ct] = r * 64 + ((kh ^ ((r >> 2) & 3)) << 4);
+    }
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int nch = K / BBK;
+    // prologue: chunks 0 .. NS-2 in flight (indices past the end re-fetch the last chunk: harmless, keeps vmcnt uniform)
+#pragma unroll
+    for (int p = 0; p < NS - 1; ++p) issue(p, p < nch ? p : nch - 1);
+    int st = 0;
+    for (int ch = 0; ch < nch; ++ch) {
+        // this wave's pieces of chunk ch have landed once at most (NS - 2) x 6 younger DMA instructions are outstanding
+        if (NS == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (NS == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (NS == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+        __syncthreads();   // every wave's pieces of chunk ch are in LDS; every wave is done reading the stage of chunk ch - 1
+        {
+            const int f = ch + NS - 1 < nch ? ch + NS - 1 : nch - 1;
+            int sn = st + NS - 1;
+            if (sn >= NS) sn -= NS;
+            issue(sn, f);
+        }
+        const char* Ab = reinterpret_cast<const char*>(sm.A[0]) + st * (BBM * BBK * 2);
+        const char* Bb = reinterpret_cast<const char*>(sm.B[0]) + st * (BBN * BBK * 2);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            bf16x8 fa[2], fb[4];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) fa[rt] = *reinterpret_cast<const bf16x8*>(Ab + (offA[rt] ^ (g << 5)));
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) fb[ct] = *reinterpret_cast<const bf16x8*>(Bb + (offB[ct] ^ (g << 5)));
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const int rt = m & 1, ct = m >> 1;
+                acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[rt], fb[ct], acc[rt][ct], 0, 0, 0);
+            }
+        }
+        st = st + 1 == NS ? 0 : st + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t m = m0 + wm * 64 + rt * 32 + acc_row(r, lane);
+            if (EPI == 1 ? (M < 0) : (m < M)) {
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) C[m * ldc + n0 + wn * 128 + ct * 32 + l32] = acc[rt][ct][r];
+            }
+        }
+}
+#define NT128S(NAME, EPI, NS, OCC)                                                                                              \
+    __global__ __launch_bounds__(256, OCC) void NAME(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B,   \
+                                                     int64_t ldb, float* __restrict__ C, int64_t ldc, int64_t M, int N, int K) { \
+        __shared__ SmemNTS<NS> sm;                                                                                              \
+        nt128s_body<EPI, NS>(A, lda, B, ldb, C, ldc, M, N, K, sm);                                                              \
+    }
+NT128S(nt128s3, 0, 3, 2)
+NT128S(nt128s3_noepi, 1, 3, 2)
+NT128S(nt128s4_noepi, 1, 4, 1)
+NT128S(nt128s6_noepi, 1, 6, 1)
+NT128S(nt128s2_noepi, 1, 2, 2)
+
+// ------------------------------------------------------------------------------------------------------------------
 // TN: C[i, n] = sum_k A[k][i] B[k][n] with BOTH operands K-major in memory (token-major activations: the dW products) --
 // no transposed copies: the MFMA fragments (8 consecutive k per lane) are gathered from the K-major LDS image by
 // ds_read_b64_tr_b16.  Measured semantics (tools/micro/tr_probe.hip): within a 16-lane group every lane r supplies the
@@ -560,11 +681,13 @@ int main(int argc, char** argv) {
     hipEventCreate(&e1);
     struct V { const char* name; kern_t k; int bm, bn, threads; };
     const V vs[] = {{"nt128x256x32", nt128, BBM, BBN, 256}, {"nt256x256x64_pipe", nt256, PM, PN, 512},
-                    {"nt128_pipe", nt128p, BBM, BBN, 256},
+                    {"nt128_pipe", nt128p, BBM, BBN, 256}, {"nt128_ring3", nt128s3, BBM, BBN, 256},
                     {"nt128_noepi", nt128_noepi, BBM, BBN, 256}, {"nt256_noepi", nt256_noepi, PM, PN, 512},
-                    {"nt128_pipe_noepi", nt128p_noepi, BBM, BBN, 256}};
-    const int nv = 6;
-    for (int v = 0; v < 3; ++v)
+                    {"nt128_pipe_noepi", nt128p_noepi, BBM, BBN, 256}, {"nt128_ring2_noepi", nt128s2_noepi, BBM, BBN, 256},
+                    {"nt128_ring3_noepi", nt128s3_noepi, BBM, BBN, 256}, {"nt128_ring4_noepi", nt128s4_noepi, BBM, BBN, 256},
+                    {"nt128_ring6_noepi", nt128s6_noepi, BBM, BBN, 256}};
+    const int nv = 11;
+    for (int v = 0; v < 4; ++v)
         for (int which = 0; which < 2; ++which) {
             const int64_t Mc = which ? 1000 : M;
             const int tiles = (int)(((Mc + vs[v].bm - 1) / vs[v].bm) * (N / vs[v].bn));
