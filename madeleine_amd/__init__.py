@@ -14,8 +14,9 @@ from .abmil import BatchedABMIL
 from .loss import GOT, InfoNCE, info_nce, init_intra_wsi_loss_function
 from .model import ABMILEmbedder, MADELEINE, create_model
 from .trainer import calculate_losses, train_loop
-from .utils import run_inference
+from .utils import create_model_from_pretrained, extract_slide_level_embeddings, load_checkpoint, run_inference
 
 __all__ = ["MADELEINE", "ABMILEmbedder", "BatchedABMIL", "create_model", "InfoNCE", "info_nce", "GOT",
-           "init_intra_wsi_loss_function", "calculate_losses", "train_loop", "run_inference"]
+           "init_intra_wsi_loss_function", "calculate_losses", "train_loop", "run_inference", "extract_slide_level_embeddings",
+           "load_checkpoint", "create_model_from_pretrained"]
 __version__ = "0.2"

@@ -1,5 +1,10 @@
-"""Host-side glue the training harness needs (mirrors of reference madeleine/utils/utils.py:27-66 and :124-201)."""
+"""Host-side glue the training harness needs (mirrors of reference madeleine/utils/utils.py:27-201 and the local half of
+madeleine/models/factory.py:17-41)."""
+import json
+import os
+import pickle
 import random
+from argparse import Namespace
 
 import numpy as np
 import torch
@@ -24,6 +29,53 @@ def run_inference(ssl_model, val_dataloader, config=None, torch_precision=None):
             slide_ids.append(ids[0])
     embeds = np.array(embeds)
     return {"embeds": embeds, "slide_ids": slide_ids}, smooth_rank_measure(torch.Tensor(embeds))
+
+
+def extract_slide_level_embeddings(args, val_dataloaders, ssl_model):
+    """utils.py:68-90: run_inference over every validation dataloader; one `<RESULS_SAVE_PATH>/<dataset>.pkl` per dataset
+    ({"embeds", "slide_ids"}), the smooth rank printed (and sent to wandb when args.log_ml and wandb is installed)."""
+    for dataset_name, loader in val_dataloaders.items():
+        print(f"\n* Extracting slide-level embeddings of {dataset_name}")
+        results, rank = run_inference(ssl_model, loader, config=args)
+        print("Rank for {} = {}".format(dataset_name, rank))
+        if getattr(args, "log_ml", False):
+            try:
+                import wandb
+                wandb.run.summary["{}_rank".format(dataset_name)] = rank
+            except ImportError:
+                pass
+        os.makedirs(args.RESULS_SAVE_PATH, exist_ok=True)
+        with open(os.path.join(args.RESULS_SAVE_PATH, f"{dataset_name}.pkl"), "wb") as f:
+            pickle.dump(results, f)
+
+
+def load_checkpoint(args, ssl_model, path_to_checkpoint=None):
+    """utils.py:92-121: load `model.pt` (explicit path, or under args.RESULS_SAVE_PATH) into ssl_model; a state dict saved
+    from nn.DataParallel / DDP ('module.' prefixes) is accepted."""
+    path = path_to_checkpoint if path_to_checkpoint is not None else os.path.join(args.RESULS_SAVE_PATH, "model.pt")
+    state = torch.load(path, map_location="cpu", weights_only=False)
+    if any(k.startswith("module.") for k in state):
+        state = {(k[7:] if k.startswith("module.") else k): v for k, v in state.items()}
+        print('Model loaded by removing module in state dict...')
+    ssl_model.load_state_dict(state)
+    return ssl_model
+
+
+def create_model_from_pretrained(local_dir: str, download: bool = False, device=None):
+    """factory.py:17-41: (model, precision) from a released checkpoint directory holding `model_config.json` + `model.pt`.
+    `download=True` first fetches MahmoodLab/madeleine with huggingface_hub into local_dir (as the reference always does);
+    the default reads what is already there (no network on the training boxes)."""
+    from .model import create_model
+    if download:
+        from huggingface_hub import snapshot_download
+        os.makedirs(local_dir, exist_ok=True)
+        print(f"* Downloading model at {local_dir}")
+        snapshot_download(repo_id="MahmoodLab/madeleine", local_dir=local_dir)
+    with open(os.path.join(local_dir, "model_config.json")) as f:
+        cfg = Namespace(**json.load(f))
+    model = create_model(cfg, device=device if device is not None else DEVICE,
+                         checkpoint_path=os.path.join(local_dir, "model.pt"))
+    return model, set_model_precision(cfg.precision)
 
 
 def set_model_precision(precision):

@@ -110,6 +110,26 @@ def test_utils_mirror():
     assert abs(r - 8.0) < 0.05
 
 
+def test_checkpoint_and_pretrained_dir_round_trip(tmp_path):
+    """N3 host glue: load_checkpoint (utils.py:92-121, incl. a DataParallel-style 'module.' state dict) and
+    create_model_from_pretrained on a local checkpoint directory (factory.py:29-41: model_config.json + model.pt)."""
+    import json
+    from types import SimpleNamespace
+    from madeleine_amd import MADELEINE, create_model_from_pretrained, load_checkpoint
+    cfgd = dict(MODALITIES=["HE", "ER"], wsi_encoder="abmil", patch_embedding_dim=64, wsi_encoder_hidden_dim=512,
+                activation="softmax", n_heads=4, precision="bfloat16")
+    src = MADELEINE(SimpleNamespace(**cfgd))
+    torch.save({"module." + k: v for k, v in src.state_dict().items()}, tmp_path / "model.pt")
+    (tmp_path / "model_config.json").write_text(json.dumps(cfgd))
+    dst = load_checkpoint(SimpleNamespace(RESULS_SAVE_PATH=str(tmp_path)), MADELEINE(SimpleNamespace(**cfgd)))
+    for k, v in src.state_dict().items():
+        assert torch.equal(v, dst.state_dict()[k]), k
+    model, precision = create_model_from_pretrained(str(tmp_path), device="cpu")
+    assert precision is torch.bfloat16
+    for k, v in src.state_dict().items():
+        assert torch.equal(v, model.state_dict()[k]), k
+
+
 def test_dataset_collate_contract():
     """N4: item / collate contract of wsi_dataset.py (fixed-N resample, zero bag for an absent stain, stacking)."""
     import pandas as pd

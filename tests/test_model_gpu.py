@@ -465,6 +465,16 @@ def test_inference_full_bag_vs_oracle_and_run_inference(dev):
     # the reference's bf16 extraction (extract_slide_embeddings.py:49 passes torch_precision): same loop under autocast
     res16, _ = run_inference(model, loader[1:], torch_precision=torch.bfloat16)
     assert rel_err(res16["embeds"], res["embeds"][1:]) < 3e-2
+    # extract_slide_level_embeddings (utils.py:68-90): one pickle per validation dataset
+    import pickle
+    import tempfile
+    from madeleine_amd import extract_slide_level_embeddings
+    with tempfile.TemporaryDirectory() as td:
+        extract_slide_level_embeddings(SimpleNamespace(precision="float32", log_ml=False, RESULS_SAVE_PATH=td), {"BCNB": loader[1:]},
+                                       model)
+        with open(f"{td}/BCNB.pkl", "rb") as f:
+            saved = pickle.load(f)
+    assert saved["slide_ids"] == ["slide_b", "slide_c"] and np.array_equal(saved["embeds"], res["embeds"][1:])
 
 
 def test_train_loop_trajectory_golden(dev, capsys):
