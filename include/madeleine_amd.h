@@ -54,7 +54,7 @@ const char* mdl_version(void);
 /* ABI revision of this header: bumped whenever an entry point's argument list changes.  A binding compares
  * mdl_abi_version() with the MDL_ABI_VERSION it was written against BEFORE calling anything else, so that a stale
  * shared object fails loudly instead of being called with shifted arguments. */
-#define MDL_ABI_VERSION 6
+#define MDL_ABI_VERSION 7
 int mdl_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -123,6 +123,21 @@ int mdl_abmil_pool_bwd(const float* E, int64_t ldE, const float* scores, const f
                        const float* stat_m, const float* stat_l, const float* d_pooled, float* dE,
                        int accumulate, float* d_scores, int accumulate_scores, int64_t n_bags, int64_t N,
                        const int64_t* cu_seqlens, int64_t max_len, int H, void* stream);
+
+/* Weighted pooling WITHOUT the softmax: pooled[b,c,:] = sum_t weights[t,c] E[t,c,:] -- the 'relu' / 'leaky_relu' / 'sigmoid'
+ * attention activations of BatchedABMIL (madeleine/models/abmil.py:56-61) pooled as Model.py:416-417 does.  weights [T,H] are the
+ * ACTIVATED scores (the elementwise activation and its derivative stay with the caller); same geometry arguments and workspace
+ * as mdl_abmil_pool_fwd; scratch_m / scratch_l [n_bags,H] are overwritten.  Backward: dE[t,c,:] (+)= weights[t,c] d_pooled[b,c,:],
+ * d_weights[t,c] = <E[t,c,:], d_pooled[b,c,:]>. */
+int mdl_abmil_wpool_fwd(const float* E, int64_t ldE, const float* weights, float* pooled, float* scratch_m, float* scratch_l,
+                        int64_t n_bags, int64_t N, const int64_t* cu_seqlens, int64_t max_len, int H, void* ws, void* stream);
+int mdl_abmil_wpool_bwd(const float* E, int64_t ldE, const float* weights, const float* d_pooled, float* dE, int accumulate,
+                        float* d_weights, int64_t n_bags, int64_t N, const int64_t* cu_seqlens, int64_t max_len, int H, void* stream);
+int mdl_abmil_wpool_fwd_bf16(const uint16_t* E, int64_t ldE, const float* weights, float* pooled, float* scratch_m, float* scratch_l,
+                             int64_t n_bags, int64_t N, const int64_t* cu_seqlens, int64_t max_len, int H, void* ws, void* stream);
+int mdl_abmil_wpool_bwd_bf16(const uint16_t* E, int64_t ldE, const float* weights, const float* d_pooled, uint16_t* dE, int accumulate,
+                             float* d_weights, int64_t n_bags, int64_t N, const int64_t* cu_seqlens, int64_t max_len, int H,
+                             void* stream);
 
 /* Views: the intra-modality path pools two random half-bags per bag with the raw scores
  * re-softmaxed over the subset (Model.py:419-440).  A view is a DENSE bag of N tokens restricted to the index list

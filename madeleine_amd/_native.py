@@ -13,7 +13,7 @@ from . import _build
 
 _LOCK = threading.Lock()
 _LIB = None
-ABI_VERSION = 6   # == MDL_ABI_VERSION of include/madeleine_amd.h this file's SIGNATURES were written against
+ABI_VERSION = 7   # == MDL_ABI_VERSION of include/madeleine_amd.h this file's SIGNATURES were written against
 
 c_f = ctypes.c_void_p  # float* (device)
 c_p = ctypes.c_void_p
@@ -63,6 +63,10 @@ SIGNATURES = {
                                         c_p]),
     "mdl_abmil_pool_fwd_bf16": (i32, [c_f, i64, c_f, c_f, c_f, c_f, i64, i64, c_p, i64, i32, c_p, c_p]),
     "mdl_abmil_pool_bwd_bf16": (i32, [c_f, i64, c_f, c_f, c_f, c_f, c_f, c_f, i32, c_f, i32, i64, i64, c_p, i64, i32, c_p]),
+    "mdl_abmil_wpool_fwd": (i32, [c_f, i64, c_f, c_f, c_f, c_f, i64, i64, c_p, i64, i32, c_p, c_p]),
+    "mdl_abmil_wpool_bwd": (i32, [c_f, i64, c_f, c_f, c_f, i32, c_f, i64, i64, c_p, i64, i32, c_p]),
+    "mdl_abmil_wpool_fwd_bf16": (i32, [c_f, i64, c_f, c_f, c_f, c_f, i64, i64, c_p, i64, i32, c_p, c_p]),
+    "mdl_abmil_wpool_bwd_bf16": (i32, [c_f, i64, c_f, c_f, c_f, i32, c_f, i64, i64, c_p, i64, i32, c_p]),
     "mdl_linear_bf16_supported": (i32, [i64, i64, i32]),
     "mdl_linear_fwd_bf16_ws_bytes": (i64, [i64, i64, i64]),
     "mdl_linear_fwd_bf16": (i32, [c_f, i64, c_f, c_f, c_f, i64, i64, i64, i64, c_p, c_p]),

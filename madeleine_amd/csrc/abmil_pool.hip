@@ -40,7 +40,10 @@ __device__ __forceinline__ BagSpan bag_span(int b, int64_t N, const int64_t* cu,
 }
 
 // blockDim.x == H*128: thread f owns channels [4f, 4f+4) (head f/128).
-template <int H, class TE, bool IDX = false>
+// LIN: `scores` already ARE the (un-normalised) weights -- the relu / leaky_relu / sigmoid attention activations of
+// abmil.py:56-61, which the reference pools without a softmax: p = s, chunk statistics (m, l) = (0, [chunk == 0]) so that
+// pool_combine's merge is the plain sum (M = 0, L = 1).
+template <int H, class TE, bool IDX = false, bool LIN = false>
 __global__ __launch_bounds__(H * 128) void pool_partial_kernel(const TE* __restrict__ E, int64_t ldE,
                                                                const float* __restrict__ scores,
                                                                float* __restrict__ part_acc,
@@ -65,8 +68,18 @@ __global__ __launch_bounds__(H * 128) void pool_partial_kernel(const TE* __restr
     const int st = tid / H, sc = tid % H;
     const int64_t prow = (st < nt) ? (IDX ? (int64_t)idx[t0 + st] : t0 + st) : 0;
     if (IDX && sc == 0 && st < nt) tok_s[st] = (int32_t)prow;
-    const float s = (st < nt) ? scores[(sp.start + prow) * H + sc] : -INFINITY;
+    const float s = (st < nt) ? scores[(sp.start + prow) * H + sc] : (LIN ? 0.f : -INFINITY);
+    if (LIN) {
+        p_s[st * H + sc] = s;
+        if (tid < H) {
+            const int64_t o = ((int64_t)b * max_chunks + chunk) * H + tid;
+            part_m[o] = 0.f;
+            part_l[o] = chunk == 0 ? 1.f : 0.f;
+        }
+        __syncthreads();
+    }
     float mx = s;
+    if (!LIN) {
 #pragma unroll
     for (int o = 32; o >= H; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
     const int lane = tid & 63, wave = tid >> 6;
@@ -91,6 +104,7 @@ __global__ __launch_bounds__(H * 128) void pool_partial_kernel(const TE* __restr
         part_m[o] = m;  // tid < H => sc == tid, st == 0
         part_l[o] = l;
     }
+    }   // !LIN
 
     // ---- weighted accumulation: thread owns one float4 column, loops over the chunk's tokens -----
     const int ca = tid / 128;
@@ -152,7 +166,8 @@ __global__ __launch_bounds__(H * 128) void pool_combine_kernel(const float* __re
 
 // One wave per token row.  Lane L, slot i in [0,2H): channels [i*256 + 4L, +4), head i/2.
 // IDX (views): d_scores == nullptr -> dE-only pass (no read of E: dE[t] += w[t,c] d_pooled[b,c,:]); both outputs accumulate.
-template <int H, class TE, bool IDX = false>
+// LIN (see pool_partial_kernel): w = the given weight, d_weight = <E[t,c,:], d_pooled[b,c,:]> (no softmax Jacobian).
+template <int H, class TE, bool IDX = false, bool LIN = false>
 __global__ __launch_bounds__(256) void pool_bwd_kernel(const TE* __restrict__ E, int64_t ldE,
                                                        const float* __restrict__ scores,
                                                        const float* __restrict__ pooled,
@@ -177,21 +192,28 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const TE* __restrict__ E,
 #pragma unroll
     for (int i = 0; i < 2 * H; ++i) {
         dp[i] = *reinterpret_cast<const f32x4*>(d_pooled + boff + i * 256);
-        const f32x4 pl = *reinterpret_cast<const f32x4*>(pooled + boff + i * 256);
-        D[i / 2] += dp[i].x * pl.x + dp[i].y * pl.y + dp[i].z * pl.z + dp[i].w * pl.w;
+        if (!LIN) {
+            const f32x4 pl = *reinterpret_cast<const f32x4*>(pooled + boff + i * 256);
+            D[i / 2] += dp[i].x * pl.x + dp[i].y * pl.y + dp[i].z * pl.z + dp[i].w * pl.w;
+        }
     }
 #pragma unroll
     for (int c = 0; c < H; ++c) {
-        D[c] = wave_sum(D[c]);  // <pooled[b,c,:], d_pooled[b,c,:]> = sum_t w_t dw_t
-        m[c] = stat_m[(int64_t)b * H + c];
-        rl[c] = 1.f / stat_l[(int64_t)b * H + c];
+        if (LIN) {
+            m[c] = 0.f;
+            rl[c] = 1.f;
+        } else {
+            D[c] = wave_sum(D[c]);  // <pooled[b,c,:], d_pooled[b,c,:]> = sum_t w_t dw_t
+            m[c] = stat_m[(int64_t)b * H + c];
+            rl[c] = 1.f / stat_l[(int64_t)b * H + c];
+        }
     }
 
     for (int t = wave; t < nt; t += 4) {
         const int64_t row = sp.start + (IDX ? (int64_t)idx[t0 + t] : t0 + t);
         float w[H], dw[H];
 #pragma unroll
-        for (int c = 0; c < H; ++c) w[c] = expf(scores[row * H + c] - m[c]) * rl[c];
+        for (int c = 0; c < H; ++c) w[c] = LIN ? scores[row * H + c] : expf(scores[row * H + c] - m[c]) * rl[c];
         if (!IDX || d_scores) {
             const TE* __restrict__ er = E + row * ldE + lane * 4;
             f32x4 x[2 * H];
@@ -216,7 +238,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const TE* __restrict__ E,
         float ds = 0.f;
 #pragma unroll
         for (int c = 0; c < H; ++c)
-            if (lane == c) ds = w[c] * (dw[c] - D[c]);
+            if (lane == c) ds = LIN ? dw[c] : w[c] * (dw[c] - D[c]);
         if (lane < H) {
             if (accumulate_scores) ds += d_scores[row * H + lane];
             d_scores[row * H + lane] = ds;
@@ -248,7 +270,7 @@ extern "C" int64_t mdl_abmil_pool_ws_bytes(int64_t n_bags, int64_t max_len, int 
         default: return MDL_E_UNSUPPORTED;           \
     }
 
-template <class TE>
+template <class TE, bool LIN = false>
 static int pool_fwd_launch(const TE* E, int64_t ldE, const float* scores, float* pooled, float* stat_m, float* stat_l,
                            int64_t n_bags, int64_t N, const int64_t* cu_seqlens, int64_t max_len, int H, void* ws, void* stream) {
     if (!E || !scores || !pooled || !stat_m || !stat_l || !ws) return MDL_E_ARG;
@@ -265,7 +287,7 @@ static int pool_fwd_launch(const TE* E, int64_t ldE, const float* scores, float*
     float* part_l = (float*)((char*)part_m + st);
     MDL_DISPATCH_H(H, {
         if (mc > 0) {
-            hipLaunchKernelGGL((pool_partial_kernel<HH, TE>), dim3(mc, (unsigned)n_bags), dim3(HH * 128), 0, s, E, ldE, scores,
+            hipLaunchKernelGGL((pool_partial_kernel<HH, TE, false, LIN>), dim3(mc, (unsigned)n_bags), dim3(HH * 128), 0, s, E, ldE, scores,
                                part_acc, part_m, part_l, N, cu_seqlens, mc);
             MDL_LAUNCH_CHECK();
         }
@@ -276,12 +298,13 @@ static int pool_fwd_launch(const TE* E, int64_t ldE, const float* scores, float*
     return MDL_OK;
 }
 
-template <class TE>
+template <class TE, bool LIN = false>
 static int pool_bwd_launch(const TE* E, int64_t ldE, const float* scores, const float* pooled, const float* stat_m,
                            const float* stat_l, const float* d_pooled, TE* dE, int accumulate, float* d_scores,
                            int accumulate_scores, int64_t n_bags, int64_t N, const int64_t* cu_seqlens, int64_t max_len, int H,
                            void* stream) {
-    if (!E || !scores || !pooled || !stat_m || !stat_l || !d_pooled || !d_scores) return MDL_E_ARG;   // dE may be NULL
+    if (!E || !scores || !d_pooled || !d_scores) return MDL_E_ARG;   // dE may be NULL
+    if (!LIN && (!pooled || !stat_m || !stat_l)) return MDL_E_ARG;
     if (n_bags < 0 || max_len < 0 || ldE < (int64_t)H * HID || (ldE & 3)) return MDL_E_ARG;
     if (!cu_seqlens && N != max_len) return MDL_E_ARG;
     if (!host_aligned16(E) || !host_aligned16(dE) || !host_aligned16(pooled) || !host_aligned16(d_pooled)) return MDL_E_ALIGN;
@@ -290,7 +313,7 @@ static int pool_bwd_launch(const TE* E, int64_t ldE, const float* scores, const 
     hipStream_t s = (hipStream_t)stream;
     const int nc = (int)((max_len + POOL_BWD_TOKENS - 1) / POOL_BWD_TOKENS);
     MDL_DISPATCH_H(H, {
-        hipLaunchKernelGGL((pool_bwd_kernel<HH, TE>), dim3(nc, (unsigned)n_bags), dim3(256), 0, s, E, ldE, scores, pooled, stat_m,
+        hipLaunchKernelGGL((pool_bwd_kernel<HH, TE, false, LIN>), dim3(nc, (unsigned)n_bags), dim3(256), 0, s, E, ldE, scores, pooled, stat_m,
                            stat_l, d_pooled, dE, accumulate, d_scores, accumulate_scores, N, cu_seqlens);
         MDL_LAUNCH_CHECK();
     });
@@ -394,4 +417,28 @@ extern "C" int mdl_abmil_pool_bwd_bf16(const uint16_t* E, int64_t ldE, const flo
                                        const int64_t* cu_seqlens, int64_t max_len, int H, void* stream) {
     return pool_bwd_launch<bf16_t>((const bf16_t*)E, ldE, scores, pooled, stat_m, stat_l, d_pooled, (bf16_t*)dE, accumulate,
                                    d_scores, accumulate_scores, n_bags, N, cu_seqlens, max_len, H, stream);
+}
+
+// ---- weighted (non-softmax) pooling: pooled[b,c,:] = sum_t weights[t,c] E[t,c,:] (abmil.py:56-61 activations + Model.py:416-417) ----
+extern "C" int mdl_abmil_wpool_fwd(const float* E, int64_t ldE, const float* weights, float* pooled, float* scratch_m, float* scratch_l,
+                                   int64_t n_bags, int64_t N, const int64_t* cu_seqlens, int64_t max_len, int H, void* ws, void* stream) {
+    return pool_fwd_launch<float, true>(E, ldE, weights, pooled, scratch_m, scratch_l, n_bags, N, cu_seqlens, max_len, H, ws, stream);
+}
+extern "C" int mdl_abmil_wpool_bwd(const float* E, int64_t ldE, const float* weights, const float* d_pooled, float* dE, int accumulate,
+                                   float* d_weights, int64_t n_bags, int64_t N, const int64_t* cu_seqlens, int64_t max_len, int H,
+                                   void* stream) {
+    return pool_bwd_launch<float, true>(E, ldE, weights, nullptr, nullptr, nullptr, d_pooled, dE, accumulate, d_weights, 0, n_bags, N,
+                                        cu_seqlens, max_len, H, stream);
+}
+extern "C" int mdl_abmil_wpool_fwd_bf16(const uint16_t* E, int64_t ldE, const float* weights, float* pooled, float* scratch_m,
+                                        float* scratch_l, int64_t n_bags, int64_t N, const int64_t* cu_seqlens, int64_t max_len, int H,
+                                        void* ws, void* stream) {
+    return pool_fwd_launch<bf16_t, true>((const bf16_t*)E, ldE, weights, pooled, scratch_m, scratch_l, n_bags, N, cu_seqlens, max_len, H,
+                                         ws, stream);
+}
+extern "C" int mdl_abmil_wpool_bwd_bf16(const uint16_t* E, int64_t ldE, const float* weights, const float* d_pooled, uint16_t* dE,
+                                        int accumulate, float* d_weights, int64_t n_bags, int64_t N, const int64_t* cu_seqlens,
+                                        int64_t max_len, int H, void* stream) {
+    return pool_bwd_launch<bf16_t, true>((const bf16_t*)E, ldE, weights, nullptr, nullptr, nullptr, d_pooled, (bf16_t*)dE, accumulate,
+                                         d_weights, 0, n_bags, N, cu_seqlens, max_len, H, stream);
 }

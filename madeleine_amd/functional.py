@@ -280,6 +280,50 @@ class SoftmaxPoolFn(torch.autograd.Function):
         return dE.view(e_shape), ds.view(s_shape), None, None
 
 
+class WeightedPoolFn(torch.autograd.Function):
+    """pooled[b,c,:] = sum_t weights[b,t,c] E[b,t,c,:] with the weights taken as they are (no softmax): the relu / leaky_relu /
+    sigmoid attention activations of abmil.py:56-61 pooled as Model.py:416-417 does."""
+
+    @staticmethod
+    def forward(ctx, E, weights, cu_seqlens, max_len):
+        _require_act(E, "E")
+        _require(weights, "weights")
+        n_bags, N, max_len, E2d = _bag_geometry(E, cu_seqlens, max_len)
+        w2d = weights.reshape(E2d.shape[0], -1)
+        lib = _native.lib()
+        H = w2d.shape[-1]
+        pooled = torch.empty(n_bags, H * HID, device=E2d.device, dtype=torch.float32)
+        scratch = torch.empty(2, n_bags, H, device=E2d.device, dtype=torch.float32)
+        ws = _ws(lib.mdl_abmil_pool_ws_bytes(n_bags, max_len, H), E2d.device)
+        with _timed("pool_fwd"):
+            rc = getattr(lib, "mdl_abmil_wpool_fwd" + _sfx(E2d))(_ptr(E2d), E2d.stride(0), _ptr(w2d), _ptr(pooled), _ptr(scratch[0]),
+                                                                 _ptr(scratch[1]), n_bags, N, _ptr(cu_seqlens), max_len, H, _ptr(ws),
+                                                                 _stream())
+        _native.check(rc, "mdl_abmil_wpool_fwd")
+        ctx.save_for_backward(E2d, w2d, cu_seqlens if cu_seqlens is not None else torch.empty(0))
+        ctx.geom = (n_bags, N, max_len, cu_seqlens is not None, E.shape, weights.shape)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, d_pooled):
+        E2d, w2d, cu = ctx.saved_tensors
+        n_bags, N, max_len, ragged, e_shape, w_shape = ctx.geom
+        cu = cu if ragged else None
+        dE = torch.empty_like(E2d)
+        dw = torch.empty_like(w2d)
+        lib = _native.lib()
+        with _timed("pool_bwd"):
+            rc = getattr(lib, "mdl_abmil_wpool_bwd" + _sfx(E2d))(_ptr(E2d), E2d.stride(0), _ptr(w2d), _ptr(d_pooled.float().contiguous()),
+                                                                 _ptr(dE), 0, _ptr(dw), n_bags, N, _ptr(cu), max_len, w2d.shape[-1],
+                                                                 _stream())
+        _native.check(rc, "mdl_abmil_wpool_bwd")
+        return dE.view(e_shape), dw.view(w_shape), None, None
+
+
+def weighted_pool(E, weights, cu_seqlens=None, max_len=None):
+    return WeightedPoolFn.apply(E, weights.contiguous(), cu_seqlens, max_len)
+
+
 # --------------------------------------------------------------------------------------------------
 # A2 + A3 chained inside one autograd node: the pooling backward only produces d_scores, and its dE term
 # w * d_pooled is added in the gate backward's dX epilogue -- dE is written exactly once.

@@ -229,11 +229,11 @@ class ABMILEmbedder(nn.Module):
         if act == 'softmax':
             pooled, scores = self.pool_headmajor(E)
         else:
-            # non-default activations (abmil.py:56-61): scores from the HIP gate kernel, weighting in torch
+            # non-default activations (abmil.py:56-61): scores from the HIP gate kernel, the elementwise activation in torch,
+            # the un-normalised weighted pooling in the HIP pool kernels' linear mode (mdl_abmil_wpool_*)
             scores = self._scores_only(E)
             w = activate(scores.unsqueeze(2), act).squeeze(2)  # elementwise; dim=1 only matters for softmax
-            BM, N, H = scores.shape
-            pooled = torch.einsum('bnh,bnhe->bhe', w, E.view(BM, N, H, -1)).reshape(BM, -1)
+            pooled = MF.weighted_pool(E, w)
         if n_views == 1:
             return pooled, E, scores
         # intra-modality views (Model.py:419-440): two random halves, raw scores re-softmaxed per subset

@@ -94,6 +94,44 @@ def test_pool_ragged_and_empty(dev):
     assert float((sd.grad.cpu() - s.grad).abs().max()) <= 1e-4 * float(s.grad.abs().max()) + 1e-6
 
 
+@pytest.mark.parametrize("bf16", [False, True])
+def test_weighted_pool_no_softmax(dev, bf16):
+    """mdl_abmil_wpool_*: the pooling of the relu / leaky_relu / sigmoid attention activations (abmil.py:56-61, Model.py:416-417 --
+    weights used as they are, negative ones included), forward + both gradients, dense and ragged (with an empty bag),
+    against the same einsum torch runs in the reference.  bf16 storage of E: one rounding of dE on the way out."""
+    from madeleine_amd import functional as MF
+    H = 4
+    lens = [300, 0, 129, 1]
+    cu = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int64)
+    T = int(cu[-1])
+    E = t((T, H * 512), "wp:E")
+    if bf16:
+        E = E.to(torch.bfloat16).float()
+    E.requires_grad_()
+    w = torch.nn.functional.leaky_relu(t((T, H), "wp:w") * 2).detach().requires_grad_()
+    g = t((len(lens), H * 512), "wp:g")
+    ref = torch.stack([torch.einsum("nh,nhe->he", w[int(cu[b]):int(cu[b + 1])],
+                                    E[int(cu[b]):int(cu[b + 1])].view(L, H, 512)).reshape(-1) for b, L in enumerate(lens)])
+    ref.backward(g)
+    Ed = E.detach().to(dev).to(torch.bfloat16 if bf16 else torch.float32).requires_grad_()
+    wd = w.detach().to(dev).requires_grad_()
+    out = MF.weighted_pool(Ed, wd, cu.to(dev), max(lens))
+    out.backward(g.to(dev))
+    assert float(out[1].abs().max()) == 0.0
+    assert rel_err(out, ref) < 1e-5 and max_rel(out, ref) < TOL
+    assert rel_err(Ed.grad.float(), E.grad) < (2.0 ** -8 if bf16 else 1e-5)
+    assert rel_err(wd.grad, w.grad) < 1e-5
+    # dense form [BM, N, H*512]
+    E3 = t((3, 200, H * 512), "wp:E3").requires_grad_()
+    w3 = torch.sigmoid(t((3, 200, H), "wp:w3")).detach().requires_grad_()
+    ref3 = torch.einsum("bnh,bnhe->bhe", w3, E3.view(3, 200, H, 512)).reshape(3, -1)
+    ref3.backward(g[:3])
+    E3d, w3d = E3.detach().to(dev).requires_grad_(), w3.detach().to(dev).requires_grad_()
+    out3 = MF.weighted_pool(E3d, w3d)
+    out3.backward(g[:3].to(dev))
+    assert rel_err(out3, ref3) < 1e-5 and rel_err(E3d.grad, E3.grad) < 1e-5 and rel_err(w3d.grad, w3.grad) < 1e-5
+
+
 def test_pool_extreme_scores(dev):
     """softmax must be max-subtracted: scores of +-80 would overflow a naive exp."""
     from madeleine_amd import functional as MF
