@@ -51,14 +51,14 @@ __global__ __launch_bounds__(256) void gate_wt_kernel(const float* __restrict__ 
 // DM: dropout mode 0 = off, 1 = counter-hash RNG, 2 = explicit uint8 masks (one code path per instantiation: the
 // three-way runtime choice per element cost 12 arch VGPRs, i.e. the third wave per SIMD).  SAVE: store the activations.
 template <int DM>
-__device__ __forceinline__ void fwd_keep2(const DropCfg& d, int64_t idx, bool& ka, bool& kb) {
+__device__ __forceinline__ void fwd_keep2(const DropCfg& d, int64_t idx, uint32_t row_key, bool& ka, bool& kb) {
     if (DM == 0) {
         ka = kb = true;
     } else if (DM == 2) {
         ka = d.ka[idx] != 0;
         kb = d.kb[idx] != 0;
     } else {
-        const uint32_t h = rng_u32(d.key, (uint64_t)idx);
+        const uint32_t h = mix32((uint32_t)idx ^ row_key);   // = rng_u32(d.key, idx), high-word part hoisted (drop_row_key)
         ka = (h & 0xFFFFu) >= d.thr;
         kb = (h >> 16) >= d.thr;
     }
@@ -130,6 +130,7 @@ __global__ __launch_bounds__(256) void gate_fwd_kernel(const float* __restrict__
                 if (t0 + wm * 64 + rt * 32 + row < T) {
                     // element index = uniform 64-bit base of the pass + 32-bit lane part
                     const int64_t idx = ((t0 + wm * 64 + rt * 32) * H + c) * HID + jc + (uint32_t)(row * H * HID + g8 * 4);
+                    const uint32_t rkey = drop_row_key(drop, idx);   // idx % 4 == 0: the 4 elements share the high word
                     if (SAVE) {
                         *reinterpret_cast<f32x4*>(act_a + idx) = a4;
                         *reinterpret_cast<f32x4*>(act_b + idx) = b4;
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(256) void gate_fwd_kernel(const float* __restrict__
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         bool keep_a, keep_b;
-                        fwd_keep2<DM>(drop, idx + e, keep_a, keep_b);
+                        fwd_keep2<DM>(drop, idx + e, rkey, keep_a, keep_b);
                         const float ad = keep_a ? a4[e] * drop.inv : 0.f;
                         const float bd = keep_b ? b4[e] * drop.inv : 0.f;
                         sum += ad * bd * wc4[e];

@@ -49,14 +49,14 @@ __global__ __launch_bounds__(256) void gate_wn_bf16_kernel(const float* __restri
 // DM: dropout mode 0 = off, 1 = counter-hash RNG, 2 = explicit uint8 masks; SAVE: store the activations (one code path per
 // instantiation keeps the unrolled epilogue inside the register budget).
 template <int DM>
-__device__ __forceinline__ void fwd_keep2_bf16(const DropCfg& d, int64_t idx, bool& ka, bool& kb) {
+__device__ __forceinline__ void fwd_keep2_bf16(const DropCfg& d, int64_t idx, uint32_t row_key, bool& ka, bool& kb) {
     if (DM == 0) {
         ka = kb = true;
     } else if (DM == 2) {
         ka = d.ka[idx] != 0;
         kb = d.kb[idx] != 0;
     } else {
-        const uint32_t h = rng_u32(d.key, (uint64_t)idx);
+        const uint32_t h = mix32((uint32_t)idx ^ row_key);   // = rng_u32(d.key, idx), high-word part hoisted (drop_row_key)
         ka = (h & 0xFFFFu) >= d.thr;
         kb = (h >> 16) >= d.thr;
     }
@@ -141,6 +141,7 @@ __global__ __launch_bounds__(256, 2) void gate_fwd_bf16_kernel(const bf16_t* __r
                 float sum = 0.f;
                 if (t0 + wm * 64 + rt * 32 + row < T) {
                     const int64_t idx = ((t0 + wm * 64 + rt * 32) * H + c) * HID + jc + (uint32_t)(row * H * HID + g4 * 8);
+                    const uint32_t rkey = drop_row_key(drop, idx);   // idx % 8 == 0: the 8 elements share the high word
                     if (SAVE) {
                         st8_bf16(act_a + idx, alo, ahi);
                         st8_bf16(act_b + idx, blo, bhi);
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void gate_fwd_bf16_kernel(const bf16_t* __r
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         bool keep_a, keep_b;
-                        fwd_keep2_bf16<DM>(drop, idx + e, keep_a, keep_b);
+                        fwd_keep2_bf16<DM>(drop, idx + e, rkey, keep_a, keep_b);
                         const float a = e < 4 ? alo[e & 3] : ahi[e & 3], b = e < 4 ? blo[e & 3] : bhi[e & 3];
                         const float w = e < 4 ? wlo[e & 3] : whi[e & 3];
                         const float ad = keep_a ? a * drop.inv : 0.f;

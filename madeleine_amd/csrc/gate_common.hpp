@@ -36,15 +36,20 @@ struct DropCfg {
     int on;
 };
 
-// keep decisions of one gate element (tanh branch, sigmoid branch)
-__device__ __forceinline__ void drop_keep2(const DropCfg& d, int64_t idx, bool& ka, bool& kb) {
+// rng_u32(key, idx) = mix32(lo32(idx) ^ key ^ (hi32(idx) * golden)): the part that depends on the high word only, hoisted once per
+// group of elements that share it (a 64-bit add, a shift and a quarter-rate v_mul_lo_u32 per element otherwise)
+__device__ __forceinline__ uint32_t drop_row_key(const DropCfg& d, int64_t idx0) {
+    return d.key ^ ((uint32_t)((uint64_t)idx0 >> 32) * 0x9E3779B9U);
+}
+// keep decisions of one gate element (tanh branch, sigmoid branch); row_key = drop_row_key of an index with the same high word
+__device__ __forceinline__ void drop_keep2(const DropCfg& d, int64_t idx, uint32_t row_key, bool& ka, bool& kb) {
     if (!d.on) {
         ka = kb = true;
     } else if (d.ka) {
         ka = d.ka[idx] != 0;
         kb = d.kb[idx] != 0;
     } else {
-        const uint32_t h = rng_u32(d.key, (uint64_t)idx);
+        const uint32_t h = mix32((uint32_t)idx ^ row_key);
         ka = (h & 0xFFFFu) >= d.thr;
         kb = (h >> 16) >= d.thr;
     }
@@ -70,10 +75,10 @@ __device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
     return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
 }
 
-__device__ __forceinline__ void gate_dz(const DropCfg& d, float ds, float wcv, float a, float b, int64_t idx, float& dza,
-                                        float& dzb, float& pab) {
+__device__ __forceinline__ void gate_dz(const DropCfg& d, float ds, float wcv, float a, float b, int64_t idx, uint32_t row_key,
+                                        float& dza, float& dzb, float& pab) {
     bool keep_a, keep_b;
-    drop_keep2(d, idx, keep_a, keep_b);
+    drop_keep2(d, idx, row_key, keep_a, keep_b);
     const float ka = keep_a ? d.inv : 0.f;
     const float kb = keep_b ? d.inv : 0.f;
     const float ad = a * ka, bd = b * kb;
@@ -115,77 +120,118 @@ static inline int gate_splits(int64_t T, int H) { return splits_for(T, 16 * H); 
 
 constexpr int DZ_ROWS = 256;  // token rows per workgroup
 
-// grid (row blocks, H), 256 threads = 128 j-quads x 2 row phases.  slabV [nblk][H][4][512]: dba | dbb | dwc | (dbc at [0]).
+// grid (row blocks, H), 256 threads = (512 / VEC) column groups x PH row phases, VEC = 16 B / sizeof(TI) columns per thread (4 fp32,
+// 8 bf16: every memory instruction moves 16 B per lane -- with 8-B accesses the bf16 pass issued twice the memory instructions per
+// byte).  slabV [nblk][H][4][512]: dba | dbb | dwc | (dbc at [0]).
+template <class T>
+__device__ __forceinline__ void ldv(const T* p, float (&v)[16 / sizeof(T)]);
+template <>
+__device__ __forceinline__ void ldv<float>(const float* p, float (&v)[4]) {
+    const f32x4 x = ld4_nt(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = x[i];
+}
+template <>
+__device__ __forceinline__ void ldv<bf16_t>(const bf16_t* p, float (&v)[8]) {
+    const bf16x8 x = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)x[i];
+}
+__device__ __forceinline__ void stv(float* p, const float (&v)[4]) { *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]}; }
+__device__ __forceinline__ void stv(bf16_t* p, const float (&v)[8]) {
+    bf16x8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (bf16_t)v[i];
+    *reinterpret_cast<bf16x8*>(p) = o;
+}
+__device__ __forceinline__ void stv(bf16_t* p, const float (&v)[4]) { st4(p, f32x4{v[0], v[1], v[2], v[3]}); }
+__device__ __forceinline__ void stv(float* p, const float (&v)[8]) {
+    *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+}
+
 template <class TI, class TO>
 __global__ __launch_bounds__(256) void gate_dz_kernel(const float* __restrict__ wc, const TI* __restrict__ act_a,
                                                       const TI* __restrict__ act_b, const float* __restrict__ d_scores,
                                                       TO* __restrict__ dz, float* __restrict__ slabV, int64_t T, int H,
                                                       DropCfg drop) {
-    __shared__ float red[128][13];
-    const int tid = threadIdx.x, q = tid & 127, ph = tid >> 7, c = blockIdx.y;
+    constexpr int VEC = 16 / sizeof(TI), NQ = HID / VEC, PH = 256 / NQ;
+    __shared__ float red[PH - 1][NQ][3 * VEC + 1];
+    const int tid = threadIdx.x, q = tid % NQ, ph = tid / NQ, c = blockIdx.y;
     const int64_t r0 = (int64_t)blockIdx.x * DZ_ROWS;
     int64_t r1 = r0 + DZ_ROWS;
     if (r1 > T) r1 = T;
-    const f32x4 vw = *reinterpret_cast<const f32x4*>(wc + c * HID + q * 4);
-    f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = sa, sw = sa;
+    float vw[VEC], sa[VEC], sb[VEC], sw[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        vw[i] = wc[c * HID + q * VEC + i];
+        sa[i] = sb[i] = sw[i] = 0.f;
+    }
     float sds = 0.f;
-    // DZ_UNROLL rows per trip, all loads issued before the arithmetic: one row per trip left ~1 KiB per wave in flight and the
-    // kernel latency-bound at ~2.5 TB/s
-    constexpr int DZ_UNROLL = 4;
-    for (int64_t rb = r0 + ph; rb < r1; rb += 2 * DZ_UNROLL) {
-        f32x4 va[DZ_UNROLL], vb[DZ_UNROLL];
-        float ds[DZ_UNROLL];
+    // DZ_UNROLL rows per trip, all loads issued before the arithmetic
+    constexpr int DZ_UNROLL = 16 / VEC;   // 4 (fp32) / 2 (bf16): 8 x 16 B in flight per thread either way
+    for (int64_t rb = r0 + ph; rb < r1; rb += PH * DZ_UNROLL) {
+        float va[DZ_UNROLL][VEC], vb[DZ_UNROLL][VEC], ds[DZ_UNROLL];
 #pragma unroll
         for (int u = 0; u < DZ_UNROLL; ++u) {
-            const int64_t r = rb + 2 * u;
+            const int64_t r = rb + PH * u;
             const bool ok = r < r1;
-            const int64_t o = ((ok ? r : rb) * H + c) * HID + q * 4;
-            va[u] = ld4_nt(act_a + o);
-            vb[u] = ld4_nt(act_b + o);
+            const int64_t o = ((ok ? r : rb) * H + c) * HID + q * VEC;
+            ldv<TI>(act_a + o, va[u]);
+            ldv<TI>(act_b + o, vb[u]);
             ds[u] = ok ? d_scores[r * H + c] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < DZ_UNROLL; ++u) {
-            const int64_t r = rb + 2 * u;
+            const int64_t r = rb + PH * u;
             if (r < r1) {
-                const int64_t o = (r * H + c) * HID + q * 4;
-                f32x4 za, zb;
+                const int64_t o = (r * H + c) * HID + q * VEC;
+                const uint32_t rkey = drop_row_key(drop, o);   // o % 512 + i < 512: the VEC elements share the high word
+                float za[VEC], zb[VEC];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float x, y, w;
-                    gate_dz(drop, ds[u], vw[i], va[u][i], vb[u][i], o + i, x, y, w);
-                    za[i] = x;
-                    zb[i] = y;
+                for (int i = 0; i < VEC; ++i) {
+                    float w;
+                    gate_dz(drop, ds[u], vw[i], va[u][i], vb[u][i], o + i, rkey, za[i], zb[i], w);
                     sw[i] += w;
+                    sa[i] += za[i];
+                    sb[i] += zb[i];
                 }
-                sa += za;
-                sb += zb;
                 sds += ds[u];
-                TO* __restrict__ out = dz + (r * H + c) * 1024 + q * 4;
-                st4(out, za);
-                st4(out + HID, zb);
+                TO* __restrict__ out = dz + (r * H + c) * 1024 + q * VEC;
+                stv(out, za);
+                stv(out + HID, zb);
             }
         }
     }
-    if (ph == 1) {
+    if (ph > 0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            red[q][i] = sa[i];
-            red[q][4 + i] = sb[i];
-            red[q][8 + i] = sw[i];
+        for (int i = 0; i < VEC; ++i) {
+            red[ph - 1][q][i] = sa[i];
+            red[ph - 1][q][VEC + i] = sb[i];
+            red[ph - 1][q][2 * VEC + i] = sw[i];
         }
-        red[q][12] = sds;
+        red[ph - 1][q][3 * VEC] = sds;
     }
     __syncthreads();
     if (ph == 0) {
-        float* __restrict__ o = slabV + ((int64_t)blockIdx.x * H + c) * 4 * HID + q * 4;
+        float* __restrict__ o = slabV + ((int64_t)blockIdx.x * H + c) * 4 * HID + q * VEC;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            o[i] = sa[i] + red[q][i];
-            o[HID + i] = sb[i] + red[q][4 + i];
-            o[2 * HID + i] = sw[i] + red[q][8 + i];
+        for (int p = 0; p < PH - 1; ++p) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                sa[i] += red[p][q][i];
+                sb[i] += red[p][q][VEC + i];
+                sw[i] += red[p][q][2 * VEC + i];
+            }
+            sds += red[p][0][3 * VEC];
         }
-        if (q == 0) o[3 * HID] = sds + red[0][12];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            o[i] = sa[i];
+            o[HID + i] = sb[i];
+            o[2 * HID + i] = sw[i];
+        }
+        if (q == 0) o[3 * HID] = sds;
     }
 }
 

@@ -75,6 +75,50 @@ __device__ __forceinline__ uint32_t act_row_key(const ActDrop& d, int64_t row_ba
     return d.key ^ ((uint32_t)((uint64_t)row_base >> 32) * 0x9E3779B9U);
 }
 
+// Column ownership of a lane inside its wave's segment of NV groups of 4 columns.  fp32: group i = columns i*256 + 4L .. +3 (one 16-B
+// load).  bf16 with an even NV: groups 2p, 2p+1 = the 8 CONSECUTIVE columns p*512 + 8L .. +7, so a lane still moves 16 B per memory
+// instruction (with the fp32 mapping the bf16 kernels issued 8-B loads / stores -- twice the memory instructions per byte -- and ran
+// SLOWER than their fp32 siblings on half the bytes).
+template <class IO, int NV>
+struct ColMap {
+    static constexpr bool WIDE = (sizeof(IO) == 2) && (NV % 2 == 0);
+    static __device__ __forceinline__ int off(int i, int lane) {
+        return WIDE ? (i >> 1) * 512 + lane * 8 + (i & 1) * 4 : i * 256 + lane * 4;
+    }
+};
+// the NV groups of one row segment (p = row base + segment base), nontemporal
+template <class IO, int NV>
+__device__ __forceinline__ void row_load(const IO* __restrict__ p, int lane, f32x4 (&v)[NV]) {
+    if constexpr (ColMap<IO, NV>::WIDE) {
+#pragma unroll
+        for (int q = 0; q < NV / 2; ++q) {
+            const bf16x8 w = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p + q * 512 + lane * 8));
+            v[2 * q] = __builtin_convertvector(__builtin_shufflevector(w, w, 0, 1, 2, 3), f32x4);
+            v[2 * q + 1] = __builtin_convertvector(__builtin_shufflevector(w, w, 4, 5, 6, 7), f32x4);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = ld4_nt(p + i * 256 + lane * 4);
+    }
+}
+template <int NV>
+__device__ __forceinline__ void row_zero(f32x4 (&v)[NV]) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+// store of group i (fp32 mapping) or, at odd i, of the pair (i-1, i) as one 16-B store (wide bf16 mapping)
+template <class IO, int NV>
+__device__ __forceinline__ void group_store(IO* __restrict__ p, int lane, int i, const f32x4& prev, const f32x4& cur) {
+    if constexpr (ColMap<IO, NV>::WIDE) {
+        if (i & 1) {
+            const bf16x4 a = __builtin_convertvector(prev, bf16x4), b = __builtin_convertvector(cur, bf16x4);
+            *reinterpret_cast<bf16x8*>(p + (i >> 1) * 512 + lane * 8) = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+    } else {
+        st4(p + i * 256 + lane * 4, cur);
+    }
+}
+
 // Geometry: a 256-thread block = 4 waves.  WPR waves share one row (each owns a 256*NV-column segment), so a block
 // works on 4/WPR rows at a time: W = 512 -> NV 2, WPR 1 (one wave per row); W = 2048 -> NV 2, WPR 4 (one block per
 // row; keeps the backward at ~110 VGPRs = 4 waves/SIMD instead of 256+ = 1 wave/SIMD with a whole row per wave).
@@ -111,22 +155,22 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_fwd_kernel(const IO* _
     constexpr int W = NV * 256 * WPR, RPB = 4 / WPR;
     __shared__ float red[1][4][2];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, slot = wv / WPR, seg = wv % WPR;
-    const int col0 = seg * NV * 256 + lane * 4;
+    typedef ColMap<IO, NV> CM;
+    const int cb = seg * NV * 256;   // first column of this wave's segment
     f32x4 g[NV], b[NV], lb[NV];   // lb: bias of the preceding Linear (added here instead of in the GEMM epilogue)
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        g[i] = *reinterpret_cast<const f32x4*>(gamma + col0 + i * 256);
-        b[i] = *reinterpret_cast<const f32x4*>(beta + col0 + i * 256);
-        lb[i] = bias ? *reinterpret_cast<const f32x4*>(bias + col0 + i * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+        g[i] = *reinterpret_cast<const f32x4*>(gamma + cb + CM::off(i, lane));
+        b[i] = *reinterpret_cast<const f32x4*>(beta + cb + CM::off(i, lane));
+        lb[i] = bias ? *reinterpret_cast<const f32x4*>(bias + cb + CM::off(i, lane)) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     // the next row's loads are issued before the current row's reductions / epilogue: a wave always has a row in flight
     // (one row at a time left the kernel latency-bound at ~50 % of the HBM rate)
     f32x4 vn[NV];
     {
         const int64_t r = (int64_t)blockIdx.x * RPB + slot;
-        const IO* __restrict__ xr = x + (r < rows ? r : 0) * W + col0;
-#pragma unroll
-        for (int i = 0; i < NV; ++i) vn[i] = (r < rows) ? ld4_nt(xr + i * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (r < rows) row_load<IO, NV>(x + r * W + cb, lane, vn);
+        else row_zero<NV>(vn);
     }
     for (int64_t base = (int64_t)blockIdx.x * RPB; base < rows; base += (int64_t)gridDim.x * RPB) {
         const int64_t r = base + slot;
@@ -137,9 +181,8 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_fwd_kernel(const IO* _
         for (int i = 0; i < NV; ++i) v[i] = vn[i] + lb[i];
         {
             const int64_t rn = r + (int64_t)gridDim.x * RPB;
-            const IO* __restrict__ xn = x + (rn < rows ? rn : 0) * W + col0;
-#pragma unroll
-            for (int i = 0; i < NV; ++i) vn[i] = (rn < rows) ? ld4_nt(xn + i * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (rn < rows) row_load<IO, NV>(x + rn * W + cb, lane, vn);
+            else row_zero<NV>(vn);
         }
 #pragma unroll
         for (int i = 0; i < NV; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
@@ -154,20 +197,23 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_fwd_kernel(const IO* _
         row_allreduce2<WPR>(q, dummy, red, slot * WPR, wv);
         const float rstd = rsqrtf(q * (1.f / W) + eps);
         if (live) {
-            IO* __restrict__ yr = y + r * W + col0;
+            IO* __restrict__ yr = y + r * W + cb;
             const int64_t rb = r * W;
             const uint32_t rkey = act_row_key(drop, rb);
+            f32x4 prev = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 f32x4 o;
                 float kp[4];
-                act_keep4(drop, rkey, (uint32_t)rb + (uint32_t)(col0 + i * 256), rb + col0 + i * 256, kp);
+                const int ci = cb + CM::off(i, lane);
+                act_keep4(drop, rkey, (uint32_t)rb + (uint32_t)ci, rb + ci, kp);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float t = (v[i][e] - mean) * rstd * g[i][e] + b[i][e];
                     o[e] = gelu_f(t) * kp[e];
                 }
-                st4(yr + i * 256, o);
+                group_store<IO, NV>(yr, lane, i, prev, o);
+                prev = o;
             }
             if (lane == 0 && seg == 0) {
                 mean_o[r] = mean;
@@ -190,13 +236,14 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_bwd_kernel(const IO* _
     __shared__ float red[1][4][2];
     __shared__ float csum[WPR < 4 ? 3 * W : 1];  // WPR < 4: several waves own the same columns -> merged through LDS
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, slot = wv / WPR, seg = wv % WPR;
-    const int col0 = seg * NV * 256 + lane * 4;
+    typedef ColMap<IO, NV> CM;
+    const int cb = seg * NV * 256;
     f32x4 g[NV], b[NV], lb[NV], sg[NV], sb[NV], sx[NV];   // sx: column sums of dx = gradient of the Linear's bias
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        g[i] = *reinterpret_cast<const f32x4*>(gamma + col0 + i * 256);
-        b[i] = *reinterpret_cast<const f32x4*>(beta + col0 + i * 256);
-        lb[i] = bias ? *reinterpret_cast<const f32x4*>(bias + col0 + i * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+        g[i] = *reinterpret_cast<const f32x4*>(gamma + cb + CM::off(i, lane));
+        b[i] = *reinterpret_cast<const f32x4*>(beta + cb + CM::off(i, lane));
+        lb[i] = bias ? *reinterpret_cast<const f32x4*>(bias + cb + CM::off(i, lane)) : f32x4{0.f, 0.f, 0.f, 0.f};
         sg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         sb[i] = sg[i];
         sx[i] = sg[i];
@@ -204,13 +251,12 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_bwd_kernel(const IO* _
     f32x4 xn[NV], gn[NV];   // next row, prefetched (see the forward kernel)
     {
         const int64_t r = (int64_t)blockIdx.x * RPB + slot;
-        const bool ok = r < rows;
-        const IO* __restrict__ xr = x + (ok ? r : 0) * W + col0;
-        const IO* __restrict__ gr = dy + (ok ? r : 0) * W + col0;
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            xn[i] = ok ? ld4_nt(xr + i * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
-            gn[i] = ok ? ld4_nt(gr + i * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (r < rows) {
+            row_load<IO, NV>(x + r * W + cb, lane, xn);
+            row_load<IO, NV>(dy + r * W + cb, lane, gn);
+        } else {
+            row_zero<NV>(xn);
+            row_zero<NV>(gn);
         }
     }
     for (int64_t base = (int64_t)blockIdx.x * RPB; base < rows; base += (int64_t)gridDim.x * RPB) {
@@ -225,13 +271,12 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_bwd_kernel(const IO* _
         }
         {
             const int64_t rn = r + (int64_t)gridDim.x * RPB;
-            const bool ok = rn < rows;
-            const IO* __restrict__ xr = x + (ok ? rn : 0) * W + col0;
-            const IO* __restrict__ gr = dy + (ok ? rn : 0) * W + col0;
-#pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                xn[i] = ok ? ld4_nt(xr + i * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
-                gn[i] = ok ? ld4_nt(gr + i * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (rn < rows) {
+                row_load<IO, NV>(x + rn * W + cb, lane, xn);
+                row_load<IO, NV>(dy + rn * W + cb, lane, gn);
+            } else {
+                row_zero<NV>(xn);
+                row_zero<NV>(gn);
             }
         }
         f32x4 xh[NV], dxh[NV];
@@ -242,7 +287,8 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_bwd_kernel(const IO* _
         for (int i = 0; i < NV; ++i) {
             const f32x4 xv = xc[i] + lb[i], gv = gc[i];
             float kp[4];
-            act_keep4(drop, rkey, (uint32_t)rb + (uint32_t)(col0 + i * 256), rb + col0 + i * 256, kp);
+            const int ci = cb + CM::off(i, lane);
+            act_keep4(drop, rkey, (uint32_t)rb + (uint32_t)ci, rb + ci, kp);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float h = (xv[e] - mean) * rstd;
@@ -260,14 +306,16 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_bwd_kernel(const IO* _
         row_allreduce2<WPR>(s1, s2, red, slot * WPR, wv);
         const float m1 = s1 * (1.f / W), m2 = s2 * (1.f / W);
         if (live) {
-            IO* __restrict__ o = dx + r * W + col0;
+            IO* __restrict__ o = dx + r * W + cb;
+            f32x4 prev = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = rstd * (dxh[i][e] - m1 - xh[i][e] * m2);
                 sx[i] += v;
-                st4(o + i * 256, v);
+                group_store<IO, NV>(o, lane, i, prev, v);
+                prev = v;
             }
         }
     }
@@ -275,9 +323,9 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_bwd_kernel(const IO* _
     if (WPR == 4) {  // every wave owns its own column segment
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            *reinterpret_cast<f32x4*>(prow + col0 + i * 256) = sg[i];
-            *reinterpret_cast<f32x4*>(prow + W + col0 + i * 256) = sb[i];
-            *reinterpret_cast<f32x4*>(prow + 2 * W + col0 + i * 256) = sx[i];
+            *reinterpret_cast<f32x4*>(prow + cb + CM::off(i, lane)) = sg[i];
+            *reinterpret_cast<f32x4*>(prow + W + cb + CM::off(i, lane)) = sb[i];
+            *reinterpret_cast<f32x4*>(prow + 2 * W + cb + CM::off(i, lane)) = sx[i];
         }
     } else {  // waves (= rows) add into one LDS row in wave order (deterministic)
 #pragma unroll
@@ -285,9 +333,9 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_bwd_kernel(const IO* _
             if (wv == w) {
 #pragma unroll
                 for (int i = 0; i < NV; ++i) {
-                    f32x4* pg = reinterpret_cast<f32x4*>(&csum[col0 + i * 256]);
-                    f32x4* pb = reinterpret_cast<f32x4*>(&csum[W + col0 + i * 256]);
-                    f32x4* px = reinterpret_cast<f32x4*>(&csum[2 * W + col0 + i * 256]);
+                    f32x4* pg = reinterpret_cast<f32x4*>(&csum[cb + CM::off(i, lane)]);
+                    f32x4* pb = reinterpret_cast<f32x4*>(&csum[W + cb + CM::off(i, lane)]);
+                    f32x4* px = reinterpret_cast<f32x4*>(&csum[2 * W + cb + CM::off(i, lane)]);
                     if (w < WPR) {   // first wave on this column segment
                         *pg = sg[i];
                         *pb = sb[i];
