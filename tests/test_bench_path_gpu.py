@@ -183,6 +183,55 @@ def test_gate_full_size_vs_library(dev, mode):
         assert rel_err(got[i], ref) < 1e-4, n
 
 
+def test_bf16_mode_full_size_gate_and_linear(dev):
+    """The bf16 mode on BASELINE config-2 geometry (what bench.py's bf16 leg runs): (i) the gate kernels -- NT forward / dX and the
+    ds_read_b64_tr_b16 "TN" dW over 72 token splits -- against their fp32 siblings (library-checked above) on bf16-representable
+    inputs with the same in-kernel dropout draw; (ii) the 512 -> 2048 Linear (mdl_linear_*_bf16, NT + TN over 96 splits) against
+    fp32 library matmuls.  Tolerances: one bf16 rounding (2^-8) of each stored tensor; fp32 parameter gradients 5e-3 (gate: the
+    bf16 rounding of the 4.3 G activation / dz values is independent per element, their 262,144-term sums agree far better than
+    that) and 1e-4 (Linear: exact products, fp32 sums in a different order)."""
+    from madeleine_amd import functional as MF
+    BM, N, H, p, seed = 64, 4096, 4, 0.25, 777
+    T = BM * N
+    gen = torch.Generator(device=dev).manual_seed(5)
+    E = torch.randn(T, H * 512, device=dev, generator=gen).to(BF)
+    s512 = 1.0 / np.sqrt(512.0)
+    wts = [((torch.rand(H, 512, 512, device=dev, generator=gen) * 2 - 1) * s512).to(BF).float() for _ in range(2)]
+    Wa, Wb = wts
+    ba, bb, wc = ((torch.rand(H, 512, device=dev, generator=gen) * 2 - 1) * s512 for _ in range(3))
+    bc = (torch.rand(H, device=dev, generator=gen) * 2 - 1) * s512
+    ds = torch.randn(T, H, device=dev, generator=gen)
+    res = {}
+    for name, EE in (("f32", E.float()), ("bf16", E)):
+        leaves = [EE.clone().requires_grad_()] + [x.clone().requires_grad_() for x in (Wa, ba, Wb, bb, wc, bc)]
+        sc = MF.gate_scores(*leaves, p_drop=p, seed=seed)
+        sc.backward(ds)
+        res[name] = [sc.detach()] + [x.grad.float() for x in leaves]
+        del leaves, sc
+    scale = float(res["f32"][0].abs().max())
+    assert float((res["bf16"][0] - res["f32"][0]).abs().max()) < 2 * 2.0 ** -8 * scale
+    rows = slice(0, T, 509)
+    assert rel_err(res["bf16"][1][rows], res["f32"][1][rows]) < 5e-3 and rel_err(res["bf16"][1][-200:], res["f32"][1][-200:]) < 5e-3
+    for i, n in enumerate(NAMES[1:], start=2):
+        assert rel_err(res["bf16"][i], res["f32"][i]) < (1e-5 if n == "bc" else 5e-3), n
+    del res
+    # (ii) Linear 512 -> 2048 at T = 262,144
+    x = E[:, :512].contiguous()
+    W = ((torch.rand(2048, 512, device=dev, generator=gen) * 2 - 1) * s512).to(BF).float().requires_grad_()
+    dy = torch.randn(T, 2048, device=dev, generator=gen).to(BF)
+    xb = x.clone().requires_grad_()
+    y = MF.linear(xb, W)
+    y.backward(dy)
+    got_dW = W.grad.clone()
+    W.grad = None
+    xr = x.float().requires_grad_()
+    yr = xr @ W.t()
+    yr.backward(dy.float())
+    assert y.dtype == BF and rel_err(y.float()[rows], yr.detach()[rows]) < 2.0 ** -8
+    assert rel_err(xb.grad.float()[rows], xr.grad[rows]) < 2.0 ** -8 and rel_err(xb.grad.float()[-300:], xr.grad[-300:]) < 2.0 ** -8
+    assert rel_err(got_dW, W.grad) < 1e-4
+
+
 # ------------------------------------------------------------------------------------------ bench.py's loss path at W = 1
 def _cl_inputs(dev, need_grad=False):
     """The inputs oracle/gen_golden.py fed to the reference's calculate_losses: the H&E entries are LEAVES of the repeated
