@@ -36,7 +36,8 @@ template <int NCT>   // 32-column tiles per wave: 4 -> 128 x 256 tile, 2 -> 128 
 __global__ __launch_bounds__(256, 2) void linb_nt_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B,
                                                          const float* __restrict__ bias, bf16_t* __restrict__ C, int64_t ldc,
                                                          int64_t T, int Kc, int ncols, int n_ct, int n_tiles) {
-    __shared__ SmemNT sm;
+    constexpr int NS = (NCT == 4) ? 2 : 3;   // measured (tools/exp_linear_bf16.py): 128 x 256: 2 stages at 3 workgroups per CU (168 VGPRs, 52 KiB) beat 3 stages at 2; 128 x 128 (K = 2048, HBM-side): the 3-stage ring wins
+    __shared__ SmemNTR<NS> sm;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -46,15 +47,17 @@ __global__ __launch_bounds__(256, 2) void linb_nt_kernel(const bf16_t* __restric
     constexpr int BN = 64 * NCT;
     const int n0 = ct * BN;
 
-    const bf16_t* srcA[2];
-    const bf16_t* srcB[NCT];
+    // LDS-DMA in the saddr form: wave-uniform 64-bit chunk base + 32-bit lane offset
+    const char* baseA = reinterpret_cast<const char*>(A + t0 * lda);
+    const char* baseB = reinterpret_cast<const char*>(B + (int64_t)n0 * Kc);
+    uint32_t voA[2], voB[NCT];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         int row, kq;
         nt_slot(wave * 2 + q, lane, row, kq);
-        int64_t t = t0 + row;
-        if (t > T - 1) t = T - 1;
-        srcA[q] = A + t * lda + kq * 8;
+        int64_t r = row;
+        if (t0 + r > T - 1) r = T - 1 - t0;   // row tail: re-read the last row, those outputs are not stored
+        voA[q] = (uint32_t)(r * lda * 2 + kq * 16);
     }
 #pragma unroll
     for (int q = 0; q < NCT; ++q) {
@@ -62,14 +65,16 @@ __global__ __launch_bounds__(256, 2) void linb_nt_kernel(const bf16_t* __restric
         nt_slot(wave * NCT + q, lane, row, kq);
         int nr = n0 + row;
         if (nr > ncols - 1) nr = ncols - 1;   // ragged last column tile: duplicate rows, their outputs are not stored
-        srcB[q] = B + (int64_t)nr * Kc + kq * 8;
+        voB[q] = (uint32_t)((int64_t)(nr - n0) * Kc * 2 + kq * 16);
     }
+    const uint32_t ldsA = lds_addr_of(&sm.A[0][0]) + wave * 2 * 1024, ldsB = lds_addr_of(&sm.B[0][0]) + wave * NCT * 1024;
     auto issue = [&](int st, int64_t ch) {
-        const int k0 = (int)ch * BBK;
+        const char* a = baseA + ch * (BBK * 2);
+        const char* b = baseB + ch * (BBK * 2);
 #pragma unroll
-        for (int q = 0; q < 2; ++q) glds16(srcA[q] + k0, &sm.A[st][(wave * 2 + q) * 512]);
+        for (int q = 0; q < 2; ++q) glds16_s(voA[q], a, ldsA + st * (BBM * BBK * 2) + q * 1024);
 #pragma unroll
-        for (int q = 0; q < NCT; ++q) glds16(srcB[q] + k0, &sm.B[st][(wave * NCT + q) * 512]);
+        for (int q = 0; q < NCT; ++q) glds16_s(voB[q], b, ldsB + st * (BBN * BBK * 2) + q * 1024);
     };
     int colb[NCT];
 #pragma unroll
@@ -78,7 +83,7 @@ __global__ __launch_bounds__(256, 2) void linb_nt_kernel(const bf16_t* __restric
     nt_offsets(wm, colb, lane, offA, offB);
     f32x16 acc[2][NCT];
     zero_acc8(acc);
-    nt_mainloop(sm, acc, Kc / BBK, issue, offA, offB);
+    nt_mainloop_ring<NS, NCT>(sm, acc, Kc / BBK, issue, offA, offB);
 
     float* tile = reinterpret_cast<float*>(&sm) + wave * (32 * 64);
     bf16_t* ob = C + t0 * ldc + n0;

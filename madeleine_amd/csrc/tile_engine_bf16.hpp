@@ -89,6 +89,68 @@ __device__ __forceinline__ void nt_mainloop(SmemNT& sm, f32x16 (&acc)[2][NCT], i
     }
 }
 
+// ---- NS-stage ring form of the NT loop ----------------------------------------------------------------------------------------
+// Round-2 finding (tools/micro/gemm_lab_bf16.hip): what bounds the two-stage loop is the number of operand
+// BYTES IN FLIGHT per CU, not issue slots or LDS bandwidth: the global -> LDS latency under load is ~1.7 us, a 32-deep bf16 chunk
+// is ~0.2 us of MFMA work, so a workgroup that has one 24-KiB stage in flight is fed at (24 KiB x workgroups per CU) / 1.7 us.
+// With two workgroups per CU (the 170-190 VGPR kernels) that is ~7 TB/s = 0.65-0.75 PF.  The ring keeps NS - 1 stages in flight
+// per workgroup: the LDS-DMA of chunk ch + NS - 1 is issued when chunk ch starts and each wave waits only for its pieces of chunk
+// ch (s_waitcnt vmcnt((NS-2) x pieces): the DMA is inline asm, hipcc would wait for vmcnt(0) at the barrier).
+template <int NS>
+struct __attribute__((aligned(16))) SmemNTR {
+    bf16_t A[NS][BBM * BBK];
+    bf16_t B[NS][BBN * BBK];
+};
+template <int NS, int NCT>
+__device__ __forceinline__ void nt_mma_chunk_r(const SmemNTR<NS>& sm, int st, f32x16 (&acc)[2][NCT], const int (&offA)[2],
+                                               const int (&offB)[NCT]) {
+    const char* Ab = reinterpret_cast<const char*>(sm.A[0]) + st * (BBM * BBK * 2);
+    const char* Bb = reinterpret_cast<const char*>(sm.B[0]) + st * (BBN * BBK * 2);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        bf16x8 fa[2], fb[NCT];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) fa[rt] = *reinterpret_cast<const bf16x8*>(Ab + (offA[rt] ^ (g << 5)));
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) fb[ct] = *reinterpret_cast<const bf16x8*>(Bb + (offB[ct] ^ (g << 5)));
+#pragma unroll
+        for (int m = 0; m < 2 * NCT; ++m) {
+            const int rt = m & 1, ct = m >> 1;
+            acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[rt], fb[ct], acc[rt][ct], 0, 0, 0);
+        }
+    }
+}
+template <int N>
+__device__ __forceinline__ void dma_wait_outstanding() {   // s_waitcnt vmcnt(N) for the inline-asm LDS-DMA
+    if (N <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+// issue(stage, chunk): this wave's 2 + NCT LDS-DMA pieces (glds16_s) of `chunk` into `stage`; chunk indices past the end are
+// clamped by the loop (the re-fetch of the last chunk into a free stage keeps the outstanding count uniform).
+template <int NS, int NCT, class Issue>
+__device__ __forceinline__ void nt_mainloop_ring(SmemNTR<NS>& sm, f32x16 (&acc)[2][NCT], int64_t nch, Issue&& issue,
+                                                 const int (&offA)[2], const int (&offB)[NCT]) {
+    if (nch <= 0) return;
+#pragma unroll
+    for (int p = 0; p < NS - 1; ++p) issue(p, p < nch ? (int64_t)p : nch - 1);
+    int st = 0;
+    for (int64_t ch = 0; ch < nch; ++ch) {
+        dma_wait_outstanding<(NS - 2) * (2 + NCT)>();   // this wave's pieces of chunk ch have landed
+        __syncthreads();                                // ... every wave's; and every wave is done reading the stage of chunk ch - 1
+        int sn = st + NS - 1;
+        if (sn >= NS) sn -= NS;
+        issue(sn, ch + NS - 1 < nch ? ch + NS - 1 : nch - 1);
+        nt_mma_chunk_r<NS, NCT>(sm, st, acc, offA, offB);
+        st = st + 1 == NS ? 0 : st + 1;
+    }
+    dma_wait_outstanding<0>();   // the clamped re-fetches of the tail must land before the epilogue reuses the staging memory
+    __syncthreads();
+}
+
 // ================================================================================================
 // TN.  Measured semantics of ds_read_b64_tr_b16 (tools/micro/tr_probe.hip): within a 16-lane group every lane r supplies the
 // address of 4 consecutive bf16 D[r][0..3] and lane l receives D[4j + (l >> 2)][l & 3], j = 0..3; with lane r pointing at

@@ -460,8 +460,8 @@ __device__ __forceinline__ void nt128s_body(const bf16_t* __restrict__ A, int64_
         else if (NS == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else if (NS == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-        __syncthreads();   // every wave's pieces of chunk ch are in LDS; every wave is done reading the stage of chunk ch - 1
-        {
+        if (EPI != 4) __syncthreads();   // every wave's pieces of chunk ch are in LDS; every wave is done reading the stage of chunk ch - 1
+        if (EPI != 3 && EPI != 4) {   // EPI 3: no LDS-DMA in the loop (operands stale): ds_read + MFMA rate alone
             const int f = ch + NS - 1 < nch ? ch + NS - 1 : nch - 1;
             int sn = st + NS - 1;
             if (sn >= NS) sn -= NS;
@@ -469,6 +469,7 @@ __device__ __forceinline__ void nt128s_body(const bf16_t* __restrict__ A, int64_
         }
         const char* Ab = reinterpret_cast<const char*>(sm.A[0]) + st * (BBM * BBK * 2);
         const char* Bb = reinterpret_cast<const char*>(sm.B[0]) + st * (BBN * BBK * 2);
+        if (EPI != 2)     // EPI 2: no ds_read / MFMA: the global -> LDS feed rate alone
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
             bf16x8 fa[2], fb[4];
@@ -496,6 +497,263 @@ __device__ __forceinline__ void nt128s_body(const bf16_t* __restrict__ A, int64_
             }
         }
 }
+// v4: warp-specialised 128 x 256 x 32: 8 waves = 4 consumer waves (ds_read + MFMA only) + 4 producer waves (LDS-DMA only), 3-stage
+// ring, one workgroup barrier per chunk.  The ~6 x (60..100)-cycle issue cost of a chunk's LDS-DMA pieces leaves the MFMA waves'
+// instruction streams; producer p issues exactly the pieces consumer p issued in v0/v3.
+template <int EPI>
+__device__ __forceinline__ void nt128ws_body(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
+                                             float* __restrict__ C, int64_t ldc, int64_t M, int N, int K, SmemNTS<3>& sm) {
+    constexpr int NS = 3;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = wave8 >= 4;
+    const int wave = wave8 & 3;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ncol = N / BBN;
+    const int nt = blockIdx.x % ncol;
+    const int64_t m0 = (int64_t)(blockIdx.x / ncol) * BBM;
+    const int n0 = nt * BBN;
+    const int nch = K / BBK;
+    if (producer) {
+        const char* baseA = reinterpret_cast<const char*>(A + m0 * lda);
+        const char* baseB = reinterpret_cast<const char*>(B + (int64_t)n0 * ldb);
+        uint32_t voA[2], voB[4];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int sl = (wave * 2 + q) * 64 + lane, row = sl >> 2, kq = (sl & 3) ^ ((row >> 2) & 3);
+            int64_t r = row;
+            if (m0 + r > M - 1) r = M - 1 - m0;
+            voA[q] = (uint32_t)(r * lda * 2 + kq * 16);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int sl = (wave * 4 + q) * 64 + lane, row = sl >> 2, kq = (sl & 3) ^ ((row >> 2) & 3);
+            voB[q] = (uint32_t)((int64_t)row * ldb * 2 + kq * 16);
+        }
+        const uint32_t ldsA = lds_addr_of(&sm.A[0][0]) + wave * 2 * 1024, ldsB = lds_addr_of(&sm.B[0][0]) + wave * 4 * 1024;
+        auto issue = [&](int st, int f) {
+            const char* a = baseA + (int64_t)f * (BBK * 2);
+            const char* b = baseB + (int64_t)f * (BBK * 2);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) glds16_s(voA[q], a, ldsA + st * (BBM * BBK * 2) + q * 1024);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) glds16_s(voB[q], b, ldsB + st * (BBN * BBK * 2) + q * 1024);
+        };
+        issue(0, 0);
+        issue(1, 1 < nch ? 1 : nch - 1);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        int sn = 2;
+        for (int ch = 0; ch < nch; ++ch) {
+            issue(sn, ch + 2 < nch ? ch + 2 : nch - 1);
+            sn = sn + 1 == NS ? 0 : sn + 1;
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+    const int l32 = lane & 31, kh = lane >> 5;
+    int offA[2], offB[4];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const int r = wm * 64 + rt * 32 + l32;
+        offA[rt] = r * 64 + ((kh ^ ((r >> 2) & 3)) << 4);
+    }
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        const int r = wn * 128 + ct * 32 + l32;
+        offB[ct] = r * 64 + ((kh ^ ((r >> 2) & 3)) << 4);
+    }
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    int st = 0;
+    for (int ch = 0; ch < nch; ++ch) {
+        const char* Ab = reinterpret_cast<const char*>(sm.A[0]) + st * (BBM * BBK * 2);
+        const char* Bb = reinterpret_cast<const char*>(sm.B[0]) + st * (BBN * BBK * 2);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            bf16x8 fa[2], fb[4];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) fa[rt] = *reinterpret_cast<const bf16x8*>(Ab + (offA[rt] ^ (g << 5)));
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) fb[ct] = *reinterpret_cast<const bf16x8*>(Bb + (offB[ct] ^ (g << 5)));
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const int rt = m & 1, ct = m >> 1;
+                acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[rt], fb[ct], acc[rt][ct], 0, 0, 0);
+            }
+        }
+        st = st + 1 == NS ? 0 : st + 1;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t m = m0 + wm * 64 + rt * 32 + acc_row(r, lane);
+            if (EPI == 1 ? (M < 0) : (m < M)) {
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) C[m * ldc + n0 + wn * 128 + ct * 32 + l32] = acc[rt][ct][r];
+            }
+        }
+}
+__global__ __launch_bounds__(512) void nt128ws(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
+                                               float* __restrict__ C, int64_t ldc, int64_t M, int N, int K) {
+    __shared__ SmemNTS<3> sm;
+    nt128ws_body<0>(A, lda, B, ldb, C, ldc, M, N, K, sm);
+}
+__global__ __launch_bounds__(512) void nt128ws_noepi(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
+                                                     float* __restrict__ C, int64_t ldc, int64_t M, int N, int K) {
+    __shared__ SmemNTS<3> sm;
+    nt128ws_body<1>(A, lda, B, ldb, C, ldc, M, N, K, sm);
+}
+
+// v5: v4 + software-pipelined consumers + a 4-stage ring that runs one chunk further ahead: chunk ch+1 has landed before the
+// barrier that ENDS chunk ch-1, so a consumer requests the first fragments of the next chunk while the current chunk's MFMAs run
+// and never waits for LDS behind a barrier.
+template <int EPI>
+__device__ __forceinline__ void nt128wsp_body(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
+                                              float* __restrict__ C, int64_t ldc, int64_t M, int N, int K, SmemNTS<4>& sm) {
+    constexpr int NS = 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = wave8 >= 4;
+    const int wave = wave8 & 3;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ncol = N / BBN;
+    const int nt = blockIdx.x % ncol;
+    const int64_t m0 = (int64_t)(blockIdx.x / ncol) * BBM;
+    const int n0 = nt * BBN;
+    const int nch = K / BBK;
+    if (producer) {
+        const char* baseA = reinterpret_cast<const char*>(A + m0 * lda);
+        const char* baseB = reinterpret_cast<const char*>(B + (int64_t)n0 * ldb);
+        uint32_t voA[2], voB[4];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int sl = (wave * 2 + q) * 64 + lane, row = sl >> 2, kq = (sl & 3) ^ ((row >> 2) & 3);
+            int64_t r = row;
+            if (m0 + r > M - 1) r = M - 1 - m0;
+            voA[q] = (uint32_t)(r * lda * 2 + kq * 16);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int sl = (wave * 4 + q) * 64 + lane, row = sl >> 2, kq = (sl & 3) ^ ((row >> 2) & 3);
+            voB[q] = (uint32_t)((int64_t)row * ldb * 2 + kq * 16);
+        }
+        const uint32_t ldsA = lds_addr_of(&sm.A[0][0]) + wave * 2 * 1024, ldsB = lds_addr_of(&sm.B[0][0]) + wave * 4 * 1024;
+        auto issue = [&](int st, int f) {
+            const char* a = baseA + (int64_t)f * (BBK * 2);
+            const char* b = baseB + (int64_t)f * (BBK * 2);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) glds16_s(voA[q], a, ldsA + st * (BBM * BBK * 2) + q * 1024);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) glds16_s(voB[q], b, ldsB + st * (BBN * BBK * 2) + q * 1024);
+        };
+        auto clampf = [&](int f) { return f < nch ? f : nch - 1; };
+        issue(0, 0);
+        issue(1, clampf(1));
+        issue(2, clampf(2));
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        int sn = 3;
+        for (int ch = 0; ch < nch; ++ch) {
+            issue(sn, clampf(ch + 3));
+            sn = sn + 1 == NS ? 0 : sn + 1;
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+    const int l32 = lane & 31, kh = lane >> 5;
+    int offA[2], offB[4];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const int r = wm * 64 + rt * 32 + l32;
+        offA[rt] = r * 64 + ((kh ^ ((r >> 2) & 3)) << 4);
+    }
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        const int r = wn * 128 + ct * 32 + l32;
+        offB[ct] = r * 64 + ((kh ^ ((r >> 2) & 3)) << 4);
+    }
+    bf16x8 fa0[2], fb0[4], fa1[2], fb1[4];
+    auto ld = [&](bf16x8 (&fa)[2], bf16x8 (&fb)[4], int st, int g) {
+        const char* Ab = reinterpret_cast<const char*>(sm.A[0]) + st * (BBM * BBK * 2);
+        const char* Bb = reinterpret_cast<const char*>(sm.B[0]) + st * (BBN * BBK * 2);
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) fa[rt] = *reinterpret_cast<const bf16x8*>(Ab + (offA[rt] ^ (g << 5)));
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) fb[ct] = *reinterpret_cast<const bf16x8*>(Bb + (offB[ct] ^ (g << 5)));
+    };
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    auto mma1 = [&](const bf16x8 (&fa)[2], const bf16x8 (&fb)[4], int m) {
+        const int rt = m & 1, ct = m >> 1;
+        acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[rt], fb[ct], acc[rt][ct], 0, 0, 0);
+    };
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    ld(fa0, fb0, 0, 0);
+    int st = 0;
+    for (int ch = 0; ch < nch; ++ch) {
+        const int stn = st + 1 == NS ? 0 : st + 1;
+        mma1(fa0, fb0, 0);
+        SB();
+        ld(fa1, fb1, st, 1);
+        SB();
+#pragma unroll
+        for (int m = 1; m < 8; ++m) mma1(fa0, fb0, m);
+        SB();
+        mma1(fa1, fb1, 0);
+        SB();
+        ld(fa0, fb0, stn, 0);   // chunk ch+1 landed before the previous barrier (past the end: a stale stage, never used)
+        SB();
+#pragma unroll
+        for (int m = 1; m < 8; ++m) mma1(fa1, fb1, m);
+        SB();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        st = stn;
+    }
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t m = m0 + wm * 64 + rt * 32 + acc_row(r, lane);
+            if (EPI == 1 ? (M < 0) : (m < M)) {
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) C[m * ldc + n0 + wn * 128 + ct * 32 + l32] = acc[rt][ct][r];
+            }
+        }
+}
+__global__ __launch_bounds__(512) void nt128wsp(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
+                                                float* __restrict__ C, int64_t ldc, int64_t M, int N, int K) {
+    __shared__ SmemNTS<4> sm;
+    nt128wsp_body<0>(A, lda, B, ldb, C, ldc, M, N, K, sm);
+}
+__global__ __launch_bounds__(512) void nt128wsp_noepi(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B,
+                                                      int64_t ldb, float* __restrict__ C, int64_t ldc, int64_t M, int N, int K) {
+    __shared__ SmemNTS<4> sm;
+    nt128wsp_body<1>(A, lda, B, ldb, C, ldc, M, N, K, sm);
+}
+
 #define NT128S(NAME, EPI, NS, OCC)                                                                                              \
     __global__ __launch_bounds__(256, OCC) void NAME(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B,   \
                                                      int64_t ldb, float* __restrict__ C, int64_t ldc, int64_t M, int N, int K) { \
@@ -507,6 +765,10 @@ NT128S(nt128s3_noepi, 1, 3, 2)
 NT128S(nt128s4_noepi, 1, 4, 1)
 NT128S(nt128s6_noepi, 1, 6, 1)
 NT128S(nt128s2_noepi, 1, 2, 2)
+NT128S(nt128s2_dmaonly, 2, 2, 2)
+NT128S(nt128s2_mmaonly, 3, 2, 2)
+NT128S(nt128s3_dmaonly, 2, 3, 2)
+NT128S(nt128s2_mmaonly_nobar, 4, 2, 2)
 
 // ------------------------------------------------------------------------------------------------------------------
 // TN: C[i, n] = sum_k A[k][i] B[k][n] with BOTH operands K-major in memory (token-major activations: the dW products) --
@@ -681,13 +943,14 @@ int main(int argc, char** argv) {
     hipEventCreate(&e1);
     struct V { const char* name; kern_t k; int bm, bn, threads; };
     const V vs[] = {{"nt128x256x32", nt128, BBM, BBN, 256}, {"nt256x256x64_pipe", nt256, PM, PN, 512},
-                    {"nt128_pipe", nt128p, BBM, BBN, 256}, {"nt128_ring3", nt128s3, BBM, BBN, 256},
+                    {"nt128_pipe", nt128p, BBM, BBN, 256}, {"nt128_ring3", nt128s3, BBM, BBN, 256}, {"nt128_wspec", nt128ws, BBM, BBN, 512}, {"nt128_wspec_pipe", nt128wsp, BBM, BBN, 512},
                     {"nt128_noepi", nt128_noepi, BBM, BBN, 256}, {"nt256_noepi", nt256_noepi, PM, PN, 512},
                     {"nt128_pipe_noepi", nt128p_noepi, BBM, BBN, 256}, {"nt128_ring2_noepi", nt128s2_noepi, BBM, BBN, 256},
                     {"nt128_ring3_noepi", nt128s3_noepi, BBM, BBN, 256}, {"nt128_ring4_noepi", nt128s4_noepi, BBM, BBN, 256},
-                    {"nt128_ring6_noepi", nt128s6_noepi, BBM, BBN, 256}};
-    const int nv = 11;
-    for (int v = 0; v < 4; ++v)
+                    {"nt128_ring6_noepi", nt128s6_noepi, BBM, BBN, 256}, {"nt128_wspec_noepi", nt128ws_noepi, BBM, BBN, 512}, {"nt128_wspec_pipe_noepi", nt128wsp_noepi, BBM, BBN, 512}, {"nt128_ring2_DMA_ONLY", nt128s2_dmaonly, BBM, BBN, 256},
+                    {"nt128_ring3_DMA_ONLY", nt128s3_dmaonly, BBM, BBN, 256}, {"nt128_ring2_MMA_ONLY", nt128s2_mmaonly, BBM, BBN, 256}, {"nt128_MMA_ONLY_NOBAR", nt128s2_mmaonly_nobar, BBM, BBN, 256}};
+    const int nv = 19;
+    for (int v = 0; v < 6; ++v)
         for (int which = 0; which < 2; ++which) {
             const int64_t Mc = which ? 1000 : M;
             const int tiles = (int)(((Mc + vs[v].bm - 1) / vs[v].bm) * (N / vs[v].bn));
@@ -706,7 +969,7 @@ int main(int argc, char** argv) {
                     for (int k = 0; k < K; ++k) s += (double)bf2f(hA[(size_t)((r0 + r) % 1024) * K + k]) * bf2f(hB[(size_t)n * K + k]);
                     maxerr = fmax(maxerr, fabs(s - hC[(size_t)r * N + n]));
                 }
-            printf("check %-18s M=%-7lld max abs err vs fp64 %.3e %s\n", vs[v].name, (long long)Mc, maxerr, maxerr < 1e-3 ? "OK" : "FAIL");
+            printf("check %-22s M=%-7lld max abs err vs fp64 %.3e %s\n", vs[v].name, (long long)Mc, maxerr, maxerr < 1e-3 ? "OK" : "FAIL");
         }
     std::vector<double> best(nv, 1e9), sum(nv, 0);
     for (int rd = 0; rd < rounds; ++rd)
@@ -722,7 +985,7 @@ int main(int argc, char** argv) {
             if (rd > 0) { sum[v] += ms; if (ms < best[v]) best[v] = ms; }
         }
     for (int v = 0; v < nv; ++v)
-        printf("%-18s mean %.3f ms (%.0f TF)  best %.3f ms (%.0f TF)\n", vs[v].name, sum[v] / (rounds - 1),
+        printf("%-22s mean %.3f ms (%.0f TF)  best %.3f ms (%.0f TF)\n", vs[v].name, sum[v] / (rounds - 1),
                2.0 * M * N * K / (sum[v] / (rounds - 1)) / 1e9, best[v], 2.0 * M * N * K / best[v] / 1e9);
     // ---- TN: the gate dW shape of one head: C[512, 1024] = A[Kt, 512]^T B[Kt, 1024], Kt = 262144 tokens in 72 splits ----
     {
