@@ -350,8 +350,10 @@ __device__ __forceinline__ void nt128p_body(const bf16_t* __restrict__ A, int64_
 #pragma unroll
         for (int m = 1; m < 8; ++m) mma1(fa0, fb0, m);
         SB();
-        DMA_WAIT();
-        __syncthreads();
+        if (EPI != 3) {
+            DMA_WAIT();
+            __syncthreads();
+        }
         ld(fa0, fb0, st ^ 1, 0);
         SB();
         const int f = (ch + 2 < nch) ? ch + 2 : nch - 1;
@@ -359,7 +361,7 @@ __device__ __forceinline__ void nt128p_body(const bf16_t* __restrict__ A, int64_
         for (int m = 0; m < 8; ++m) {
             mma1(fa1, fb1, m);
             SB();
-            if (m < 6) dma(st, f, m);
+            if (EPI != 3 && m < 6) dma(st, f, m);
             SB();
         }
     }
@@ -370,7 +372,121 @@ __device__ __forceinline__ void nt128p_body(const bf16_t* __restrict__ A, int64_
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int64_t m = m0 + wm * 64 + rt * 32 + acc_row(r, lane);
-            if (EPI == 1 ? (M < 0) : (m < M)) {
+            if (EPI >= 1 ? (M < 0) : (m < M)) {
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) C[m * ldc + n0 + wn * 128 + ct * 32 + l32] = acc[rt][ct][r];
+            }
+        }
+}
+template <int NS>
+struct __attribute__((aligned(16))) SmemNTS {
+    bf16_t A[NS][BBM * BBK];
+    bf16_t B[NS][BBN * BBK];
+};
+// v6: v2 (in-wave pipelined) on a 3-stage ring: the DMA of chunk ch+3 is issued behind the barrier of chunk ch (stage of chunk ch is
+// free once its fragments are in registers), so ~2.5 stages per workgroup are in flight instead of ~1.
+template <int EPI>
+__device__ __forceinline__ void nt128pr_body(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
+                                            float* __restrict__ C, int64_t ldc, int64_t M, int N, int K, SmemNTS<3>& sm) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ncol = N / BBN;
+    const int nt = blockIdx.x % ncol;
+    const int64_t m0 = (int64_t)(blockIdx.x / ncol) * BBM;
+    const int n0 = nt * BBN;
+    const char* baseA = reinterpret_cast<const char*>(A + m0 * lda);
+    const char* baseB = reinterpret_cast<const char*>(B + (int64_t)n0 * ldb);
+    uint32_t voA[2], voB[4];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int sl = (wave * 2 + q) * 64 + lane, row = sl >> 2, kq = (sl & 3) ^ ((row >> 2) & 3);
+        int64_t r = row;
+        if (m0 + r > M - 1) r = M - 1 - m0;
+        voA[q] = (uint32_t)(r * lda * 2 + kq * 16);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int sl = (wave * 4 + q) * 64 + lane, row = sl >> 2, kq = (sl & 3) ^ ((row >> 2) & 3);
+        voB[q] = (uint32_t)((int64_t)row * ldb * 2 + kq * 16);
+    }
+    auto dma = [&](int st, int f, int piece) {   // 0,1: A; 2..5: B
+        if (piece < 2) glds16_s(voA[piece], baseA + (int64_t)f * (BBK * 2), lds_addr_of(&sm.A[st][(wave * 2 + piece) * 512]));
+        else glds16_s(voB[piece - 2], baseB + (int64_t)f * (BBK * 2), lds_addr_of(&sm.B[st][(wave * 4 + piece - 2) * 512]));
+    };
+    const int l32 = lane & 31, kh = lane >> 5;
+    int offA[2], offB[4];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const int r = wm * 64 + rt * 32 + l32;
+        offA[rt] = r * 64 + ((kh ^ ((r >> 2) & 3)) << 4);
+    }
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        const int r = wn * 128 + ct * 32 + l32;
+        offB[ct] = r * 64 + ((kh ^ ((r >> 2) & 3)) << 4);
+    }
+    bf16x8 fa0[2], fb0[4], fa1[2], fb1[4];
+    auto ld = [&](bf16x8 (&fa)[2], bf16x8 (&fb)[4], int st, int g) {
+        const char* Ab = reinterpret_cast<const char*>(sm.A[st]);
+        const char* Bb = reinterpret_cast<const char*>(sm.B[st]);
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) fa[rt] = *reinterpret_cast<const bf16x8*>(Ab + (offA[rt] ^ (g << 5)));
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) fb[ct] = *reinterpret_cast<const bf16x8*>(Bb + (offB[ct] ^ (g << 5)));
+    };
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    auto mma1 = [&](const bf16x8 (&fa)[2], const bf16x8 (&fb)[4], int m) {
+        const int rt = m & 1, ct = m >> 1;
+        acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[rt], fb[ct], acc[rt][ct], 0, 0, 0);
+    };
+    const int nch = K / BBK;
+    auto clampf = [&](int f) { return f < nch ? f : nch - 1; };
+#pragma unroll
+    for (int c3 = 0; c3 < 3; ++c3)
+#pragma unroll
+        for (int p = 0; p < 6; ++p) dma(c3, clampf(c3), p);
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    __syncthreads();
+    ld(fa0, fb0, 0, 0);
+    int st = 0;
+    for (int ch = 0; ch < nch; ++ch) {
+        const int stn = st == 2 ? 0 : st + 1;
+        mma1(fa0, fb0, 0);
+        SB();
+        ld(fa1, fb1, st, 1);
+        SB();
+#pragma unroll
+        for (int m = 1; m < 8; ++m) mma1(fa0, fb0, m);
+        SB();
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // chunk ch+1 has landed (chunk ch+2 may still be in flight)
+        __syncthreads();                                   // every read of stage st has completed in every wave
+        ld(fa0, fb0, stn, 0);
+        SB();
+        const int f = clampf(ch + 3);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            mma1(fa1, fb1, m);
+            SB();
+            if (m < 6) dma(st, f, m);
+            SB();
+        }
+        st = stn;
+    }
+    DMA_WAIT();
+    __syncthreads();
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t m = m0 + wm * 64 + rt * 32 + acc_row(r, lane);
+            if (EPI >= 1 ? (M < 0) : (m < M)) {
 #pragma unroll
                 for (int ct = 0; ct < 4; ++ct) C[m * ldc + n0 + wn * 128 + ct * 32 + l32] = acc[rt][ct][r];
             }
@@ -381,21 +497,31 @@ __global__ __launch_bounds__(256) void nt128p(const bf16_t* __restrict__ A, int6
     __shared__ SmemNT sm;
     nt128p_body<0>(A, lda, B, ldb, C, ldc, M, N, K, sm);
 }
+__global__ __launch_bounds__(256) void nt128p_mmaonly(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
+                                                      float* __restrict__ C, int64_t ldc, int64_t M, int N, int K) {
+    __shared__ SmemNT sm;
+    nt128p_body<3>(A, lda, B, ldb, C, ldc, M, N, K, sm);
+}
 __global__ __launch_bounds__(256) void nt128p_noepi(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
                                                     float* __restrict__ C, int64_t ldc, int64_t M, int N, int K) {
     __shared__ SmemNT sm;
     nt128p_body<1>(A, lda, B, ldb, C, ldc, M, N, K, sm);
+}
+__global__ __launch_bounds__(256) void nt128pr(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
+                                               float* __restrict__ C, int64_t ldc, int64_t M, int N, int K) {
+    __shared__ SmemNTS<3> sm;
+    nt128pr_body<0>(A, lda, B, ldb, C, ldc, M, N, K, sm);
+}
+__global__ __launch_bounds__(256) void nt128pr_noepi(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
+                                                     float* __restrict__ C, int64_t ldc, int64_t M, int N, int K) {
+    __shared__ SmemNTS<3> sm;
+    nt128pr_body<1>(A, lda, B, ldb, C, ldc, M, N, K, sm);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
 // v3: 128 x 256 x 32, 4 waves, NS-stage LDS ring (NS x 24 KiB): the LDS-DMA of chunk ch + NS - 1 is issued when chunk ch starts,
 // so NS - 1 chunks (not one) cover the global->LDS latency.  With v_mfma_f32_32x32x16_bf16 a 32-deep chunk is only 16 x 32 =
 // 512 MFMA cycles (~0.2 us) of work per wave: one chunk of lookahead (v0) leaves every chunk waiting ~1 us for its operands.
-template <int NS>
-struct __attribute__((aligned(16))) SmemNTS {
-    bf16_t A[NS][BBM * BBK];
-    bf16_t B[NS][BBN * BBK];
-};
 template <int EPI, int NS>
 __device__ __forceinline__ void nt128s_body(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
                                             float* __restrict__ C, int64_t ldc, int64_t M, int N, int K, SmemNTS<NS>& sm) {
@@ -943,14 +1069,14 @@ int main(int argc, char** argv) {
     hipEventCreate(&e1);
     struct V { const char* name; kern_t k; int bm, bn, threads; };
     const V vs[] = {{"nt128x256x32", nt128, BBM, BBN, 256}, {"nt256x256x64_pipe", nt256, PM, PN, 512},
-                    {"nt128_pipe", nt128p, BBM, BBN, 256}, {"nt128_ring3", nt128s3, BBM, BBN, 256}, {"nt128_wspec", nt128ws, BBM, BBN, 512}, {"nt128_wspec_pipe", nt128wsp, BBM, BBN, 512},
+                    {"nt128_pipe", nt128p, BBM, BBN, 256}, {"nt128_ring3", nt128s3, BBM, BBN, 256}, {"nt128_wspec", nt128ws, BBM, BBN, 512}, {"nt128_wspec_pipe", nt128wsp, BBM, BBN, 512}, {"nt128_pipe_ring3", nt128pr, BBM, BBN, 256},
                     {"nt128_noepi", nt128_noepi, BBM, BBN, 256}, {"nt256_noepi", nt256_noepi, PM, PN, 512},
                     {"nt128_pipe_noepi", nt128p_noepi, BBM, BBN, 256}, {"nt128_ring2_noepi", nt128s2_noepi, BBM, BBN, 256},
                     {"nt128_ring3_noepi", nt128s3_noepi, BBM, BBN, 256}, {"nt128_ring4_noepi", nt128s4_noepi, BBM, BBN, 256},
                     {"nt128_ring6_noepi", nt128s6_noepi, BBM, BBN, 256}, {"nt128_wspec_noepi", nt128ws_noepi, BBM, BBN, 512}, {"nt128_wspec_pipe_noepi", nt128wsp_noepi, BBM, BBN, 512}, {"nt128_ring2_DMA_ONLY", nt128s2_dmaonly, BBM, BBN, 256},
-                    {"nt128_ring3_DMA_ONLY", nt128s3_dmaonly, BBM, BBN, 256}, {"nt128_ring2_MMA_ONLY", nt128s2_mmaonly, BBM, BBN, 256}, {"nt128_MMA_ONLY_NOBAR", nt128s2_mmaonly_nobar, BBM, BBN, 256}};
-    const int nv = 19;
-    for (int v = 0; v < 6; ++v)
+                    {"nt128_ring3_DMA_ONLY", nt128s3_dmaonly, BBM, BBN, 256}, {"nt128_ring2_MMA_ONLY", nt128s2_mmaonly, BBM, BBN, 256}, {"nt128_MMA_ONLY_NOBAR", nt128s2_mmaonly_nobar, BBM, BBN, 256}, {"nt128_pipe_MMA_ONLY", nt128p_mmaonly, BBM, BBN, 256}, {"nt128_pipe_ring3_noepi", nt128pr_noepi, BBM, BBN, 256}};
+    const int nv = 22;
+    for (int v = 0; v < 7; ++v)
         for (int which = 0; which < 2; ++which) {
             const int64_t Mc = which ? 1000 : M;
             const int tiles = (int)(((Mc + vs[v].bm - 1) / vs[v].bm) * (N / vs[v].bn));
