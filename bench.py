@@ -426,19 +426,32 @@ def main():
                                "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                                "algorithmic_bytes_per_launch": alg, "avg_ms": round(ms, 4), "launches": n}
+        if "gate_bwd_gemm" in prof and "gate_bwd" not in prof:   # the fused A2+A3 backward is timed in its two phases
+            prof["gate_bwd"] = (prof["gate_bwd_gemm"][0] + prof["gate_bwd_dz"][0], prof["gate_bwd_gemm"][1])
         if "gate_fwd" in prof and "gate_bwd" in prof:
             msf, _ = prof["gate_fwd"]
-            msb, _ = prof["gate_bwd"]
+            # MFMA-bound part of the backward: the dX / dW contractions (+ slab reduction).  The HBM-bound dz pass that precedes them
+            # (reads the saved activations, writes dz) is timed separately and reported with its own HBM rate.
+            split = "gate_bwd_gemm" in prof
+            msb = prof["gate_bwd_gemm"][0] if split else prof["gate_bwd"][0]
             flop_f = tokens * H * 2 * 512 * 1024
             tf_f = flop_f / (msf * 1e-3) / 1e12
             tf_b = 2 * flop_f / (msb * 1e-3) / 1e12
             tf = 3 * flop_f / ((msf + msb) * 1e-3) / 1e12
             mpeak = F32_MFMA_PEAK_TF if a.precision == "float32" else 2500.0
-            out["roofline_mfma"] = {"kernel": "abmil_gate fwd + bwd(dX, dW) on " + ("v_mfma_f32_32x32x2_f32" if a.precision == "float32"
-                                                                                     else "v_mfma_f32_32x32x16_bf16"), "bound": "mfma",
+            out["roofline_mfma"] = {"kernel": "abmil_gate fwd + bwd contractions (dX, dW) on " + ("v_mfma_f32_32x32x2_f32" if a.precision == "float32"
+                                                                                                  else "v_mfma_f32_32x32x16_bf16"), "bound": "mfma",
                                     "achieved": round(tf, 2), "peak": mpeak, "unit": "TFLOP/s",
                                     "frac": round(tf / mpeak, 4), "fwd_tflops": round(tf_f, 2),
-                                    "bwd_tflops": round(tf_b, 2), "fwd_ms": round(msf, 3), "bwd_ms": round(msb, 3)}
+                                    "bwd_tflops": round(tf_b, 2), "fwd_ms": round(msf, 3), "bwd_ms": round(msb, 3),
+                                    "bwd_includes_dz_pass": not split}
+            if split:
+                esz = 4 if a.precision == "float32" else 2
+                msz = prof["gate_bwd_dz"][0]
+                dz_bytes = tokens * H * 2048 * esz   # reads act_a, act_b [T,H,512] each, writes dz [T,H,1024]
+                out["roofline_mfma"]["dz_pass"] = {"bound": "hbm", "ms": round(msz, 3), "algorithmic_bytes": dz_bytes,
+                                                   "achieved_GBs": round(dz_bytes / (msz * 1e-3) / 1e9, 1),
+                                                   "frac": round(dz_bytes / (msz * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         out["kernel_ms"] = {k: round(v[0], 4) for k, v in prof.items()}
         if bf16_leg is not None:
             out["bf16_mode"] = bf16_leg

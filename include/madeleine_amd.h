@@ -54,7 +54,7 @@ const char* mdl_version(void);
 /* ABI revision of this header: bumped whenever an entry point's argument list changes.  A binding compares
  * mdl_abi_version() with the MDL_ABI_VERSION it was written against BEFORE calling anything else, so that a stale
  * shared object fails loudly instead of being called with shifted arguments. */
-#define MDL_ABI_VERSION 7
+#define MDL_ABI_VERSION 8
 int mdl_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -164,6 +164,23 @@ int mdl_abmil_attnpool_bwd(const float* E, int64_t ldE, const float* Wa, const f
                            uint64_t seed, const uint8_t* keep_a, const uint8_t* keep_b, const float* scores,
                            const float* stat_m, const float* stat_l, const float* d_pooled, const int32_t* row_bag,
                            int64_t N, void* ws, void* stream);
+
+/* Profiling form of mdl_abmil_attnpool_bwd: `phases` bit 0 = the HBM-bound dz pass (+ the bias / wc column-sum reduction), bit 1 = the
+ * MFMA-bound dX / dW contractions (+ the dW slab reduction); 3 = what mdl_abmil_attnpool_bwd runs.  Calling it with 1 and then 2 on
+ * the same arguments and workspace gives the same results and lets the caller time the two halves with its own events (bench.py's
+ * roofline_mfma counts the contractions only). */
+int mdl_abmil_attnpool_bwd_phases(const float* E, int64_t ldE, const float* Wa, const float* Wb, const float* wc,
+                                  const float* act_a, const float* act_b, const float* d_scores, float* dE, float* dWa,
+                                  float* dWb, float* dba, float* dbb, float* dwc, float* dbc, int64_t T, int H,
+                                  float p_drop, uint64_t seed, const uint8_t* keep_a, const uint8_t* keep_b,
+                                  const float* scores, const float* stat_m, const float* stat_l, const float* d_pooled,
+                                  const int32_t* row_bag, int64_t N, void* ws, void* stream, int phases);
+int mdl_abmil_attnpool_bwd_phases_bf16(const uint16_t* E, int64_t ldE, const float* Wa, const float* Wb, const float* wc,
+                                       const uint16_t* act_a, const uint16_t* act_b, const float* d_scores, uint16_t* dE,
+                                       float* dWa, float* dWb, float* dba, float* dbb, float* dwc, float* dbc, int64_t T,
+                                       int H, float p_drop, uint64_t seed, const uint8_t* keep_a, const uint8_t* keep_b,
+                                       const float* scores, const float* stat_m, const float* stat_l, const float* d_pooled,
+                                       const int32_t* row_bag, int64_t N, void* ws, void* stream, int phases);
 
 /* ------------------------------------------------------------------------------------------------
  * N1 -- fused LayerNorm -> GELU(erf) -> Dropout of the pre-attention MLP.  Replaces the

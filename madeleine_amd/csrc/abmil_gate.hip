@@ -458,9 +458,12 @@ extern "C" int64_t mdl_abmil_gate_bwd_ws_bytes(int64_t T, int H) {
 static int gate_bwd_impl(const float* E, int64_t ldE, const float* Wa, const float* Wb, const float* wc, const float* act_a,
                          const float* act_b, const float* d_scores, float* dE, int accumulate, float* dWa, float* dWb, float* dba,
                          float* dbb, float* dwc, float* dbc, int64_t T, int H, float p_drop, uint64_t seed, const uint8_t* keep_a,
-                         const uint8_t* keep_b, void* ws, void* stream, const PoolTerm& pt) {
+                         const uint8_t* keep_b, void* ws, void* stream, const PoolTerm& pt, int phases = 3) {
+    // phases: bit 0 = dz pass (HBM-bound) + its column-sum reduction, bit 1 = the dX / dW contractions (MFMA-bound) + slab reduction.
+    // The product path passes 3; the *_phases entry points let a profiler time the two halves separately on the same workspace.
     if (!E || !Wa || !Wb || !wc || !act_a || !act_b || !d_scores || !dE || !dWa || !dWb || !dba || !dbb || !dwc || !ws)
         return MDL_E_ARG;
+    if (phases < 1 || phases > 3) return MDL_E_ARG;
     if ((keep_a == nullptr) != (keep_b == nullptr)) return MDL_E_ARG;
     if (T < 0 || H < 1 || H > MDL_MAX_HEADS || ldE < (int64_t)H * HID || (ldE & 3)) return MDL_E_ARG;
     if (H != 1 && H != 2 && H != 4 && H != 8) return MDL_E_UNSUPPORTED;
@@ -476,30 +479,36 @@ static int gate_bwd_impl(const float* E, int64_t ldE, const float* Wa, const flo
     float* slabW = dz + (T + GBK) * H * 1024;
     float* slabV = slabW + (int64_t)S * H * HID * 1024;
     const int64_t nblk = dz_blocks(T);
-    {   // zero pad rows of dz (K-tail of the dW GEMM)
-        const hipError_t e = hipMemsetAsync(dz + T * H * 1024, 0, (size_t)GBK * H * 1024 * sizeof(float), s);
-        if (e != hipSuccess) return (int)e;
-    }
-    if (T > 0) {
-        if (nblk > 0x7fffffff) return MDL_E_UNSUPPORTED;
-        hipLaunchKernelGGL((gate_dz_kernel<float, float>), dim3((unsigned)nblk, H), dim3(256), 0, s, wc, act_a, act_b, d_scores, dz, slabV, T, H,
-                           d);
+    if (phases & 1) {
+        {   // zero pad rows of dz (K-tail of the dW GEMM)
+            const hipError_t e = hipMemsetAsync(dz + T * H * 1024, 0, (size_t)GBK * H * 1024 * sizeof(float), s);
+            if (e != hipSuccess) return (int)e;
+        }
+        if (T > 0) {
+            if (nblk > 0x7fffffff) return MDL_E_UNSUPPORTED;
+            hipLaunchKernelGGL((gate_dz_kernel<float, float>), dim3((unsigned)nblk, H), dim3(256), 0, s, wc, act_a, act_b, d_scores, dz, slabV,
+                               T, H, d);
+            MDL_LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL(gate_reduce_v_kernel, dim3((H * 4 * HID + 31) / 32), dim3(256), 0, s, (const float*)slabV, dba, dbb,
+                           dwc, dbc, H, (int)nblk);
         MDL_LAUNCH_CHECK();
-        const int64_t n_tt = (T + GBM - 1) / GBM;
-        const int64_t grid = xcd_head_grid(n_tt, 2, H);
-        if (grid > 0x7fffffff) return MDL_E_UNSUPPORTED;
-        hipLaunchKernelGGL(gate_bwd_dx_kernel, dim3((unsigned)grid), dim3(256), 0, s, (const float*)dz, Wa, Wb, dE, ldE,
-                           accumulate, T, H, pt);
+    }
+    if (phases & 2) {
+        if (T > 0) {
+            const int64_t n_tt = (T + GBM - 1) / GBM;
+            const int64_t grid = xcd_head_grid(n_tt, 2, H);
+            if (grid > 0x7fffffff) return MDL_E_UNSUPPORTED;
+            hipLaunchKernelGGL(gate_bwd_dx_kernel, dim3((unsigned)grid), dim3(256), 0, s, (const float*)dz, Wa, Wb, dE, ldE,
+                               accumulate, T, H, pt);
+            MDL_LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL(gate_bwd_dw_kernel, dim3((unsigned)xcd_head_grid(S, 4 * GATE_JT, H)), dim3(256), 0, s, E, ldE,
+                           (const float*)dz, slabW, T, H, tps, S);
+        MDL_LAUNCH_CHECK();
+        hipLaunchKernelGGL(gate_reduce_w_kernel, dim3(32, 16, H), dim3(256), 0, s, (const float*)slabW, dWa, dWb, H, S);
         MDL_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(gate_bwd_dw_kernel, dim3((unsigned)xcd_head_grid(S, 4 * GATE_JT, H)), dim3(256), 0, s, E, ldE,
-                       (const float*)dz, slabW, T, H, tps, S);
-    MDL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gate_reduce_w_kernel, dim3(32, 16, H), dim3(256), 0, s, (const float*)slabW, dWa, dWb, H, S);
-    MDL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gate_reduce_v_kernel, dim3((H * 4 * HID + 31) / 32), dim3(256), 0, s, (const float*)slabV, dba, dbb,
-                       dwc, dbc, H, (int)nblk);
-    MDL_LAUNCH_CHECK();
     return MDL_OK;
 }
 
@@ -521,6 +530,17 @@ extern "C" int mdl_abmil_attnpool_bwd(const float* E, int64_t ldE, const float* 
     if (!scores || !stat_m || !stat_l || !d_pooled || (!row_bag && N < 1)) return MDL_E_ARG;
     return gate_bwd_impl(E, ldE, Wa, Wb, wc, act_a, act_b, d_scores, dE, 0, dWa, dWb, dba, dbb, dwc, dbc, T, H, p_drop, seed, keep_a,
                          keep_b, ws, stream, PoolTerm{scores, stat_m, stat_l, d_pooled, row_bag, N});
+}
+
+extern "C" int mdl_abmil_attnpool_bwd_phases(const float* E, int64_t ldE, const float* Wa, const float* Wb, const float* wc,
+                                             const float* act_a, const float* act_b, const float* d_scores, float* dE, float* dWa,
+                                             float* dWb, float* dba, float* dbb, float* dwc, float* dbc, int64_t T, int H,
+                                             float p_drop, uint64_t seed, const uint8_t* keep_a, const uint8_t* keep_b,
+                                             const float* scores, const float* stat_m, const float* stat_l, const float* d_pooled,
+                                             const int32_t* row_bag, int64_t N, void* ws, void* stream, int phases) {
+    if (!scores || !stat_m || !stat_l || !d_pooled || (!row_bag && N < 1)) return MDL_E_ARG;
+    return gate_bwd_impl(E, ldE, Wa, Wb, wc, act_a, act_b, d_scores, dE, 0, dWa, dWb, dba, dbb, dwc, dbc, T, H, p_drop, seed, keep_a,
+                         keep_b, ws, stream, PoolTerm{scores, stat_m, stat_l, d_pooled, row_bag, N}, phases);
 }
 
 extern "C" int mdl_abmil_gate_dropout_mask(uint8_t* keep, int64_t T, int H, int which, float p_drop, uint64_t seed,

@@ -398,9 +398,10 @@ static int gate_bwd_bf16_impl(const uint16_t* E, int64_t ldE, const float* Wa, c
                               const uint16_t* act_a, const uint16_t* act_b, const float* d_scores, uint16_t* dE, int accumulate,
                               float* dWa, float* dWb, float* dba, float* dbb, float* dwc, float* dbc, int64_t T, int H, float p_drop,
                               uint64_t seed, const uint8_t* keep_a, const uint8_t* keep_b, void* ws, void* stream,
-                              const PoolTerm& pt) {
+                              const PoolTerm& pt, int phases = 3) {
     if (!E || !Wa || !Wb || !wc || !act_a || !act_b || !d_scores || !dE || !dWa || !dWb || !dba || !dbb || !dwc || !ws)
         return MDL_E_ARG;
+    if (phases < 1 || phases > 3) return MDL_E_ARG;   // bit 0: dz pass + its reduction, bit 1: dX / dW contractions (see abmil_gate.hip)
     if ((keep_a == nullptr) != (keep_b == nullptr)) return MDL_E_ARG;
     if (T < 0 || H < 1 || H > MDL_MAX_HEADS || ldE < (int64_t)H * HID || (ldE & 7)) return MDL_E_ARG;
     if (H != 1 && H != 2 && H != 4 && H != 8) return MDL_E_UNSUPPORTED;
@@ -417,29 +418,37 @@ static int gate_bwd_bf16_impl(const uint16_t* E, int64_t ldE, const float* Wa, c
     float* slabW = (float*)(base + L.oslabW);
     float* slabV = (float*)(base + L.oslabV);
     if (L.nblk > 0x7fffffff) return MDL_E_UNSUPPORTED;
-    {   // zero pad rows of dz (K-tail of the dW contraction)
-        const hipError_t e = hipMemsetAsync(dz + T * H * 1024, 0, (size_t)TNK * H * 1024 * 2, s);
-        if (e != hipSuccess) return (int)e;
+    if (phases & 1) {
+        {   // zero pad rows of dz (K-tail of the dW contraction)
+            const hipError_t e = hipMemsetAsync(dz + T * H * 1024, 0, (size_t)TNK * H * 1024 * 2, s);
+            if (e != hipSuccess) return (int)e;
+        }
+        if (T > 0) {
+            hipLaunchKernelGGL((gate_dz_kernel<bf16_t, bf16_t>), dim3((unsigned)L.nblk, H), dim3(256), 0, s, wc, (const bf16_t*)act_a,
+                               (const bf16_t*)act_b, d_scores, dz, slabV, T, H, d);
+            MDL_LAUNCH_CHECK();
+        }
+        const int rc = gate_launch_reduce_v(slabV, dba, dbb, dwc, dbc, H, (int)L.nblk, s);
+        if (rc) return rc;
     }
-    if (T > 0) {
-        hipLaunchKernelGGL(gate_wn_bf16_kernel, dim3(16, 32, H), dim3(256), 0, s, Wa, Wb, WN);
+    if (phases & 2) {
+        if (T > 0) {
+            hipLaunchKernelGGL(gate_wn_bf16_kernel, dim3(16, 32, H), dim3(256), 0, s, Wa, Wb, WN);
+            MDL_LAUNCH_CHECK();
+            const int64_t n_tt = (T + BBM - 1) / BBM;
+            const int64_t grid = xcd_head_grid(n_tt, 2, H);
+            if (grid > 0x7fffffff) return MDL_E_UNSUPPORTED;
+            hipLaunchKernelGGL(gate_dx_bf16_kernel, dim3((unsigned)grid), dim3(256), 0, s, (const bf16_t*)dz, (const bf16_t*)WN,
+                               (bf16_t*)dE, ldE, accumulate, T, H, pt);
+            MDL_LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL(gate_dw_bf16_kernel, dim3((unsigned)xcd_head_grid(L.S, 16, H)), dim3(256), 0, s, (const bf16_t*)E, ldE,
+                           (const bf16_t*)dz, slabW, T, H, L.tps, L.S);
         MDL_LAUNCH_CHECK();
-        hipLaunchKernelGGL((gate_dz_kernel<bf16_t, bf16_t>), dim3((unsigned)L.nblk, H), dim3(256), 0, s, wc, (const bf16_t*)act_a,
-                           (const bf16_t*)act_b, d_scores, dz, slabV, T, H, d);
-        MDL_LAUNCH_CHECK();
-        const int64_t n_tt = (T + BBM - 1) / BBM;
-        const int64_t grid = xcd_head_grid(n_tt, 2, H);
-        if (grid > 0x7fffffff) return MDL_E_UNSUPPORTED;
-        hipLaunchKernelGGL(gate_dx_bf16_kernel, dim3((unsigned)grid), dim3(256), 0, s, (const bf16_t*)dz, (const bf16_t*)WN,
-                           (bf16_t*)dE, ldE, accumulate, T, H, pt);
-        MDL_LAUNCH_CHECK();
+        const int rc = gate_launch_reduce_w(slabW, dWa, dWb, H, L.S, s);
+        if (rc) return rc;
     }
-    hipLaunchKernelGGL(gate_dw_bf16_kernel, dim3((unsigned)xcd_head_grid(L.S, 16, H)), dim3(256), 0, s, (const bf16_t*)E, ldE,
-                       (const bf16_t*)dz, slabW, T, H, L.tps, L.S);
-    MDL_LAUNCH_CHECK();
-    int rc = gate_launch_reduce_w(slabW, dWa, dWb, H, L.S, s);
-    if (rc) return rc;
-    return gate_launch_reduce_v(slabV, dba, dbb, dwc, dbc, H, (int)L.nblk, s);
+    return MDL_OK;
 }
 
 extern "C" int mdl_abmil_gate_bwd_bf16(const uint16_t* E, int64_t ldE, const float* Wa, const float* Wb, const float* wc,
@@ -460,4 +469,15 @@ extern "C" int mdl_abmil_attnpool_bwd_bf16(const uint16_t* E, int64_t ldE, const
     if (!scores || !stat_m || !stat_l || !d_pooled || (!row_bag && N < 1)) return MDL_E_ARG;
     return gate_bwd_bf16_impl(E, ldE, Wa, Wb, wc, act_a, act_b, d_scores, dE, 0, dWa, dWb, dba, dbb, dwc, dbc, T, H, p_drop, seed,
                               keep_a, keep_b, ws, stream, PoolTerm{scores, stat_m, stat_l, d_pooled, row_bag, N});
+}
+
+extern "C" int mdl_abmil_attnpool_bwd_phases_bf16(const uint16_t* E, int64_t ldE, const float* Wa, const float* Wb, const float* wc,
+                                                  const uint16_t* act_a, const uint16_t* act_b, const float* d_scores, uint16_t* dE,
+                                                  float* dWa, float* dWb, float* dba, float* dbb, float* dwc, float* dbc, int64_t T,
+                                                  int H, float p_drop, uint64_t seed, const uint8_t* keep_a, const uint8_t* keep_b,
+                                                  const float* scores, const float* stat_m, const float* stat_l, const float* d_pooled,
+                                                  const int32_t* row_bag, int64_t N, void* ws, void* stream, int phases) {
+    if (!scores || !stat_m || !stat_l || !d_pooled || (!row_bag && N < 1)) return MDL_E_ARG;
+    return gate_bwd_bf16_impl(E, ldE, Wa, Wb, wc, act_a, act_b, d_scores, dE, 0, dWa, dWb, dba, dbb, dwc, dbc, T, H, p_drop, seed,
+                              keep_a, keep_b, ws, stream, PoolTerm{scores, stat_m, stat_l, d_pooled, row_bag, N}, phases);
 }

@@ -145,13 +145,22 @@ def attnpool_bwd_raw(E2d, Wa, Wb, wc, act_a, act_b, d_scores, dE, p_drop, seed, 
     dbc = torch.empty(H, device=dev, dtype=torch.float32)
     sfx = _sfx(E2d)
     ws = _ws(getattr(lib, "mdl_abmil_gate_bwd%s_ws_bytes" % sfx)(T, H), dev)
-    with _timed("gate_bwd"):
-        rc = getattr(lib, "mdl_abmil_attnpool_bwd" + sfx)(_ptr(E2d), E2d.stride(0), _ptr(Wa), _ptr(Wb), _ptr(wc), _ptr(act_a),
-                                                         _ptr(act_b), _ptr(d_scores), _ptr(dE), _ptr(dWa), _ptr(dWb), _ptr(dba),
-                                                         _ptr(dbb), _ptr(dwc), _ptr(dbc), T, H, float(p_drop), int(seed),
-                                                         _ptr(keep_a), _ptr(keep_b), _ptr(scores), _ptr(stat_m), _ptr(stat_l),
-                                                         _ptr(d_pooled), _ptr(row_bag), int(N), _ptr(ws), _stream())
-    _native.check(rc, "mdl_abmil_attnpool_bwd")
+    args = (_ptr(E2d), E2d.stride(0), _ptr(Wa), _ptr(Wb), _ptr(wc), _ptr(act_a), _ptr(act_b), _ptr(d_scores), _ptr(dE), _ptr(dWa),
+            _ptr(dWb), _ptr(dba), _ptr(dbb), _ptr(dwc), _ptr(dbc), T, H, float(p_drop), int(seed), _ptr(keep_a), _ptr(keep_b),
+            _ptr(scores), _ptr(stat_m), _ptr(stat_l), _ptr(d_pooled), _ptr(row_bag), int(N), _ptr(ws), _stream())
+    if TIMER is not None:
+        # profiling: the HBM-bound dz pass and the MFMA-bound contractions as two calls on the same workspace, timed separately
+        # ("gate_bwd" stays their sum in KernelTimer.report)
+        fn = getattr(lib, "mdl_abmil_attnpool_bwd_phases" + sfx)
+        with _timed("gate_bwd_dz"):
+            rc = fn(*args, 1)
+        _native.check(rc, "mdl_abmil_attnpool_bwd_phases")
+        with _timed("gate_bwd_gemm"):
+            rc = fn(*args, 2)
+        _native.check(rc, "mdl_abmil_attnpool_bwd_phases")
+    else:
+        rc = getattr(lib, "mdl_abmil_attnpool_bwd" + sfx)(*args)
+        _native.check(rc, "mdl_abmil_attnpool_bwd")
     return dWa, dWb, dba, dbb, dwc, dbc
 
 
