@@ -225,6 +225,18 @@ def secondary_inference_leg(dev, MF, MADELEINE, n_patches=30000, bags=20):
     if "pool_fwd" in prof:
         alg = n_patches * (4 * 512 * 4 + 4 * 4) + 4 * 512 * 4
         out["pool_fwd_GBs"] = round(alg / (prof["pool_fwd"][0] * 1e-3) / 1e9, 1)
+    # the reference's extraction script runs this loop under bf16 autocast (extract_slide_embeddings.py:49 -> utils.py:52-55)
+    with torch.no_grad(), torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+        for _ in range(3):
+            model.encode_he(bag, dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(bags):
+            model.encode_he(bag, dev)
+        torch.cuda.synchronize()
+        el16 = time.perf_counter() - t0
+    out["bf16_autocast"] = {"value": round(bags / el16, 2), "unit": "bags/s", "ms_per_bag": round(1e3 * el16 / bags, 3),
+                            "patches_per_sec": round(bags * n_patches / el16)}
     return out
 
 
