@@ -880,6 +880,123 @@ __global__ __launch_bounds__(512) void nt128wsp_noepi(const bf16_t* __restrict__
     nt128wsp_body<1>(A, lda, B, ldb, C, ldc, M, N, K, sm);
 }
 
+// v7: v3 with NS = 4 but the LDS-DMA issued in PAIRS of chunks: chunk 2k and 2k+1 are the two 64-B halves of the same 128-B cache
+// lines; issued back to back from the same wave their requests can merge in the L1 (one line crossing of the L2->CU fabric instead
+// of two, cf. tools/micro/feed_rate.hip).  Even iterations: wait for the pair in flight, barrier, issue the next pair; odd: barrier.
+template <int EPI>
+__device__ __forceinline__ void nt128pair_body(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
+                                               float* __restrict__ C, int64_t ldc, int64_t M, int N, int K, SmemNTS<4>& sm) {
+    constexpr int NS = 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ncol = N / BBN;
+    const int nt = blockIdx.x % ncol;
+    const int64_t m0 = (int64_t)(blockIdx.x / ncol) * BBM;
+    const int n0 = nt * BBN;
+    const char* baseA = reinterpret_cast<const char*>(A + m0 * lda);
+    const char* baseB = reinterpret_cast<const char*>(B + (int64_t)n0 * ldb);
+    uint32_t voA[2], voB[4];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int sl = (wave * 2 + q) * 64 + lane, row = sl >> 2, kq = (sl & 3) ^ ((row >> 2) & 3);
+        int64_t r = row;
+        if (m0 + r > M - 1) r = M - 1 - m0;
+        voA[q] = (uint32_t)(r * lda * 2 + kq * 16);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int sl = (wave * 4 + q) * 64 + lane, row = sl >> 2, kq = (sl & 3) ^ ((row >> 2) & 3);
+        voB[q] = (uint32_t)((int64_t)row * ldb * 2 + kq * 16);
+    }
+    const uint32_t ldsA = lds_addr_of(&sm.A[0][0]) + wave * 2 * 1024, ldsB = lds_addr_of(&sm.B[0][0]) + wave * 4 * 1024;
+    const int nch = K / BBK;   // even
+    auto issue_pair = [&](int st0, int f0) {   // chunks f0, f0+1 -> stages st0, st0+1 (f0 even, st0 in {0, 2})
+        const int f = f0 < nch ? f0 : nch - 2;
+        const char* a = baseA + (int64_t)f * (BBK * 2);
+        const char* b = baseB + (int64_t)f * (BBK * 2);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            glds16_s(voA[q], a, ldsA + st0 * (BBM * BBK * 2) + q * 1024);
+            glds16_s(voA[q], a + BBK * 2, ldsA + (st0 + 1) * (BBM * BBK * 2) + q * 1024);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            glds16_s(voB[q], b, ldsB + st0 * (BBN * BBK * 2) + q * 1024);
+            glds16_s(voB[q], b + BBK * 2, ldsB + (st0 + 1) * (BBN * BBK * 2) + q * 1024);
+        }
+    };
+    const int l32 = lane & 31, kh = lane >> 5;
+    int offA[2], offB[4];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const int r = wm * 64 + rt * 32 + l32;
+        offA[rt] = r * 64 + ((kh ^ ((r >> 2) & 3)) << 4);
+    }
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        const int r = wn * 128 + ct * 32 + l32;
+        offB[ct] = r * 64 + ((kh ^ ((r >> 2) & 3)) << 4);
+    }
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    issue_pair(0, 0);
+    int st = 0;
+    for (int ch = 0; ch < nch; ++ch) {
+        if ((ch & 1) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the pair (ch, ch+1) has landed
+        __syncthreads();
+        if ((ch & 1) == 0) issue_pair(st ^ 2, ch + 2);                        // stages of the pair consumed two iterations ago
+        const char* Ab = reinterpret_cast<const char*>(sm.A[0]) + st * (BBM * BBK * 2);
+        const char* Bb = reinterpret_cast<const char*>(sm.B[0]) + st * (BBN * BBK * 2);
+        if (EPI != 2)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            bf16x8 fa[2], fb[4];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) fa[rt] = *reinterpret_cast<const bf16x8*>(Ab + (offA[rt] ^ (g << 5)));
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) fb[ct] = *reinterpret_cast<const bf16x8*>(Bb + (offB[ct] ^ (g << 5)));
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const int rt = m & 1, ct = m >> 1;
+                acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[rt], fb[ct], acc[rt][ct], 0, 0, 0);
+            }
+        }
+        st = (st + 1) & 3;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t m = m0 + wm * 64 + rt * 32 + acc_row(r, lane);
+            if (EPI >= 1 ? (M < 0) : (m < M)) {
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) C[m * ldc + n0 + wn * 128 + ct * 32 + l32] = acc[rt][ct][r];
+            }
+        }
+}
+__global__ __launch_bounds__(256) void nt128pair(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
+                                                 float* __restrict__ C, int64_t ldc, int64_t M, int N, int K) {
+    __shared__ SmemNTS<4> sm;
+    nt128pair_body<0>(A, lda, B, ldb, C, ldc, M, N, K, sm);
+}
+__global__ __launch_bounds__(256) void nt128pair_noepi(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
+                                                       float* __restrict__ C, int64_t ldc, int64_t M, int N, int K) {
+    __shared__ SmemNTS<4> sm;
+    nt128pair_body<1>(A, lda, B, ldb, C, ldc, M, N, K, sm);
+}
+__global__ __launch_bounds__(256) void nt128pair_dmaonly(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B,
+                                                         int64_t ldb, float* __restrict__ C, int64_t ldc, int64_t M, int N, int K) {
+    __shared__ SmemNTS<4> sm;
+    nt128pair_body<2>(A, lda, B, ldb, C, ldc, M, N, K, sm);
+}
+
 #define NT128S(NAME, EPI, NS, OCC)                                                                                              \
     __global__ __launch_bounds__(256, OCC) void NAME(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B,   \
                                                      int64_t ldb, float* __restrict__ C, int64_t ldc, int64_t M, int N, int K) { \
@@ -1069,14 +1186,15 @@ int main(int argc, char** argv) {
     hipEventCreate(&e1);
     struct V { const char* name; kern_t k; int bm, bn, threads; };
     const V vs[] = {{"nt128x256x32", nt128, BBM, BBN, 256}, {"nt256x256x64_pipe", nt256, PM, PN, 512},
-                    {"nt128_pipe", nt128p, BBM, BBN, 256}, {"nt128_ring3", nt128s3, BBM, BBN, 256}, {"nt128_wspec", nt128ws, BBM, BBN, 512}, {"nt128_wspec_pipe", nt128wsp, BBM, BBN, 512}, {"nt128_pipe_ring3", nt128pr, BBM, BBN, 256},
+                    {"nt128_pipe", nt128p, BBM, BBN, 256}, {"nt128_ring3", nt128s3, BBM, BBN, 256}, {"nt128_wspec", nt128ws, BBM, BBN, 512}, {"nt128_wspec_pipe", nt128wsp, BBM, BBN, 512}, {"nt128_pipe_ring3", nt128pr, BBM, BBN, 256}, {"nt128_pair4", nt128pair, BBM, BBN, 256},
                     {"nt128_noepi", nt128_noepi, BBM, BBN, 256}, {"nt256_noepi", nt256_noepi, PM, PN, 512},
                     {"nt128_pipe_noepi", nt128p_noepi, BBM, BBN, 256}, {"nt128_ring2_noepi", nt128s2_noepi, BBM, BBN, 256},
                     {"nt128_ring3_noepi", nt128s3_noepi, BBM, BBN, 256}, {"nt128_ring4_noepi", nt128s4_noepi, BBM, BBN, 256},
                     {"nt128_ring6_noepi", nt128s6_noepi, BBM, BBN, 256}, {"nt128_wspec_noepi", nt128ws_noepi, BBM, BBN, 512}, {"nt128_wspec_pipe_noepi", nt128wsp_noepi, BBM, BBN, 512}, {"nt128_ring2_DMA_ONLY", nt128s2_dmaonly, BBM, BBN, 256},
-                    {"nt128_ring3_DMA_ONLY", nt128s3_dmaonly, BBM, BBN, 256}, {"nt128_ring2_MMA_ONLY", nt128s2_mmaonly, BBM, BBN, 256}, {"nt128_MMA_ONLY_NOBAR", nt128s2_mmaonly_nobar, BBM, BBN, 256}, {"nt128_pipe_MMA_ONLY", nt128p_mmaonly, BBM, BBN, 256}, {"nt128_pipe_ring3_noepi", nt128pr_noepi, BBM, BBN, 256}};
-    const int nv = 22;
-    for (int v = 0; v < 7; ++v)
+                    {"nt128_ring3_DMA_ONLY", nt128s3_dmaonly, BBM, BBN, 256}, {"nt128_ring2_MMA_ONLY", nt128s2_mmaonly, BBM, BBN, 256}, {"nt128_MMA_ONLY_NOBAR", nt128s2_mmaonly_nobar, BBM, BBN, 256}, {"nt128_pipe_MMA_ONLY", nt128p_mmaonly, BBM, BBN, 256}, {"nt128_pipe_ring3_noepi", nt128pr_noepi, BBM, BBN, 256}, {"nt128_pair4_noepi", nt128pair_noepi, BBM, BBN, 256},
+                    {"nt128_pair4_DMA_ONLY", nt128pair_dmaonly, BBM, BBN, 256}};
+    const int nv = 25;
+    for (int v = 0; v < 8; ++v)
         for (int which = 0; which < 2; ++which) {
             const int64_t Mc = which ? 1000 : M;
             const int tiles = (int)(((Mc + vs[v].bm - 1) / vs[v].bm) * (N / vs[v].bn));
