@@ -249,6 +249,71 @@ __global__ __launch_bounds__(256, 2) void gate_dx_bf16_kernel(const bf16_t* __re
     else epilogue_rows8<false>(acc, tile, wm, colb, lane, (int)(T - t0), emit);
 }
 
+// ------------------------------------------------------------------------------------------------
+// dX on the 256 x 256 x 64 tile (tile_engine_bf16.hpp: the long contraction K = 1024 is where that tile wins): same products and
+// epilogue as gate_dx_bf16_kernel, 256 token rows x 256 of the head's 512 input channels per workgroup of 8 waves.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void gate_dx256_bf16_kernel(const bf16_t* __restrict__ dz, const bf16_t* __restrict__ WN,
+                                                              bf16_t* __restrict__ dE, int64_t ldE, int accumulate, int64_t T, int H,
+                                                              PoolTerm pt) {
+    __shared__ SmemQ sm;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const XcdHead xh = xcd_head(blockIdx.x, H);
+    const int nt = xh.li % 2, c = xh.c, tt = (xh.li / 2) * xh.nshare + xh.share;
+    const int64_t t0 = (int64_t)tt * QM;
+    if (t0 >= T) return;  // block-uniform
+    const int n0 = nt * QN;
+
+    const char* baseA = reinterpret_cast<const char*>(dz + (t0 * H + c) * 1024);
+    const char* baseB = reinterpret_cast<const char*>(WN + ((int64_t)c * HID + n0) * 1024);
+    const uint32_t rowA = (uint32_t)H * 1024u * 2u;
+    uint32_t voA[4], voB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int row, ch;
+        nt256_slot(wave, i, lane, row, ch);
+        int64_t ra = row;
+        if (t0 + ra > T - 1) ra = T - 1 - t0;
+        voA[i] = (uint32_t)ra * rowA + ch * 16;
+        voB[i] = (uint32_t)row * 2048u + ch * 16;
+    }
+    auto dma = [&](int st, int64_t f, int piece) {
+        const int i = piece & 3;
+        if (piece < 4) glds16_s(voA[i], baseA + f * (QK * 2), lds_addr_of(&sm.A[st][(wave * 4 + i) * 1024]));
+        else glds16_s(voB[i], baseB + f * (QK * 2), lds_addr_of(&sm.B[st][(wave * 4 + i) * 1024]));
+    };
+    f32x16 acc[4][2];
+    nt256_mainloop(sm, acc, 1024 / QK, wm, wn, lane, dma);
+
+    bf16_t* ob = dE + t0 * ldE + (int64_t)c * HID + n0;
+    auto emit = [&](int row_u, int rl, int lane_col, const f32x4& lo, const f32x4& hi, int) {
+        bf16_t* o = ob + (int64_t)row_u * ldE + ((uint32_t)rl * (uint32_t)ldE + (uint32_t)lane_col);
+        f32x4 a = lo, b = hi;
+        if (pt.scores) {  // fused A3 term: + w[t,c] * d_pooled[bag(t), c, :]
+            int bag;
+            const float w = pool_term_weight(pt, t0 + row_u + rl, c, H, bag);
+            const float* __restrict__ dp = pt.d_pooled + ((int64_t)bag * H + c) * HID + n0 + lane_col;
+            const f32x4 d0 = *reinterpret_cast<const f32x4*>(dp), d1 = *reinterpret_cast<const f32x4*>(dp + 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a[i] = fmaf(w, d0[i], lo[i]);
+                b[i] = fmaf(w, d1[i], hi[i]);
+            }
+        } else if (accumulate) {
+            const bf16x8 old = *reinterpret_cast<const bf16x8*>(o);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a[i] += (float)old[i];
+                b[i] += (float)old[4 + i];
+            }
+        }
+        st8_bf16(o, a, b);
+    };
+    nt256_epilogue(acc, sm, wave, wm, wn, lane, (int)((T - t0 < QM) ? (T - t0) : QM), emit);
+}
+
 // ================================================================================================
 // dW: slabW[sp][c][k'][n] = sum_{t in split sp} E[t, c, k'] dz[t, c, n]        ("TN": both operands token-major = K-major)
 // Round 2: no transposed copies of E and dz any more.  The MFMA fragments (8 consecutive k = tokens per lane) are gathered
@@ -435,11 +500,19 @@ static int gate_bwd_bf16_impl(const uint16_t* E, int64_t ldE, const float* Wa, c
         if (T > 0) {
             hipLaunchKernelGGL(gate_wn_bf16_kernel, dim3(16, 32, H), dim3(256), 0, s, Wa, Wb, WN);
             MDL_LAUNCH_CHECK();
-            const int64_t n_tt = (T + BBM - 1) / BBM;
-            const int64_t grid = xcd_head_grid(n_tt, 2, H);
-            if (grid > 0x7fffffff) return MDL_E_UNSUPPORTED;
-            hipLaunchKernelGGL(gate_dx_bf16_kernel, dim3((unsigned)grid), dim3(256), 0, s, (const bf16_t*)dz, (const bf16_t*)WN,
-                               (bf16_t*)dE, ldE, accumulate, T, H, pt);
+            if (T >= 4096) {   // long contraction (K = 1024): the 256 x 256 x 64 tile (measured: 1.58 -> see DESIGN.md)
+                const int64_t n_tt = (T + QM - 1) / QM;
+                const int64_t grid = xcd_head_grid(n_tt, 2, H);
+                if (grid > 0x7fffffff) return MDL_E_UNSUPPORTED;
+                hipLaunchKernelGGL(gate_dx256_bf16_kernel, dim3((unsigned)grid), dim3(512), 0, s, (const bf16_t*)dz, (const bf16_t*)WN,
+                                   (bf16_t*)dE, ldE, accumulate, T, H, pt);
+            } else {
+                const int64_t n_tt = (T + BBM - 1) / BBM;
+                const int64_t grid = xcd_head_grid(n_tt, 2, H);
+                if (grid > 0x7fffffff) return MDL_E_UNSUPPORTED;
+                hipLaunchKernelGGL(gate_dx_bf16_kernel, dim3((unsigned)grid), dim3(256), 0, s, (const bf16_t*)dz, (const bf16_t*)WN,
+                                   (bf16_t*)dE, ldE, accumulate, T, H, pt);
+            }
             MDL_LAUNCH_CHECK();
         }
         hipLaunchKernelGGL(gate_dw_bf16_kernel, dim3((unsigned)xcd_head_grid(L.S, 16, H)), dim3(256), 0, s, (const bf16_t*)E, ldE,

@@ -101,6 +101,60 @@ __global__ __launch_bounds__(256, 2) void linb_nt_kernel(const bf16_t* __restric
     else epilogue_rows8<false>(acc, tile, wm, colb, lane, (int)(T - t0), emit);
 }
 
+// ---- NT product on the 256 x 256 x 64 tile (8 waves) ----------------------------------------------------------------------------
+// Round-2 lab result (tools/micro/gemm_lab_bf16.hip): the only loop variant that moves the ~1 PF ceiling of the
+// bf16 engine is the one with twice the MFMA work per staged byte AND whole 128-B cache lines per row and chunk (BK = 64): 1.2 PF
+// for the main loop against 1.0.  Workgroup = 8 waves (2 x 4), each 128 x 64 = 4 x 2 MFMA tiles; LDS stage = 256 rows x 128 B per
+// operand, 16-B chunk c of row r stored at chunk c ^ ((r >> 1) & 7) (conflict-free ds_read_b128 on 128-B rows); two stages =
+// 128 KiB, one workgroup per CU; the in-wave pipeline of the fp32 engine (fragments of k-step s+1 requested behind the first MFMA
+// of step s, one barrier per chunk before its last step, the next-but-one chunk's 8 LDS-DMA pieces between that step's MFMAs).
+// Used for T >= 4096 rows, output width % 256 == 0, contraction >= 1024 and % 64 == 0 (the dX of the 512 -> 2048 Linear); the 128 x 256 x 32 kernel covers the rest.
+__global__ __launch_bounds__(512) void linb_nt256_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B,
+                                                         const float* __restrict__ bias, bf16_t* __restrict__ C, int64_t ldc,
+                                                         int64_t T, int Kc, int n_ct, int n_tiles) {
+    __shared__ SmemQ sm;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;   // rows wm*128 + rt*32 (rt < 4), columns wn*64 + ct*32 (ct < 2)
+    const int lid = xcd_remap(blockIdx.x, n_tiles);
+    const int ct_id = lid % n_ct;
+    const int64_t t0 = (int64_t)(lid / n_ct) * QM;
+    const int n0 = ct_id * QN;
+
+    // DMA: one instruction = 8 rows x 128 B; wave w issues row blocks 4w .. 4w+3 of each operand
+    const char* baseA = reinterpret_cast<const char*>(A + t0 * lda);
+    const char* baseB = reinterpret_cast<const char*>(B + (int64_t)n0 * Kc);
+    uint32_t voA[4], voB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int row, c;
+        nt256_slot(wave, i, lane, row, c);
+        int64_t ra = row;
+        if (t0 + ra > T - 1) ra = T - 1 - t0;   // row tail: re-read the last row (not stored)
+        voA[i] = (uint32_t)(ra * lda * 2 + c * 16);
+        voB[i] = (uint32_t)((int64_t)row * Kc * 2 + c * 16);
+    }
+    auto dma = [&](int st, int64_t f, int piece) {   // piece 0..7: 0-3 = A row blocks, 4-7 = B row blocks
+        const int i = piece & 3;
+        if (piece < 4) glds16_s(voA[i], baseA + f * (QK * 2), lds_addr_of(&sm.A[st][(wave * 4 + i) * 1024]));
+        else glds16_s(voB[i], baseB + f * (QK * 2), lds_addr_of(&sm.B[st][(wave * 4 + i) * 1024]));
+    };
+    f32x16 acc[4][2];
+    nt256_mainloop(sm, acc, Kc / QK, wm, wn, lane, dma);
+
+    bf16_t* ob = C + t0 * ldc + n0;
+    auto emit = [&](int row_u, int rl, int lane_col, const f32x4& lo, const f32x4& hi, int) {
+        bf16_t* o = ob + (int64_t)row_u * ldc + ((uint32_t)rl * (uint32_t)ldc + (uint32_t)lane_col);
+        f32x4 a = lo, b = hi;
+        if (bias) {
+            a += *reinterpret_cast<const f32x4*>(bias + n0 + lane_col);
+            b += *reinterpret_cast<const f32x4*>(bias + n0 + lane_col + 4);
+        }
+        st8_bf16(o, a, b);
+    };
+    nt256_epilogue(acc, sm, wave, wm, wn, lane, (int)((T - t0 < QM) ? (T - t0) : QM), emit);
+}
+
 // ---- TN product: slab[sp][n0 + m][k0 + n] = sum_{t in split sp} dY[t][n0 + m] X[t][k0 + n] --------------
 // Token rows past T: X re-reads row T-1, dY reads a zero row (per-lane address form of the LDS-DMA, last chunk only).
 __global__ __launch_bounds__(256, 2) void linb_tn_kernel(const bf16_t* __restrict__ dY, int64_t lddy, const bf16_t* __restrict__ X,
@@ -239,6 +293,7 @@ static inline LinbWs linb_ws(int64_t T, int N, int K) {
     w.total = o + 64;
     return w;
 }
+static inline bool linb_use_q(int64_t T, int64_t Kc) { return T >= 4096 && Kc >= 1024 && (Kc % QK) == 0; }   // 256 x 256 x 64 tile: wins on long contractions (measured: K = 2048 0.70 -> 0.61 ms; K = 512 loses, one workgroup per CU exposes prologue + epilogue)
 static inline bool linb_geom_fwd(int64_t N, int64_t K) { return N > 0 && K > 0 && N % 128 == 0 && K % BBK == 0 && N <= (1 << 20) && K <= (1 << 20); }
 static inline bool linb_geom_bwd(int64_t N, int64_t K) { return linb_geom_fwd(N, K); }
 
@@ -267,6 +322,15 @@ extern "C" int mdl_linear_fwd_bf16(const uint16_t* X, int64_t ldx, const float* 
     hipLaunchKernelGGL(linb_w_cast_kernel, dim3((unsigned)((N * K / 4 + 255) / 256)), dim3(256), 0, s, W, Wb, N * K);
     MDL_LAUNCH_CHECK();
     const bool wide = (N % BBN) == 0;
+    if (wide && linb_use_q(T, K)) {
+        const int n_ct = (int)(N / QN);
+        const int64_t tiles = ((T + QM - 1) / QM) * n_ct;
+        if (tiles > 0x7fffffff) return MDL_E_UNSUPPORTED;
+        hipLaunchKernelGGL(linb_nt256_kernel, dim3((unsigned)tiles), dim3(512), 0, s, (const bf16_t*)X, ldx, (const bf16_t*)Wb, bias,
+                           (bf16_t*)Y, ldy, T, (int)K, n_ct, (int)tiles);
+        MDL_LAUNCH_CHECK();
+        return MDL_OK;
+    }
     const int n_ct = (int)(N / (wide ? BBN : 128));
     const int64_t tiles = ((T + BBM - 1) / BBM) * n_ct;
     if (tiles > 0x7fffffff) return MDL_E_UNSUPPORTED;
@@ -315,12 +379,21 @@ extern "C" int mdl_linear_bwd_bf16(const uint16_t* X, int64_t ldx, const float* 
     if (dX) {   // dX = dY W: NT with B = W^T rows [K][N]
         hipLaunchKernelGGL(linb_w_transpose_kernel, dim3((unsigned)(K / 32), (unsigned)(N / 32)), dim3(256), 0, s, W, WT, (int)N, (int)K);
         MDL_LAUNCH_CHECK();
+        if ((K % QN) == 0 && linb_use_q(T, N)) {
+            const int n_ct = (int)(K / QN);
+            const int64_t tiles = ((T + QM - 1) / QM) * n_ct;
+            if (tiles > 0x7fffffff) return MDL_E_UNSUPPORTED;
+            hipLaunchKernelGGL(linb_nt256_kernel, dim3((unsigned)tiles), dim3(512), 0, s, (const bf16_t*)dY, lddy, (const bf16_t*)WT,
+                               (const float*)nullptr, (bf16_t*)dX, lddx, T, (int)N, n_ct, (int)tiles);
+            MDL_LAUNCH_CHECK();
+        } else {
         const int n_ct = (int)((K + BBN - 1) / BBN);
         const int64_t tiles = ((T + BBM - 1) / BBM) * n_ct;
         if (tiles > 0x7fffffff) return MDL_E_UNSUPPORTED;
         hipLaunchKernelGGL(linb_nt_kernel<4>, dim3((unsigned)tiles), dim3(256), 0, s, (const bf16_t*)dY, lddy, (const bf16_t*)WT,
                            (const float*)nullptr, (bf16_t*)dX, lddx, T, (int)N, (int)K, n_ct, (int)tiles);
         MDL_LAUNCH_CHECK();
+        }
     }
     {
         const int64_t tiles = (int64_t)L.S * (N / 128) * ((K + 255) / 256);

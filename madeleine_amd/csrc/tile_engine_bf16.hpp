@@ -151,6 +151,114 @@ __device__ __forceinline__ void nt_mainloop_ring(SmemNTR<NS>& sm, f32x16 (&acc)[
     __syncthreads();
 }
 
+// ---- NT on the 256 x 256 x 64 tile (8 waves) --------------------------------------------------------------------------------------
+// Round-2 lab result (tools/micro/gemm_lab_bf16.hip): the only loop variant that moves the ~1 PF ceiling of the
+// bf16 engine is the one with twice the MFMA work per staged byte AND whole 128-B cache lines per row and chunk (BK = 64): 1.2 PF
+// for the main loop against 1.0.  Workgroup = 8 waves (2 x 4), each 128 x 64 = 4 x 2 MFMA tiles; LDS stage = 256 rows x 128 B per
+// operand, 16-B chunk c of row r stored at chunk c ^ ((r >> 1) & 7) (conflict-free ds_read_b128 on 128-B rows); two stages =
+// 128 KiB, one workgroup per CU; the in-wave pipeline of the fp32 engine (fragments of k-step s+1 requested behind the first MFMA
+// of step s, one barrier per chunk before its last step, the next-but-one chunk's 8 LDS-DMA pieces between that step's MFMAs).
+// It wins on long contractions (K >= 1024); on K = 512 one workgroup per CU exposes the tile prologue and epilogue.
+constexpr int QM = 256, QN = 256, QK = 64, Q_STAGE = QM * QK * 2;
+struct __attribute__((aligned(16))) SmemQ {
+    char A[2][Q_STAGE];
+    char B[2][Q_STAGE];
+};
+// LDS-DMA piece i (0..3) of wave w for either operand: 8 rows x 128 B; this lane fetches global 16-B chunk c of row `row` (tile-relative)
+// and the DMA deposits it at LDS slot (wave*4 + i)*1024 + lane*16 = row*128 + (c ^ ((row >> 1) & 7))*16.
+__device__ __forceinline__ void nt256_slot(int wave, int i, int lane, int& row, int& c) {
+    row = (wave * 4 + i) * 8 + (lane >> 3);
+    c = (lane & 7) ^ ((row >> 1) & 7);
+}
+// dma(stage, chunk, piece): piece 0..3 = this wave's A row blocks, 4..7 = its B row blocks (glds16_s).  acc is zeroed here.
+template <class Dma>
+__device__ __forceinline__ void nt256_mainloop(SmemQ& sm, f32x16 (&acc)[4][2], int64_t nch, int wm, int wn, int lane, Dma&& dma) {
+    const int l32 = lane & 31, kh = lane >> 5;
+    uint32_t offA[4], offB[2];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+        const int r = wm * 128 + rt * 32 + l32;
+        offA[rt] = r * 128 + ((kh ^ ((r >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        const int r = wn * 64 + ct * 32 + l32;
+        offB[ct] = r * 128 + ((kh ^ ((r >> 1) & 7)) << 4);
+    }
+    bf16x8 fa0[4], fb0[2], fa1[4], fb1[2];
+    auto ld = [&](bf16x8 (&fa)[4], bf16x8 (&fb)[2], int st, int ks) {
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) fa[rt] = *reinterpret_cast<const bf16x8*>(&sm.A[st][offA[rt] ^ (ks << 5)]);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) fb[ct] = *reinterpret_cast<const bf16x8*>(&sm.B[st][offB[ct] ^ (ks << 5)]);
+    };
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    auto mma1 = [&](const bf16x8 (&fa)[4], const bf16x8 (&fb)[2], int m) {
+        const int rt = m >> 1, ct = m & 1;
+        acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[rt], fb[ct], acc[rt][ct], 0, 0, 0);
+    };
+#define NT256_SB() __builtin_amdgcn_sched_barrier(0)
+#define NT256_KSTEP(FA, FB, LOADS)                                              \
+    mma1(FA, FB, 0);                                                            \
+    NT256_SB();                                                                 \
+    LOADS;                                                                      \
+    NT256_SB();                                                                 \
+    _Pragma("unroll") for (int m = 1; m < 8; ++m) mma1(FA, FB, m);              \
+    NT256_SB();
+    if (nch <= 0) return;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) dma(0, (int64_t)0, p);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    {
+        const int64_t f = nch > 1 ? 1 : 0;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) dma(1, f, p);
+    }
+    ld(fa0, fb0, 0, 0);
+    for (int64_t ch = 0; ch < nch; ++ch) {
+        const int st = (int)(ch & 1);
+        NT256_KSTEP(fa0, fb0, ld(fa1, fb1, st, 1))
+        NT256_KSTEP(fa1, fb1, ld(fa0, fb0, st, 2))
+        NT256_KSTEP(fa0, fb0, ld(fa1, fb1, st, 3))
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        ld(fa0, fb0, st ^ 1, 0);
+        NT256_SB();
+        const int64_t f = (ch + 2 < nch) ? ch + 2 : nch - 1;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            mma1(fa1, fb1, m);
+            NT256_SB();
+            dma(st, f, m);
+            NT256_SB();
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped re-fetches of the tail
+    __syncthreads();                                    // staging memory is free for the epilogue
+#undef NT256_KSTEP
+#undef NT256_SB
+}
+// epilogue of the 256-tile: the wave's 128 x 64 sub-tile through its private 32 x 64 LDS transpose tile, as two 64-row halves of
+// epilogue_rows8 (emit sees tile-relative rows / columns)
+template <class Emit>
+__device__ __forceinline__ void nt256_epilogue(const f32x16 (&acc)[4][2], SmemQ& sm, int wave, int wm, int wn, int lane, int rows_valid,
+                                               Emit&& emit) {
+    float* tile = reinterpret_cast<float*>(&sm) + wave * (32 * 64);
+    const int colb[2] = {wn * 64, wn * 64 + 32};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const f32x16 (&half)[2][2] = reinterpret_cast<const f32x16 (&)[2][2]>(acc[2 * h]);
+        if (rows_valid >= QM) epilogue_rows8<true>(half, tile, wm * 2 + h, colb, lane, QM, emit);
+        else epilogue_rows8<false>(half, tile, wm * 2 + h, colb, lane, rows_valid, emit);
+    }
+}
+
 // ================================================================================================
 // TN.  Measured semantics of ds_read_b64_tr_b16 (tools/micro/tr_probe.hip): within a 16-lane group every lane r supplies the
 // address of 4 consecutive bf16 D[r][0..3] and lane l receives D[4j + (l >> 2)][l & 3], j = 0..3; with lane r pointing at
