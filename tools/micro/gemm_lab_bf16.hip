@@ -1152,6 +1152,166 @@ __global__ __launch_bounds__(256, 2) void tn128_noswz(const bf16_t* A, int64_t l
     tn128_body<0, 0>(A, lda, B, ldb, C, ldc, Kt, Mi, N, kps, sm);
 }
 
+// TN on the 256 x 256 x 64 tile: 8 waves (2 x 4, 128 x 64 each), K-major stage images [64 k][256] bf16 (512-B k-rows, 64-B unit u of
+// k-row t at unit u ^ (t & 3)), fragments by ds_read_b64_tr_b16, in-wave pipelined like nt256 (asm reads: lgkmcnt waits by hand).
+constexpr int UK = 64;
+struct __attribute__((aligned(16))) SmemTQ {
+    char A[2][UK * 256 * 2];   // 32 KiB per stage
+    char B[2][UK * 256 * 2];
+};
+template <int OFF>
+__device__ __forceinline__ u32x2 ds_tr16o(uint32_t a) {
+    u32x2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(a), "i"(OFF));
+    return v;
+}
+struct TqFrag {
+    u32x2 a[4][2], b[2][2];
+};
+template <int KS>   // k-step 0..3 of the staged chunk: + KS * 16 k-rows = KS * 8192 B; second k half: + 4 rows = 2048 B
+__device__ __forceinline__ void tq_load(TqFrag& f, const uint32_t (&aA)[4], const uint32_t (&aB)[2]) {
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+        f.a[rt][0] = ds_tr16o<KS * 8192>(aA[rt]);
+        f.a[rt][1] = ds_tr16o<KS * 8192 + 2048>(aA[rt]);
+    }
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        f.b[ct][0] = ds_tr16o<KS * 8192>(aB[ct]);
+        f.b[ct][1] = ds_tr16o<KS * 8192 + 2048>(aB[ct]);
+    }
+}
+__device__ __forceinline__ void tq_mma(f32x16 (&acc)[4][2], const TqFrag& f, int m) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const int rt = m >> 1, ct = m & 1;
+    const u32x4 av = {f.a[rt][0].x, f.a[rt][0].y, f.a[rt][1].x, f.a[rt][1].y};
+    const u32x4 bv = {f.b[ct][0].x, f.b[ct][0].y, f.b[ct][1].x, f.b[ct][1].y};
+    acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc[rt][ct], 0, 0, 0);
+}
+template <int EPI>
+__device__ __forceinline__ void tn256_body(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
+                                           float* __restrict__ C, int64_t ldc, int64_t Kt, int Mi, int N, int64_t k_per_split,
+                                           SmemTQ& sm) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int nit = Mi / 256, nnt = N / 256;
+    const int it = blockIdx.x % nit, nt = (blockIdx.x / nit) % nnt, sp = blockIdx.x / (nit * nnt);
+    const int i0 = it * 256, n0 = nt * 256;
+    const int64_t ks = (int64_t)sp * k_per_split;
+    int64_t ke = ks + k_per_split;
+    if (ke > Kt) ke = Kt;
+    const int nch = (int)((ke - ks + UK - 1) / UK);
+    // DMA: one instruction = 2 k-rows x 512 B; wave w issues k-row pairs 4w .. 4w+3 of each operand (32 pairs per stage)
+    const char* baseA = reinterpret_cast<const char*>(A + ks * lda + i0);
+    const char* baseB = reinterpret_cast<const char*>(B + ks * ldb + n0);
+    uint32_t voA[4], voB[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int kr = (wave * 4 + q) * 2 + (lane >> 5), c = lane & 31;   // 16-B chunk position c of k-row kr holds global chunk c ^ ((kr&3)<<2)
+        const int src = c ^ ((kr & 3) << 2);
+        voA[q] = (uint32_t)((int64_t)kr * lda * 2 + src * 16);
+        voB[q] = (uint32_t)((int64_t)kr * ldb * 2 + src * 16);
+    }
+    auto dma = [&](int st, int f, int piece) {
+        const int q = piece & 3;
+        if (piece < 4) glds16_s(voA[q], baseA + (int64_t)f * UK * lda * 2, lds_addr_of(&sm.A[st][(wave * 4 + q) * 1024]));
+        else glds16_s(voB[q], baseB + (int64_t)f * UK * ldb * 2, lds_addr_of(&sm.B[st][(wave * 4 + q) * 1024]));
+    };
+    const int g = lane >> 4, r = lane & 15;
+    const int kb = (g >> 1) * 8 + (r >> 2);
+    uint32_t a0[4], b0[2];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+        a0[rt] = lds_addr_of(&sm.A[0][0]) + kb * 512 + (((wm * 128 + rt * 32 + (g & 1) * 16 + (r & 3) * 4) * 2) ^ ((kb & 3) << 6));
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+        b0[ct] = lds_addr_of(&sm.B[0][0]) + kb * 512 + (((wn * 64 + ct * 32 + (g & 1) * 16 + (r & 3) * 4) * 2) ^ ((kb & 3) << 6));
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    if (nch > 0) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) dma(0, 0, p);
+        DMA_WAIT();
+        __syncthreads();
+        {
+            const int f = nch > 1 ? 1 : 0;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) dma(1, f, p);
+        }
+        TqFrag f0, f1;
+        tq_load<0>(f0, a0, b0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        SB();
+        for (int ch = 0; ch < nch; ++ch) {
+            const int st = ch & 1;
+            uint32_t aA[4], aB[2], nA[4], nB[2];
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+                aA[rt] = a0[rt] + st * (UK * 512);
+                nA[rt] = a0[rt] + (st ^ 1) * (UK * 512);
+            }
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                aB[ct] = b0[ct] + st * (UK * 512);
+                nB[ct] = b0[ct] + (st ^ 1) * (UK * 512);
+            }
+#define TQ_STEP(CUR, NXT, KS)                                                   \
+    tq_mma(acc, CUR, 0);                                                        \
+    SB();                                                                       \
+    tq_load<KS>(NXT, aA, aB);                                                   \
+    SB();                                                                       \
+    _Pragma("unroll") for (int m = 1; m < 8; ++m) tq_mma(acc, CUR, m);          \
+    SB();                                                                       \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                         \
+    SB();
+            TQ_STEP(f0, f1, 1)
+            TQ_STEP(f1, f0, 2)
+            TQ_STEP(f0, f1, 3)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            SB();
+            __syncthreads();
+            tq_load<0>(f0, nA, nB);
+            SB();
+            const int f = (ch + 2 < nch) ? ch + 2 : nch - 1;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                tq_mma(acc, f1, m);
+                SB();
+                dma(st, f, m);
+                SB();
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            SB();
+        }
+#undef TQ_STEP
+        DMA_WAIT();
+        __syncthreads();
+    }
+    const int l32 = lane & 31;
+    float* __restrict__ so = C + (int64_t)sp * Mi * ldc;
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int i = i0 + wm * 128 + rt * 32 + acc_row(e, lane);
+            if (EPI == 1 ? (Kt < 0) : true) {
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) so[(int64_t)i * ldc + n0 + wn * 64 + ct * 32 + l32] = acc[rt][ct][e];
+            }
+        }
+}
+__global__ __launch_bounds__(512) void tn256(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, float* C, int64_t ldc, int64_t Kt,
+                                             int Mi, int N, int64_t kps) {
+    __shared__ SmemTQ sm;
+    tn256_body<0>(A, lda, B, ldb, C, ldc, Kt, Mi, N, kps, sm);
+}
+
 typedef void (*kern_t)(const bf16_t*, int64_t, const bf16_t*, int64_t, float*, int64_t, int64_t, int, int);
 static uint16_t f2bf(float f) {
     uint32_t u;
@@ -1250,13 +1410,14 @@ int main(int argc, char** argv) {
         }
         typedef void (*tn_t)(const bf16_t*, int64_t, const bf16_t*, int64_t, float*, int64_t, int64_t, int, int, int64_t);
         struct TV { const char* name; tn_t k; };
-        const TV tv[] = {{"tn128_swz", tn128}, {"tn128_noswz", tn128_noswz}};
-        const int grid = (Mi / 128) * (Nn / 256) * S;
-        for (int v = 0; v < 2; ++v) {
+        const TV tv[] = {{"tn128_swz", tn128}, {"tn128_noswz", tn128_noswz}, {"tn256_pipe", tn256}};
+        for (int v = 0; v < 3; ++v) {
+            const int bm = v == 2 ? 256 : 128, thr = v == 2 ? 512 : 256;
+            const int grid = (Mi / bm) * (Nn / 256) * S;
             // correctness on a small K (one split of 96 tokens incl. a partial... K multiple of 32 here)
             hipMemset(Ct, 0xff, (size_t)Mi * Nn * 4);
-            hipLaunchKernelGGL(tv[v].k, dim3((Mi / 128) * (Nn / 256)), dim3(256), 0, 0, (const bf16_t*)At, (int64_t)Mi, (const bf16_t*)Bt,
-                               (int64_t)Nn, Ct, (int64_t)Nn, (int64_t)96, Mi, Nn, (int64_t)96);
+            hipLaunchKernelGGL(tv[v].k, dim3((Mi / bm) * (Nn / 256)), dim3(thr), 0, 0, (const bf16_t*)At, (int64_t)Mi, (const bf16_t*)Bt,
+                               (int64_t)Nn, Ct, (int64_t)Nn, (int64_t)(v == 2 ? 192 : 96), Mi, Nn, (int64_t)(v == 2 ? 192 : 96));
             hipDeviceSynchronize();
             std::vector<float> hC((size_t)Mi * Nn);
             hipMemcpy(hC.data(), Ct, hC.size() * 4, hipMemcpyDeviceToHost);
@@ -1264,15 +1425,15 @@ int main(int argc, char** argv) {
             for (int i = 0; i < Mi; i += 7)
                 for (int n = 0; n < Nn; n += 11) {
                     double s2 = 0;
-                    for (int k = 0; k < 96; ++k) s2 += (double)bf2f(hAt[(size_t)k * Mi + i]) * bf2f(hBt[(size_t)k * Nn + n]);
+                    for (int k = 0; k < (v == 2 ? 192 : 96); ++k) s2 += (double)bf2f(hAt[(size_t)k * Mi + i]) * bf2f(hBt[(size_t)k * Nn + n]);
                     maxerr = fmax(maxerr, fabs(s2 - hC[(size_t)i * Nn + n]));
                 }
             printf("check %-12s K=96 max abs err vs fp64 %.3e %s\n", tv[v].name, maxerr, maxerr < 1e-3 ? "OK" : "FAIL");
             double sum2 = 0, best2 = 1e9;
             for (int rd = 0; rd < rounds; ++rd) {
                 hipEventRecord(e0);
-                hipLaunchKernelGGL(tv[v].k, dim3(grid), dim3(256), 0, 0, (const bf16_t*)At, (int64_t)Mi, (const bf16_t*)Bt, (int64_t)Nn, Ct,
-                                   (int64_t)Nn, Kt, Mi, Nn, kps);
+                hipLaunchKernelGGL(tv[v].k, dim3(grid), dim3(thr), 0, 0, (const bf16_t*)At, (int64_t)Mi, (const bf16_t*)Bt, (int64_t)Nn, Ct,
+                                   (int64_t)Nn, Kt, Mi, Nn, (v == 2 ? (kps + 63) / 64 * 64 : kps));
                 hipEventRecord(e1);
                 hipEventSynchronize(e1);
                 float ms;
