@@ -38,7 +38,7 @@ def _build_model(dev):
     return build(MODS5[:M], D, "wdp", dev).eval()   # eval: dropout off, gradients still flow (parity mode)
 
 
-def _step(model, feats, labels_local, dev, use_got, labels_global=None):
+def _step(model, feats, labels_local, dev, use_got, labels_global=None, sync=True):
     from madeleine_amd import InfoNCE
     from madeleine_amd import distributed as DP
     from madeleine_amd import functional as MF
@@ -48,7 +48,11 @@ def _step(model, feats, labels_local, dev, use_got, labels_global=None):
     loss, flag = DP.calculate_losses_dp(mods[1:], InfoNCE(temperature=0.01), MF.HipGotImpl if use_got else None, embs, toks,
                                         labels_local[:, 1:], args, labels_global_withoutHE=labels_global, use_local_loss=use_got)
     model.zero_grad()
-    loss.backward()
+    if sync or not hasattr(model, "no_sync"):
+        loss.backward()
+    else:
+        with model.no_sync():
+            loss.backward()
     return loss.detach(), flag
 
 
@@ -59,7 +63,7 @@ def _single(dev, use_got):
     return float(loss), {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters() if p.grad is not None}
 
 
-def _worker(rank, world, port, backend, use_got, ret):
+def _worker(rank, world, port, backend, use_got, ret, ddp=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       HSA_ENABLE_IPC_MODE_LEGACY="0")
     dev = torch.device("cuda", rank if backend == "nccl" else 0)
@@ -68,6 +72,9 @@ def _worker(rank, world, port, backend, use_got, ret):
     try:
         from madeleine_amd import distributed as DP
         model = _build_model(dev)
+        if ddp:   # the wrapper bench.py uses for N > 1: bucketed gradient all-reduce (mean), unused-parameter detection
+            model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], find_unused_parameters=not use_got,
+                                                              bucket_cap_mb=8, gradient_as_bucket_view=True)
         Bl = B // world
         sl = slice(rank * Bl, (rank + 1) * Bl)
         pending = DP.all_gather_labels_async(LABELS[sl, 1:])          # host-side label exchange (gloo group)
@@ -79,10 +86,13 @@ def _worker(rank, world, port, backend, use_got, ret):
             if p.grad is None:
                 continue
             g = p.grad.detach().clone()
-            g = DP._all_reduce_sum(g) / world
-            grads[k] = g.cpu()
+            if not ddp:
+                g = DP._all_reduce_sum(g) / world
+            elif not use_got and "token_projector" in k:
+                continue                                               # zero-filled by DDP: the loss does not depend on it
+            grads[k[7:] if k.startswith("module.") else k] = g.cpu()
         # loss value of the global batch: replicated global part + sum over ranks of the local parts (undo the W scaling)
-        loss_nogot, _ = _step(model, t((B, M, N, D), "dpg:feats")[sl], LABELS[sl], dev, False, labels_global=lab_g)
+        loss_nogot, _ = _step(model, t((B, M, N, D), "dpg:feats")[sl], LABELS[sl], dev, False, labels_global=lab_g, sync=False)
         local = ((loss - loss_nogot) / world).reshape(1).clone()
         local = DP._all_reduce_sum(local)
         if rank == 0:
@@ -113,3 +123,24 @@ def test_two_ranks_equal_global_batch(backend, use_got):
         got = torch.from_numpy(ret["grads"][k])
         err = float((got - g).norm())
         assert err <= 1e-4 * float(g.norm()) + 1e-6 * top, (k, err, float(g.norm()))
+
+
+@pytest.mark.parametrize("use_got", [False, True])
+def test_two_ranks_under_ddp_equal_global_batch(use_got):
+    """The same decomposition with the model wrapped in DistributedDataParallel exactly as bench.py wraps it for N > 1 (8-MB
+    buckets, bucket views, unused-parameter detection when the local loss is off): DDP's own bucketed mean of the gradients,
+    the packed all-gather in forward and the [S,6] all-reduce inside the backward of the GOT node while DDP's hooks are live."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    ref_loss, ref_grads = _single(torch.device("cuda:0"), use_got)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), "gloo", use_got, ret, True), nprocs=2, join=True)
+    assert ret["flag"]
+    assert abs(ret["loss"] - ref_loss) < 1e-4 * abs(ref_loss), (ret["loss"], ref_loss)
+    top = max(float(g.norm()) for g in ref_grads.values())
+    for k, got in ret["grads"].items():
+        g = ref_grads[k]
+        err = float((torch.from_numpy(got) - g).norm())
+        assert err <= 1e-4 * float(g.norm()) + 1e-6 * top, (k, err, float(g.norm()))
+    assert len(ret["grads"]) >= len(ref_grads) - 2
