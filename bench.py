@@ -286,6 +286,7 @@ def main():
         # configuration): DDP must be told, or it raises on the second step.
         # 20 MB of fp32 gradients: 8-MB buckets start their all-reduce while the pre_attn backward is still running
         # (the default single 25-MB bucket would only fire after the last gradient), bucket views avoid the copy-back.
+        # (kept as find_unused_parameters: freezing the projector instead would change which tensors the optimizer owns)
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], find_unused_parameters=not use_got,
                                                         bucket_cap_mb=8, gradient_as_bucket_view=True)
     opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
