@@ -7,7 +7,7 @@ state_dict keys and shapes (reference and HuggingFace checkpoints load unchanged
 
   * pre_attn (3 x Linear + fused LayerNorm-GELU-Dropout), token_projector and projector run in the hand-written
     fp32 matrix-core Linear kernels (functional.linear / ln_gelu_drop) -- in the bf16
-    mode (torch.autocast(bfloat16)) the Linears are bf16 library GEMMs as under autocast;
+    mode (torch.autocast(bfloat16)) in their bf16 siblings (mdl_linear_*_bf16: bf16 activations, fp32 parameters);
   * gated attention scores + softmax-over-patches + weighted pooling, forward and backward, are the
     hand-written HIP kernels behind madeleine_amd.functional.attn_pool.
 
