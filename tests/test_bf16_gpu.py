@@ -51,7 +51,7 @@ def test_ln_gelu_drop_bf16_vs_fp32_kernel(dev, W, rows):
 @pytest.mark.parametrize("T,N,K,bias", [(1000, 512, 512, False), (4133, 256, 512, True), (257, 2048, 256, True),
                                          (20000, 512, 1024, False), (1500, 128, 2048, True), (700, 384, 256, False),
                                          (3000, 512, 800, False), (999, 256, 96, True), (5003, 512, 512, True),
-                                         (4100, 256, 2048, False)])
+                                         (4100, 256, 2048, False), (4357, 1024, 256, True)])
 def test_linear_bf16_vs_fp32_math(dev, T, N, K, bias):
     """mdl_linear_*_bf16 (hand-written bf16 MFMA Linears) against fp32 matmuls of the same bf16-representable operands.  The
     products of bf16 values are exact in fp32 and accumulation is fp32, so Y / dX differ from the reference by the output
