@@ -80,6 +80,29 @@ def collate(batch):
             "slide_ids": [item['slide_id'] for item in batch]}
 
 
+class SimpleDataset(Dataset):
+    """Mirror of wsi_dataset.py:102-120 (the extraction-side dataset run_inference iterates): every `*.h5` file of a directory ->
+    (features [N, D] float tensor, slide id = file name without the extension)."""
+
+    def __init__(self, features_path, feature_loader: Optional[Callable] = None):
+        self.features_path = features_path
+        self.fnames = sorted(fn for fn in os.listdir(features_path) if fn.endswith('.h5'))
+        self.feature_loader = feature_loader or load_features
+
+    def __len__(self):
+        return len(self.fnames)
+
+    def __getitem__(self, index):
+        feats = self.feature_loader(os.path.join(self.features_path, self.fnames[index]))
+        return feats, os.path.splitext(self.fnames[index])[0]
+
+
+def simple_collate(batch):
+    """wsi_dataset.py:122-125 -> (features [B, N, D], list of slide ids)."""
+    features, slide_ids = zip(*batch)
+    return torch.stack(features), list(slide_ids)
+
+
 class SyntheticSlideDataset(Dataset):
     """Synthetic stand-in with the same item contract (unit-normal patch features, Bernoulli stain presence with the
     ACROBAT rates of SURVEY.md section 8(d)); used by bench.py --host-input and the tests."""

@@ -186,3 +186,26 @@ def test_h5_feature_files_without_h5py(tmp_path):
     assert float(batch["feats"][1, 1].abs().max()) == 0.0                             # absent stain -> zero bag
     rows = {tuple(r.tolist()) for r in torch.from_numpy(feats[("c0", "ER")])}
     assert all(tuple(r.tolist()) in rows for r in batch["feats"][0, 1])               # resampled rows come from the file
+
+
+def test_simple_dataset_for_extraction(tmp_path):
+    """N3/N4: the extraction-side dataset (wsi_dataset.py:102-125): one item per .h5 file = (features [N,D], slide id), batch 1
+    through simple_collate -> the (feats [1,N,D], [slide_id]) pairs run_inference consumes."""
+    import numpy as np
+    from torch.utils.data import DataLoader
+    from madeleine_amd import h5io
+    from madeleine_amd.data import SimpleDataset, simple_collate
+    rng = np.random.default_rng(1)
+    arrs = {"s_b": rng.standard_normal((9, 16)).astype(np.float32), "s_a": rng.standard_normal((5, 1, 16)).astype(np.float32)}
+    for k, a in arrs.items():
+        h5io.write_datasets(str(tmp_path / f"{k}.h5"), {"features": a})
+    (tmp_path / "notes.txt").write_text("not a feature file")
+    ds = SimpleDataset(str(tmp_path))
+    assert len(ds) == 2
+    seen = {}
+    for feats, ids in DataLoader(ds, batch_size=1, collate_fn=simple_collate):
+        assert feats.dim() == 3 and feats.shape[0] == 1 and len(ids) == 1
+        seen[ids[0]] = feats[0]
+    assert set(seen) == {"s_a", "s_b"}
+    assert torch.equal(seen["s_a"], torch.from_numpy(arrs["s_a"].squeeze())) and torch.equal(seen["s_b"], torch.from_numpy(arrs["s_b"]))
+
