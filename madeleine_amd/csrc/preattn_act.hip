@@ -43,6 +43,40 @@ __device__ __forceinline__ float gelu_grad_f(float v) {
     return norm_cdf_f(v) + v * pdf;
 }
 
+// bf16 mode only (the fp32 parity path keeps the erfc forms above): Phi(x) ~= sigmoid(x P(x^2)), P = p0 + p1 x^2 + p2 x^4 fitted to the
+// exact x Phi(x) on [-6, 6] by minimax-weighted least squares (tools/fit_gelu_sigmoid.py): |x sigma(x P) - GELU(x)| <= 2.5e-5 and the
+// derivative of the approximation is within 1.1e-4 of GELU'(x) -- two orders of magnitude below the bf16 grid of the O(1) values these
+// kernels store (2^-9 relative), at 15 VALU issue slots instead of 26 (forward) and 21 instead of 33 (backward): the bf16 kernels are
+// VALU-bound, not HBM-bound.  The argument is clamped to [-6, 6] (beyond it Phi is 0 / 1 to 1e-9; the quartic term would otherwise
+// change sign near |x| = 15).  Coefficients below are pre-multiplied by -log2(e) for v_exp_f32.
+constexpr float GS_P0 = 1.59501576f, GS_P1 = 7.40113011e-2f, GS_P2 = -7.03034956e-4f, GS_NL2E = -1.4426950408889634f;
+__device__ __forceinline__ float gelu_sig_f(float x) {
+    const float xc = __builtin_amdgcn_fmed3f(x, -6.f, 6.f);
+    const float x2 = xc * xc;
+    const float q = fmaf(x2, fmaf(x2, GS_P2 * GS_NL2E, GS_P1 * GS_NL2E), GS_P0 * GS_NL2E);
+    const float e = __builtin_amdgcn_exp2f(xc * q);          // exp(-xc P(xc^2))
+    return x * __builtin_amdgcn_rcpf(1.f + e);
+}
+__device__ __forceinline__ float gelu_sig_grad_f(float x) {   // d/dx [x sigma(x P(x^2))] = s + x s (1 - s) (p0 + 3 p1 x^2 + 5 p2 x^4)
+    const float xc = __builtin_amdgcn_fmed3f(x, -6.f, 6.f);
+    const float x2 = xc * xc;
+    const float q = fmaf(x2, fmaf(x2, GS_P2 * GS_NL2E, GS_P1 * GS_NL2E), GS_P0 * GS_NL2E);
+    const float e = __builtin_amdgcn_exp2f(xc * q);
+    const float sg = __builtin_amdgcn_rcpf(1.f + e);
+    const float r = fmaf(x2, fmaf(x2, 5.f * GS_P2, 3.f * GS_P1), GS_P0);
+    return fmaf(xc * r, (e * sg) * sg, sg);                  // s (1 - s) = e s^2
+}
+template <class IO>
+__device__ __forceinline__ float act_gelu(float v) {
+    if constexpr (sizeof(IO) == 2) return gelu_sig_f(v);
+    else return gelu_f(v);
+}
+template <class IO>
+__device__ __forceinline__ float act_gelu_grad(float v) {
+    if constexpr (sizeof(IO) == 2) return gelu_sig_grad_f(v);
+    else return gelu_grad_f(v);
+}
+
 struct ActDrop {
     float inv;
     uint32_t thr, key;
@@ -210,7 +244,7 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_fwd_kernel(const IO* _
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float t = (v[i][e] - mean) * rstd * g[i][e] + b[i][e];
-                    o[e] = gelu_f(t) * kp[e];
+                    o[e] = act_gelu<IO>(t) * kp[e];
                 }
                 group_store<IO, NV>(yr, lane, i, prev, o);
                 prev = o;
@@ -293,7 +327,7 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_bwd_kernel(const IO* _
             for (int e = 0; e < 4; ++e) {
                 const float h = (xv[e] - mean) * rstd;
                 const float t = h * g[i][e] + b[i][e];
-                const float dt = gv[e] * kp[e] * gelu_grad_f(t);  // d/d(LN output); rows past the end carry gv = 0
+                const float dt = gv[e] * kp[e] * act_gelu_grad<IO>(t);  // d/d(LN output); rows past the end carry gv = 0
                 sg[i][e] += dt * h;
                 sb[i][e] += dt;
                 const float dh = dt * g[i][e];
@@ -458,7 +492,17 @@ static int ln_bwd_launch(const IO* x, const float* bias, const float* gamma, con
         return MDL_E_ALIGN;
     hipStream_t s = (hipStream_t)stream;
     const ActDrop d = make_act_drop(p_drop, seed, keep);
-    const int nb = rows > 0 ? act_blocks(rows, W) : 0;
+    int nb = rows > 0 ? act_blocks(rows, W) : 0;
+    if (W == 2048 && sizeof(IO) == 2 && nb > 0) {
+        // bf16, 2048 wide: 2 waves per row (NV = 4, 226 VGPRs) instead of 4 -- with the cheaper GELU form the 4-wave version was bound
+        // by its per-row block barriers, not by VALU or HBM: 0.97 -> 0.83 ms at config 2 (tools/exp_ln.py)
+        int64_t b2 = (rows + 1) / 2;
+        if (b2 > 2048) b2 = 2048;
+        nb = (int)b2;
+        hipLaunchKernelGGL((ln_gelu_drop_bwd_kernel<4, 2, IO>), dim3(nb), dim3(ACT_BLOCK), 0, s, x, bias, gamma, beta, mean, rstd, dy, dx,
+                           (float*)ws, rows, d);
+        MDL_LAUNCH_CHECK();
+    } else
     MDL_DISPATCH_W(W, {
         if (nb > 0) {
             hipLaunchKernelGGL((ln_gelu_drop_bwd_kernel<NV, WPR, IO>), dim3(nb), dim3(ACT_BLOCK), 0, s, x, bias, gamma, beta, mean, rstd, dy,

@@ -42,10 +42,12 @@ def test_ln_gelu_drop_bf16_vs_fp32_kernel(dev, W, rows):
         y.backward(dy.to(y.dtype))
         outs[name] = (y.detach().float(), xx.grad.float(), g.grad.clone(), b.grad.clone())
     assert outs["bf16"][0].dtype == torch.float32
-    # y and dx differ by one bf16 rounding of the output; dgamma/dbeta are fp32 sums of identical per-element terms
+    # y and dx differ by one bf16 rounding of the output.  The bf16 kernels evaluate GELU as x sigmoid(x P(x^2)) (preattn_act.hip:
+    # |value error| <= 2.5e-5, |derivative error| <= 1.1e-4 against the erf form the fp32 kernels keep -- far inside the bf16 grid), so
+    # dgamma / dbeta, fp32 sums of per-element terms that are no longer bit-identical, agree to the derivative's accuracy: 5e-4.
     assert rel_err(outs["bf16"][0], outs["f32"][0]) < EPS_BF16
     assert rel_err(outs["bf16"][1], outs["f32"][1]) < EPS_BF16
-    assert rel_err(outs["bf16"][2], outs["f32"][2]) < 1e-5 and rel_err(outs["bf16"][3], outs["f32"][3]) < 1e-5
+    assert rel_err(outs["bf16"][2], outs["f32"][2]) < 5e-4 and rel_err(outs["bf16"][3], outs["f32"][3]) < 5e-4
 
 
 @pytest.mark.parametrize("T,N,K,bias", [(1000, 512, 512, False), (4133, 256, 512, True), (257, 2048, 256, True),
