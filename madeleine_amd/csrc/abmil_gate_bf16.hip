@@ -390,7 +390,7 @@ struct BwdWs {
 };
 static inline BwdWs bwd_ws(int64_t T, int H) {
     BwdWs w;
-    w.S = gate_splits(T, H);
+    w.S = splits_for(T, 16 * H, 512);   // gate_dw_bf16_kernel: 200 VGPRs = two workgroups per CU
     int64_t tps = (T + w.S - 1) / w.S;
     w.tps = ((tps + TNK - 1) / TNK) * TNK;  // whole 32-token chunks: a chunk never straddles two splits
     if (w.tps < TNK) w.tps = TNK;

@@ -104,11 +104,12 @@ static inline DropCfg make_drop(float p, uint64_t seed, const uint8_t* ka, const
 // so that the total number of output tiles (tiles_per_split x splits) is a whole number of "rounds" of the 768 workgroup
 // slots of the chip (256 CUs x 3 resident workgroups of this tile engine): 4096 equal tiles on 768 slots is 5.33 rounds,
 // i.e. a last round that is 2/3 idle; 3072 or 768 tiles are exact.  Splits stay >= 1024 tokens and <= 192.
-static inline int splits_for(int64_t T, int tiles_per_split) {
+// `slots`: resident workgroups of the kernel on the chip: 768 for the 156-VGPR fp32 TN kernels, 512 for the bf16 TN kernels (200-216
+// VGPRs: two per CU) -- with 768 assumed the bf16 Linear dW launched 768 tiles on 512 slots (1.5 rounds).
+static inline int splits_for(int64_t T, int tiles_per_split, int64_t slots = 768) {
     int64_t s = (T + 4095) / 4096;
     if (s < 1) s = 1;
     if (s > 64) s = 64;
-    const int64_t slots = 768;
     if (s * tiles_per_split >= slots / 2) {
         const int64_t rounds = (s * tiles_per_split + slots - 1) / slots;
         const int64_t want = (rounds * slots + tiles_per_split - 1) / tiles_per_split;

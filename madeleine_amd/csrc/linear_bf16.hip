@@ -278,7 +278,7 @@ struct LinbWs {
 static inline LinbWs linb_ws(int64_t T, int N, int K) {
     LinbWs w;
     const int tiles = (N / 128) * ((K + 255) / 256);
-    w.S = splits_for(T, tiles > 0 ? tiles : 1);
+    w.S = splits_for(T, tiles > 0 ? tiles : 1, 512);
     int64_t tps = (T + w.S - 1) / w.S;
     w.tps = ((tps + TNK - 1) / TNK) * TNK;
     if (w.tps < TNK) w.tps = TNK;
