@@ -493,9 +493,9 @@ static int ln_bwd_launch(const IO* x, const float* bias, const float* gamma, con
     hipStream_t s = (hipStream_t)stream;
     const ActDrop d = make_act_drop(p_drop, seed, keep);
     int nb = rows > 0 ? act_blocks(rows, W) : 0;
-    if (W == 2048 && sizeof(IO) == 2 && nb > 0) {
-        // bf16, 2048 wide: 2 waves per row (NV = 4, 226 VGPRs) instead of 4 -- with the cheaper GELU form the 4-wave version was bound
-        // by its per-row block barriers, not by VALU or HBM: 0.97 -> 0.83 ms at config 2 (tools/exp_ln.py)
+    if (W == 2048 && nb > 0) {
+        // 2048 wide: 2 waves per row (NV = 4, ~226 VGPRs) instead of 4 -- the 4-wave version was bound by its per-row block barriers
+        // rather than by VALU or HBM: bf16 0.97 -> 0.82 ms, fp32 1.35 -> 1.25 ms at config 2 (tools/exp_ln.py)
         int64_t b2 = (rows + 1) / 2;
         if (b2 > 2048) b2 = 2048;
         nb = (int)b2;
