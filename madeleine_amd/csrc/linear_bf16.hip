@@ -232,7 +232,15 @@ __global__ __launch_bounds__(256) void linb_reduce_kernel(const float* __restric
     const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= n) return;
     f32x4 v = *reinterpret_cast<const f32x4*>(slab + i);
-    for (int s = 1; s < S; ++s) v += *reinterpret_cast<const f32x4*>(slab + (int64_t)s * n + i);
+    int s = 1;
+    for (; s + 8 <= S; s += 8) {   // 8 reads in flight, additions in slab order
+        f32x4 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const f32x4*>(slab + (int64_t)(s + u) * n + i);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v += t[u];
+    }
+    for (; s < S; ++s) v += *reinterpret_cast<const f32x4*>(slab + (int64_t)s * n + i);
     *reinterpret_cast<f32x4*>(out + i) = v;
 }
 
