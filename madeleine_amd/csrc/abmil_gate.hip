@@ -312,8 +312,18 @@ __global__ __launch_bounds__(256) void gate_reduce_w_kernel(const float* __restr
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int k = kb + ty + i * 8;
+        const float* __restrict__ src = slabW + ((int64_t)c * HID + k) * 1024 + nb + tx;
+        const int64_t st = (int64_t)H * HID * 1024;
         float v = 0.f;
-        for (int s = 0; s < S; ++s) v += slabW[(((int64_t)s * H + c) * HID + k) * 1024 + nb + tx];
+        int sp = 0;
+        for (; sp + 8 <= S; sp += 8) {   // 8 slab reads in flight per thread, additions in slab order
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = src[(int64_t)(sp + u) * st];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v += t[u];
+        }
+        for (; sp < S; ++sp) v += src[(int64_t)sp * st];
         tile[ty + i * 8][tx] = v;
     }
     __syncthreads();
