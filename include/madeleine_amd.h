@@ -230,9 +230,10 @@ int mdl_infonce_bwd(const float* d_loss, const float* d_row_loss, const int32_t*
  * Linear(2048, 512) on the pooled embeddings (Model.py:145).
  * X [T,K] (row stride ldx), W [N,K] contiguous (torch's Linear.weight), bias [N] or NULL, Y [T,N] (row stride ldy).
  * Supported (MDL_E_UNSUPPORTED otherwise):
- *   T > 256 : K % 32 == 0 and N % 128 == 0 -- matrix-core tile engine (128 x 256 tile for N % 256 == 0, the 256 x 128 "tall"
- *             geometry otherwise); the backward additionally needs K % 256 == 0 when dX != NULL or N % 256 != 0;
- *   T <= 256: any K, N % 4 == 0 -- LDS-tiled fp32 FMA kernel (the slide projector's 64 rows).
+ *   T > 256 : N % 256 == 0 with K % 32 == 0 -- matrix-core tile engine, 128 x 256 tile; dX (output width K) runs the
+ *             ragged-column variant of the tile when K % 256 != 0 (config 5: K = 768 + 32 stain channels);
+ *             N % 256 == 128 with K % 256 == 0 -- the 256 x 128 "tall" geometry (token_projector);
+ *   T <= 256: K % 4 == 0, N % 4 == 0 -- LDS-tiled fp32 FMA kernel (the slide projector's 64 rows).
  *   mdl_linear_fwd : Y = X W^T (+ bias)
  *   mdl_linear_bwd : dW [N,K] = dY^T X  (always);  dX [T,K] = dY W  when dX != NULL;  dbias [N] = column sums of dY when != NULL
  */

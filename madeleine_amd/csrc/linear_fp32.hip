@@ -6,7 +6,8 @@
 //     forward : Y[t, n]  = sum_k X[t, k]  W[n, k]     = lin_nn(A = X,  B = W^T [K][N] (transposed copy, <= 4 MiB))
 //     dX      : dX[t, k] = sum_n dY[t, n] W[n, k]     = lin_nn(A = dY, B = W   [N][K] as stored)
 //     dW      : dW[n, k] = sum_t dY[t, n] X[t, k]     = lin_tn(A = X, B = dY), split over tokens, slabs reduced + transposed
-// Shapes: N % 128 == 0, K % 32 == 0, row strides % 4 == 0.  N % 256 == 0 runs the 128 x 256 tile; N = 128 (mod 256) -- the
+// Shapes: N % 256 == 0 with K % 32 == 0, or N % 128 == 0 with K % 256 == 0; row strides % 4 == 0.  N % 256 == 0 runs the 128 x 256
+// tile (its dX, whose output width is K, on the ragged-column variant when K % 256 != 0); N = 128 (mod 256) -- the
 // token_projector Linear(2048, 128), reference Model.py:140 -- the "tall" 256 x 128 geometry of the same engine (waves
 // stacked in M) and, for dW, the role-swapped lin_tn (dY as the 128-wide operand, the slab is dW itself).  T <= 256 rows --
 // the slide projector Linear(2048, 512) on the pooled embeddings, Model.py:145 -- runs a plain LDS-tiled fp32 FMA kernel
@@ -32,6 +33,10 @@ __global__ __launch_bounds__(256) void lin_transpose_kernel(const float* __restr
 // A lands as the XOR-swizzled row image (ds_read_b128 fragments, k-pair permutation), B as one 1-KiB row per wave
 // instruction (conflict-free ds_read_b32) -- exactly the gate forward's staging (tile_engine.hpp).  Consecutive workgroups
 // of an XCD share the token tile (xcd_remap), so A is fetched from HBM once per XCD.
+// RAGN: Nc is not a multiple of 256 (Nc % 4 == 0): the last column tile fetches column n0 for its out-of-range columns (their
+// accumulators are discarded) and masks its stores -- the dX of a Linear whose input width is not a multiple of 256 (config 5's
+// 768 + 32 = 800 channels, reference Model.py:132 makes that input require a gradient through embedding.weight).
+template <bool RAGN>
 __global__ __launch_bounds__(256) void lin_nn_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
                                                      float* __restrict__ C, int64_t ldc, int64_t T, int Nc, int Kc,
                                                      int n_tiles, const float* __restrict__ bias) {
@@ -39,7 +44,7 @@ __global__ __launch_bounds__(256) void lin_nn_kernel(const float* __restrict__ A
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: SGPR addressing downstream
     const int wm = wave >> 1, wn = wave & 1;
-    const int ncol = Nc / LBN;
+    const int ncol = RAGN ? (Nc + LBN - 1) / LBN : Nc / LBN;
     const int lid = xcd_remap(blockIdx.x, n_tiles);
     const int nt = lid % ncol;
     const int64_t t0 = (int64_t)(lid / ncol) * LBM;
@@ -49,7 +54,7 @@ __global__ __launch_bounds__(256) void lin_nn_kernel(const float* __restrict__ A
     const char* baseB = reinterpret_cast<const char*>(B + n0 + (int64_t)(wave * 4) * Nc);
     uint32_t voA[2];
     rows_voff(voA, T - t0, lda, wave, lane);
-    const uint32_t voB = lane * 16;
+    const uint32_t voB = (RAGN && n0 + lane * 4 >= Nc) ? 0u : lane * 16;
     const int64_t rowB = (int64_t)Nc * 4;
     const int colb[4] = {wn * 128, wn * 128 + 32, wn * 128 + 64, wn * 128 + 96};
     f32x16 acc[2][4];
@@ -61,6 +66,7 @@ __global__ __launch_bounds__(256) void lin_nn_kernel(const float* __restrict__ A
     char* cb = reinterpret_cast<char*>(C + t0 * ldc + n0);
     const uint32_t ldc4 = (uint32_t)ldc * 4u;
     auto emit = [&](int row_u, int rl, int lane_col, const f32x4& v, int) {
+        if (RAGN && n0 + lane_col >= Nc) return;
         f32x4 r = v;
         if (bias) r += *reinterpret_cast<const f32x4*>(bias + n0 + lane_col);
         *reinterpret_cast<f32x4*>(cb + (int64_t)row_u * ldc4 + ((uint32_t)rl * ldc4 + (uint32_t)lane_col * 4u)) = r;
@@ -336,11 +342,16 @@ static inline int64_t up16b(int64_t b) { return (b + 15) & ~(int64_t)15; }
 
 using namespace mdl;
 
+// Supported geometries (mirrored by functional.linear_supported):
+//   T <= 256 rows          : N % 4 == 0, K % 4 == 0 (fp32 FMA kernel)
+//   N % 256 == 0           : K % 32 == 0 (dX through the ragged-column tile when K is not a multiple of 256)
+//   N % 256 == 128         : K % 256 == 0 (tall tile, role-swapped dW)
 static int lin_check(int64_t T, int N, int K) {
     if (T < 0 || N < 1 || K < 1) return MDL_E_ARG;
-    if (T <= LIN_SMALL_T) return (N % 4) ? MDL_E_UNSUPPORTED : MDL_OK;
-    if ((N % 128) || (K % 32)) return MDL_E_UNSUPPORTED;
-    return MDL_OK;
+    if (T <= LIN_SMALL_T) return ((N % 4) || (K % 4)) ? MDL_E_UNSUPPORTED : MDL_OK;
+    if ((N % LBN) == 0) return (K % 32) ? MDL_E_UNSUPPORTED : MDL_OK;
+    if ((N % 128) == 0) return (K % LBN) ? MDL_E_UNSUPPORTED : MDL_OK;
+    return MDL_E_UNSUPPORTED;
 }
 static inline bool lin_wide(int N) { return (N % LBN) == 0; }
 static inline int lin_splits_any(int64_t T, int N, int K) {
@@ -384,8 +395,8 @@ extern "C" int mdl_linear_fwd(const float* X, int64_t ldx, const float* W, const
     if (lin_wide(N)) {
         const int64_t tiles = ((T + LBM - 1) / LBM) * (N / LBN);
         if (tiles > 0x7fffffff) return MDL_E_UNSUPPORTED;
-        hipLaunchKernelGGL(lin_nn_kernel, dim3((unsigned)tiles), dim3(256), 0, s, X, ldx, (const float*)WT, Y, ldy, T, N, K, (int)tiles,
-                           bias);
+        hipLaunchKernelGGL(lin_nn_kernel<false>, dim3((unsigned)tiles), dim3(256), 0, s, X, ldx, (const float*)WT, Y, ldy, T, N, K,
+                           (int)tiles, bias);
     } else {
         const int64_t tiles = ((T + 255) / 256) * (N / 128);
         if (tiles > 0x7fffffff) return MDL_E_UNSUPPORTED;
@@ -408,7 +419,7 @@ extern "C" int64_t mdl_linear_bwd_ws_bytes(int64_t T, int N, int K) {
     return up16b((int64_t)S * K * N * 4) + up16b((int64_t)(N > K ? N : K) * 4 + 1024) + up16b((int64_t)LIN_COLSUM_BLOCKS * N * 4) + 64;
 }
 
-/* dX may be NULL (first layer: the bags need no gradient); dbias may be NULL.  dX requires K % 256 == 0 (large T). */
+/* dX may be NULL (first layer without stain encoding: the bags need no gradient); dbias may be NULL. */
 extern "C" int mdl_linear_bwd(const float* X, int64_t ldx, const float* W, const float* dY, int64_t ldy, float* dX, int64_t lddx,
                               float* dW, float* dbias, int64_t T, int N, int K, void* ws, void* stream) {
     const int rc = lin_check(T, N, K);
@@ -432,7 +443,6 @@ extern "C" int mdl_linear_bwd(const float* X, int64_t ldx, const float* W, const
         return MDL_OK;
     }
     const bool wide = lin_wide(N);
-    if ((dX || !wide) && (K % LBN)) return MDL_E_UNSUPPORTED;
     const int S = lin_splits_any(T, N, K);
     const int64_t tps = lin_tps(T, S);
     float* slab = (float*)ws;
@@ -443,10 +453,14 @@ extern "C" int mdl_linear_bwd(const float* X, int64_t ldx, const float* W, const
         if (e != hipSuccess) return (int)e;
     }
     if (dX && T > 0) {  // dX[t, k] = sum_n dY[t, n] W[n][k]: W as stored is the K(= n)-major B operand
-        const int64_t tiles = ((T + LBM - 1) / LBM) * (K / LBN);
+        const int64_t tiles = ((T + LBM - 1) / LBM) * ((K + LBN - 1) / LBN);
         if (tiles > 0x7fffffff) return MDL_E_UNSUPPORTED;
-        hipLaunchKernelGGL(lin_nn_kernel, dim3((unsigned)tiles), dim3(256), 0, s, dY, ldy, W, dX, lddx, T, K, N, (int)tiles,
-                           (const float*)nullptr);
+        if (K % LBN)
+            hipLaunchKernelGGL(lin_nn_kernel<true>, dim3((unsigned)tiles), dim3(256), 0, s, dY, ldy, W, dX, lddx, T, K, N, (int)tiles,
+                               (const float*)nullptr);
+        else
+            hipLaunchKernelGGL(lin_nn_kernel<false>, dim3((unsigned)tiles), dim3(256), 0, s, dY, ldy, W, dX, lddx, T, K, N, (int)tiles,
+                               (const float*)nullptr);
         MDL_LAUNCH_CHECK();
     }
     if (wide) {

@@ -141,9 +141,15 @@ def host_group():
         return dist.group.WORLD
     if "g" not in _HOST_GROUP:
         try:
-            _HOST_GROUP["g"] = dist.new_group(backend="gloo")
+            g = dist.new_group(backend="gloo")
         except Exception:  # no usable interface for gloo: device fallback
-            _HOST_GROUP["g"] = None
+            g = None
+        # every rank must take the same path afterwards (one rank on the device all-gather while the others wait on gloo would
+        # deadlock): agree on the outcome over the default group
+        ok = torch.tensor([0 if g is None else 1], dtype=torch.int32,
+                          device=torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        _HOST_GROUP["g"] = g if int(ok.item()) == 1 else None
     return _HOST_GROUP["g"]
 
 
@@ -190,6 +196,10 @@ def gather_packed(wsi_embs: Dict[str, torch.Tensor], modalities: Sequence[str], 
         return wsi_embs, labels_local.to(wsi_embs["HE"].device), None if extrema_local is None else extrema_local.unsqueeze(0)
     emb, geom = _pack_embeddings(wsi_embs, modalities)
     dev, dt = emb.device, emb.dtype
+    if extrema_local is not None and dt not in (torch.float32, torch.float64):
+        # the thresholds travel in the embedding payload: a narrower dtype would round them away from the local cost extrema
+        # the GOT backward routes their gradient by
+        raise TypeError("gather_packed: slide embeddings must be float32 / float64 when GOT extrema are packed (got %s)" % dt)
     lab = labels_local.to(device=dev, dtype=dt).reshape(-1)
     ext = extrema_local.to(dt).reshape(-1) if extrema_local is not None else emb.new_zeros(0)
     payload = torch.cat([emb, lab, ext]).unsqueeze(0)                               # [1, P]
@@ -362,6 +372,10 @@ def calculate_losses_dp(STAINS, loss_fn_interMod, got_impl, wsi_embs, token_embs
     elif W == 1:
         labels_g = labels_l
     else:
+        if group is not None and group is not dist.group.WORLD:
+            # the host label exchange runs over the world (gloo) group: with a sub-group the caller must supply the labels of
+            # exactly the ranks the embeddings are gathered over
+            raise ValueError("calculate_losses_dp(group=<sub-group>) needs labels_global_withoutHE from the caller")
         labels_g = all_gather_labels_async(labels_l).wait()
     mods = ["HE"] + list(STAINS)
 

@@ -551,32 +551,40 @@ class LinearBf16Fn(torch.autograd.Function):
 
 
 def linear_supported(x, W) -> bool:
-    """Geometries of mdl_linear_* (include/madeleine_amd.h).  fp32: at most 256 rows -> any K, N % 4 == 0; otherwise
-    N % 128 == 0, K % 32 == 0, and K % 256 == 0 when the input needs a gradient or N is not a multiple of 256.
-    bf16 activations (fp32 weight): more than 256 rows, N % 128 == 0, K % 32 == 0 (mdl_linear_*_bf16)."""
+    """Geometries of mdl_linear_* (include/madeleine_amd.h).  fp32: at most 256 rows -> K % 4 == 0, N % 4 == 0; otherwise
+    N % 256 == 0 with K % 32 == 0, or N % 256 == 128 with K % 256 == 0.  bf16 activations (fp32 weight): N % 128 == 0,
+    K % 32 == 0 (mdl_linear_*_bf16; at most 256 rows run the fp32 small-M kernel on an fp32 copy of the rows)."""
     N, K = W.shape
     if W.dtype != torch.float32 or not x.is_cuda:
         return False
     T = x.numel() // max(1, x.shape[-1])
-    if x.dtype == torch.bfloat16:
-        return T > 256 and bool(_native.lib().mdl_linear_bf16_supported(N, K, 1))
-    if x.dtype != torch.float32:
+    if x.dtype not in ACT_DTYPES:
         return False
     if T <= 256:
-        return N % 4 == 0
-    return N % 128 == 0 and K % 32 == 0 and (K % 256 == 0 or not (x.requires_grad or N % 256))
+        return N % 4 == 0 and K % 4 == 0
+    if x.dtype == torch.bfloat16:
+        return bool(_native.lib().mdl_linear_bf16_supported(N, K, 1))
+    return (N % 256 == 0 and K % 32 == 0) or (N % 128 == 0 and K % 256 == 0)
 
 
 def linear(x, W, bias=None):
-    """Linear over the last axis through the HIP kernels (fp32, or bf16 activations with fp32 parameters); other geometries /
-    dtypes use the library GEMM."""
+    """Linear over the last axis through the HIP kernels (fp32, or bf16 activations with fp32 parameters).  There is no library
+    fallback: a geometry outside linear_supported raises (every Linear of the encoder -- reference Model.py:140, :145, :351, :355,
+    :359 with patch_embedding_dim (+ 32 stain channels) a multiple of 32 -- is inside it)."""
     if not linear_supported(x, W):
-        if x.dtype != W.dtype:
-            return torch.nn.functional.linear(x, W.to(x.dtype), None if bias is None else bias.to(x.dtype))
-        return torch.nn.functional.linear(x, W, bias)
+        raise NotImplementedError(
+            "madeleine_amd.linear: unsupported geometry / dtype (x %s %s on %s, weight %s %s); the HIP kernels need a ROCm device, "
+            "fp32 weights, fp32 / bf16 activations and in_features a multiple of 32 (4 for at most 256 rows), out_features a "
+            "multiple of 256 (or of 128 with in_features a multiple of 256; of 4 for at most 256 rows)"
+            % (tuple(x.shape), x.dtype, x.device, tuple(W.shape), W.dtype))
     lead = x.shape[:-1]
-    fn = LinearBf16Fn if x.dtype == torch.bfloat16 else LinearFn
-    y = fn.apply(x.reshape(-1, x.shape[-1]).contiguous(), W.contiguous(), None if bias is None else bias.contiguous())
+    x2 = x.reshape(-1, x.shape[-1]).contiguous()
+    Wc, bc = W.contiguous(), None if bias is None else bias.contiguous()
+    if x.dtype == torch.bfloat16 and x2.shape[0] <= 256:
+        # a handful of rows (one short bag under autocast): exact fp32 FMA kernel on the widened rows, result stored as bf16
+        y = LinearFn.apply(x2.float(), Wc, bc).to(torch.bfloat16)
+    else:
+        y = (LinearBf16Fn if x.dtype == torch.bfloat16 else LinearFn).apply(x2, Wc, bc)
     return y.view(*lead, W.shape[0])
 
 

@@ -65,7 +65,7 @@ def create_model(model_cfg: Union[str, Dict], device: Union[str, torch.device] =
     """Mirror of Model.py:15-43."""
     model = MADELEINE(config=model_cfg, stain_encoding=False).to(device)
     if checkpoint_path:
-        state_dict = torch.load(checkpoint_path, weights_only=False, map_location=device)
+        state_dict = torch.load(checkpoint_path, weights_only=True, map_location=device)   # a state dict: safe unpickler
         model.load_state_dict(_strip_module_prefix(state_dict), strict=True)
         print("* Loaded weights successfully!")
     return model

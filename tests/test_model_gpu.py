@@ -570,3 +570,85 @@ def test_three_views_gradients_vs_oracle(dev):
             assert p.grad is None or float(p.grad.norm()) == 0.0, k
             continue
         assert float((p.grad.cpu() - ref_g).norm()) <= TOL * float(ref_g.norm()) + 1e-5 * top, k
+
+
+def _oracle_ragged_step(bags, lens, sd, mods, labels, temperature, use_got, local_weight, n_loss=256):
+    """The reference run PER BAG (batch 1 -- SURVEY.md section 7 'Ragged bags': the oracle of config 5), with the train branch's
+    stain-index quirk r // B, then the reference-shaped dicts and calculate_losses.  sd tensors require grad."""
+    B, M = len(bags), len(bags[0])
+    slides, toks = [], []
+    for b in range(B):
+        for m in range(M):
+            sidx = (b * M + m) // B
+            x = torch.cat([bags[b][m], sd["embedding.weight"][sidx].expand(lens[b][m], -1)], dim=-1).unsqueeze(0)
+            out = R.abmil_embed(x, sd)
+            slides.append(torch.nn.functional.linear(out["slide"].reshape(1, -1), sd["projector.weight"], sd["projector.bias"]))
+            toks.append(torch.nn.functional.linear(out["tokens"].reshape(1, lens[b][m], -1)[:, :n_loss],
+                                                   sd["token_projector.weight"], sd["token_projector.bias"]))
+    slide = torch.cat(slides).view(B, M, 1, -1)
+    tok = torch.cat(toks).view(B, M, n_loss, -1)
+    embs, tks = {}, {}
+    for i, name in enumerate(mods):
+        s, tt = slide[:, i], tok[:, i]
+        if name == "HE":
+            s, tt = s.unsqueeze(3).repeat(1, 1, 1, M - 1), tt.unsqueeze(3).repeat(1, 1, 1, M - 1)
+        embs[name], tks[name] = s, tt
+    g = lambda a, b, symmetric=False: R.info_nce(a, b, temperature, symmetric)            # noqa: E731
+    loc = (lambda a, b, subsample=None: R.got(a, b, subsample)) if use_got else None       # noqa: E731
+    return R.calculate_losses(mods[1:], g, loc, None, embs, tks, labels[:, 1:], True, local_weight)
+
+
+@pytest.mark.parametrize("use_got", [False, True])
+def test_forward_ragged_unequal_backward_vs_oracle(dev, use_got):
+    """Config 5 as a TRAINABLE path: bags of different lengths (300 / 257 / 1500 / 4097 ...), d = 768,
+    stain encoding on, InfoNCE (+ GOT) -- loss and EVERY parameter gradient (incl. embedding.weight, which makes the first
+    Linear's 800-wide input require a gradient) of the packed / ragged fused backward (row_bag pooling term in the gate dX
+    epilogue) against the oracle run per bag; then the bf16 mode against the fp32 mode on the same inputs."""
+    from madeleine_amd import GOT, InfoNCE, calculate_losses
+    B, M, D = 4, 2, 768
+    mods = MODS5[:M]
+    lens = [[300, 4097], [257, 1500], [1024, 777], [2049, 513]]
+    model = build(mods, D, "wrag", dev, stain_encoding=True).eval()
+    bags = [[t((lens[b][m], D), f"ragb:f{b}{m}") for m in range(M)] for b in range(B)]
+    labels = torch.ones(B, M)
+    args = SimpleNamespace(global_loss="info-nce", symmetric_cl=True, local_loss_weight=0.5)
+    T_ = 0.1   # well-conditioned InfoNCE gradient (the saturated T = 0.001 regime is covered by test_hip_kernels._grad_ok)
+
+    def run(bf16):
+        model.zero_grad()
+        with torch.autocast(device_type="cuda", dtype=torch.bfloat16, enabled=bf16):
+            embs, toks = model.forward_ragged(bags, dev)
+            torch.manual_seed(11)
+            loss, flag = calculate_losses(mods[1:], InfoNCE(temperature=T_), GOT if use_got else None, None, embs, toks,
+                                          labels[:, 1:], args)
+        assert flag
+        loss.backward()
+        return float(loss), {k: (p.grad.detach().float().cpu().clone() if p.grad is not None else torch.zeros(p.shape))
+                             for k, p in model.named_parameters()}
+
+    loss, grads = run(False)
+    sd = {k: v.detach().cpu().clone().requires_grad_() for k, v in model.state_dict().items()}
+    torch.manual_seed(11)
+    ref_loss, flag = _oracle_ragged_step(bags, lens, sd, mods, labels, T_, use_got, 0.5)
+    ref_loss.backward()
+    assert abs(loss - float(ref_loss)) < 1e-4 * abs(float(ref_loss)), (loss, float(ref_loss))
+    top = max(float(v.grad.norm()) for v in sd.values() if v.grad is not None)
+    for k, g in grads.items():
+        ref = sd[k].grad if sd[k].grad is not None else torch.zeros_like(g)      # token_projector without the local loss
+        err = float((g - ref).norm())
+        assert err <= TOL * float(ref.norm()) + 1e-5 * top, (k, err, float(ref.norm()))
+    assert float(sd["embedding.weight"].grad.norm()) > 1e-4 * top        # the first Linear's dX really carries signal
+
+    loss_b, grads_b = run(True)
+    assert abs(loss_b - loss) < 0.05 * abs(loss) + 1e-3
+    assert all(torch.isfinite(g).all() for g in grads_b.values())
+    if use_got:
+        # Gromov-Wasserstein is chaotic on some instances (DESIGN.md section 4: the fp32 reference itself moves by 1e-2 under a
+        # token permutation); a 2^-8 perturbation of the token embeddings moves the transport plans of this one, so the direction
+        # of the GOT gradient is not a bf16-vs-fp32 invariant (measured cosine 0.55).  Value and finiteness only.
+        return
+    for k, g in grads.items():
+        if float(g.norm()) < 1e-4 * top:
+            continue
+        cos = float(torch.dot(grads_b[k].flatten(), g.flatten()) / (grads_b[k].norm() * g.norm()).clamp_min(1e-30))
+        assert cos > (0.99 if g.dim() >= 2 else 0.9), (k, cos)
