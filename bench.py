@@ -192,12 +192,106 @@ def secondary_c3_leg(dev, D, MF, InfoNCE, MADELEINE, steps=5, warmup=2):
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     prof = MF.TIMER.report()
+    work = MF.TIMER.work()
     MF.TIMER = None
     k = [int(labels[:, s].sum()) for s in range(1, M)]
     return {"value": round(B * steps / el, 3), "unit": "slides/s", "ms_per_step": round(1e3 * el / steps, 3), "steps": steps,
             "workload": f"c3: {B} slides x {M} stains (cases per stain {k}) x {N} x {Dm}, InfoNCE + GOT, train mode, AdamW",
             "final_loss": float(loss.detach()),
-            "kernel_ms": {n: round(v[0], 4) for n, v in prof.items()}, "kernel_calls_per_step": {n: v[1] // steps for n, v in prof.items()}}
+            "kernel_ms": {n: round(v[0], 4) for n, v in prof.items()}, "kernel_calls_per_step": {n: v[1] // steps for n, v in prof.items()},
+            "kernel_roofline": kernel_rooflines(prof, work)}
+
+
+def kernel_rooflines(prof, work, precision="float32"):
+    """Achieved rate of every kernel family that declared its algorithmic work (functional.KernelTimer.work): TFLOP/s against the
+    dense MFMA peak of the dtype for the contractions, GB/s against the 8 TB/s HBM3E peak for the bandwidth-bound passes.  Event
+    times are un-profiled clocks (rocprofv3 lowers the clocks: the durations in profiles/ are 7-12 % longer)."""
+    mpeak = F32_MFMA_PEAK_TF if precision == "float32" else 2500.0
+    out = {}
+    for name, (kind, per_call) in sorted(work.items()):
+        if name not in prof or prof[name][0] <= 0:
+            continue
+        ms = prof[name][0]
+        if kind == "flop":
+            ach = per_call / (ms * 1e-3) / 1e12
+            out[name] = {"bound": "mfma", "avg_ms": round(ms, 4), "achieved": round(ach, 1), "unit": "TFLOP/s", "peak": mpeak,
+                         "frac": round(ach / mpeak, 4)}
+        else:
+            ach = per_call / (ms * 1e-3) / 1e9
+            out[name] = {"bound": "hbm", "avg_ms": round(ms, 4), "achieved": round(ach, 1), "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                         "frac": round(ach / HBM_PEAK_GBS, 4)}
+    return out
+
+
+def secondary_c4_rank_leg(dev, D, MF, InfoNCE, MADELEINE, world=8, steps=4, warmup=2):
+    """What ONE rank of BASELINE configs[3] (8 x MI355X, 256-slide global batch, 5 stains) executes per step, on one GPU: its 32
+    local cases through the encoder, the replicated global InfoNCE over k_global <= 256 cases, and its share of GOT with the
+    GLOBAL token count n = min(k_global, 256) (loss.py:282: indices are randperm(k) with k = the number of participating cases of
+    the global batch) and supplied threshold extrema.  The other 7 ranks' contribution to the all-gathered payload is emulated
+    (their presence labels drawn with the same ACROBAT rates; their slide embeddings = detached perturbed copies of the local
+    ones); no collective runs.  Reports the step time and, against the single-rank c3 step, the weak-scaling ceiling that the
+    n = k_global GOT growth alone implies (communication not included)."""
+    from madeleine_amd.trainer import calculate_losses
+    B, M, N, Dm, _, _ = CONFIGS["c3"]
+    mods = MODS5[:M]
+    torch.manual_seed(42)
+    model = MADELEINE(make_cfg(M, Dm)).to(dev).train()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
+    gen = torch.Generator(device=dev).manual_seed(1234)
+    feats = torch.randn(B, M, N, Dm, device=dev, generator=gen)
+    rates = torch.tensor([1.0, 0.46, 0.73, 0.73, 0.73])
+    lab_g = (torch.rand(world * B, M, generator=torch.Generator().manual_seed(77)) < rates).float()
+    lab_g[:, 0] = 1
+    labels = lab_g[:B]
+    feats = feats * labels.to(dev)[:, :, None, None]
+    data = {"feats": feats, "modality_labels": labels}
+    crit = InfoNCE(temperature=0.001)
+    largs = SimpleNamespace(global_loss="info-nce", symmetric_cl=True, local_loss_weight=1.0)
+    k_g = [int(lab_g[:, s].sum()) for s in range(1, M)]
+    noise = {m: 0.05 * torch.randn((world - 1) * B, 1, 512, device=dev, generator=gen) for m in mods}
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        embs, toks = model(data, device=dev)
+        problems = []
+        for s_idx, stain in enumerate(mods[1:]):
+            n = min(k_g[s_idx], 256)
+            rows = labels[:, 1 + s_idx].bool().nonzero(as_tuple=True)[0].to(dev)
+            problems.append((toks["HE"][:, :n, :, s_idx].index_select(0, rows).float().contiguous(),
+                             toks[stain][:, :n].index_select(0, rows).float().contiguous()))
+        ext = D.got_local_extrema(problems, MF.HipGotImpl)      # "gathered" extrema: this rank's own stand in for the global ones
+        embs_g = {}
+        for m in mods:
+            loc = embs[m][..., 0] if m == "HE" else embs[m]                      # [B,1,512]
+            oth = loc.detach().repeat(world - 1, 1, 1) + noise[m]
+            full = torch.cat([loc, oth])
+            embs_g[m] = full.unsqueeze(3).expand(-1, -1, -1, M - 1) if m == "HE" else full
+        loss_g, flag = calculate_losses(mods[1:], crit, None, None, embs_g, None, lab_g[:, 1:], largs)
+        outs = D.got_multi(problems, MF.HipGotImpl, None, extrema=ext)
+        loss = loss_g + float(world) * (outs[:, 0] + outs[:, 1]).sum()
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    MF.TIMER = MF.KernelTimer()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    prof = MF.TIMER.report()
+    MF.TIMER = None
+    got_ms = sum(prof[k][0] * prof[k][1] / steps for k in ("got_fwd", "got_bwd", "got_bwd_finish") if k in prof)
+    return {"ms_per_step": round(1e3 * el / steps, 3), "steps": steps, "emulated_world": world,
+            "workload": f"one rank of c4: {B} local slides x {M} stains x {N} x {Dm}; global batch {world * B} emulated: cases per stain "
+                        f"{k_g} -> GOT token count n = min(k_global, 256) = {[min(k, 256) for k in k_g]}, replicated InfoNCE over "
+                        f"k_global rows; no collective",
+            "final_loss": float(loss.detach()), "got_ms_per_step_sum_over_stains": round(got_ms, 3),
+            "kernel_ms": {n: round(v[0], 4) for n, v in prof.items()},
+            "kernel_calls_per_step": {n: v[1] // steps for n, v in prof.items()}}
 
 
 def secondary_inference_leg(dev, MF, MADELEINE, n_patches=30000, bags=20):
@@ -251,7 +345,9 @@ def main():
     ap.add_argument("--host-input", action="store_true",
                     help="batches start in host memory and go through the pinned double-buffered H2D stager "
                          "(PCIe-inclusive rate; NOT the headline value, which is measured on device-resident bags)")
-    ap.add_argument("--cpu-sample", type=int, default=4, help="slides in the bounded CPU-oracle sample")
+    ap.add_argument("--cpu-sample", type=int, default=32,
+                    help="slides in the CPU-oracle sample: default = the FULL 32-slide step (1 warm-up + 1 timed, ~45 s on 16 cores); "
+                         "a smaller sample underestimates the CPU rate (4 slides: 1.0-1.1 slides/s against 1.46 for the full step)")
     ap.add_argument("--precision", default="float32", choices=["float32", "bfloat16"],
                     help="float32 = the parity path (headline value).  bfloat16 = the reference's `precision: bfloat16` "
                          "runs: forward + losses under torch.autocast, bf16 activation storage + bf16 MFMA in the kernels")
@@ -353,13 +449,14 @@ def main():
     for _ in range(a.warmup):
         step()
     fence()
-    MF.TIMER = MF.KernelTimer()
+    MF.TIMER = None if os.environ.get("BENCH_NO_TIMER") else MF.KernelTimer()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = step()
     fence()
     elapsed = time.perf_counter() - t0
-    prof = MF.TIMER.report()
+    prof = MF.TIMER.report() if MF.TIMER is not None else {}
+    work = MF.TIMER.work() if MF.TIMER is not None else {}
     MF.TIMER = None
     final_loss = float(loss.detach())
     bf16_leg = None
@@ -376,15 +473,17 @@ def main():
         fence()
         eb = time.perf_counter() - tb
         pb = MF.TIMER.report()
+        wb = MF.TIMER.work()
         MF.TIMER = None
         bf16_leg = {"value": round(B * nb / eb, 3), "unit": "slides/s", "ms_per_step": round(1e3 * eb / nb, 3), "steps": nb,
                     "dtype": "bf16 activation storage + v_mfma_f32_32x32x16_bf16, fp32 accumulate/epilogues/params "
                              "(torch.autocast(bfloat16), the reference's `precision: bfloat16`)",
-                    "final_loss": float(lb.detach()), "kernel_ms": {k: round(v[0], 4) for k, v in pb.items()}}
+                    "final_loss": float(lb.detach()), "kernel_ms": {k: round(v[0], 4) for k, v in pb.items()},
+                    "kernel_roofline": kernel_rooflines(pb, wb, "bfloat16")}
     if host_iter is not None:
         host_iter.close()   # stops and joins the stager thread
 
-    c3_leg = infer_leg = None
+    c3_leg = infer_leg = c4_leg = None
     if a.config == "c2" and a.precision == "float32" and world == 1 and not a.no_extra_legs and host_iter is None:
         # free the c2 working set first (the c3 step keeps ~60 GiB live)
         feats = data = None
@@ -392,6 +491,9 @@ def main():
         c3_leg = secondary_c3_leg(dev, D, MF, InfoNCE, MADELEINE)
         torch.cuda.empty_cache()
         infer_leg = secondary_inference_leg(dev, MF, MADELEINE)
+        torch.cuda.empty_cache()
+        c4_leg = secondary_c4_rank_leg(dev, D, MF, InfoNCE, MADELEINE)
+        c4_leg["implied_weak_scaling_ceiling_vs_c3_single_rank"] = round(c3_leg["ms_per_step"] / c4_leg["ms_per_step"], 4)
         torch.cuda.empty_cache()
 
     tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -456,8 +558,12 @@ def main():
                                                                                                   else "v_mfma_f32_32x32x16_bf16"), "bound": "mfma",
                                     "achieved": round(tf, 2), "peak": mpeak, "unit": "TFLOP/s",
                                     "frac": round(tf / mpeak, 4), "fwd_tflops": round(tf_f, 2),
-                                    "bwd_tflops": round(tf_b, 2), "fwd_ms": round(msf, 3), "bwd_ms": round(msb, 3),
-                                    "bwd_includes_dz_pass": not split}
+                                    "bwd_contractions_tflops": round(tf_b, 2), "fwd_ms": round(msf, 3),
+                                    "bwd_contractions_ms": round(msb, 3), "bwd_includes_dz_pass": not split,
+                                    # the same FLOPs over forward + the WHOLE backward (dz pass included): comparable across rounds
+                                    "fwd_plus_full_bwd_tflops": round(3 * flop_f / ((msf + prof["gate_bwd"][0]) * 1e-3) / 1e12, 2),
+                                    "clock": "HIP events in the un-profiled timed region (profiles/ run 7-12 % slower: rocprofv3 "
+                                             "lowers the clocks)"}
             if split:
                 esz = 4 if a.precision == "float32" else 2
                 msz = prof["gate_bwd_dz"][0]
@@ -466,18 +572,28 @@ def main():
                                                    "achieved_GBs": round(dz_bytes / (msz * 1e-3) / 1e9, 1),
                                                    "frac": round(dz_bytes / (msz * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         out["kernel_ms"] = {k: round(v[0], 4) for k, v in prof.items()}
+        out["kernel_calls_per_step"] = {k: v[1] // a.steps for k, v in prof.items()}
+        out["kernel_roofline"] = kernel_rooflines(prof, work, a.precision)
         if bf16_leg is not None:
             out["bf16_mode"] = bf16_leg
         if c3_leg is not None:
             out["c3_mode"] = c3_leg
         if infer_leg is not None:
             out["inference_mode"] = infer_leg
+        if c4_leg is not None:
+            out["c4_rank_emulation"] = c4_leg
         if world == 1 and not a.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(min(a.cpu_sample, B), M, N, Dm, use_got)
-            except Exception as e:  # never lose the GPU line because the host box is short on RAM
-                out["cpu_baseline"] = {"value": None, "unit": "slides/s", "cores": usable_cores(), "kind": "port",
-                                       "sample": f"failed: {type(e).__name__}: {e}"}
+                nb = min(a.cpu_sample, B)
+                out["cpu_baseline"] = cpu_baseline(nb, M, N, Dm, use_got, steps=1 if nb >= 16 else 2)
+                out["cpu_baseline"]["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+            except Exception as e:  # never lose the GPU line because the host box is short on RAM: fall back to a 4-slide sample
+                try:
+                    out["cpu_baseline"] = cpu_baseline(min(4, B), M, N, Dm, use_got)
+                    out["cpu_baseline"]["sample"] += f" (the full-step sample failed: {type(e).__name__})"
+                except Exception as e2:
+                    out["cpu_baseline"] = {"value": None, "unit": "slides/s", "cores": usable_cores(), "kind": "port",
+                                           "sample": f"failed: {type(e2).__name__}: {e2}"}
         print(json.dumps(out), flush=True)
 
     if world > 1:

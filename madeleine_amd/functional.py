@@ -51,14 +51,22 @@ def _require(t: torch.Tensor, name: str, dtype=torch.float32):
 
 class KernelTimer:
     """Optional per-call HIP-event timing of the C-ABI launches (bench.py's roofline leg).  Events are recorded
-    on the stream the kernels are launched on (torch's current stream); nothing is synchronised until report()."""
+    on the stream the kernels are launched on (torch's current stream); nothing is synchronised until report().
+    A call may declare its algorithmic work -- ("flop", n) for the matrix-core contractions, ("byte", n) for the HBM-bound
+    passes -- so that bench.py can print achieved TFLOP/s / GB/s per kernel family (work())."""
 
     def __init__(self):
         self.pairs = {}
+        self.works = {}
 
-    def start(self, name):
+    def start(self, name, work=None):
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         self.pairs.setdefault(name, []).append((ev0, ev1))
+        if work is not None:
+            kind, amount = work
+            w = self.works.setdefault(name, [kind, 0.0, 0])
+            w[1] += float(amount)
+            w[2] += 1
         ev0.record()
         return ev1
 
@@ -66,16 +74,20 @@ class KernelTimer:
         torch.cuda.synchronize()
         return {k: (sum(a.elapsed_time(b) for a, b in v) / len(v), len(v)) for k, v in self.pairs.items()}
 
+    def work(self):
+        """{name: (kind, work per call on average)} for the calls that declared it."""
+        return {k: (w[0], w[1] / max(1, w[2])) for k, w in self.works.items()}
+
 
 TIMER: Optional[KernelTimer] = None
 
 
 class _timed:
-    def __init__(self, name):
-        self.name = name
+    def __init__(self, name, work=None):
+        self.name, self.work = name, work
 
     def __enter__(self):
-        self.ev = TIMER.start(self.name) if TIMER is not None else None
+        self.ev = TIMER.start(self.name, self.work) if TIMER is not None else None
 
     def __exit__(self, *exc):
         if self.ev is not None:
@@ -106,7 +118,7 @@ def gate_fwd_raw(E2d, Wa, ba, Wb, bb, wc, bc, p_drop, seed, keep_a, keep_b, save
     act_b = torch.empty(T, H, HID, device=dev, dtype=E2d.dtype) if save_act else None
     sfx = _sfx(E2d)
     ws = _ws(getattr(lib, "mdl_abmil_gate_fwd%s_ws_bytes" % sfx)(T, H), dev)
-    with _timed("gate_fwd"):
+    with _timed("gate_fwd", ("flop", 2.0 * T * H * HID * 2 * HID)):
         rc = getattr(lib, "mdl_abmil_gate_fwd" + sfx)(_ptr(E2d), E2d.stride(0), _ptr(Wa), _ptr(ba), _ptr(Wb), _ptr(bb), _ptr(wc), _ptr(bc),
                                     _ptr(scores), _ptr(act_a), _ptr(act_b), T, H, float(p_drop), int(seed),
                                     _ptr(keep_a), _ptr(keep_b), _ptr(ws), _stream())
@@ -124,7 +136,7 @@ def gate_bwd_raw(E2d, Wa, Wb, wc, act_a, act_b, d_scores, dE, accumulate, p_drop
     dbc = torch.empty(H, device=dev, dtype=torch.float32)
     sfx = _sfx(E2d)
     ws = _ws(getattr(lib, "mdl_abmil_gate_bwd%s_ws_bytes" % sfx)(T, H), dev)
-    with _timed("gate_bwd"):
+    with _timed("gate_bwd", ("flop", 4.0 * T * H * HID * 2 * HID)):
         rc = getattr(lib, "mdl_abmil_gate_bwd" + sfx)(_ptr(E2d), E2d.stride(0), _ptr(Wa), _ptr(Wb), _ptr(wc), _ptr(act_a), _ptr(act_b),
                                     _ptr(d_scores), _ptr(dE), int(accumulate), _ptr(dWa), _ptr(dWb), _ptr(dba), _ptr(dbb),
                                     _ptr(dwc), _ptr(dbc), T, H, float(p_drop), int(seed), _ptr(keep_a), _ptr(keep_b),
@@ -152,10 +164,10 @@ def attnpool_bwd_raw(E2d, Wa, Wb, wc, act_a, act_b, d_scores, dE, p_drop, seed, 
         # profiling: the HBM-bound dz pass and the MFMA-bound contractions as two calls on the same workspace, timed separately
         # ("gate_bwd" stays their sum in KernelTimer.report)
         fn = getattr(lib, "mdl_abmil_attnpool_bwd_phases" + sfx)
-        with _timed("gate_bwd_dz"):
+        with _timed("gate_bwd_dz", ("byte", float(T) * H * 4 * HID * E2d.element_size())):   # reads a, b; writes dza | dzb
             rc = fn(*args, 1)
         _native.check(rc, "mdl_abmil_attnpool_bwd_phases")
-        with _timed("gate_bwd_gemm"):
+        with _timed("gate_bwd_gemm", ("flop", 4.0 * T * H * HID * 2 * HID)):
             rc = fn(*args, 2)
         _native.check(rc, "mdl_abmil_attnpool_bwd_phases")
     else:
@@ -172,7 +184,8 @@ def pool_fwd_raw(E2d, scores, n_bags, N, cu_seqlens, max_len):
     stat_m = torch.empty(n_bags, H, device=dev, dtype=torch.float32)
     stat_l = torch.empty(n_bags, H, device=dev, dtype=torch.float32)
     ws = _ws(lib.mdl_abmil_pool_ws_bytes(n_bags, max_len, H), dev)
-    with _timed("pool_fwd"):
+    T = E2d.shape[0]
+    with _timed("pool_fwd", ("byte", float(T) * H * (HID * E2d.element_size() + 4) + n_bags * H * HID * 4.0)):
         rc = getattr(lib, "mdl_abmil_pool_fwd" + _sfx(E2d))(_ptr(E2d), E2d.stride(0), _ptr(scores), _ptr(pooled), _ptr(stat_m), _ptr(stat_l), n_bags,
                                     N, _ptr(cu_seqlens), max_len, H, _ptr(ws), _stream())
     _native.check(rc, "mdl_abmil_pool_fwd")
@@ -183,7 +196,9 @@ def pool_bwd_raw(E2d, scores, pooled, stat_m, stat_l, d_pooled, dE, accumulate, 
                  cu_seqlens, max_len):
     lib = _native.lib()
     H = scores.shape[-1]
-    with _timed("pool_bwd"):
+    T = E2d.shape[0]
+    nb = float(T) * H * (HID * E2d.element_size() * (1 if dE is None else 2) + 8) + n_bags * H * HID * 4.0
+    with _timed("pool_bwd", ("byte", nb)):
         rc = getattr(lib, "mdl_abmil_pool_bwd" + _sfx(E2d))(_ptr(E2d), E2d.stride(0), _ptr(scores), _ptr(pooled), _ptr(stat_m), _ptr(stat_l),
                                     _ptr(d_pooled), _ptr(dE), int(accumulate), _ptr(d_scores), int(accumulate_scores), n_bags, N,
                                     _ptr(cu_seqlens), max_len, H, _stream())
@@ -431,7 +446,7 @@ class LNGeluDropFn(torch.autograd.Function):
         y = torch.empty_like(x)
         mean = torch.empty(rows, device=x.device, dtype=torch.float32)
         rstd = torch.empty_like(mean)
-        with _timed("ln_gelu_drop_fwd"):
+        with _timed("ln_gelu_drop_fwd", ("byte", 2.0 * x.numel() * x.element_size())):
             rc = getattr(lib, "mdl_ln_gelu_drop_fwd" + _sfx(x))(_ptr(x), _ptr(bias), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean),
                                                               _ptr(rstd), rows, W, float(eps), float(p_drop), int(seed),
                                                               _ptr(keep), _stream())
@@ -455,7 +470,7 @@ class LNGeluDropFn(torch.autograd.Function):
         dg, db = torch.empty_like(gamma), torch.empty_like(beta)
         dbias = torch.empty_like(bias) if has_bias else None
         ws = _ws(lib.mdl_ln_gelu_drop_bwd_ws_bytes(rows, W), x.device)
-        with _timed("ln_gelu_drop_bwd"):
+        with _timed("ln_gelu_drop_bwd", ("byte", 3.0 * x.numel() * x.element_size())):
             rc = getattr(lib, "mdl_ln_gelu_drop_bwd" + _sfx(x))(_ptr(x), _ptr(bias), _ptr(gamma), _ptr(beta), _ptr(mean),
                                                               _ptr(rstd), _ptr(dy), _ptr(dx), _ptr(dg), _ptr(db), _ptr(dbias),
                                                               rows, W, p_drop, seed, _ptr(keep), _ptr(ws), _stream())
@@ -486,7 +501,7 @@ class LinearFn(torch.autograd.Function):
         N = W.shape[0]
         y = torch.empty(T, N, device=x.device, dtype=torch.float32)
         ws = _ws(lib.mdl_linear_fwd_ws_bytes(T, N, K), x.device)
-        with _timed("linear_fwd"):
+        with _timed("linear_fwd", ("flop", 2.0 * T * N * K)):
             rc = lib.mdl_linear_fwd(_ptr(x), x.stride(0), _ptr(W), _ptr(bias), _ptr(y), N, T, N, K, _ptr(ws), _stream())
         _native.check(rc, "mdl_linear_fwd")
         ctx.save_for_backward(x, W)
@@ -504,7 +519,7 @@ class LinearFn(torch.autograd.Function):
         dW = torch.empty_like(W)
         db = torch.empty(N, device=x.device, dtype=torch.float32) if ctx.has_bias else None
         ws = _ws(lib.mdl_linear_bwd_ws_bytes(T, N, K), x.device)
-        with _timed("linear_bwd"):
+        with _timed("linear_bwd", ("flop", 2.0 * T * N * K * (2 if dx is not None else 1))):
             rc = lib.mdl_linear_bwd(_ptr(x), x.stride(0), _ptr(W), _ptr(dy), N, _ptr(dx), K, _ptr(dW), _ptr(db), T, N, K, _ptr(ws),
                                     _stream())
         _native.check(rc, "mdl_linear_bwd")
@@ -525,7 +540,7 @@ class LinearBf16Fn(torch.autograd.Function):
         N = W.shape[0]
         y = torch.empty(T, N, device=x.device, dtype=torch.bfloat16)
         ws = _ws(lib.mdl_linear_fwd_bf16_ws_bytes(T, N, K), x.device)
-        with _timed("linear_fwd"):
+        with _timed("linear_fwd", ("flop", 2.0 * T * N * K)):
             rc = lib.mdl_linear_fwd_bf16(_ptr(x), x.stride(0), _ptr(W), _ptr(bias), _ptr(y), N, T, N, K, _ptr(ws), _stream())
         _native.check(rc, "mdl_linear_fwd_bf16")
         ctx.save_for_backward(x, W)
@@ -543,7 +558,7 @@ class LinearBf16Fn(torch.autograd.Function):
         dW = torch.empty_like(W)
         db = torch.empty(N, device=x.device, dtype=torch.float32) if ctx.has_bias else None
         ws = _ws(lib.mdl_linear_bwd_bf16_ws_bytes(T, N, K), x.device)
-        with _timed("linear_bwd"):
+        with _timed("linear_bwd", ("flop", 2.0 * T * N * K * (2 if dx is not None else 1))):
             rc = lib.mdl_linear_bwd_bf16(_ptr(x), x.stride(0), _ptr(W), _ptr(dy), N, _ptr(dx), K, _ptr(dW), _ptr(db), T, N, K,
                                          _ptr(ws), _stream())
         _native.check(rc, "mdl_linear_bwd_bf16")
@@ -605,8 +620,9 @@ class InfoNCEFn(torch.autograd.Function):
         loss = torch.empty(S, device=Q.device, dtype=torch.float32)
         rows = torch.empty(S, Kmax, device=Q.device, dtype=torch.float32) if per_row else None
         ws = _ws(lib.mdl_infonce_ws_bytes(S, Kmax, D), Q.device)
-        rc = lib.mdl_infonce_fwd(_ptr(Q), _ptr(P), _ptr(cnt), _ptr(loss), _ptr(rows), S, Kmax, D, float(temperature), int(symmetric),
-                                 _ptr(ws), _stream())
+        with _timed("infonce_fwd"):
+            rc = lib.mdl_infonce_fwd(_ptr(Q), _ptr(P), _ptr(cnt), _ptr(loss), _ptr(rows), S, Kmax, D, float(temperature),
+                                     int(symmetric), _ptr(ws), _stream())
         _native.check(rc, "mdl_infonce_fwd")
         ctx.save_for_backward(cnt, ws)
         ctx.cfg = (S, Kmax, D, float(temperature), int(symmetric), bool(per_row))
@@ -628,11 +644,15 @@ class InfoNCEFn(torch.autograd.Function):
             g = d_rows.float().contiguous() if d_rows is not None else torch.zeros(S, Kmax, device=dev)
             if d_loss is not None:
                 g = g + d_loss.float().unsqueeze(1) / cnt.clamp_min(1).unsqueeze(1).float()
-            rc = lib.mdl_infonce_bwd(None, _ptr(g.contiguous()), _ptr(cnt), _ptr(dQ), _ptr(dP), S, Kmax, D, temperature, symmetric,
-                                     _ptr(ws), _stream())
+            g = g.contiguous()
+            with _timed("infonce_bwd"):
+                rc = lib.mdl_infonce_bwd(None, _ptr(g), _ptr(cnt), _ptr(dQ), _ptr(dP), S, Kmax, D, temperature, symmetric,
+                                         _ptr(ws), _stream())
         else:
-            rc = lib.mdl_infonce_bwd(_ptr(d_loss.float().contiguous()), None, _ptr(cnt), _ptr(dQ), _ptr(dP), S, Kmax, D, temperature,
-                                     symmetric, _ptr(ws), _stream())
+            d_loss = d_loss.float().contiguous()
+            with _timed("infonce_bwd"):
+                rc = lib.mdl_infonce_bwd(_ptr(d_loss), None, _ptr(cnt), _ptr(dQ), _ptr(dP), S, Kmax, D, temperature,
+                                         symmetric, _ptr(ws), _stream())
         _native.check(rc, "mdl_infonce_bwd")
         return dQ, dP, None, None, None, None
 
@@ -757,7 +777,8 @@ class HipGotImpl:
         lib = _native.lib()
         k, n, d = V.shape
         dV, dQ = torch.empty_like(V), torch.empty_like(Q)
-        rc = lib.mdl_got_bwd_finish(_ptr(V), _ptr(Q), _ptr(dV), _ptr(dQ), _ptr(dmm_total.contiguous()), k, n, d, _ptr(ws),
-                                    _stream())
+        dmm_total = dmm_total.contiguous()
+        with _timed("got_bwd_finish"):
+            rc = lib.mdl_got_bwd_finish(_ptr(V), _ptr(Q), _ptr(dV), _ptr(dQ), _ptr(dmm_total), k, n, d, _ptr(ws), _stream())
         _native.check(rc, "mdl_got_bwd_finish")
         return dV, dQ
