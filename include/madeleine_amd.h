@@ -54,7 +54,7 @@ const char* mdl_version(void);
 /* ABI revision of this header: bumped whenever an entry point's argument list changes.  A binding compares
  * mdl_abi_version() with the MDL_ABI_VERSION it was written against BEFORE calling anything else, so that a stale
  * shared object fails loudly instead of being called with shifted arguments. */
-#define MDL_ABI_VERSION 8
+#define MDL_ABI_VERSION 9
 int mdl_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -157,10 +157,12 @@ int mdl_abmil_pool_view_bwd(const float* E, int64_t ldE, const float* scores, co
  * Step 2 = mdl_abmil_gate_bwd whose dX epilogue adds the pooling term  w[t,c] * d_pooled[bag(t), c, :]
  * (w = exp(scores - stat_m) / stat_l) while writing dE once -- instead of the pooling backward writing dE and the gate
  * backward reading it back to accumulate (saves one write + one read of |E|).  row_bag int32 [T] gives the bag of
- * every token row (ragged bags); row_bag == NULL means dense bags of N tokens (bag = t / N).  ws as mdl_abmil_gate_bwd. */
+ * every token row (ragged bags); row_bag == NULL means dense bags of N tokens (bag = t / N).  ws as mdl_abmil_gate_bwd.
+ * accumulate != 0: dE already holds another consumer's gradient of E (the token_projector's dX, Model.py:140) and the epilogue
+ * adds to it -- the read-modify-write rides under the MFMA-bound contraction instead of a separate 3 x |E| add pass. */
 int mdl_abmil_attnpool_bwd(const float* E, int64_t ldE, const float* Wa, const float* Wb, const float* wc,
-                           const float* act_a, const float* act_b, const float* d_scores, float* dE, float* dWa,
-                           float* dWb, float* dba, float* dbb, float* dwc, float* dbc, int64_t T, int H, float p_drop,
+                           const float* act_a, const float* act_b, const float* d_scores, float* dE, int accumulate,
+                           float* dWa, float* dWb, float* dba, float* dbb, float* dwc, float* dbc, int64_t T, int H, float p_drop,
                            uint64_t seed, const uint8_t* keep_a, const uint8_t* keep_b, const float* scores,
                            const float* stat_m, const float* stat_l, const float* d_pooled, const int32_t* row_bag,
                            int64_t N, void* ws, void* stream);
@@ -170,15 +172,15 @@ int mdl_abmil_attnpool_bwd(const float* E, int64_t ldE, const float* Wa, const f
  * the same arguments and workspace gives the same results and lets the caller time the two halves with its own events (bench.py's
  * roofline_mfma counts the contractions only). */
 int mdl_abmil_attnpool_bwd_phases(const float* E, int64_t ldE, const float* Wa, const float* Wb, const float* wc,
-                                  const float* act_a, const float* act_b, const float* d_scores, float* dE, float* dWa,
-                                  float* dWb, float* dba, float* dbb, float* dwc, float* dbc, int64_t T, int H,
+                                  const float* act_a, const float* act_b, const float* d_scores, float* dE, int accumulate,
+                                  float* dWa, float* dWb, float* dba, float* dbb, float* dwc, float* dbc, int64_t T, int H,
                                   float p_drop, uint64_t seed, const uint8_t* keep_a, const uint8_t* keep_b,
                                   const float* scores, const float* stat_m, const float* stat_l, const float* d_pooled,
                                   const int32_t* row_bag, int64_t N, void* ws, void* stream, int phases);
 int mdl_abmil_attnpool_bwd_phases_bf16(const uint16_t* E, int64_t ldE, const float* Wa, const float* Wb, const float* wc,
                                        const uint16_t* act_a, const uint16_t* act_b, const float* d_scores, uint16_t* dE,
-                                       float* dWa, float* dWb, float* dba, float* dbb, float* dwc, float* dbc, int64_t T,
-                                       int H, float p_drop, uint64_t seed, const uint8_t* keep_a, const uint8_t* keep_b,
+                                       int accumulate, float* dWa, float* dWb, float* dba, float* dbb, float* dwc, float* dbc,
+                                       int64_t T, int H, float p_drop, uint64_t seed, const uint8_t* keep_a, const uint8_t* keep_b,
                                        const float* scores, const float* stat_m, const float* stat_l, const float* d_pooled,
                                        const int32_t* row_bag, int64_t N, void* ws, void* stream, int phases);
 
@@ -333,8 +335,8 @@ int mdl_abmil_gate_bwd_bf16(const uint16_t* E, int64_t ldE, const float* Wa, con
                             void* ws, void* stream);
 int mdl_abmil_attnpool_bwd_bf16(const uint16_t* E, int64_t ldE, const float* Wa, const float* Wb, const float* wc,
                                 const uint16_t* act_a, const uint16_t* act_b, const float* d_scores, uint16_t* dE,
-                                float* dWa, float* dWb, float* dba, float* dbb, float* dwc, float* dbc, int64_t T, int H,
-                                float p_drop, uint64_t seed, const uint8_t* keep_a, const uint8_t* keep_b,
+                                int accumulate, float* dWa, float* dWb, float* dba, float* dbb, float* dwc, float* dbc, int64_t T,
+                                int H, float p_drop, uint64_t seed, const uint8_t* keep_a, const uint8_t* keep_b,
                                 const float* scores, const float* stat_m, const float* stat_l, const float* d_pooled,
                                 const int32_t* row_bag, int64_t N, void* ws, void* stream);
 

@@ -13,7 +13,7 @@ from . import _build
 
 _LOCK = threading.Lock()
 _LIB = None
-ABI_VERSION = 8   # == MDL_ABI_VERSION of include/madeleine_amd.h this file's SIGNATURES were written against
+ABI_VERSION = 9   # == MDL_ABI_VERSION of include/madeleine_amd.h this file's SIGNATURES were written against
 
 c_f = ctypes.c_void_p  # float* (device)
 c_p = ctypes.c_void_p
@@ -31,11 +31,11 @@ SIGNATURES = {
     "mdl_abmil_gate_bwd_ws_bytes": (i64, [i64, i32]),
     "mdl_abmil_gate_bwd": (i32, [c_f, i64, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, c_f, c_f, c_f, c_f, c_f, c_f, i64, i32, f32,
                                  u64, c_p, c_p, c_p, c_p]),
-    "mdl_abmil_attnpool_bwd": (i32, [c_f, i64, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i64, i32, f32, u64, c_p, c_p, c_f, c_f,
+    "mdl_abmil_attnpool_bwd": (i32, [c_f, i64, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, c_f, c_f, c_f, c_f, c_f, c_f, i64, i32, f32, u64, c_p, c_p, c_f, c_f,
                                      c_f, c_f, c_p, i64, c_p, c_p]),
-    "mdl_abmil_attnpool_bwd_phases": (i32, [c_f, i64, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i64, i32, f32, u64, c_p, c_p,
+    "mdl_abmil_attnpool_bwd_phases": (i32, [c_f, i64, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, c_f, c_f, c_f, c_f, c_f, c_f, i64, i32, f32, u64, c_p, c_p,
                                             c_f, c_f, c_f, c_f, c_p, i64, c_p, c_p, i32]),
-    "mdl_abmil_attnpool_bwd_phases_bf16": (i32, [c_f, i64, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i64, i32, f32, u64, c_p,
+    "mdl_abmil_attnpool_bwd_phases_bf16": (i32, [c_f, i64, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, c_f, c_f, c_f, c_f, c_f, c_f, i64, i32, f32, u64, c_p,
                                                  c_p, c_f, c_f, c_f, c_f, c_p, i64, c_p, c_p, i32]),
     "mdl_abmil_gate_dropout_mask": (i32, [c_p, i64, i32, i32, f32, u64, c_p]),
     "mdl_abmil_pool_ws_bytes": (i64, [i64, i64, i32]),
@@ -80,7 +80,7 @@ SIGNATURES = {
     "mdl_abmil_gate_fwd_bf16": (i32, [c_f, i64, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i64, i32, f32, u64, c_p, c_p, c_p,
                                       c_p]),
     "mdl_abmil_gate_bwd_bf16_ws_bytes": (i64, [i64, i32]),
-    "mdl_abmil_attnpool_bwd_bf16": (i32, [c_f, i64, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i64, i32, f32, u64, c_p, c_p, c_f, c_f,
+    "mdl_abmil_attnpool_bwd_bf16": (i32, [c_f, i64, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, c_f, c_f, c_f, c_f, c_f, c_f, i64, i32, f32, u64, c_p, c_p, c_f, c_f,
                                      c_f, c_f, c_p, i64, c_p, c_p]),
     "mdl_abmil_gate_bwd_bf16": (i32, [c_f, i64, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, c_f, c_f, c_f, c_f, c_f, c_f, i64, i32,
                                       f32, u64, c_p, c_p, c_p, c_p]),

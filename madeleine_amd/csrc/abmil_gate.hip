@@ -227,9 +227,8 @@ __global__ __launch_bounds__(256) void gate_bwd_dx_kernel(const float* __restric
             const f32x4 dp = *reinterpret_cast<const f32x4*>(pt.d_pooled + ((int64_t)bag * H + c) * HID + n0 + lane_col);
 #pragma unroll
             for (int i = 0; i < 4; ++i) r[i] = fmaf(w, dp[i], v[i]);
-        } else if (accumulate) {
-            r += *o;
         }
+        if (accumulate) r += *o;   // e.g. the token_projector's dX already sits in dE (fused A2 + A3 + token-projector backward)
         *o = r;
     };
     if (t0 + GBM <= T) tile_epilogue_rows<true, 2>(acc, sm, wave, wm, colb, lane, GBM, emit);
@@ -532,24 +531,25 @@ extern "C" int mdl_abmil_gate_bwd(const float* E, int64_t ldE, const float* Wa, 
 }
 
 extern "C" int mdl_abmil_attnpool_bwd(const float* E, int64_t ldE, const float* Wa, const float* Wb, const float* wc,
-                                      const float* act_a, const float* act_b, const float* d_scores, float* dE, float* dWa,
-                                      float* dWb, float* dba, float* dbb, float* dwc, float* dbc, int64_t T, int H,
+                                      const float* act_a, const float* act_b, const float* d_scores, float* dE, int accumulate,
+                                      float* dWa, float* dWb, float* dba, float* dbb, float* dwc, float* dbc, int64_t T, int H,
                                       float p_drop, uint64_t seed, const uint8_t* keep_a, const uint8_t* keep_b,
                                       const float* scores, const float* stat_m, const float* stat_l, const float* d_pooled,
                                       const int32_t* row_bag, int64_t N, void* ws, void* stream) {
     if (!scores || !stat_m || !stat_l || !d_pooled || (!row_bag && N < 1)) return MDL_E_ARG;
-    return gate_bwd_impl(E, ldE, Wa, Wb, wc, act_a, act_b, d_scores, dE, 0, dWa, dWb, dba, dbb, dwc, dbc, T, H, p_drop, seed, keep_a,
+    return gate_bwd_impl(E, ldE, Wa, Wb, wc, act_a, act_b, d_scores, dE, accumulate, dWa, dWb, dba, dbb, dwc, dbc, T, H, p_drop, seed, keep_a,
                          keep_b, ws, stream, PoolTerm{scores, stat_m, stat_l, d_pooled, row_bag, N});
 }
 
 extern "C" int mdl_abmil_attnpool_bwd_phases(const float* E, int64_t ldE, const float* Wa, const float* Wb, const float* wc,
-                                             const float* act_a, const float* act_b, const float* d_scores, float* dE, float* dWa,
-                                             float* dWb, float* dba, float* dbb, float* dwc, float* dbc, int64_t T, int H,
-                                             float p_drop, uint64_t seed, const uint8_t* keep_a, const uint8_t* keep_b,
-                                             const float* scores, const float* stat_m, const float* stat_l, const float* d_pooled,
-                                             const int32_t* row_bag, int64_t N, void* ws, void* stream, int phases) {
+                                             const float* act_a, const float* act_b, const float* d_scores, float* dE,
+                                             int accumulate, float* dWa, float* dWb, float* dba, float* dbb, float* dwc, float* dbc,
+                                             int64_t T, int H, float p_drop, uint64_t seed, const uint8_t* keep_a,
+                                             const uint8_t* keep_b, const float* scores, const float* stat_m, const float* stat_l,
+                                             const float* d_pooled, const int32_t* row_bag, int64_t N, void* ws, void* stream,
+                                             int phases) {
     if (!scores || !stat_m || !stat_l || !d_pooled || (!row_bag && N < 1)) return MDL_E_ARG;
-    return gate_bwd_impl(E, ldE, Wa, Wb, wc, act_a, act_b, d_scores, dE, 0, dWa, dWb, dba, dbb, dwc, dbc, T, H, p_drop, seed, keep_a,
+    return gate_bwd_impl(E, ldE, Wa, Wb, wc, act_a, act_b, d_scores, dE, accumulate, dWa, dWb, dba, dbb, dwc, dbc, T, H, p_drop, seed, keep_a,
                          keep_b, ws, stream, PoolTerm{scores, stat_m, stat_l, d_pooled, row_bag, N}, phases);
 }
 

@@ -235,7 +235,8 @@ __global__ __launch_bounds__(256, 2) void gate_dx_bf16_kernel(const bf16_t* __re
                 a[i] = fmaf(w, d0[i], lo[i]);
                 b[i] = fmaf(w, d1[i], hi[i]);
             }
-        } else if (accumulate) {
+        }
+        if (accumulate) {
             const bf16x8 old = *reinterpret_cast<const bf16x8*>(o);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -301,7 +302,8 @@ __global__ __launch_bounds__(512) void gate_dx256_bf16_kernel(const bf16_t* __re
                 a[i] = fmaf(w, d0[i], lo[i]);
                 b[i] = fmaf(w, d1[i], hi[i]);
             }
-        } else if (accumulate) {
+        }
+        if (accumulate) {
             const bf16x8 old = *reinterpret_cast<const bf16x8*>(o);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -535,22 +537,23 @@ extern "C" int mdl_abmil_gate_bwd_bf16(const uint16_t* E, int64_t ldE, const flo
 
 extern "C" int mdl_abmil_attnpool_bwd_bf16(const uint16_t* E, int64_t ldE, const float* Wa, const float* Wb, const float* wc,
                                            const uint16_t* act_a, const uint16_t* act_b, const float* d_scores, uint16_t* dE,
-                                           float* dWa, float* dWb, float* dba, float* dbb, float* dwc, float* dbc, int64_t T, int H,
-                                           float p_drop, uint64_t seed, const uint8_t* keep_a, const uint8_t* keep_b,
+                                           int accumulate, float* dWa, float* dWb, float* dba, float* dbb, float* dwc, float* dbc,
+                                           int64_t T, int H, float p_drop, uint64_t seed, const uint8_t* keep_a, const uint8_t* keep_b,
                                            const float* scores, const float* stat_m, const float* stat_l, const float* d_pooled,
                                            const int32_t* row_bag, int64_t N, void* ws, void* stream) {
     if (!scores || !stat_m || !stat_l || !d_pooled || (!row_bag && N < 1)) return MDL_E_ARG;
-    return gate_bwd_bf16_impl(E, ldE, Wa, Wb, wc, act_a, act_b, d_scores, dE, 0, dWa, dWb, dba, dbb, dwc, dbc, T, H, p_drop, seed,
+    return gate_bwd_bf16_impl(E, ldE, Wa, Wb, wc, act_a, act_b, d_scores, dE, accumulate, dWa, dWb, dba, dbb, dwc, dbc, T, H, p_drop, seed,
                               keep_a, keep_b, ws, stream, PoolTerm{scores, stat_m, stat_l, d_pooled, row_bag, N});
 }
 
 extern "C" int mdl_abmil_attnpool_bwd_phases_bf16(const uint16_t* E, int64_t ldE, const float* Wa, const float* Wb, const float* wc,
                                                   const uint16_t* act_a, const uint16_t* act_b, const float* d_scores, uint16_t* dE,
-                                                  float* dWa, float* dWb, float* dba, float* dbb, float* dwc, float* dbc, int64_t T,
-                                                  int H, float p_drop, uint64_t seed, const uint8_t* keep_a, const uint8_t* keep_b,
-                                                  const float* scores, const float* stat_m, const float* stat_l, const float* d_pooled,
-                                                  const int32_t* row_bag, int64_t N, void* ws, void* stream, int phases) {
+                                                  int accumulate, float* dWa, float* dWb, float* dba, float* dbb, float* dwc,
+                                                  float* dbc, int64_t T, int H, float p_drop, uint64_t seed, const uint8_t* keep_a,
+                                                  const uint8_t* keep_b, const float* scores, const float* stat_m,
+                                                  const float* stat_l, const float* d_pooled, const int32_t* row_bag, int64_t N,
+                                                  void* ws, void* stream, int phases) {
     if (!scores || !stat_m || !stat_l || !d_pooled || (!row_bag && N < 1)) return MDL_E_ARG;
-    return gate_bwd_bf16_impl(E, ldE, Wa, Wb, wc, act_a, act_b, d_scores, dE, 0, dWa, dWb, dba, dbb, dwc, dbc, T, H, p_drop, seed,
+    return gate_bwd_bf16_impl(E, ldE, Wa, Wb, wc, act_a, act_b, d_scores, dE, accumulate, dWa, dWb, dba, dbb, dwc, dbc, T, H, p_drop, seed,
                               keep_a, keep_b, ws, stream, PoolTerm{scores, stat_m, stat_l, d_pooled, row_bag, N}, phases);
 }

@@ -146,8 +146,9 @@ def gate_bwd_raw(E2d, Wa, Wb, wc, act_a, act_b, d_scores, dE, accumulate, p_drop
 
 
 def attnpool_bwd_raw(E2d, Wa, Wb, wc, act_a, act_b, d_scores, dE, p_drop, seed, keep_a, keep_b, scores, stat_m, stat_l, d_pooled,
-                     row_bag, N):
-    """Gate backward whose dX epilogue also adds the pooling term (mdl_abmil_attnpool_bwd): dE is written once."""
+                     row_bag, N, accumulate=0):
+    """Gate backward whose dX epilogue also adds the pooling term (mdl_abmil_attnpool_bwd): dE is written once; with
+    `accumulate` the epilogue adds to what dE already holds (another consumer's gradient of E)."""
     lib = _native.lib()
     T, H = E2d.shape[0], Wa.shape[0]
     dev = E2d.device
@@ -157,7 +158,7 @@ def attnpool_bwd_raw(E2d, Wa, Wb, wc, act_a, act_b, d_scores, dE, p_drop, seed, 
     dbc = torch.empty(H, device=dev, dtype=torch.float32)
     sfx = _sfx(E2d)
     ws = _ws(getattr(lib, "mdl_abmil_gate_bwd%s_ws_bytes" % sfx)(T, H), dev)
-    args = (_ptr(E2d), E2d.stride(0), _ptr(Wa), _ptr(Wb), _ptr(wc), _ptr(act_a), _ptr(act_b), _ptr(d_scores), _ptr(dE), _ptr(dWa),
+    args = (_ptr(E2d), E2d.stride(0), _ptr(Wa), _ptr(Wb), _ptr(wc), _ptr(act_a), _ptr(act_b), _ptr(d_scores), _ptr(dE), int(accumulate), _ptr(dWa),
             _ptr(dWb), _ptr(dba), _ptr(dbb), _ptr(dwc), _ptr(dbc), T, H, float(p_drop), int(seed), _ptr(keep_a), _ptr(keep_b),
             _ptr(scores), _ptr(stat_m), _ptr(stat_l), _ptr(d_pooled), _ptr(row_bag), int(N), _ptr(ws), _stream())
     if TIMER is not None:
@@ -230,6 +231,36 @@ def pool_view_bwd_raw(E2d, scores, pooled, stat_m, stat_l, d_pooled, dE, d_score
                                                                 _ptr(stat_l), _ptr(d_pooled), _ptr(dE), _ptr(d_scores), n_bags, N,
                                                                 _ptr(token_idx), token_idx.numel(), H, _stream())
     _native.check(rc, "mdl_abmil_pool_view_bwd")
+
+
+def linear_fwd_raw(x2d, W, bias):
+    """Y = X W^T (+ bias) through mdl_linear_fwd / mdl_linear_fwd_bf16 (by the storage type of x2d)."""
+    lib = _native.lib()
+    T, K = x2d.shape
+    N = W.shape[0]
+    sfx = _sfx(x2d)
+    y = torch.empty(T, N, device=x2d.device, dtype=x2d.dtype)
+    ws = _ws(getattr(lib, "mdl_linear_fwd%s_ws_bytes" % sfx)(T, N, K), x2d.device)
+    with _timed("linear_fwd", ("flop", 2.0 * T * N * K)):
+        rc = getattr(lib, "mdl_linear_fwd" + sfx)(_ptr(x2d), x2d.stride(0), _ptr(W), _ptr(bias), _ptr(y), N, T, N, K, _ptr(ws), _stream())
+    _native.check(rc, "mdl_linear_fwd" + sfx)
+    return y
+
+
+def linear_bwd_raw(x2d, W, dy, dx, want_dbias):
+    """(dW, dbias) of the Linear; dX is written into `dx` ([T,K], may be None)."""
+    lib = _native.lib()
+    T, K = x2d.shape
+    N = W.shape[0]
+    sfx = _sfx(x2d)
+    dW = torch.empty_like(W)
+    db = torch.empty(N, device=x2d.device, dtype=torch.float32) if want_dbias else None
+    ws = _ws(getattr(lib, "mdl_linear_bwd%s_ws_bytes" % sfx)(T, N, K), x2d.device)
+    with _timed("linear_bwd", ("flop", 2.0 * T * N * K * (2 if dx is not None else 1))):
+        rc = getattr(lib, "mdl_linear_bwd" + sfx)(_ptr(x2d), x2d.stride(0), _ptr(W), _ptr(dy), N, _ptr(dx), K, _ptr(dW), _ptr(db), T, N, K,
+                                                  _ptr(ws), _stream())
+    _native.check(rc, "mdl_linear_bwd" + sfx)
+    return dW, db
 
 
 def _bag_geometry(E, cu_seqlens, max_len):
@@ -353,11 +384,14 @@ def weighted_pool(E, weights, cu_seqlens=None, max_len=None):
 # w * d_pooled is added in the gate backward's dX epilogue -- dE is written exactly once.
 # --------------------------------------------------------------------------------------------------
 class AttnPoolFn(torch.autograd.Function):
-    """(pooled [n_bags,(1+V,)H*512], raw scores [T,H]) = multi-head gated-ABMIL pooling (Model.py:406-417) and, with
-    `views` = V int32 token-index lists (dense bags only), the V re-softmaxed sub-bag poolings of Model.py:419-440."""
+    """(pooled [n_bags,(1+V,)H*512], raw scores [T,H], token projections [T,P]) = multi-head gated-ABMIL pooling (Model.py:406-417)
+    and, with `views` = V int32 token-index lists (dense bags only), the V re-softmaxed sub-bag poolings of Model.py:419-440.
+    With Wtok [P, H*512] (+ btok) the token_projector Linear (Model.py:140) -- the other consumer of E -- is part of the node: its dX
+    is written into dE first and the gate dX epilogue accumulates onto it, so the two gradients of E are never summed by a separate
+    3 x |E| elementwise pass (3.8 ms per config-3 step); without it the third output is an empty tensor."""
 
     @staticmethod
-    def forward(ctx, E, Wa, ba, Wb, bb, wc, bc, p_drop, seed, keep_a, keep_b, cu_seqlens, max_len, *views):
+    def forward(ctx, E, Wa, ba, Wb, bb, wc, bc, p_drop, seed, keep_a, keep_b, cu_seqlens, max_len, Wtok, btok, *views):
         _require_act(E, "E")
         for t, n in ((Wa, "Wa"), (ba, "ba"), (Wb, "Wb"), (bb, "bb"), (wc, "wc"), (bc, "bc")):
             _require(t, n)
@@ -366,25 +400,36 @@ class AttnPoolFn(torch.autograd.Function):
             raise NotImplementedError("token-index views are defined on dense bags (the reference's n_views path stacks equal-N bags)")
         for v in views:
             _require(v, "view token indices", torch.int32)
-        need = any(ctx.needs_input_grad[:7])
+        ctx.set_materialize_grads(False)
+        need = any(ctx.needs_input_grad[:7]) or any(ctx.needs_input_grad[13:15])
         scores, act_a, act_b = gate_fwd_raw(E2d, Wa, ba, Wb, bb, wc, bc, p_drop, seed, keep_a, keep_b, need)
         pooled, m, l = pool_fwd_raw(E2d, scores, n_bags, N, cu_seqlens, max_len)
         vstate = [pool_view_fwd_raw(E2d, scores, n_bags, N, v) for v in views]
+        if Wtok is not None:
+            _require(Wtok, "token_projector weight")
+            if btok is not None:
+                _require(btok, "token_projector bias")
+            tok = linear_fwd_raw(E2d, Wtok, btok)
+        else:
+            tok = E2d.new_empty(0)
+            ctx.mark_non_differentiable(tok)
         if need:
             flat = [t for st in vstate for t in st]
+            none = torch.empty(0)
             ctx.save_for_backward(E2d, Wa, Wb, wc, act_a, act_b, scores, pooled, m, l,
-                                  cu_seqlens if cu_seqlens is not None else torch.empty(0), *views, *flat)
-            ctx.cfg = (p_drop, seed, keep_a, keep_b, n_bags, N, max_len, cu_seqlens is not None, E.shape, len(views))
+                                  cu_seqlens if cu_seqlens is not None else none, Wtok if Wtok is not None else none, *views, *flat)
+            ctx.cfg = (p_drop, seed, keep_a, keep_b, n_bags, N, max_len, cu_seqlens is not None, E.shape, len(views),
+                       Wtok is not None, btok is not None)
         if views:
             pooled = torch.stack([pooled] + [st[0] for st in vstate], dim=1)
-        return pooled, scores
+        return pooled, scores, tok
 
     @staticmethod
-    def backward(ctx, d_pooled, d_scores_in):
-        p_drop, seed, keep_a, keep_b, n_bags, N, max_len, ragged, e_shape, V = ctx.cfg
+    def backward(ctx, d_pooled, d_scores_in, d_tok):
+        p_drop, seed, keep_a, keep_b, n_bags, N, max_len, ragged, e_shape, V, has_tok, has_btok = ctx.cfg
         saved = ctx.saved_tensors
-        E2d, Wa, Wb, wc, act_a, act_b, scores, pooled, m, l, cu = saved[:11]
-        views, vflat = saved[11:11 + V], saved[11 + V:]
+        E2d, Wa, Wb, wc, act_a, act_b, scores, pooled, m, l, cu, Wtok = saved[:12]
+        views, vflat = saved[12:12 + V], saved[12 + V:]
         cu = cu if ragged else None
         dE = torch.empty_like(E2d)
         if d_scores_in is not None:
@@ -397,6 +442,12 @@ class AttnPoolFn(torch.autograd.Function):
             d_pooled = torch.zeros(n_bags, 1 + V, pooled.shape[-1], device=pooled.device) if V else torch.zeros_like(pooled)
         d_pooled = d_pooled.float().contiguous()
         d_main = d_pooled[:, 0].contiguous() if V else d_pooled
+        # the other consumer of E first: the token_projector's dX goes straight into dE (no separate gradient tensor, no add pass)
+        dWtok = dbtok = None
+        acc_e = 0
+        if has_tok and d_tok is not None:
+            dWtok, dbtok = linear_bwd_raw(E2d, Wtok, d_tok.to(E2d.dtype).contiguous(), dE, has_btok)
+            acc_e = 1
         # scores-only pooling backward (one read of E), then the gate backward whose dX epilogue adds the pooling term
         pool_bwd_raw(E2d, scores, pooled, m, l, d_main, None, 0, ds, acc_s, n_bags, N, cu, max_len)
         for i in range(V):   # the views' score gradients must be in ds before the gate backward consumes it
@@ -406,15 +457,21 @@ class AttnPoolFn(torch.autograd.Function):
         if ragged:   # bag index of every packed token row, on the device (no sync)
             row_bag = torch.searchsorted(cu[1:].contiguous(), torch.arange(E2d.shape[0], device=E2d.device), right=True).to(torch.int32)
         dWa, dWb, dba, dbb, dwc, dbc = attnpool_bwd_raw(E2d, Wa, Wb, wc, act_a, act_b, ds, dE, p_drop, seed, keep_a, keep_b,
-                                                        scores, m, l, d_main, row_bag, N if not ragged else 0)
+                                                        scores, m, l, d_main, row_bag, N if not ragged else 0, acc_e)
         for i in range(V):   # ... and their dE terms are added once dE has been written (no read of E)
             vp, vm, vl = vflat[3 * i:3 * i + 3]
             pool_view_bwd_raw(E2d, scores, vp, vm, vl, d_pooled[:, 1 + i].contiguous(), dE, None, n_bags, N, views[i])
-        return (dE.view(e_shape), dWa, dba, dWb, dbb, dwc, dbc, None, None, None, None, None, None) + (None,) * V
+        return (dE.view(e_shape), dWa, dba, dWb, dbb, dwc, dbc, None, None, None, None, None, None, dWtok, dbtok) + (None,) * V
 
 
-def attn_pool(E, Wa, ba, Wb, bb, wc, bc, p_drop=0.0, seed=0, keep_a=None, keep_b=None, cu_seqlens=None, max_len=None, views=()):
-    return AttnPoolFn.apply(E, Wa, ba, Wb, bb, wc, bc, float(p_drop), int(seed), keep_a, keep_b, cu_seqlens, max_len, *views)
+def attn_pool(E, Wa, ba, Wb, bb, wc, bc, p_drop=0.0, seed=0, keep_a=None, keep_b=None, cu_seqlens=None, max_len=None, views=(),
+              tok_proj=None):
+    """-> (pooled, raw scores), or (pooled, raw scores, token projections [T,P]) with tok_proj = (Wtok [P,H*512], btok or None)."""
+    Wtok, btok = tok_proj if tok_proj is not None else (None, None)
+    pooled, scores, tok = AttnPoolFn.apply(E, Wa, ba, Wb, bb, wc, bc, float(p_drop), int(seed), keep_a, keep_b, cu_seqlens, max_len,
+                                           None if Wtok is None else Wtok.contiguous(), None if btok is None else btok.contiguous(),
+                                           *views)
+    return (pooled, scores) if tok_proj is None else (pooled, scores, tok)
 
 
 def gate_scores(E2d, Wa, ba, Wb, bb, wc, bc, p_drop=0.0, seed=0, keep_a=None, keep_b=None):
@@ -488,22 +545,16 @@ def ln_gelu_drop(x, gamma, beta, eps=1e-5, p_drop=0.0, seed=0, keep=None, bias=N
 # --------------------------------------------------------------------------------------------------
 class LinearFn(torch.autograd.Function):
     """Y = X W^T (+ bias) (Model.py:351, :355, :359 without the bias, which ln_gelu_drop adds; Model.py:140 token_projector and
-    Model.py:145 projector with their bias); X [T,K], W [N,K]."""
+    Model.py:145 projector with their bias); X [T,K] fp32 or bf16 (bf16 mode: x, y and their gradients bf16; W, bias and their
+    gradients fp32 -- mdl_linear_*_bf16), W [N,K]."""
 
     @staticmethod
     def forward(ctx, x, W, bias):
-        _require(x, "x")
+        _require_act(x, "x")
         _require(W, "weight")
         if bias is not None:
             _require(bias, "bias")
-        lib = _native.lib()
-        T, K = x.shape
-        N = W.shape[0]
-        y = torch.empty(T, N, device=x.device, dtype=torch.float32)
-        ws = _ws(lib.mdl_linear_fwd_ws_bytes(T, N, K), x.device)
-        with _timed("linear_fwd", ("flop", 2.0 * T * N * K)):
-            rc = lib.mdl_linear_fwd(_ptr(x), x.stride(0), _ptr(W), _ptr(bias), _ptr(y), N, T, N, K, _ptr(ws), _stream())
-        _native.check(rc, "mdl_linear_fwd")
+        y = linear_fwd_raw(x, W, bias)
         ctx.save_for_backward(x, W)
         ctx.has_bias = bias is not None
         return y
@@ -511,58 +562,12 @@ class LinearFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, W = ctx.saved_tensors
-        lib = _native.lib()
-        T, K = x.shape
-        N = W.shape[0]
-        dy = dy.float().contiguous()
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        dW = torch.empty_like(W)
-        db = torch.empty(N, device=x.device, dtype=torch.float32) if ctx.has_bias else None
-        ws = _ws(lib.mdl_linear_bwd_ws_bytes(T, N, K), x.device)
-        with _timed("linear_bwd", ("flop", 2.0 * T * N * K * (2 if dx is not None else 1))):
-            rc = lib.mdl_linear_bwd(_ptr(x), x.stride(0), _ptr(W), _ptr(dy), N, _ptr(dx), K, _ptr(dW), _ptr(db), T, N, K, _ptr(ws),
-                                    _stream())
-        _native.check(rc, "mdl_linear_bwd")
+        dW, db = linear_bwd_raw(x, W, dy.to(x.dtype).contiguous(), dx, ctx.has_bias)
         return dx, dW, db
 
 
-class LinearBf16Fn(torch.autograd.Function):
-    """bf16 mode of LinearFn: x, y and their gradients bf16; W, bias and their gradients fp32 (mdl_linear_*_bf16)."""
-
-    @staticmethod
-    def forward(ctx, x, W, bias):
-        _require(x, "x", torch.bfloat16)
-        _require(W, "weight")
-        if bias is not None:
-            _require(bias, "bias")
-        lib = _native.lib()
-        T, K = x.shape
-        N = W.shape[0]
-        y = torch.empty(T, N, device=x.device, dtype=torch.bfloat16)
-        ws = _ws(lib.mdl_linear_fwd_bf16_ws_bytes(T, N, K), x.device)
-        with _timed("linear_fwd", ("flop", 2.0 * T * N * K)):
-            rc = lib.mdl_linear_fwd_bf16(_ptr(x), x.stride(0), _ptr(W), _ptr(bias), _ptr(y), N, T, N, K, _ptr(ws), _stream())
-        _native.check(rc, "mdl_linear_fwd_bf16")
-        ctx.save_for_backward(x, W)
-        ctx.has_bias = bias is not None
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        x, W = ctx.saved_tensors
-        lib = _native.lib()
-        T, K = x.shape
-        N = W.shape[0]
-        dy = dy.to(torch.bfloat16).contiguous()
-        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        dW = torch.empty_like(W)
-        db = torch.empty(N, device=x.device, dtype=torch.float32) if ctx.has_bias else None
-        ws = _ws(lib.mdl_linear_bwd_bf16_ws_bytes(T, N, K), x.device)
-        with _timed("linear_bwd", ("flop", 2.0 * T * N * K * (2 if dx is not None else 1))):
-            rc = lib.mdl_linear_bwd_bf16(_ptr(x), x.stride(0), _ptr(W), _ptr(dy), N, _ptr(dx), K, _ptr(dW), _ptr(db), T, N, K,
-                                         _ptr(ws), _stream())
-        _native.check(rc, "mdl_linear_bwd_bf16")
-        return dx, dW, db
+LinearBf16Fn = LinearFn   # one node for both storage types (kept for callers of the round-2 name)
 
 
 def linear_supported(x, W) -> bool:

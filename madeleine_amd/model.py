@@ -176,16 +176,19 @@ class ABMILEmbedder(nn.Module):
                 kb.reshape(T, self.n_heads, MF.HID).to(torch.uint8).contiguous()
         return p, MF.new_dropout_seed(), None, None
 
-    def pool_headmajor(self, E_hm: torch.Tensor, views=()):
+    def pool_headmajor(self, E_hm: torch.Tensor, views=(), tok_proj=None):
         """E_hm [BM,N,H*512] -> (pooled_hm [BM,(1+V,)H*512], raw scores [BM,N,H]) through the fused HIP path; `views` = V int32
-        token-index lists pooled in the same autograd node (no index_select copies of E)."""
+        token-index lists pooled in the same autograd node (no index_select copies of E).  tok_proj = (W [P,H*512] head-major
+        columns, bias): the token projection [BM,N,P] comes out of the same node (third result), see functional.AttnPoolFn."""
         for h in self.attn:
             h._check_geometry()
         BM, N, _ = E_hm.shape
         wa, ba, wb, bb, wc, bc = self.gate_params_stacked()
         p, seed, ka, kb = self._gate_dropout((BM, N))
-        pooled, scores = MF.attn_pool(E_hm, wa, ba, wb, bb, wc, bc, p, seed, ka, kb, views=views)
-        return pooled, scores.view(BM, N, self.n_heads)
+        out = MF.attn_pool(E_hm, wa, ba, wb, bb, wc, bc, p, seed, ka, kb, views=views, tok_proj=tok_proj)
+        if tok_proj is None:
+            return out[0], out[1].view(BM, N, self.n_heads)
+        return out[0], out[1].view(BM, N, self.n_heads), out[2].view(BM, N, -1)
 
     def pool_headmajor_ragged(self, E_hm: torch.Tensor, cu_seqlens: torch.Tensor, max_len: int):
         """Packed E_hm [T,H*512] + cu_seqlens int64 [n_bags+1] -> (pooled_hm [n_bags,H*512], raw scores [T,H])."""
@@ -211,11 +214,23 @@ class ABMILEmbedder(nn.Module):
         lead = pooled_hm.shape[:-1]
         return pooled_hm.view(*lead, self.n_heads, -1).transpose(-1, -2).contiguous()  # [...,512,H]
 
-    def forward_headmajor(self, bags, n_views=1):
-        """Fast path used by MADELEINE: returns (pooled_hm [BM,(V,)H*512], E_hm, raw scores [BM,N,H])."""
+    def forward_headmajor(self, bags, n_views=1, tok_proj=None):
+        """Fast path used by MADELEINE: returns (pooled_hm [BM,(V,)H*512], E_hm, raw scores [BM,N,H]) and, with tok_proj = (W, bias)
+        of a Linear over the head-major token embeddings (MADELEINE's token_projector), its output [BM,N,P] as a fourth result."""
         if self.agg_type != 'regular':
             raise NotImplementedError('Agg type not supported. Options are "regular".')
         E = self.embed_tokens_headmajor(bags)
+        act = self.attn[0].activation
+        if tok_proj is not None:
+            if act == 'softmax' and n_views == 1:
+                pooled, scores, tok = self.pool_headmajor(E, tok_proj=tok_proj)      # one autograd node for both consumers of E
+                return pooled, E, scores, tok
+            with torch.autocast(device_type="cuda", enabled=False):
+                tok = MF.linear(E, tok_proj[0], tok_proj[1])
+            return self.forward_headmajor_from_tokens(E, n_views) + (tok,)
+        return self.forward_headmajor_from_tokens(E, n_views)
+
+    def forward_headmajor_from_tokens(self, E, n_views=1):
         act = self.attn[0].activation
         if act == 'softmax' and n_views != 1:
             # intra-modality views (Model.py:419-440): two random halves of the token axis (numpy RNG, as the reference),
@@ -408,8 +423,9 @@ class MADELEINE(nn.Module):
                     stain_of_row = stain_of_row[compact]
             if self.stain_encoding:
                 x = self._cat_stain(x, stain_of_row)
-            pooled, E, _ = emb.forward_headmajor(x, n_views=n_views)
-            tok = self._project_tokens(E)                                             # [rows,N,128]
+            # token_projector (Model.py:140) inside the pooling node: the two gradients of E are accumulated in the gate dX epilogue
+            pooled, E, _, tok = emb.forward_headmajor(x, n_views=n_views, tok_proj=(
+                emb.permuted(self.token_projector.weight, 1), self.token_projector.bias))   # tok [rows,N,128]
             slide = self._project_slide(pooled.view(x.shape[0], -1, pooled.shape[-1]))  # [rows,V,512]
             if expand is not None:       # absent rows take the outputs of their all-zero representative
                 expand = expand.to(device)
