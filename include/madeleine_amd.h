@@ -340,6 +340,42 @@ int mdl_abmil_attnpool_bwd_bf16(const uint16_t* E, int64_t ldE, const float* Wa,
                                 const float* scores, const float* stat_m, const float* stat_l, const float* d_pooled,
                                 const int32_t* row_bag, int64_t N, void* ws, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Split-fp16 contraction engine (round 3; csrc/split_engine.hpp): the fp32 contractions of the path -- nn.Linear of
+ * madeleine/models/Model.py:351, :355, :359, :140 and the gate products of madeleine/models/abmil.py:49-52 -- with fp32-level accuracy
+ * on v_mfma_f32_32x32x16_f16: every operand value as two fp16 planes hi + lo of (power-of-two scale) x value, every product as
+ * ah bh + ah bl + al bh accumulated in fp32 (measured error below a plain fp32 fmaf chain, tools/micro/split_lab.hip).
+ * SPLIT IMAGE of X [rows, K], K % 32 == 0: uint16 [rows][K / 32][2][32] -- the hi and the lo plane of every 32-column block side
+ * by side (128 B = the bytes of the fp32 block); row stride rsb bytes (>= 4 K, % 16 == 0).  scale: device float[2] = {scale, absmax}.
+ *   mdl_split_image   : image of a fp32 tensor (exact absmax -> scale with max |scale x| in [2^13, 2^14)), + pad_rows zero rows
+ *   mdl_split_gemm_nt : C [M,N] (+)= sum_k A[m][k] B[n][k] (+ bias[n])   A, B images with K columns (rows m, n)
+ *   mdl_split_gemm_tn : out [N][Mi] = sum_t B[t][n] A[t][m]              A, B images with T rows (contraction = rows); B must be
+ *                       followed by >= 32 all-zero rows; ws = mdl_split_gemm_tn_ws_bytes (token-split slabs, reduced in fixed order)
+ */
+int mdl_split_image(const float* X, int64_t ldx, int64_t rows, int K, void* img, int64_t rsb, int64_t pad_rows, float* scale,
+                    void* stream);
+int mdl_split_gemm_nt(const void* A, int64_t a_rsb, const float* a_scale, const void* B, int64_t b_rsb, const float* b_scale, float* C,
+                      int64_t ldc, int64_t M, int N, int K, const float* bias, int accumulate, float* absmax_out, void* stream);
+int64_t mdl_split_gemm_tn_ws_bytes(int64_t T, int Mi, int N);
+int mdl_split_gemm_tn(const void* A, int64_t a_rsb, const float* a_scale, int Mi, const void* B, int64_t b_rsb, const float* b_scale,
+                      int N, float* out, int64_t T, void* ws, void* stream);
+
+/* A2 on the split engine (csrc/abmil_gate_split.hip): mdl_abmil_gate_fwd / mdl_abmil_attnpool_bwd(_phases) with E given as a split
+ * image (rows of e_rsb bytes holding the H*512 head-major channels, scale e_scale) -- everything else (parameters, scores, saved
+ * activations, gradients, dropout, pooling term, `accumulate`) as in the fp32 entry points.  scores == NULL in the backward: no
+ * pooling term (plain gate backward).  dE_absmax (device float, may be NULL, zeroed by the caller) is raised to max |dE|. */
+int64_t mdl_abmil_gate_fwd_split_ws_bytes(int64_t T, int H);
+int mdl_abmil_gate_fwd_split(const void* E_img, int64_t e_rsb, const float* e_scale, const float* Wa, const float* ba, const float* Wb,
+                             const float* bb, const float* wc, const float* bc, float* scores, float* act_a, float* act_b, int64_t T,
+                             int H, float p_drop, uint64_t seed, const uint8_t* keep_a, const uint8_t* keep_b, void* ws, void* stream);
+int64_t mdl_abmil_gate_bwd_split_ws_bytes(int64_t T, int H);
+int mdl_abmil_attnpool_bwd_split(const void* E_img, int64_t e_rsb, const float* e_scale, const float* Wa, const float* Wb, const float* wc,
+                                 const float* act_a, const float* act_b, const float* d_scores, float* dE, int64_t ldE, int accumulate,
+                                 float* dWa, float* dWb, float* dba, float* dbb, float* dwc, float* dbc, int64_t T, int H, float p_drop,
+                                 uint64_t seed, const uint8_t* keep_a, const uint8_t* keep_b, const float* scores, const float* stat_m,
+                                 const float* stat_l, const float* d_pooled, const int32_t* row_bag, int64_t N, float* dE_absmax, void* ws,
+                                 void* stream, int phases);
+
 #ifdef __cplusplus
 }
 #endif

@@ -82,6 +82,16 @@ SIGNATURES = {
     "mdl_abmil_gate_bwd_bf16_ws_bytes": (i64, [i64, i32]),
     "mdl_abmil_attnpool_bwd_bf16": (i32, [c_f, i64, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, c_f, c_f, c_f, c_f, c_f, c_f, i64, i32, f32, u64, c_p, c_p, c_f, c_f,
                                      c_f, c_f, c_p, i64, c_p, c_p]),
+    # split-fp16 engine
+    "mdl_split_image": (i32, [c_f, i64, i64, i32, c_p, i64, i64, c_f, c_p]),
+    "mdl_split_gemm_nt": (i32, [c_p, i64, c_f, c_p, i64, c_f, c_f, i64, i64, i32, i32, c_f, i32, c_f, c_p]),
+    "mdl_split_gemm_tn_ws_bytes": (i64, [i64, i32, i32]),
+    "mdl_split_gemm_tn": (i32, [c_p, i64, c_f, i32, c_p, i64, c_f, i32, c_f, i64, c_p, c_p]),
+    "mdl_abmil_gate_fwd_split_ws_bytes": (i64, [i64, i32]),
+    "mdl_abmil_gate_fwd_split": (i32, [c_p, i64, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i64, i32, f32, u64, c_p, c_p, c_p, c_p]),
+    "mdl_abmil_gate_bwd_split_ws_bytes": (i64, [i64, i32]),
+    "mdl_abmil_attnpool_bwd_split": (i32, [c_p, i64, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i64, i32, c_f, c_f, c_f, c_f, c_f, c_f, i64, i32,
+                                           f32, u64, c_p, c_p, c_f, c_f, c_f, c_f, c_p, i64, c_f, c_p, c_p, i32]),
     "mdl_abmil_gate_bwd_bf16": (i32, [c_f, i64, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, c_f, c_f, c_f, c_f, c_f, c_f, i64, i32,
                                       f32, u64, c_p, c_p, c_p, c_p]),
 }

@@ -1,0 +1,556 @@
+// abmil_gate_split.hip -- A2 (gated attention scores, reference madeleine/models/abmil.py:41-68 called per head from
+// madeleine/models/Model.py:406-409) forward and backward with the three contractions on the split-fp16 engine (split_engine.hpp):
+// fp32 values, fp32-level accuracy, 3 v_mfma_f32_32x32x16_f16 per 16 k instead of 8 v_mfma_f32_32x32x2_f32.  Same maths, same
+// dropout counter hash, same partial-score / finalize / slab-reduction scheme as abmil_gate.hip (whose kernels remain the 'fp32'
+// GEMM mode); the epilogues are fp32.
+//   forward : A = image(E) rows of head c (K = 512)      B = image([Wa;Wb]) rows (a j | b j)     fused tanh / sigmoid / dropout / wc
+//   dz      : d(za)|d(zb) written as an IMAGE directly by the HBM-bound pass (scale from the rigorous bound max|ds| max|wc| / (1-p)^2)
+//   dX      : A = image(dz) rows (t, c) (K = 1024)       B = image([Wa;Wb]^T) rows e              dE (+)= . + pooling term
+//   dW      : TN over tokens: A = image(E) head columns, B = image(dz) head columns              slabs -> gate_reduce_w
+#include "split_engine.hpp"
+
+namespace mdl {
+
+// ---- weight images --------------------------------------------------------------------------------------------------------------------
+// sc[1] = max(|Wa|, |Wb|) (sp_absmax on both), sc[0] = its scale.
+// WK [H][1024 rows: a j 0..511 | b j 0..511][512 k]: the forward's B operand
+__global__ __launch_bounds__(256) void sp_gate_wk_kernel(const float* __restrict__ Wa, const float* __restrict__ Wb, char* __restrict__ WK,
+                                                         int H, const float* __restrict__ sc) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // over H * 1024 * 64 groups of 8 k
+    if (i >= (int64_t)H * 1024 * 64) return;
+    const int k = (int)(i % 64) * 8, r = (int)((i / 64) % 1024), c = (int)(i / (64 * 1024));
+    const float* src = (r < HID) ? Wa + ((int64_t)c * HID + r) * HID + k : Wb + ((int64_t)c * HID + r - HID) * HID + k;
+    const float s = sc[0];
+    const f32x4 x0 = *reinterpret_cast<const f32x4*>(src), x1 = *reinterpret_cast<const f32x4*>(src + 4);
+    const float v[8] = {x0.x * s, x0.y * s, x0.z * s, x0.w * s, x1.x * s, x1.y * s, x1.z * s, x1.w * s};
+    u32x4 hi, lo;
+    sp_split8(v, hi, lo);
+    char* row = WK + ((int64_t)c * 1024 + r) * (HID * 4);
+    *reinterpret_cast<u32x4*>(row + sp_img_off(k, 0)) = hi;
+    *reinterpret_cast<u32x4*>(row + sp_img_off(k, 1)) = lo;
+}
+// WN [H][512 rows e][1024 columns: a j | b j] = [Wa;Wb]^T: the dX product's B operand   (32 x 32 LDS transpose)
+__global__ __launch_bounds__(256) void sp_gate_wn_kernel(const float* __restrict__ Wa, const float* __restrict__ Wb, char* __restrict__ WN,
+                                                         const float* __restrict__ sc) {
+    __shared__ float tile[32][33];
+    const int c = blockIdx.z, jb = blockIdx.y * 32, eb = blockIdx.x * 32;  // jb over 1024 (a | b), eb over 512
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float* __restrict__ W = (jb < HID) ? Wa + ((int64_t)c * HID + jb) * HID : Wb + ((int64_t)c * HID + jb - HID) * HID;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tile[ty + i * 8][tx] = W[(int64_t)(ty + i * 8) * HID + eb + tx];   // tile[j][e]
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int e = threadIdx.x >> 2, g = threadIdx.x & 3;   // row e, 8 consecutive j
+        const float s = sc[0];
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = tile[g * 8 + u][e] * s;
+        u32x4 hi, lo;
+        sp_split8(v, hi, lo);
+        char* row = WN + ((int64_t)c * HID + eb + e) * (1024 * 4);
+        *reinterpret_cast<u32x4*>(row + sp_img_off(jb + g * 8, 0)) = hi;
+        *reinterpret_cast<u32x4*>(row + sp_img_off(jb + g * 8, 1)) = lo;
+    }
+}
+// out[0] = scale for a bound in[0] * in[1] * mult (dz: max|ds| * max|wc| / (1-p)^2); out[1] = the bound
+__global__ void sp_bound_scale_kernel(const float* __restrict__ in, float mult, float* __restrict__ out) {
+    const float b = in[0] * in[1] * mult;
+    out[1] = b;
+    out[0] = sp_scale_for(b);
+}
+
+// ================================================================================================
+// forward
+// ================================================================================================
+template <int DM>
+__device__ __forceinline__ void sp_keep2(const DropCfg& d, int64_t idx, uint32_t row_key, bool& ka, bool& kb) {
+    if (DM == 0) {
+        ka = kb = true;
+    } else if (DM == 2) {
+        ka = d.ka[idx] != 0;
+        kb = d.kb[idx] != 0;
+    } else {
+        const uint32_t h = mix32((uint32_t)idx ^ row_key);
+        ka = (h & 0xFFFFu) >= d.thr;
+        kb = (h >> 16) >= d.thr;
+    }
+}
+
+// Tile: 256 tokens x (128 a | 128 b) gate columns j0 .. j0 + 127 of head c.  Tile column n = wn * 64 + ct * 32 + l: ct = 0 -> a column
+// j0 + wn * 32 + l, ct = 1 -> b column j0 + wn * 32 + l, so that a wave holds za and zb of the same (token, j) in acc[rt][0] / [rt][1].
+template <int DM, bool SAVE>
+__global__ __launch_bounds__(512) void sp_gate_fwd_kernel(const char* __restrict__ Ei, int64_t e_rsb, const float* __restrict__ e_sc,
+                                                          const char* __restrict__ WK, const float* __restrict__ w_sc,
+                                                          const float* __restrict__ ba, const float* __restrict__ bb,
+                                                          const float* __restrict__ wc, float* __restrict__ part,
+                                                          float* __restrict__ act_a, float* __restrict__ act_b, int64_t T, int H,
+                                                          int n_ttiles, DropCfg drop) {
+    __shared__ SmemSP sm;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const XcdHead xh = xcd_head(blockIdx.x, H);
+    const int jt = xh.li % GATE_JT, c = xh.c, tt = (xh.li / GATE_JT) * xh.nshare + xh.share;
+    if (tt >= n_ttiles) return;  // block-uniform
+    const int64_t t0 = (int64_t)tt * SPM;
+    const int j0 = jt * 128;
+
+    const char* baseA = Ei + t0 * e_rsb + (int64_t)c * (HID * 4);
+    const char* baseB = WK + (int64_t)c * 1024 * (HID * 4);
+    uint32_t voA[4], voB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int row, ch;
+        sp_nt_slot(wave, i, lane, row, ch);
+        int64_t ra = row;
+        if (t0 + ra > T - 1) ra = T - 1 - t0;
+        voA[i] = (uint32_t)(ra * e_rsb + ch * 16);
+        const int wrow = ((row >> 5) & 1) * HID + j0 + (row >> 6) * 32 + (row & 31);   // tile row -> row of the head's [a | b] block
+        voB[i] = (uint32_t)(wrow * (HID * 4) + ch * 16);
+    }
+    f32x16 acc[4][2];
+    sp_zero(acc);
+    sp_nt_mainloop(sm, acc, HID / 32, wm, wn, lane, [&](int st, int f, int piece) {
+        const int i = piece & 3;
+        if (piece < 4) glds16_s(voA[i], sp_uniform(baseA + (int64_t)f * 128), lds_addr_of(&sm.A[st][(wave * 4 + i) * 1024]));
+        else glds16_s(voB[i], sp_uniform(baseB + (int64_t)f * 128), lds_addr_of(&sm.B[st][(wave * 4 + i) * 1024]));
+    });
+
+    // ---- epilogue: 4 passes (rt) of a 32-row x (32 a | 32 b)-column block through the wave's LDS tile (as abmil_gate.hip)
+    const float inv = 1.f / (e_sc[0] * w_sc[0]);
+    const int l32 = lane & 31;
+    float* tile = reinterpret_cast<float*>(&sm) + wave * (32 * 64);
+    float* sred = reinterpret_cast<float*>(&sm) + 8 * (32 * 64) + wn * SPM + wm * 128;   // [4 (wn)][256 rows]
+    const int g8 = lane & 7, r8 = lane >> 3;
+    const int jc = j0 + wn * 32;   // first gate column of this wave
+    const float bav = ba[c * HID + jc + l32], bbv = bb[c * HID + jc + l32];
+    const f32x4 wc4 = *reinterpret_cast<const f32x4*>(wc + c * HID + jc + g8 * 4);
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            tile[acc_row(r, lane) * 64 + l32] = fast_tanh(fmaf(acc[rt][0][r], inv, bav));
+            tile[acc_row(r, lane) * 64 + 32 + l32] = fast_sigmoid(fmaf(acc[rt][1][r], inv, bbv));
+            if ((r & 3) == 3) SP_SB();
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = i * 8 + r8;
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(&tile[row * 64 + g8 * 4]);
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(&tile[row * 64 + 32 + g8 * 4]);
+            float sum = 0.f;
+            if (t0 + wm * 128 + rt * 32 + row < T) {
+                const int64_t idx = ((t0 + wm * 128 + rt * 32) * H + c) * HID + jc + (uint32_t)(row * H * HID + g8 * 4);
+                const uint32_t rkey = drop_row_key(drop, idx);   // idx % 4 == 0: the 4 elements share the high word
+                if (SAVE) {
+                    *reinterpret_cast<f32x4*>(act_a + idx) = a4;
+                    *reinterpret_cast<f32x4*>(act_b + idx) = b4;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    bool keep_a, keep_b;
+                    sp_keep2<DM>(drop, idx + e, rkey, keep_a, keep_b);
+                    const float ad = keep_a ? a4[e] * drop.inv : 0.f;
+                    const float bd = keep_b ? b4[e] * drop.inv : 0.f;
+                    sum += ad * bd * wc4[e];
+                }
+            }
+            sum += __shfl_xor(sum, 1, 64);
+            sum += __shfl_xor(sum, 2, 64);
+            sum += __shfl_xor(sum, 4, 64);
+            if (g8 == 0) sred[rt * 32 + row] = sum;
+            SP_SB();
+        }
+    }
+    __syncthreads();
+    if (tid < SPM) {
+        const int64_t t = t0 + tid;
+        const float* sr = reinterpret_cast<const float*>(&sm) + 8 * (32 * 64);
+        if (t < T) part[(t * H + c) * GATE_JT + jt] = ((sr[tid] + sr[SPM + tid]) + sr[2 * SPM + tid]) + sr[3 * SPM + tid];
+    }
+}
+
+// ================================================================================================
+// backward, stage 1: d(za) | d(zb) as a split image [T + 32][H][1024] (+ the column sums), scale dz_sc[0] from the bound
+// ================================================================================================
+__global__ __launch_bounds__(256) void sp_gate_dz_kernel(const float* __restrict__ wc, const float* __restrict__ act_a,
+                                                         const float* __restrict__ act_b, const float* __restrict__ d_scores,
+                                                         char* __restrict__ dzi, const float* __restrict__ dz_sc,
+                                                         float* __restrict__ slabV, int64_t T, int H, DropCfg drop) {
+    constexpr int VEC = 4, NQ = HID / VEC, PH = 256 / NQ;   // 128 column groups x 2 row phases
+    __shared__ float red[PH - 1][NQ][3 * VEC + 1];
+    const int tid = threadIdx.x, q = tid % NQ, ph = tid / NQ, c = blockIdx.y;
+    const int64_t r0 = (int64_t)blockIdx.x * DZ_ROWS;
+    int64_t r1 = r0 + DZ_ROWS;
+    if (r1 > T) r1 = T;
+    const float s = dz_sc[0];
+    float vw[VEC], sa[VEC], sb[VEC], sw[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        vw[i] = wc[c * HID + q * VEC + i];
+        sa[i] = sb[i] = sw[i] = 0.f;
+    }
+    float sds = 0.f;
+    const int64_t offa = sp_img_off(q * VEC, 0), offb = sp_img_off(HID + q * VEC, 0);
+    constexpr int UNR = 4;
+    for (int64_t rb = r0 + ph; rb < r1; rb += PH * UNR) {
+        float va[UNR][VEC], vb[UNR][VEC], ds[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int64_t r = rb + PH * u;
+            const bool ok = r < r1;
+            const int64_t o = ((ok ? r : rb) * H + c) * HID + q * VEC;
+            ldv<float>(act_a + o, va[u]);
+            ldv<float>(act_b + o, vb[u]);
+            ds[u] = ok ? d_scores[r * H + c] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int64_t r = rb + PH * u;
+            if (r < r1) {
+                const int64_t o = (r * H + c) * HID + q * VEC;
+                const uint32_t rkey = drop_row_key(drop, o);
+                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                uint32_t ha[2], la[2], hb[2], lb[2];
+                float za[VEC], zb[VEC];
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    float w;
+                    gate_dz(drop, ds[u], vw[i], va[u][i], vb[u][i], o + i, rkey, za[i], zb[i], w);
+                    sw[i] += w;
+                    sa[i] += za[i];
+                    sb[i] += zb[i];
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const float a0 = za[2 * i] * s, a1 = za[2 * i + 1] * s, b0 = zb[2 * i] * s, b1 = zb[2 * i + 1] * s;
+                    const _Float16 ha0 = (_Float16)a0, ha1 = (_Float16)a1, hb0 = (_Float16)b0, hb1 = (_Float16)b1;
+                    ha[i] = __builtin_bit_cast(uint32_t, h2{ha0, ha1});
+                    hb[i] = __builtin_bit_cast(uint32_t, h2{hb0, hb1});
+                    la[i] = __builtin_bit_cast(uint32_t, h2{(_Float16)(a0 - (float)ha0), (_Float16)(a1 - (float)ha1)});
+                    lb[i] = __builtin_bit_cast(uint32_t, h2{(_Float16)(b0 - (float)hb0), (_Float16)(b1 - (float)hb1)});
+                }
+                sds += ds[u];
+                char* row = dzi + (r * H + c) * (int64_t)(1024 * 4);
+                *reinterpret_cast<u32x2*>(row + offa) = u32x2{ha[0], ha[1]};
+                *reinterpret_cast<u32x2*>(row + offa + 64) = u32x2{la[0], la[1]};
+                *reinterpret_cast<u32x2*>(row + offb) = u32x2{hb[0], hb[1]};
+                *reinterpret_cast<u32x2*>(row + offb + 64) = u32x2{lb[0], lb[1]};
+            }
+        }
+    }
+    if (ph > 0) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            red[ph - 1][q][i] = sa[i];
+            red[ph - 1][q][VEC + i] = sb[i];
+            red[ph - 1][q][2 * VEC + i] = sw[i];
+        }
+        red[ph - 1][q][3 * VEC] = sds;
+    }
+    __syncthreads();
+    if (ph == 0) {
+        float* __restrict__ o = slabV + ((int64_t)blockIdx.x * H + c) * 4 * HID + q * VEC;
+#pragma unroll
+        for (int p = 0; p < PH - 1; ++p) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                sa[i] += red[p][q][i];
+                sb[i] += red[p][q][VEC + i];
+                sw[i] += red[p][q][2 * VEC + i];
+            }
+            sds += red[p][0][3 * VEC];
+        }
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            o[i] = sa[i];
+            o[HID + i] = sb[i];
+            o[2 * HID + i] = sw[i];
+        }
+        if (q == 0) o[3 * HID] = sds;
+    }
+}
+
+// ================================================================================================
+// backward, stage 2: dE[t, c, n0 + n] (+)= sum_j dz[t, c, j] WN[c][n0 + n][j]  (+ pooling term), K = 1024
+// ================================================================================================
+__global__ __launch_bounds__(512) void sp_gate_dx_kernel(const char* __restrict__ dzi, const float* __restrict__ dz_sc,
+                                                         const char* __restrict__ WN, const float* __restrict__ w_sc,
+                                                         float* __restrict__ dE, int64_t ldE, int accumulate, int64_t T, int H,
+                                                         PoolTerm pt, float* __restrict__ absmax_out) {
+    __shared__ SmemSP sm;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const XcdHead xh = xcd_head(blockIdx.x, H);
+    const int nt = xh.li % 2, c = xh.c, tt = (xh.li / 2) * xh.nshare + xh.share;
+    const int64_t t0 = (int64_t)tt * SPM;
+    if (t0 >= T) return;  // block-uniform
+    const int n0 = nt * SPN;
+
+    const uint32_t rowA = (uint32_t)H * 4096u;
+    const char* baseA = dzi + (t0 * H + c) * (int64_t)4096;
+    const char* baseB = WN + ((int64_t)c * HID + n0) * 4096;
+    uint32_t voA[4], voB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int row, ch;
+        sp_nt_slot(wave, i, lane, row, ch);
+        int64_t ra = row;
+        if (t0 + ra > T - 1) ra = T - 1 - t0;
+        voA[i] = (uint32_t)ra * rowA + ch * 16;
+        voB[i] = (uint32_t)row * 4096u + ch * 16;
+    }
+    f32x16 acc[4][2];
+    sp_zero(acc);
+    sp_nt_mainloop(sm, acc, 1024 / 32, wm, wn, lane, [&](int st, int f, int piece) {
+        const int i = piece & 3;
+        if (piece < 4) glds16_s(voA[i], sp_uniform(baseA + (int64_t)f * 128), lds_addr_of(&sm.A[st][(wave * 4 + i) * 1024]));
+        else glds16_s(voB[i], sp_uniform(baseB + (int64_t)f * 128), lds_addr_of(&sm.B[st][(wave * 4 + i) * 1024]));
+    });
+    const float inv = 1.f / (dz_sc[0] * w_sc[0]);
+    float amax = 0.f;
+    char* ob = reinterpret_cast<char*>(dE + t0 * ldE + (int64_t)c * HID + n0);
+    const uint32_t ld4 = (uint32_t)ldE * 4u;
+    auto emit = [&](int row, int col, const f32x4& v) {
+        f32x4* o = reinterpret_cast<f32x4*>(ob + (int64_t)row * ld4 + (uint32_t)col * 4u);
+        f32x4 r = v * inv;
+        if (pt.scores) {  // fused A3 term: + w[t,c] * d_pooled[bag(t), c, :]  (cache-resident row)
+            int bag;
+            const float w = pool_term_weight(pt, t0 + row, c, H, bag);
+            const f32x4 dp = *reinterpret_cast<const f32x4*>(pt.d_pooled + ((int64_t)bag * H + c) * HID + n0 + col);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) r[i] = fmaf(w, dp[i], r[i]);
+        }
+        if (accumulate) r += *o;
+        *o = r;
+        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));
+    };
+    if (t0 + SPM <= T) sp_epilogue_rows<true, 2>(acc, sm, wave, wm, wn, lane, SPM, emit);
+    else sp_epilogue_rows<false, 2>(acc, sm, wave, wm, wn, lane, (int)(T - t0), emit);
+    if (absmax_out) sp_atomic_absmax(absmax_out, amax);
+}
+
+// ================================================================================================
+// backward, stage 3: slabW[sp][c][k' 512][1024: a | b] = sum_{t in split} E[t, c, k'] dz[t, c, n]      (TN over tokens)
+// ================================================================================================
+__global__ __launch_bounds__(512) void sp_gate_dw_kernel(const char* __restrict__ Ei, int64_t e_rsb, const float* __restrict__ e_sc,
+                                                         const char* __restrict__ dzi, const float* __restrict__ dz_sc,
+                                                         float* __restrict__ slabW, int64_t T, int H, int64_t tok_per_split,
+                                                         int n_splits) {
+    __shared__ SmemSP sm;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const XcdHead xh = xcd_head(blockIdx.x, H);
+    const int kt = xh.li % 2, ntile = (xh.li / 2) % 4, c = xh.c, sp = (xh.li / 8) * xh.nshare + xh.share;
+    if (sp >= n_splits) return;  // block-uniform
+    const int i0 = kt * SPM, n0 = ntile * SPN;
+    const int64_t ts = (int64_t)sp * tok_per_split;
+    int64_t te = ts + tok_per_split;
+    if (te > T) te = T;
+    const int64_t nch = (te > ts) ? (te - ts + SPK - 1) / SPK : 0;
+
+    uint32_t tokq[4], coA[4], coB[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int kr = (wave * 4 + q) * 2 + (lane >> 5), p = kr >> 5, src = (lane & 31) ^ ((kr & 3) << 2);
+        tokq[q] = kr & 31;
+        coA[q] = (uint32_t)sp_img_off(i0 + src * 8, p);
+        coB[q] = (uint32_t)sp_img_off(n0 + src * 8, p);
+    }
+    const uint32_t rowB = (uint32_t)H * 4096u;
+    const char* baseA = Ei + ts * e_rsb + (int64_t)c * (HID * 4);
+    const char* baseB = dzi + (ts * H + c) * (int64_t)4096;
+    f32x16 acc[4][2];
+    sp_zero(acc);
+    sp_tn_mainloop(sm, acc, nch, wm, wn, lane, [&](int st, int64_t f, int piece) {
+        const int q = piece & 3;
+        if (piece < 4) {   // E rows past T - 1 re-read row T - 1: their dz rows are the zero pad
+            uint32_t tk = tokq[q];
+            const int64_t left = T - 1 - (ts + f * SPK);
+            if (left < SPK) tk = tk < (uint32_t)left ? tk : (uint32_t)left;
+            glds16_s(tk * (uint32_t)e_rsb + coA[q], sp_uniform(baseA + f * SPK * e_rsb), lds_addr_of(&sm.A[st][(wave * 4 + q) * 1024]));
+        } else {
+            glds16_s(tokq[q] * rowB + coB[q], sp_uniform(baseB + f * SPK * (int64_t)rowB), lds_addr_of(&sm.B[st][(wave * 4 + q) * 1024]));
+        }
+    });
+    const float inv = 1.f / (e_sc[0] * dz_sc[0]);
+    float* so = slabW + (((int64_t)sp * H + c) * HID + i0) * 1024 + n0;
+    auto emit = [&](int row, int col, const f32x4& v) { *reinterpret_cast<f32x4*>(so + (int64_t)row * 1024 + col) = v * inv; };
+    sp_epilogue_rows<true>(acc, sm, wave, wm, wn, lane, SPM, emit);
+}
+
+// split_gemm.hip
+int sp_launch_absmax(const float* X, int64_t ldx, int64_t rows, int K, float* out, hipStream_t s);
+int sp_launch_absmax_flat(const float* x, int64_t n, float* out, hipStream_t s);
+int sp_launch_scale(float* sc, hipStream_t s);
+
+static inline int64_t up16s(int64_t b) { return (b + 15) & ~(int64_t)15; }
+struct SpBwdWs {
+    int S;
+    int64_t tps, nblk;
+    int64_t oWN, odz, oslabW, oslabV, osc, total;
+};
+static inline SpBwdWs sp_bwd_ws(int64_t T, int H) {
+    SpBwdWs w;
+    w.S = splits_for(T, 8 * H, 256);   // 2 x 4 tiles per head and split; one workgroup per CU
+    int64_t tps = (T + w.S - 1) / w.S;
+    w.tps = ((tps + SPK - 1) / SPK) * SPK;
+    if (w.tps < SPK) w.tps = SPK;
+    w.nblk = (T + DZ_ROWS - 1) / DZ_ROWS;
+    int64_t o = 0;
+    w.oWN = o; o += up16s((int64_t)H * HID * 1024 * 4);
+    w.odz = o; o += up16s((T + SPK) * H * 1024 * 4);       // + 32 zero rows: token tail of the dW contraction
+    w.oslabW = o; o += up16s((int64_t)w.S * H * HID * 1024 * 4);
+    w.oslabV = o; o += up16s(w.nblk * H * 4 * HID * 4);
+    w.osc = o; o += 64;                                      // floats: [0,1] W scale / absmax | [2,3] max|ds|, max|wc| | [4,5] dz scale / bound
+    w.total = o + 64;
+    return w;
+}
+
+}  // namespace mdl
+
+using namespace mdl;
+
+extern "C" int64_t mdl_abmil_gate_fwd_split_ws_bytes(int64_t T, int H) {
+    if (T < 0 || H < 1 || H > MDL_MAX_HEADS) return MDL_E_ARG;
+    // WK image [H][1024][512] | score partials [T][H][4] | scale floats
+    return (int64_t)H * 1024 * HID * 4 + T * H * GATE_JT * 4 + 128;
+}
+
+/* mdl_abmil_gate_fwd on the split engine: E as a split image (rows of e_rsb bytes holding the H*512 head-major channels, scale e_scale);
+ * everything else as mdl_abmil_gate_fwd (fp32 parameters, scores, saved activations). */
+extern "C" int mdl_abmil_gate_fwd_split(const void* E_img, int64_t e_rsb, const float* e_scale, const float* Wa, const float* ba,
+                                        const float* Wb, const float* bb, const float* wc, const float* bc, float* scores, float* act_a,
+                                        float* act_b, int64_t T, int H, float p_drop, uint64_t seed, const uint8_t* keep_a,
+                                        const uint8_t* keep_b, void* ws, void* stream) {
+    if (!E_img || !e_scale || !Wa || !ba || !Wb || !bb || !wc || !bc || !scores || !ws) return MDL_E_ARG;
+    if ((act_a == nullptr) != (act_b == nullptr)) return MDL_E_ARG;
+    if ((keep_a == nullptr) != (keep_b == nullptr)) return MDL_E_ARG;
+    if (T < 0 || H < 1 || H > MDL_MAX_HEADS || e_rsb < (int64_t)H * HID * 4 || (e_rsb & 15) || e_rsb * SPM > 0x7fffffff) return MDL_E_ARG;
+    if (!(p_drop >= 0.f && p_drop < 1.f)) return MDL_E_ARG;
+    if (!host_aligned16(E_img) || !host_aligned16(Wa) || !host_aligned16(Wb) || !host_aligned16(ws)) return MDL_E_ALIGN;
+    if (T == 0) return MDL_OK;
+    if (H != 1 && H != 2 && H != 4 && H != 8) return MDL_E_UNSUPPORTED;
+    const int64_t n_tt = (T + SPM - 1) / SPM;
+    const int64_t grid = xcd_head_grid(n_tt, GATE_JT, H);
+    if (grid > 0x7fffffff) return MDL_E_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const DropCfg d = make_drop(p_drop, seed, keep_a, keep_b);
+    char* WK = (char*)ws;
+    float* part = (float*)(WK + (int64_t)H * 1024 * HID * 4);
+    float* sc = part + T * H * GATE_JT;
+    {
+        const hipError_t e = hipMemsetAsync(sc, 0, 2 * sizeof(float), s);
+        if (e != hipSuccess) return (int)e;
+    }
+    int rc = sp_launch_absmax(Wa, HID, (int64_t)H * HID, HID, sc + 1, s);
+    if (rc) return rc;
+    rc = sp_launch_absmax(Wb, HID, (int64_t)H * HID, HID, sc + 1, s);
+    if (rc) return rc;
+    rc = sp_launch_scale(sc, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(sp_gate_wk_kernel, dim3((unsigned)((int64_t)H * 1024 * 64 / 256)), dim3(256), 0, s, Wa, Wb, WK, H, (const float*)sc);
+    MDL_LAUNCH_CHECK();
+    const int dm = !d.on ? 0 : (d.ka ? 2 : 1);
+#define MDL_GATE_FWD_SP(DM, SAVE)                                                                                                     \
+    hipLaunchKernelGGL((sp_gate_fwd_kernel<DM, SAVE>), dim3((unsigned)grid), dim3(512), 0, s, (const char*)E_img, e_rsb, e_scale,     \
+                       (const char*)WK, (const float*)sc, ba, bb, wc, part, act_a, act_b, T, H, (int)n_tt, d)
+    if (act_a) {
+        if (dm == 0) MDL_GATE_FWD_SP(0, true);
+        else if (dm == 1) MDL_GATE_FWD_SP(1, true);
+        else MDL_GATE_FWD_SP(2, true);
+    } else {
+        if (dm == 0) MDL_GATE_FWD_SP(0, false);
+        else if (dm == 1) MDL_GATE_FWD_SP(1, false);
+        else MDL_GATE_FWD_SP(2, false);
+    }
+#undef MDL_GATE_FWD_SP
+    MDL_LAUNCH_CHECK();
+    return gate_launch_finalize(part, bc, scores, T * H, H, s);
+}
+
+extern "C" int64_t mdl_abmil_gate_bwd_split_ws_bytes(int64_t T, int H) {
+    if (T < 0 || H < 1 || H > MDL_MAX_HEADS) return MDL_E_ARG;
+    return sp_bwd_ws(T, H).total;
+}
+
+/* mdl_abmil_attnpool_bwd (scores == NULL: plain mdl_abmil_gate_bwd) on the split engine; E as a split image.  dE_absmax (device float,
+ * may be NULL; zeroed by the caller) is raised to max |dE|.  phases as mdl_abmil_attnpool_bwd_phases. */
+extern "C" int mdl_abmil_attnpool_bwd_split(const void* E_img, int64_t e_rsb, const float* e_scale, const float* Wa, const float* Wb,
+                                            const float* wc, const float* act_a, const float* act_b, const float* d_scores, float* dE,
+                                            int64_t ldE, int accumulate, float* dWa, float* dWb, float* dba, float* dbb, float* dwc,
+                                            float* dbc, int64_t T, int H, float p_drop, uint64_t seed, const uint8_t* keep_a,
+                                            const uint8_t* keep_b, const float* scores, const float* stat_m, const float* stat_l,
+                                            const float* d_pooled, const int32_t* row_bag, int64_t N, float* dE_absmax, void* ws,
+                                            void* stream, int phases) {
+    if (!E_img || !e_scale || !Wa || !Wb || !wc || !act_a || !act_b || !d_scores || !dE || !dWa || !dWb || !dba || !dbb || !dwc || !ws)
+        return MDL_E_ARG;
+    if (phases < 1 || phases > 3) return MDL_E_ARG;
+    if ((keep_a == nullptr) != (keep_b == nullptr)) return MDL_E_ARG;
+    if (scores && (!stat_m || !stat_l || !d_pooled || (!row_bag && N < 1))) return MDL_E_ARG;
+    if (T < 0 || H < 1 || H > MDL_MAX_HEADS || ldE < (int64_t)H * HID || (ldE & 3) || e_rsb < (int64_t)H * HID * 4 || (e_rsb & 15) ||
+        e_rsb * SPK > 0x7fffffff)
+        return MDL_E_ARG;
+    if (H != 1 && H != 2 && H != 4 && H != 8) return MDL_E_UNSUPPORTED;
+    if (!(p_drop >= 0.f && p_drop < 1.f)) return MDL_E_ARG;
+    if (!host_aligned16(E_img) || !host_aligned16(dE) || !host_aligned16(Wa) || !host_aligned16(Wb) || !host_aligned16(act_a) ||
+        !host_aligned16(act_b) || !host_aligned16(wc) || !host_aligned16(ws))
+        return MDL_E_ALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    const DropCfg d = make_drop(p_drop, seed, keep_a, keep_b);
+    const SpBwdWs L = sp_bwd_ws(T, H);
+    char* base = (char*)ws;
+    char* WN = base + L.oWN;
+    char* dzi = base + L.odz;
+    float* slabW = (float*)(base + L.oslabW);
+    float* slabV = (float*)(base + L.oslabV);
+    float* sc = (float*)(base + L.osc);
+    if (L.nblk > 0x7fffffff) return MDL_E_UNSUPPORTED;
+    const PoolTerm pt{scores, stat_m, stat_l, d_pooled, row_bag, N};
+    if (phases & 1) {
+        hipError_t e = hipMemsetAsync(sc, 0, 8 * sizeof(float), s);
+        if (e != hipSuccess) return (int)e;
+        e = hipMemsetAsync(dzi + T * H * (int64_t)4096, 0, (size_t)SPK * H * 4096, s);   // zero pad rows of dz
+        if (e != hipSuccess) return (int)e;
+        // scales: weights from their exact absmax; dz from the bound |dz| <= max|ds| max|wc| / (1-p)^2
+        int rc = sp_launch_absmax(Wa, HID, (int64_t)H * HID, HID, sc + 1, s);
+        if (rc) return rc;
+        rc = sp_launch_absmax(Wb, HID, (int64_t)H * HID, HID, sc + 1, s);
+        if (rc) return rc;
+        rc = sp_launch_scale(sc, s);
+        if (rc) return rc;
+        rc = sp_launch_absmax_flat(d_scores, T * H, sc + 2, s);
+        if (rc) return rc;
+        rc = sp_launch_absmax_flat(wc, (int64_t)H * HID, sc + 3, s);
+        if (rc) return rc;
+        hipLaunchKernelGGL(sp_bound_scale_kernel, dim3(1), dim3(1), 0, s, (const float*)(sc + 2), d.inv * d.inv, sc + 4);
+        MDL_LAUNCH_CHECK();
+        if (T > 0) {
+            hipLaunchKernelGGL(sp_gate_dz_kernel, dim3((unsigned)L.nblk, H), dim3(256), 0, s, wc, act_a, act_b, d_scores, dzi,
+                               (const float*)(sc + 4), slabV, T, H, d);
+            MDL_LAUNCH_CHECK();
+        }
+        rc = gate_launch_reduce_v(slabV, dba, dbb, dwc, dbc, H, (int)L.nblk, s);
+        if (rc) return rc;
+    }
+    if (phases & 2) {
+        if (T > 0) {
+            hipLaunchKernelGGL(sp_gate_wn_kernel, dim3(16, 32, H), dim3(256), 0, s, Wa, Wb, WN, (const float*)sc);
+            MDL_LAUNCH_CHECK();
+            const int64_t n_tt = (T + SPM - 1) / SPM;
+            const int64_t grid = xcd_head_grid(n_tt, 2, H);
+            if (grid > 0x7fffffff) return MDL_E_UNSUPPORTED;
+            hipLaunchKernelGGL(sp_gate_dx_kernel, dim3((unsigned)grid), dim3(512), 0, s, (const char*)dzi, (const float*)(sc + 4),
+                               (const char*)WN, (const float*)sc, dE, ldE, accumulate, T, H, pt, dE_absmax);
+            MDL_LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL(sp_gate_dw_kernel, dim3((unsigned)xcd_head_grid(L.S, 8, H)), dim3(512), 0, s, (const char*)E_img, e_rsb, e_scale,
+                           (const char*)dzi, (const float*)(sc + 4), slabW, T, H, L.tps, L.S);
+        MDL_LAUNCH_CHECK();
+        const int rc = gate_launch_reduce_w(slabW, dWa, dWb, H, L.S, s);
+        if (rc) return rc;
+    }
+    return MDL_OK;
+}

@@ -331,6 +331,13 @@ static inline int64_t lin_small_ws(int M, int N, int K) { return (int64_t)lin_sm
 constexpr int LIN_SMALL_T = 256;   // at most this many rows: lin_small_kernel
 constexpr int LIN_COLSUM_BLOCKS = 512;
 
+// shared with split_gemm.hip: dW[n][k] = sum_s slab[s][k][n]
+int lin_launch_reduce(const float* slab, float* dW, int K, int N, int S, hipStream_t s) {
+    hipLaunchKernelGGL(lin_reduce_kernel, dim3(N / 32, K / 32), dim3(256), 0, s, slab, dW, K, N, S);
+    MDL_LAUNCH_CHECK();
+    return MDL_OK;
+}
+
 static inline int lin_splits(int64_t T, int N, int K) { return splits_for(T, ((K + LBM - 1) / LBM) * (N / LBN)); }
 static inline int64_t lin_tps(int64_t T, int S) {
     const int64_t tps = (T + S - 1) / S;

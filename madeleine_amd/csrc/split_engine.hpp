@@ -1,0 +1,325 @@
+// split_engine.hpp -- fp32-ACCURATE contractions on the fp16 matrix cores (round 3).
+//
+// Every fp32 contraction of the step is exact-fp32 work (parity at InfoNCE temperature 0.001 needs it), and
+// v_mfma_f32_32x32x2_f32 tops out at 157 TFLOP/s.  Here each fp32 operand value x (times a per-tensor power-of-two scale s) is
+// carried as TWO fp16 planes
+//         hi = RN16(s x),   lo = RN16(s x - hi)            ->  s x = hi + lo  up to 2^-23 |s x|
+// and a product as THREE v_mfma_f32_32x32x16_f16 terms accumulated in fp32:
+//         a b ~= ah bh + ah bl + al bh                      (al bl <= 2^-22 |a b| is dropped)
+// Each 16-bit product is exact in fp32; the accumulation is the matrix core's fp32 accumulation.  Measured (tools/micro/split_lab.hip,
+// K = 512 .. 2048, against fp64): max |err| / sum_k |a_k b_k| = 1.6e-7, rms 2.0e-8 -- BELOW the plain fp32 fmaf chain's 3.4e-7 / 3.0e-8
+// (fewer roundings: 16 k per accumulate).  3 x 32 MFMA cycles per 16 k against 8 x 64 for the fp32 instruction: the same contraction
+// in 19 % of the matrix-core cycles; the lab kernel sustains 290-330 TFLOP/s fp32-equivalent against the fp32 engine's 141.
+// fp16 has 5 exponent bits: s is chosen per tensor such that max |s x| < 2^15 (from an exact absmax or a rigorous bound); relative
+// representation error <= max(2^-23, 2^-25 / |s x|): values within 2^-16 of the maximum keep 21+ bits, smaller ones degrade
+// gracefully (absolute error <= 2^-38 of the tensor maximum -- far below the fp32 rounding of any sum they enter).
+//
+// SPLIT IMAGE of a matrix X [rows][K] (K % 32 == 0): uint16 [rows][K / 32][2 planes][32]  -- 128 B per row and 32-k block (one
+// cache line: hi plane | lo plane), i.e. exactly the bytes of the fp32 row.  One image serves both operand roles:
+//   NT  C[m][n] = sum_k A[m][k] B[n][k]   rows of both images are K-contiguous          (forward products, dX)
+//   TN  C[m][n] = sum_t A[t][m] B[t][n]   rows of both images are the contraction index  (dW; fragments by ds_read_b64_tr_b16)
+// Tile: 256 x 256 per 512-thread workgroup (8 waves as 2 x 4, 128 x 64 = 4 x 2 MFMA tiles per wave), one chunk = one 32-k block of
+// both operands = 2 x 32 KiB by LDS-DMA, two stages (128 KiB, one workgroup per CU), 48 MFMAs per wave and chunk, the in-wave
+// software pipeline of the other engines (fragments of the next MFMA set requested behind the first MFMA of the current one, one
+// barrier per chunk before its last set, the next-but-one chunk's DMA between that set's MFMAs).
+#pragma once
+#include "gate_common.hpp"
+
+namespace mdl {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int SPM = 256, SPN = 256, SPK = 32;
+constexpr int SP_STAGE = 256 * 128;   // bytes per operand per stage
+struct __attribute__((aligned(16))) SmemSP {
+    char A[2][SP_STAGE];
+    char B[2][SP_STAGE];
+};
+
+// a wave-uniform pointer the compiler can keep in SGPRs (saddr operand of the LDS-DMA)
+__device__ __forceinline__ const char* sp_uniform(const char* p) {
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+}
+
+#define SP_SB() __builtin_amdgcn_sched_barrier(0)
+#define SP_DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+
+__device__ __forceinline__ void sp_zero(f32x16 (&acc)[4][2]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+}
+__device__ __forceinline__ f32x16 sp_mfma(const u32x4& a, const u32x4& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+// ---- NT ---------------------------------------------------------------------------------------------------------------------------
+// LDS stage row = 128 B = 8 chunks of 16 B; chunk index = ks * 2 + kh with ks = plane * 2 + s (s = 16-k half of the block); 16-B
+// chunk c of tile row r is stored at chunk position c ^ ((r >> 1) & 7) (conflict-free ds_read_b128 on 128-B rows).
+// DMA piece i (0..3) of wave w for one operand: rows (4w + i) * 8 .. + 7; this lane deposits global chunk c of row `row`.
+__device__ __forceinline__ void sp_nt_slot(int wave, int i, int lane, int& row, int& c) {
+    row = (wave * 4 + i) * 8 + (lane >> 3);
+    c = (lane & 7) ^ ((row >> 1) & 7);
+}
+// dma(stage, block, piece): piece 0..3 = this wave's A row groups, 4..7 = its B row groups (glds16_s).
+template <class Dma>
+__device__ __forceinline__ void sp_nt_mainloop(SmemSP& sm, f32x16 (&acc)[4][2], int nblk, int wm, int wn, int lane, Dma&& dma) {
+    const int l32 = lane & 31, kh = lane >> 5;
+    uint32_t offA[4], offB[2];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+        const int r = wm * 128 + rt * 32 + l32;
+        offA[rt] = r * 128 + ((kh ^ ((r >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        const int r = wn * 64 + ct * 32 + l32;
+        offB[ct] = r * 128 + ((kh ^ ((r >> 1) & 7)) << 4);
+    }
+    auto ldA = [&](u32x4 (&fa)[4], int st, int ks) {
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) fa[rt] = *reinterpret_cast<const u32x4*>(&sm.A[st][offA[rt] ^ (ks << 5)]);
+    };
+    auto ldB = [&](u32x4 (&fb)[2], int st, int ks) {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) fb[ct] = *reinterpret_cast<const u32x4*>(&sm.B[st][offB[ct] ^ (ks << 5)]);
+    };
+    auto mma1 = [&](const u32x4 (&fa)[4], const u32x4 (&fb)[2], int m) {
+        const int rt = m >> 1, ct = m & 1;
+        acc[rt][ct] = sp_mfma(fa[rt], fb[ct], acc[rt][ct]);
+    };
+#define SP_SET(FA, FB, LOADS)                                                   \
+    mma1(FA, FB, 0);                                                            \
+    SP_SB();                                                                    \
+    LOADS;                                                                      \
+    SP_SB();                                                                    \
+    _Pragma("unroll") for (int m = 1; m < 8; ++m) mma1(FA, FB, m);              \
+    SP_SB();
+    if (nblk <= 0) return;
+    u32x4 a0[4], a1[4], a2[4], b0[2], b1[2], b2[2];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) dma(0, 0, p);
+    SP_DMA_WAIT();
+    __syncthreads();
+    {
+        const int f = nblk > 1 ? 1 : 0;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) dma(1, f, p);
+    }
+    ldA(a0, 0, 0);
+    ldB(b0, 0, 0);
+    for (int ch = 0; ch < nblk; ++ch) {
+        const int st = ch & 1;
+        // ks: 0 = hi k 0-15, 1 = hi k 16-31, 2 = lo k 0-15, 3 = lo k 16-31;  a0 = A hi s0, b0 = B hi s0 on entry
+        SP_SET(a0, b0, ldB(b1, st, 2))                   // hi hi, s0   | B lo s0
+        SP_SET(a0, b1, ldA(a1, st, 2))                   // hi lo, s0   | A lo s0
+        SP_SET(a1, b0, ldA(a2, st, 1); ldB(b2, st, 1))   // lo hi, s0   | A hi s1, B hi s1
+        SP_SET(a2, b2, ldB(b1, st, 3))                   // hi hi, s1   | B lo s1
+        SP_SET(a2, b1, ldA(a1, st, 3))                   // hi lo, s1   | A lo s1
+        // last set of the chunk: every read of stage st has been requested -> barrier, then the next chunk's first fragments and
+        // the DMA of block ch + 2 between this set's MFMAs (the last two iterations re-fetch the last block: branch-free body)
+        SP_DMA_WAIT();
+        __syncthreads();
+        ldA(a0, st ^ 1, 0);
+        ldB(b0, st ^ 1, 0);
+        SP_SB();
+        const int f = (ch + 2 < nblk) ? ch + 2 : nblk - 1;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            mma1(a1, b2, m);                             // lo hi, s1
+            SP_SB();
+            dma(st, f, m);
+            SP_SB();
+        }
+    }
+    SP_DMA_WAIT();
+    __syncthreads();   // staging memory is free for the epilogue
+#undef SP_SET
+}
+
+// ---- TN ---------------------------------------------------------------------------------------------------------------------------
+// LDS stage image of one operand: [64 kr][256 columns] fp16, kr = plane * 32 + token of the 32-token chunk, 512 B per kr row, 64-B
+// unit u of row kr stored at unit u ^ (kr & 3).  Fragments (8 consecutive tokens of the lane's output row / column) are gathered by
+// ds_read_b64_tr_b16 (lane mapping: tile_engine_bf16.hpp).  k-step KS = plane * 2 + s: + KS * 16 kr rows = KS * 8192 B.
+// DMA piece q (0..3) of wave w for one operand: kr rows (4w + q) * 2 + (lane >> 5); stored 16-B chunk position lane & 31 holds the
+// global chunk (lane & 31) ^ ((kr & 3) << 2)  (8 columns each).
+template <int OFF>
+__device__ __forceinline__ u32x2 sp_tr16(uint32_t lds_byte_addr) {
+    u32x2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(lds_byte_addr), "i"(OFF));
+    return v;
+}
+struct SpFragA {
+    u32x2 v[4][2];
+};
+struct SpFragB {
+    u32x2 v[2][2];
+};
+template <int KS>
+__device__ __forceinline__ void sp_tn_ldA(SpFragA& f, const uint32_t (&a)[4]) {
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+        f.v[rt][0] = sp_tr16<KS * 8192>(a[rt]);
+        f.v[rt][1] = sp_tr16<KS * 8192 + 2048>(a[rt]);
+    }
+}
+template <int KS>
+__device__ __forceinline__ void sp_tn_ldB(SpFragB& f, const uint32_t (&b)[2]) {
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        f.v[ct][0] = sp_tr16<KS * 8192>(b[ct]);
+        f.v[ct][1] = sp_tr16<KS * 8192 + 2048>(b[ct]);
+    }
+}
+__device__ __forceinline__ void sp_tn_mma(f32x16 (&acc)[4][2], const SpFragA& fa, const SpFragB& fb, int m) {
+    const int rt = m >> 1, ct = m & 1;
+    const u32x4 av = {fa.v[rt][0].x, fa.v[rt][0].y, fa.v[rt][1].x, fa.v[rt][1].y};
+    const u32x4 bv = {fb.v[ct][0].x, fb.v[ct][0].y, fb.v[ct][1].x, fb.v[ct][1].y};
+    acc[rt][ct] = sp_mfma(av, bv, acc[rt][ct]);
+}
+#define SP_LGKM_WAIT() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+// acc[rt][ct] += sum over nch chunks of 32 tokens of A[t][wm*128 + rt*32 ..] B[t][wn*64 + ct*32 ..];  dma(stage, chunk, piece 0..7)
+template <class Dma>
+__device__ __forceinline__ void sp_tn_mainloop(SmemSP& sm, f32x16 (&acc)[4][2], int64_t nch, int wm, int wn, int lane, Dma&& dma) {
+    const int g = lane >> 4, r = lane & 15;
+    const int kb = (g >> 1) * 8 + (r >> 2);
+    uint32_t a_0[4], b_0[2];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+        a_0[rt] = lds_addr_of(&sm.A[0][0]) + kb * 512 + (((wm * 128 + rt * 32 + (g & 1) * 16 + (r & 3) * 4) * 2) ^ ((kb & 3) << 6));
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+        b_0[ct] = lds_addr_of(&sm.B[0][0]) + kb * 512 + (((wn * 64 + ct * 32 + (g & 1) * 16 + (r & 3) * 4) * 2) ^ ((kb & 3) << 6));
+    if (nch <= 0) return;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) dma(0, (int64_t)0, p);
+    SP_DMA_WAIT();
+    __syncthreads();
+    {
+        const int64_t f = nch > 1 ? 1 : 0;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) dma(1, f, p);
+    }
+    SpFragA a0, a1, a2;
+    SpFragB b0, b1, b2;
+    sp_tn_ldA<0>(a0, a_0);
+    sp_tn_ldB<0>(b0, b_0);
+    SP_LGKM_WAIT();
+    SP_SB();
+#define SP_TSET(FA, FB, LOADS)                                                  \
+    sp_tn_mma(acc, FA, FB, 0);                                                  \
+    SP_SB();                                                                    \
+    LOADS;                                                                      \
+    SP_SB();                                                                    \
+    _Pragma("unroll") for (int m = 1; m < 8; ++m) sp_tn_mma(acc, FA, FB, m);    \
+    SP_SB();                                                                    \
+    SP_LGKM_WAIT();                                                             \
+    SP_SB();
+    for (int64_t ch = 0; ch < nch; ++ch) {
+        const int st = (int)(ch & 1);
+        uint32_t aA[4], aB[2], nA[4], nB[2];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+            aA[rt] = a_0[rt] + st * SP_STAGE;
+            nA[rt] = a_0[rt] + (st ^ 1) * SP_STAGE;
+        }
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            aB[ct] = b_0[ct] + st * SP_STAGE;
+            nB[ct] = b_0[ct] + (st ^ 1) * SP_STAGE;
+        }
+        SP_TSET(a0, b0, sp_tn_ldB<2>(b1, aB))                          // hi hi, s0 | B lo s0
+        SP_TSET(a0, b1, sp_tn_ldA<2>(a1, aA))                          // hi lo, s0 | A lo s0
+        SP_TSET(a1, b0, sp_tn_ldA<1>(a2, aA); sp_tn_ldB<1>(b2, aB))    // lo hi, s0 | A hi s1, B hi s1
+        SP_TSET(a2, b2, sp_tn_ldB<3>(b1, aB))                          // hi hi, s1 | B lo s1
+        SP_TSET(a2, b1, sp_tn_ldA<3>(a1, aA))                          // hi lo, s1 | A lo s1
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        SP_SB();
+        __syncthreads();
+        sp_tn_ldA<0>(a0, nA);
+        sp_tn_ldB<0>(b0, nB);
+        SP_SB();
+        const int64_t f = (ch + 2 < nch) ? ch + 2 : nch - 1;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            sp_tn_mma(acc, a1, b2, m);                                 // lo hi, s1
+            SP_SB();
+            dma(st, f, m);
+            SP_SB();
+        }
+        SP_LGKM_WAIT();
+        SP_SB();
+    }
+    SP_DMA_WAIT();
+    __syncthreads();
+#undef SP_TSET
+}
+
+// ---- epilogue through LDS ---------------------------------------------------------------------------------------------------------
+// Hands the wave's 128 x 64 sub-tile to emit(row, col, v) as row-contiguous float4s: columns col .. col + 3 of tile row `row` (tile
+// coordinates); 16 lanes cover 256 contiguous bytes of a row.  FULL = false skips rows >= rows_valid.  Call after the main loop
+// returned (staging memory free); wave-private LDS regions, no block barrier inside.
+template <bool FULL, int INFLIGHT = 4, class Emit>
+__device__ __forceinline__ void sp_epilogue_rows(const f32x16 (&acc)[4][2], SmemSP& sm, int wave, int wm, int wn, int lane,
+                                                 int rows_valid, Emit&& emit) {
+    float* tile = reinterpret_cast<float*>(&sm) + wave * (32 * 64);
+    const int l32 = lane & 31, rl = lane >> 4, c4 = lane & 15;
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) tile[acc_row(r, lane) * 64 + ct * 32 + l32] = acc[rt][ct][r];
+#pragma unroll
+        for (int h = 0; h < 8 / INFLIGHT; ++h) {   // INFLIGHT reads in flight, then their consumers (bounds the VGPRs)
+            f32x4 v[INFLIGHT];
+#pragma unroll
+            for (int j = 0; j < INFLIGHT; ++j)
+                v[j] = *reinterpret_cast<const f32x4*>(&tile[((h * INFLIGHT + j) * 4 + rl) * 64 + c4 * 4]);
+#pragma unroll
+            for (int j = 0; j < INFLIGHT; ++j) {
+                const int row = wm * 128 + rt * 32 + (h * INFLIGHT + j) * 4 + rl;
+                if (FULL || row < rows_valid) emit(row, wn * 64 + c4 * 4, v[j]);
+            }
+            SP_SB();
+        }
+    }
+}
+
+// absmax bookkeeping: non-negative floats order like their bit patterns
+__device__ __forceinline__ void sp_atomic_absmax(float* dst, float v) {
+    v = wave_max(v);
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(dst), __float_as_uint(v));
+}
+// scale 2^e with absmax * 2^e in [2^13, 2^14)  (1 for absmax = 0 / non-finite)
+__device__ __forceinline__ float sp_scale_for(float absmax) {
+    if (!(absmax > 0.f) || !(absmax < 3.0e38f)) return 1.f;
+    int e;
+    frexpf(absmax, &e);   // absmax = f 2^e, f in [0.5, 1)
+    return ldexpf(1.f, 14 - e);
+}
+// the two planes of 8 consecutive values (already scaled)
+__device__ __forceinline__ void sp_split8(const float (&v)[8], u32x4& hi, u32x4& lo) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    uint32_t h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const _Float16 h0 = (_Float16)v[2 * i], h1 = (_Float16)v[2 * i + 1];
+        const _Float16 l0 = (_Float16)(v[2 * i] - (float)h0), l1 = (_Float16)(v[2 * i + 1] - (float)h1);
+        h[i] = __builtin_bit_cast(uint32_t, h2{h0, h1});
+        l[i] = __builtin_bit_cast(uint32_t, h2{l0, l1});
+    }
+    hi = u32x4{h[0], h[1], h[2], h[3]};
+    lo = u32x4{l[0], l[1], l[2], l[3]};
+}
+// byte offset of the 16-B group holding columns k .. k + 7 (k % 8 == 0) of plane p within an image row
+__device__ __forceinline__ int64_t sp_img_off(int k, int p) { return (int64_t)(k >> 5) * 128 + p * 64 + (k & 31) * 2; }
+
+}  // namespace mdl

@@ -1,0 +1,266 @@
+// split_gemm.hip -- the generic entry points of the split-fp16 engine (split_engine.hpp): image construction from fp32 tensors and
+// the two contraction forms on images.  They carry every Linear of the encoder in the "split" GEMM mode (functional.LinearFn):
+//     forward : Y = X W^T            mdl_split_gemm_nt(A = image(X),  B = image(W))          reference Model.py:351, :355, :359
+//     dX      : dX = dY W            mdl_split_gemm_nt(A = image(dY), B = image(W^T))
+//     dW      : dW = dY^T X          mdl_split_gemm_tn(A = image(X),  B = image(dY)), split over tokens, slabs reduced + transposed
+// (the gate kernels with their fused epilogues on the same engine live in abmil_gate_split.hip).
+#include "split_engine.hpp"
+
+namespace mdl {
+
+int lin_launch_reduce(const float* slab, float* dW, int K, int N, int S, hipStream_t s);   // linear_fp32.hip
+
+// ---- image construction -------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sp_absmax_kernel(const float* __restrict__ X, int64_t ldx, int64_t rows, int K,
+                                                        float* __restrict__ out) {
+    const int64_t n4 = rows * (K / 4);
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / (K / 4);
+        const int c = (int)(i % (K / 4)) * 4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(X + r * ldx + c);
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    sp_atomic_absmax(out, m);
+}
+// sc[0] = scale from the absmax in sc[1]
+__global__ void sp_scale_kernel(float* __restrict__ sc) { sc[0] = sp_scale_for(sc[1]); }
+
+__global__ __launch_bounds__(256) void sp_absmax_flat_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+    sp_atomic_absmax(out, m);
+}
+// launchers shared with abmil_gate_split.hip / preattn_act.hip: *out is raised to max |X| (the caller zeroes it)
+int sp_launch_absmax(const float* X, int64_t ldx, int64_t rows, int K, float* out, hipStream_t s) {
+    if (rows <= 0) return MDL_OK;
+    const int64_t n4 = rows * (K / 4);
+    int nb = (int)((n4 + 256 * 8 - 1) / (256 * 8));
+    if (nb > 4096) nb = 4096;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(sp_absmax_kernel, dim3(nb), dim3(256), 0, s, X, ldx, rows, K, out);
+    MDL_LAUNCH_CHECK();
+    return MDL_OK;
+}
+int sp_launch_absmax_flat(const float* x, int64_t n, float* out, hipStream_t s) {
+    if (n <= 0) return MDL_OK;
+    int nb = (int)((n + 256 * 8 - 1) / (256 * 8));
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(sp_absmax_flat_kernel, dim3(nb), dim3(256), 0, s, x, n, out);
+    MDL_LAUNCH_CHECK();
+    return MDL_OK;
+}
+int sp_launch_scale(float* sc, hipStream_t s) {   // sc[0] = scale for the absmax in sc[1]
+    hipLaunchKernelGGL(sp_scale_kernel, dim3(1), dim3(1), 0, s, sc);
+    MDL_LAUNCH_CHECK();
+    return MDL_OK;
+}
+
+// img[r][k / 32][plane][k % 32] = planes of sc[0] * X[r][k]; one thread = 8 consecutive k
+__global__ __launch_bounds__(256) void sp_convert_kernel(const float* __restrict__ X, int64_t ldx, int64_t rows, int K,
+                                                         char* __restrict__ img, int64_t rsb, const float* __restrict__ sc) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int g = K / 8;
+    if (i >= rows * g) return;
+    const int64_t r = i / g;
+    const int k = (int)(i % g) * 8;
+    const float s = sc[0];
+    const f32x4 x0 = *reinterpret_cast<const f32x4*>(X + r * ldx + k), x1 = *reinterpret_cast<const f32x4*>(X + r * ldx + k + 4);
+    const float v[8] = {x0.x * s, x0.y * s, x0.z * s, x0.w * s, x1.x * s, x1.y * s, x1.z * s, x1.w * s};
+    u32x4 hi, lo;
+    sp_split8(v, hi, lo);
+    char* row = img + r * rsb;
+    *reinterpret_cast<u32x4*>(row + sp_img_off(k, 0)) = hi;
+    *reinterpret_cast<u32x4*>(row + sp_img_off(k, 1)) = lo;
+}
+
+// ---- NT -------------------------------------------------------------------------------------------------------------------------------
+// C[m][n] (+)= inv * sum_k A[m][k] B[n][k] (+ bias[n]);  rows m >= M / n >= N re-read the last valid row (discarded).
+__global__ __launch_bounds__(512) void sp_nt_kernel(const char* __restrict__ A, int64_t a_rsb, const float* __restrict__ a_sc,
+                                                    const char* __restrict__ B, int64_t b_rsb, const float* __restrict__ b_sc,
+                                                    float* __restrict__ C, int64_t ldc, int64_t M, int N, int nblk, int n_tiles,
+                                                    const float* __restrict__ bias, int accumulate, float* __restrict__ absmax_out) {
+    __shared__ SmemSP sm;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int ncol = (N + SPN - 1) / SPN;
+    const int lid = xcd_remap(blockIdx.x, n_tiles);
+    const int nt = lid % ncol;
+    const int64_t m0 = (int64_t)(lid / ncol) * SPM;
+    const int n0 = nt * SPN;
+
+    const char* baseA = A + m0 * a_rsb;
+    const char* baseB = B + (int64_t)n0 * b_rsb;
+    uint32_t voA[4], voB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int row, c;
+        sp_nt_slot(wave, i, lane, row, c);
+        int64_t ra = row, rb = row;
+        if (m0 + ra > M - 1) ra = M - 1 - m0;
+        if (n0 + rb > N - 1) rb = N - 1 - n0;
+        voA[i] = (uint32_t)(ra * a_rsb + c * 16);
+        voB[i] = (uint32_t)(rb * b_rsb + c * 16);
+    }
+    f32x16 acc[4][2];
+    sp_zero(acc);
+    sp_nt_mainloop(sm, acc, nblk, wm, wn, lane, [&](int st, int f, int piece) {
+        const int i = piece & 3;
+        if (piece < 4) glds16_s(voA[i], baseA + (int64_t)f * 128, lds_addr_of(&sm.A[st][(wave * 4 + i) * 1024]));
+        else glds16_s(voB[i], baseB + (int64_t)f * 128, lds_addr_of(&sm.B[st][(wave * 4 + i) * 1024]));
+    });
+    const float inv = 1.f / (a_sc[0] * b_sc[0]);
+    float amax = 0.f;
+    char* cb = reinterpret_cast<char*>(C + m0 * ldc + n0);
+    const uint32_t ldc4 = (uint32_t)ldc * 4u;
+    const int cols_valid = N - n0;
+    auto emit = [&](int row, int col, const f32x4& v) {
+        if (col >= cols_valid) return;
+        f32x4 r = v * inv;
+        if (bias) r += *reinterpret_cast<const f32x4*>(bias + n0 + col);
+        f32x4* o = reinterpret_cast<f32x4*>(cb + (int64_t)row * ldc4 + (uint32_t)col * 4u);
+        if (accumulate) r += *o;
+        *o = r;
+        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));
+    };
+    if (m0 + SPM <= M) sp_epilogue_rows<true>(acc, sm, wave, wm, wn, lane, SPM, emit);
+    else sp_epilogue_rows<false>(acc, sm, wave, wm, wn, lane, (int)(M - m0), emit);
+    if (absmax_out) sp_atomic_absmax(absmax_out, amax);
+}
+
+// ---- TN -------------------------------------------------------------------------------------------------------------------------------
+// slab[sp][m][n] = inv * sum_{t in split sp} A[t][m] B[t][n].  A rows t >= T re-read row T - 1; the B image must continue with >= 32
+// all-zero rows after row T - 1 (their products vanish).  Columns >= Mi / >= N fetch column 0 (discarded).
+__global__ __launch_bounds__(512) void sp_tn_kernel(const char* __restrict__ A, int64_t a_rsb, const float* __restrict__ a_sc, int Mi,
+                                                    const char* __restrict__ B, int64_t b_rsb, const float* __restrict__ b_sc, int N,
+                                                    float* __restrict__ slab, int64_t T, int64_t tok_per_split, int n_tiles) {
+    __shared__ SmemSP sm;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int nmt = (Mi + SPM - 1) / SPM, nnt = (N + SPN - 1) / SPN;
+    const int lid = xcd_remap(blockIdx.x, n_tiles);
+    const int mt = lid % nmt, nt = (lid / nmt) % nnt, sp = lid / (nmt * nnt);
+    const int i0 = mt * SPM, n0 = nt * SPN;
+    const int64_t ts = (int64_t)sp * tok_per_split;
+    int64_t te = ts + tok_per_split;
+    if (te > T) te = T;
+    const int64_t nch = (te > ts) ? (te - ts + SPK - 1) / SPK : 0;
+
+    // per piece q: kr = (4w + q) * 2 + (lane >> 5): plane = kr >> 5, token = kr & 31; global chunk src = (lane & 31) ^ ((kr & 3) << 2)
+    uint32_t tokq[4], coA[4], coB[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int kr = (wave * 4 + q) * 2 + (lane >> 5), p = kr >> 5, src = (lane & 31) ^ ((kr & 3) << 2);
+        tokq[q] = kr & 31;
+        const int ca = i0 + src * 8, cbn = n0 + src * 8;
+        coA[q] = (uint32_t)sp_img_off(ca < Mi ? ca : 0, p);
+        coB[q] = (uint32_t)sp_img_off(cbn < N ? cbn : 0, p);
+    }
+    const char* baseA = A + ts * a_rsb;
+    const char* baseB = B + ts * b_rsb;
+    f32x16 acc[4][2];
+    sp_zero(acc);
+    sp_tn_mainloop(sm, acc, nch, wm, wn, lane, [&](int st, int64_t f, int piece) {
+        const int q = piece & 3;
+        if (piece < 4) {
+            uint32_t tk = tokq[q];
+            const int64_t left = T - 1 - (ts + f * SPK);   // >= 0
+            if (left < SPK) tk = tk < (uint32_t)left ? tk : (uint32_t)left;   // uniform branch: only the chunk at the end of A
+            glds16_s(tk * (uint32_t)a_rsb + coA[q], baseA + f * SPK * a_rsb, lds_addr_of(&sm.A[st][(wave * 4 + q) * 1024]));
+        } else {
+            glds16_s(tokq[q] * (uint32_t)b_rsb + coB[q], baseB + f * SPK * b_rsb, lds_addr_of(&sm.B[st][(wave * 4 + q) * 1024]));
+        }
+    });
+    const float inv = 1.f / (a_sc[0] * b_sc[0]);
+    float* so = slab + (int64_t)sp * Mi * N + (int64_t)i0 * N + n0;
+    const int cols_valid = N - n0;
+    auto emit = [&](int row, int col, const f32x4& v) {
+        if (col >= cols_valid) return;
+        *reinterpret_cast<f32x4*>(so + (int64_t)row * N + col) = v * inv;
+    };
+    if (i0 + SPM <= Mi) sp_epilogue_rows<true>(acc, sm, wave, wm, wn, lane, SPM, emit);
+    else sp_epilogue_rows<false>(acc, sm, wave, wm, wn, lane, Mi - i0, emit);
+}
+
+static inline int sp_tn_splits(int64_t T, int Mi, int N) {
+    const int tiles = ((Mi + SPM - 1) / SPM) * ((N + SPN - 1) / SPN);
+    return splits_for(T, tiles, 256);   // one workgroup per CU
+}
+static inline int64_t sp_tn_tps(int64_t T, int S) {
+    const int64_t tps = (T + S - 1) / S;
+    return ((tps + SPK - 1) / SPK) * SPK;
+}
+
+}  // namespace mdl
+
+using namespace mdl;
+
+/* Builds the split image of X [rows, K] (row stride ldx floats): img rows of rsb bytes (>= 4 K), `pad_rows` all-zero rows appended
+ * (the B operand of mdl_split_gemm_tn needs 32).  scale (device float[2]) receives {scale, absmax}. */
+extern "C" int mdl_split_image(const float* X, int64_t ldx, int64_t rows, int K, void* img, int64_t rsb, int64_t pad_rows,
+                               float* scale, void* stream) {
+    if (!X || !img || !scale || rows < 0 || K < 32 || (K % 32) || ldx < K || (ldx & 3) || rsb < (int64_t)K * 4 || (rsb & 15) || pad_rows < 0)
+        return MDL_E_ARG;
+    if (!host_aligned16(X) || !host_aligned16(img)) return MDL_E_ALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(scale, 0, 2 * sizeof(float), s);
+    if (e != hipSuccess) return (int)e;
+    if (pad_rows > 0) {
+        e = hipMemsetAsync((char*)img + rows * rsb, 0, (size_t)(pad_rows * rsb), s);
+        if (e != hipSuccess) return (int)e;
+    }
+    int rc = sp_launch_absmax(X, ldx, rows, K, scale + 1, s);
+    if (rc) return rc;
+    rc = sp_launch_scale(scale, s);
+    if (rc) return rc;
+    if (rows > 0) {
+        const int64_t n = rows * (K / 8);
+        hipLaunchKernelGGL(sp_convert_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, X, ldx, rows, K, (char*)img, rsb,
+                           (const float*)scale);
+        MDL_LAUNCH_CHECK();
+    }
+    return MDL_OK;
+}
+
+/* C [M, N] (row stride ldc floats) (+)= sum_k A[m][k] B[n][k] (+ bias[n]) on the split images A (M rows) and B (N rows) of K columns;
+ * a_scale / b_scale: device floats, the images' scales.  absmax_out (device float, may be NULL): atomically raised to max |C|
+ * (the caller zeroes it).  N % 4 == 0, K % 32 == 0. */
+extern "C" int mdl_split_gemm_nt(const void* A, int64_t a_rsb, const float* a_scale, const void* B, int64_t b_rsb, const float* b_scale,
+                                 float* C, int64_t ldc, int64_t M, int N, int K, const float* bias, int accumulate, float* absmax_out,
+                                 void* stream) {
+    if (!A || !B || !C || !a_scale || !b_scale || M < 0 || N < 4 || (N & 3) || K < 32 || (K % 32) || ldc < N || (ldc & 3)) return MDL_E_ARG;
+    if (a_rsb < (int64_t)K * 4 || b_rsb < (int64_t)K * 4 || (a_rsb & 15) || (b_rsb & 15)) return MDL_E_ARG;
+    if (!host_aligned16(A) || !host_aligned16(B) || !host_aligned16(C) || !host_aligned16(bias)) return MDL_E_ALIGN;
+    if (M == 0) return MDL_OK;
+    const int64_t tiles = ((M + SPM - 1) / SPM) * ((N + SPN - 1) / SPN);
+    if (tiles > 0x7fffffff || a_rsb * SPM > 0x7fffffff || b_rsb * SPN > 0x7fffffff) return MDL_E_UNSUPPORTED;
+    hipLaunchKernelGGL(sp_nt_kernel, dim3((unsigned)tiles), dim3(512), 0, (hipStream_t)stream, (const char*)A, a_rsb, a_scale,
+                       (const char*)B, b_rsb, b_scale, C, ldc, M, N, K / 32, (int)tiles, bias, accumulate, absmax_out);
+    MDL_LAUNCH_CHECK();
+    return MDL_OK;
+}
+
+extern "C" int64_t mdl_split_gemm_tn_ws_bytes(int64_t T, int Mi, int N) {
+    if (T < 0 || Mi < 32 || N < 32) return MDL_E_ARG;
+    return (int64_t)sp_tn_splits(T, Mi, N) * Mi * N * 4 + 64;
+}
+
+/* out [N][Mi] (contiguous: a Linear's dW with A = image(X), B = image(dY)) = sum_t B[t][n] A[t][m] over the T rows of the two
+ * token-major images (Mi / N columns).  The B image must be followed by >= 32 all-zero rows.  Mi % 32 == 0, N % 32 == 0. */
+extern "C" int mdl_split_gemm_tn(const void* A, int64_t a_rsb, const float* a_scale, int Mi, const void* B, int64_t b_rsb,
+                                 const float* b_scale, int N, float* out, int64_t T, void* ws, void* stream) {
+    if (!A || !B || !out || !ws || !a_scale || !b_scale || T < 0 || Mi < 32 || (Mi % 32) || N < 32 || (N % 32)) return MDL_E_ARG;
+    if (a_rsb < (int64_t)Mi * 4 || b_rsb < (int64_t)N * 4 || (a_rsb & 15) || (b_rsb & 15) || a_rsb * 32 > 0x7fffffff || b_rsb * 32 > 0x7fffffff)
+        return MDL_E_ARG;
+    if (!host_aligned16(A) || !host_aligned16(B) || !host_aligned16(out) || !host_aligned16(ws)) return MDL_E_ALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    const int S = sp_tn_splits(T, Mi, N);
+    const int64_t tps = sp_tn_tps(T, S);
+    const int tiles = ((Mi + SPM - 1) / SPM) * ((N + SPN - 1) / SPN) * S;
+    hipLaunchKernelGGL(sp_tn_kernel, dim3(tiles), dim3(512), 0, s, (const char*)A, a_rsb, a_scale, Mi, (const char*)B, b_rsb, b_scale, N,
+                       (float*)ws, T, tps, tiles);
+    MDL_LAUNCH_CHECK();
+    return lin_launch_reduce((const float*)ws, out, Mi, N, S, s);
+}

@@ -7,6 +7,7 @@ points; anything else raises (there is no CPU or eager fallback).
 
 Layouts (see include/madeleine_amd.h): token embeddings are head-major [T, H*512]; scores [T, H].
 """
+import os
 from typing import Optional
 
 import torch
@@ -126,6 +127,52 @@ def gate_fwd_raw(E2d, Wa, ba, Wb, bb, wc, bc, p_drop, seed, keep_a, keep_b, save
     return scores, act_a, act_b
 
 
+def gate_fwd_split_raw(Ei, Wa, ba, Wb, bb, wc, bc, p_drop, seed, keep_a, keep_b, save_act: bool):
+    """gate_fwd_raw on the split engine: Ei = SplitImage of the head-major token embeddings [T, H*512]."""
+    lib = _native.lib()
+    T, H = Ei.rows, Wa.shape[0]
+    dev = Ei.data.device
+    scores = torch.empty(T, H, device=dev, dtype=torch.float32)
+    act_a = torch.empty(T, H, HID, device=dev, dtype=torch.float32) if save_act else None
+    act_b = torch.empty(T, H, HID, device=dev, dtype=torch.float32) if save_act else None
+    ws = _ws(lib.mdl_abmil_gate_fwd_split_ws_bytes(T, H), dev)
+    with _timed("gate_fwd", ("flop", 2.0 * T * H * HID * 2 * HID)):
+        rc = lib.mdl_abmil_gate_fwd_split(_ptr(Ei.data), Ei.K * 4, _ptr(Ei.scale), _ptr(Wa), _ptr(ba), _ptr(Wb), _ptr(bb), _ptr(wc), _ptr(bc),
+                                          _ptr(scores), _ptr(act_a), _ptr(act_b), T, H, float(p_drop), int(seed), _ptr(keep_a), _ptr(keep_b),
+                                          _ptr(ws), _stream())
+    _native.check(rc, "mdl_abmil_gate_fwd_split")
+    return scores, act_a, act_b
+
+
+def attnpool_bwd_split_raw(Ei, Wa, Wb, wc, act_a, act_b, d_scores, dE, p_drop, seed, keep_a, keep_b, scores, stat_m, stat_l, d_pooled,
+                           row_bag, N, accumulate=0, dE_absmax=None):
+    """attnpool_bwd_raw (scores None: gate_bwd_raw) on the split engine."""
+    lib = _native.lib()
+    T, H = Ei.rows, Wa.shape[0]
+    dev = Ei.data.device
+    dWa, dWb = torch.empty_like(Wa), torch.empty_like(Wb)
+    dba = torch.empty(H, HID, device=dev, dtype=torch.float32)
+    dbb, dwc = torch.empty_like(dba), torch.empty_like(dba)
+    dbc = torch.empty(H, device=dev, dtype=torch.float32)
+    ws = _ws(lib.mdl_abmil_gate_bwd_split_ws_bytes(T, H), dev)
+
+    def call(phases):
+        rc = lib.mdl_abmil_attnpool_bwd_split(_ptr(Ei.data), Ei.K * 4, _ptr(Ei.scale), _ptr(Wa), _ptr(Wb), _ptr(wc), _ptr(act_a), _ptr(act_b),
+                                              _ptr(d_scores), _ptr(dE), dE.stride(0), int(accumulate), _ptr(dWa), _ptr(dWb), _ptr(dba), _ptr(dbb),
+                                              _ptr(dwc), _ptr(dbc), T, H, float(p_drop), int(seed), _ptr(keep_a), _ptr(keep_b), _ptr(scores),
+                                              _ptr(stat_m), _ptr(stat_l), _ptr(d_pooled), _ptr(row_bag), int(N), _ptr(dE_absmax), _ptr(ws),
+                                              _stream(), phases)
+        _native.check(rc, "mdl_abmil_attnpool_bwd_split")
+    if TIMER is not None:
+        with _timed("gate_bwd_dz", ("byte", float(T) * H * 4 * HID * 4)):
+            call(1)
+        with _timed("gate_bwd_gemm", ("flop", 4.0 * T * H * HID * 2 * HID)):
+            call(2)
+    else:
+        call(3)
+    return dWa, dWb, dba, dbb, dwc, dbc
+
+
 def gate_bwd_raw(E2d, Wa, Wb, wc, act_a, act_b, d_scores, dE, accumulate, p_drop, seed, keep_a, keep_b):
     lib = _native.lib()
     T, H = E2d.shape[0], Wa.shape[0]
@@ -233,6 +280,117 @@ def pool_view_bwd_raw(E2d, scores, pooled, stat_m, stat_l, d_pooled, dE, d_score
     _native.check(rc, "mdl_abmil_pool_view_bwd")
 
 
+# --------------------------------------------------------------------------------------------------
+# split-fp16 engine (include/madeleine_amd.h, csrc/split_engine.hpp): fp32-accurate contractions on v_mfma_f32_32x32x16_f16
+# --------------------------------------------------------------------------------------------------
+GEMM_MODE = os.environ.get("MADELEINE_GEMM", "split")   # "split": 3-term split-fp16 products; "fp32": v_mfma_f32_32x32x2_f32
+
+
+def gemm_mode() -> str:
+    return GEMM_MODE
+
+
+def set_gemm_mode(mode: str):
+    """'split' (default): the fp32 contractions run as ah bh + ah bl + al bh on the fp16 matrix cores (fp32-level accuracy, ~2x the
+    rate); 'fp32': the exact-fp32 matrix-core kernels (v_mfma_f32_32x32x2_f32)."""
+    global GEMM_MODE
+    if mode not in ("split", "fp32"):
+        raise ValueError("gemm mode must be 'split' or 'fp32'")
+    GEMM_MODE = mode
+
+
+class SplitImage:
+    """Split image of a [rows, K] fp32 tensor: `data` float32 [rows + pad, K] (opaque bytes: per 32-column block the fp16 hi plane
+    | lo plane), `scale` float32 [2] = {scale, absmax} on the device."""
+    __slots__ = ("data", "scale", "rows", "K")
+
+    def __init__(self, data, scale, rows, K):
+        self.data, self.scale, self.rows, self.K = data, scale, rows, K
+
+
+def split_image(x2d, pad_rows=0) -> SplitImage:
+    _require(x2d, "x")
+    lib = _native.lib()
+    rows, K = x2d.shape
+    data = torch.empty(rows + pad_rows, K, device=x2d.device, dtype=torch.float32)
+    scale = torch.empty(2, device=x2d.device, dtype=torch.float32)
+    with _timed("split_image", ("byte", 12.0 * rows * K)):   # absmax read + convert read + write
+        rc = lib.mdl_split_image(_ptr(x2d), x2d.stride(0), rows, K, _ptr(data), K * 4, pad_rows, _ptr(scale), _stream())
+    _native.check(rc, "mdl_split_image")
+    return SplitImage(data, scale, rows, K)
+
+
+def split_gemm_nt(A: SplitImage, B: SplitImage, bias=None, out=None, accumulate=False, absmax_out=None, name="split_nt"):
+    """C [A.rows, B.rows] (+)= A B^T (+ bias) on two images with the same K."""
+    lib = _native.lib()
+    M, N, K = A.rows, B.rows, A.K
+    if B.K != K:
+        raise ValueError("split_gemm_nt: contraction lengths differ")
+    C = out if out is not None else torch.empty(M, N, device=A.data.device, dtype=torch.float32)
+    with _timed(name, ("flop", 2.0 * M * N * K)):
+        rc = lib.mdl_split_gemm_nt(_ptr(A.data), K * 4, _ptr(A.scale), _ptr(B.data), K * 4, _ptr(B.scale), _ptr(C), C.stride(0), M, N, K,
+                                   _ptr(bias), int(accumulate), _ptr(absmax_out), _stream())
+    _native.check(rc, "mdl_split_gemm_nt")
+    return C
+
+
+def split_gemm_tn(A: SplitImage, B: SplitImage, name="split_tn"):
+    """out [B.K, A.K] = B^T A summed over the rows (tokens) of the two images; B must carry >= 32 zero pad rows."""
+    lib = _native.lib()
+    T, Mi, N = A.rows, A.K, B.K
+    if B.rows != T or B.data.shape[0] < T + 32:
+        raise ValueError("split_gemm_tn: images need the same number of rows and B 32 zero pad rows")
+    out = torch.empty(N, Mi, device=A.data.device, dtype=torch.float32)
+    ws = _ws(lib.mdl_split_gemm_tn_ws_bytes(T, Mi, N), A.data.device)
+    with _timed(name, ("flop", 2.0 * T * Mi * N)):
+        rc = lib.mdl_split_gemm_tn(_ptr(A.data), Mi * 4, _ptr(A.scale), Mi, _ptr(B.data), N * 4, _ptr(B.scale), N, _ptr(out), T, _ptr(ws),
+                                   _stream())
+    _native.check(rc, "mdl_split_gemm_tn")
+    return out
+
+
+def _split_gate(E2d) -> bool:
+    """The gate (A2) contractions take the split engine for fp32 token embeddings in the 'split' GEMM mode."""
+    return GEMM_MODE == "split" and E2d.dtype == torch.float32 and E2d.shape[0] > 0
+
+
+def split_linear_supported(T, N, K) -> bool:
+    """Geometries the split engine takes for a Linear [T,K] x [N,K]: fwd K % 32, N % 4; dX: N % 32 (contraction), K % 4; dW: both % 32."""
+    return T > 256 and K % 32 == 0 and N % 32 == 0
+
+
+class SplitLinearFn(torch.autograd.Function):
+    """LinearFn in the split GEMM mode: Y = X W^T (+ bias) with fp32 inputs / outputs, the contraction on the split-fp16 engine.
+    x may be given as a ready SplitImage (`x_img`, from a producer kernel that writes images directly); otherwise it is built here."""
+
+    @staticmethod
+    def forward(ctx, x, W, bias):
+        _require(x, "x")
+        _require(W, "weight")
+        if bias is not None:
+            _require(bias, "bias")
+        xi = split_image(x)
+        y = split_gemm_nt(xi, split_image(W), bias, name="linear_fwd")
+        ctx.xi = xi
+        ctx.save_for_backward(W)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (W,) = ctx.saved_tensors
+        xi = ctx.xi
+        ctx.xi = None
+        dy = dy.float().contiguous()
+        dyi = split_image(dy, pad_rows=32)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = split_gemm_nt(dyi, split_image(W.t().contiguous()), name="linear_bwd")
+        dW = split_gemm_tn(xi, dyi, name="linear_bwd")
+        db = dy.sum(0) if ctx.has_bias else None
+        return dx, dW, db
+
+
 def linear_fwd_raw(x2d, W, bias):
     """Y = X W^T (+ bias) through mdl_linear_fwd / mdl_linear_fwd_bf16 (by the storage type of x2d)."""
     lib = _native.lib()
@@ -290,7 +448,13 @@ class GateScoresFn(torch.autograd.Function):
         for t, n in ((Wa, "Wa"), (ba, "ba"), (Wb, "Wb"), (bb, "bb"), (wc, "wc"), (bc, "bc")):
             _require(t, n)
         need = any(ctx.needs_input_grad[:7])
-        scores, act_a, act_b = gate_fwd_raw(E2d, Wa, ba, Wb, bb, wc, bc, p_drop, seed, keep_a, keep_b, need)
+        ctx.Ei = None
+        if _split_gate(E2d):
+            Ei = split_image(E2d)
+            scores, act_a, act_b = gate_fwd_split_raw(Ei, Wa, ba, Wb, bb, wc, bc, p_drop, seed, keep_a, keep_b, need)
+            ctx.Ei = Ei if need else None
+        else:
+            scores, act_a, act_b = gate_fwd_raw(E2d, Wa, ba, Wb, bb, wc, bc, p_drop, seed, keep_a, keep_b, need)
         if need:
             ctx.save_for_backward(E2d, Wa, Wb, wc, act_a, act_b)
             ctx.drop = (p_drop, seed, keep_a, keep_b)
@@ -302,8 +466,13 @@ class GateScoresFn(torch.autograd.Function):
         p_drop, seed, keep_a, keep_b = ctx.drop
         d_scores = d_scores.float().contiguous()
         dE = torch.empty_like(E2d)
-        dWa, dWb, dba, dbb, dwc, dbc = gate_bwd_raw(E2d, Wa, Wb, wc, act_a, act_b, d_scores, dE, 0, p_drop, seed, keep_a,
-                                                    keep_b)
+        if ctx.Ei is not None:
+            dWa, dWb, dba, dbb, dwc, dbc = attnpool_bwd_split_raw(ctx.Ei, Wa, Wb, wc, act_a, act_b, d_scores, dE, p_drop, seed, keep_a,
+                                                                  keep_b, None, None, None, None, None, 0)
+            ctx.Ei = None
+        else:
+            dWa, dWb, dba, dbb, dwc, dbc = gate_bwd_raw(E2d, Wa, Wb, wc, act_a, act_b, d_scores, dE, 0, p_drop, seed, keep_a,
+                                                        keep_b)
         return dE, dWa, dba, dWb, dbb, dwc, dbc, None, None, None, None
 
 
@@ -402,7 +571,13 @@ class AttnPoolFn(torch.autograd.Function):
             _require(v, "view token indices", torch.int32)
         ctx.set_materialize_grads(False)
         need = any(ctx.needs_input_grad[:7]) or any(ctx.needs_input_grad[13:15])
-        scores, act_a, act_b = gate_fwd_raw(E2d, Wa, ba, Wb, bb, wc, bc, p_drop, seed, keep_a, keep_b, need)
+        ctx.Ei = None
+        if _split_gate(E2d):
+            Ei = split_image(E2d)
+            scores, act_a, act_b = gate_fwd_split_raw(Ei, Wa, ba, Wb, bb, wc, bc, p_drop, seed, keep_a, keep_b, need)
+            ctx.Ei = Ei if need else None
+        else:
+            scores, act_a, act_b = gate_fwd_raw(E2d, Wa, ba, Wb, bb, wc, bc, p_drop, seed, keep_a, keep_b, need)
         pooled, m, l = pool_fwd_raw(E2d, scores, n_bags, N, cu_seqlens, max_len)
         vstate = [pool_view_fwd_raw(E2d, scores, n_bags, N, v) for v in views]
         if Wtok is not None:
@@ -456,8 +631,13 @@ class AttnPoolFn(torch.autograd.Function):
         row_bag = None
         if ragged:   # bag index of every packed token row, on the device (no sync)
             row_bag = torch.searchsorted(cu[1:].contiguous(), torch.arange(E2d.shape[0], device=E2d.device), right=True).to(torch.int32)
-        dWa, dWb, dba, dbb, dwc, dbc = attnpool_bwd_raw(E2d, Wa, Wb, wc, act_a, act_b, ds, dE, p_drop, seed, keep_a, keep_b,
-                                                        scores, m, l, d_main, row_bag, N if not ragged else 0, acc_e)
+        if ctx.Ei is not None:
+            dWa, dWb, dba, dbb, dwc, dbc = attnpool_bwd_split_raw(ctx.Ei, Wa, Wb, wc, act_a, act_b, ds, dE, p_drop, seed, keep_a, keep_b,
+                                                                  scores, m, l, d_main, row_bag, N if not ragged else 0, acc_e)
+            ctx.Ei = None
+        else:
+            dWa, dWb, dba, dbb, dwc, dbc = attnpool_bwd_raw(E2d, Wa, Wb, wc, act_a, act_b, ds, dE, p_drop, seed, keep_a, keep_b,
+                                                            scores, m, l, d_main, row_bag, N if not ragged else 0, acc_e)
         for i in range(V):   # ... and their dE terms are added once dE has been written (no read of E)
             vp, vm, vl = vflat[3 * i:3 * i + 3]
             pool_view_bwd_raw(E2d, scores, vp, vm, vl, d_pooled[:, 1 + i].contiguous(), dE, None, n_bags, N, views[i])
@@ -603,6 +783,8 @@ def linear(x, W, bias=None):
     if x.dtype == torch.bfloat16 and x2.shape[0] <= 256:
         # a handful of rows (one short bag under autocast): exact fp32 FMA kernel on the widened rows, result stored as bf16
         y = LinearFn.apply(x2.float(), Wc, bc).to(torch.bfloat16)
+    elif x.dtype == torch.float32 and GEMM_MODE == "split" and split_linear_supported(x2.shape[0], W.shape[0], W.shape[1]):
+        y = SplitLinearFn.apply(x2, Wc, bc)
     else:
         y = (LinearBf16Fn if x.dtype == torch.bfloat16 else LinearFn).apply(x2, Wc, bc)
     return y.view(*lead, W.shape[0])

@@ -1,0 +1,104 @@
+"""Split-fp16 contraction engine (csrc/split_engine.hpp, include/madeleine_amd.h): image construction and the NT / TN products
+through the C ABI against fp64, at the tolerance of the exact-fp32 kernels (1e-6 relative, tests/test_hip_kernels.py:test_linear_vs_torch)
+-- the engine replaces fp32 contractions of the reference (nn.Linear, madeleine/models/Model.py:351) and must not cost accuracy."""
+import numpy as np
+import pytest
+import torch
+
+from tests._util import rel_err, t
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _decode(img, rows, K):
+    """fp64 value of every element of a split image: (hi + lo) / scale."""
+    raw = img.data[:rows].contiguous().view(torch.int16).view(rows, K // 32, 2, 32)
+    hl = raw.view(torch.float16).double()
+    return (hl[:, :, 0] + hl[:, :, 1]).reshape(rows, K) / float(img.scale[0])
+
+
+@pytest.mark.parametrize("rows,K,spread", [(300, 512, 1.0), (77, 2048, 1e4), (1, 32, 1.0)])
+def test_split_image_represents_fp32(dev, rows, K, spread):
+    """hi + lo carries 21+ bits of every value that lies within 2^16 of the tensor maximum (relative error <= max(2^-23,
+    2^-25 / |scaled value|)); the scale is a power of two with the scaled maximum in [2^13, 2^14); pad rows are zero."""
+    from madeleine_amd import functional as MF
+    x = t((rows, K), f"spi:{rows}{K}") * torch.logspace(0, np.log10(spread), K)
+    img = MF.split_image(x.to(dev), pad_rows=32)
+    s, amax = float(img.scale[0]), float(img.scale[1])
+    assert amax == float(x.abs().max()) and np.log2(s) == int(np.log2(s)) and 2 ** 13 <= amax * s < 2 ** 14
+    dec = _decode(img, rows, K).cpu()
+    big = x.abs() >= amax * 2.0 ** -16
+    assert float(((dec - x.double()).abs() / x.double().abs().clamp_min(1e-300))[big].max()) < 2.0 ** -21
+    small = ~big                                                               # graceful below: absolute error <= 2^-38 of the maximum
+    assert (not small.any()) or float((dec - x.double()).abs()[small].max()) <= amax * 2.0 ** -38
+    assert float(img.data[rows:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 512, 512), (1000, 2048, 512), (513, 800, 512), (2500, 512, 1056), (257, 4, 32),
+                                   (256 * 3, 256, 2048)])
+def test_split_gemm_nt_vs_fp64(dev, M, N, K):
+    from madeleine_amd import functional as MF
+    a = t((M, K), f"spn:a{M}{K}") * 3
+    b = 0.05 * t((N, K), f"spn:b{N}{K}")
+    bias = 0.3 * t((N,), f"spn:c{N}")
+    ref = a.double() @ b.double().t()
+    A, B = MF.split_image(a.to(dev)), MF.split_image(b.to(dev))
+    C = MF.split_gemm_nt(A, B)
+    assert rel_err(C, ref) < 1e-6
+    amax = torch.zeros(1, device=dev)
+    C2 = MF.split_gemm_nt(A, B, bias.to(dev), out=C.clone(), accumulate=True, absmax_out=amax)
+    assert rel_err(C2, 2 * ref + bias.double()) < 1e-6
+    assert float(amax) == float(C2.abs().max())
+
+
+def test_split_gemm_nt_error_not_above_fp32_chain(dev):
+    """Elementwise, relative to sum_k |a_k b_k|: the 3-term split product is at least as accurate as an fp32 fmaf accumulation
+    (here: the exact-fp32 matrix-core kernel of the 'fp32' GEMM mode)."""
+    from madeleine_amd import functional as MF
+    M, N, K = 1024, 512, 2048
+    a, b = t((M, K), "spe:a") * 2, t((N, K), "spe:b") / 45.0
+    ref = a.double() @ b.double().t()
+    mag = a.double().abs() @ b.double().abs().t()
+    C = MF.split_gemm_nt(MF.split_image(a.to(dev)), MF.split_image(b.to(dev))).cpu().double()
+    C32 = MF.LinearFn.apply(a.to(dev), b.to(dev), None).cpu().double()
+    e_split, e_f32 = ((C - ref).abs() / mag), ((C32 - ref).abs() / mag)
+    assert float(e_split.max()) < 4e-7 and float(e_split.pow(2).mean().sqrt()) <= 1.5 * float(e_f32.pow(2).mean().sqrt())
+
+
+@pytest.mark.parametrize("T,Mi,N", [(1000, 512, 512), (12325, 512, 2048), (4129, 800, 512), (33, 32, 32), (70000, 512, 1024)])
+def test_split_gemm_tn_vs_fp64(dev, T, Mi, N):
+    """dW-type product over the token rows of two images: ragged token tail, several token splits, ragged column tiles."""
+    from madeleine_amd import functional as MF
+    x = t((T, Mi), f"spt:x{T}{Mi}") * 2
+    dy = t((T, N), f"spt:d{T}{N}") * torch.logspace(0, -3, T).unsqueeze(1)        # tokens with 1000x smaller gradients
+    ref = dy.double().t() @ x.double()
+    out = MF.split_gemm_tn(MF.split_image(x.to(dev)), MF.split_image(dy.to(dev), pad_rows=32))
+    assert tuple(out.shape) == (N, Mi)
+    assert rel_err(out, ref) < 1e-6
+
+
+def test_split_linear_autograd_matches_fp32_mode(dev):
+    """functional.linear in the two GEMM modes: same values / gradients (1e-6 against fp64), bias path included."""
+    from madeleine_amd import functional as MF
+    T, N, K = 3000, 512, 800
+    x, W, b, dy = t((T, K), "spl:x"), 0.05 * t((N, K), "spl:w"), 0.3 * t((N,), "spl:b"), t((T, N), "spl:dy")
+    x64, W64, b64 = (v.double().requires_grad_() for v in (x, W, b))
+    (x64 @ W64.t() + b64).backward(dy.double())
+    old = MF.gemm_mode()
+    try:
+        for mode in ("split", "fp32"):
+            MF.set_gemm_mode(mode)
+            xd, Wd, bd = (v.to(dev).requires_grad_() for v in (x, W, b))
+            y = MF.linear(xd, Wd, bd)
+            y.backward(dy.to(dev))
+            assert rel_err(y, (x64 @ W64.t() + b64).detach()) < 1e-6, mode
+            assert rel_err(xd.grad, x64.grad) < 1e-6 and rel_err(Wd.grad, W64.grad) < 1e-6 and rel_err(bd.grad, b64.grad) < 1e-6, mode
+    finally:
+        MF.set_gemm_mode(old)
