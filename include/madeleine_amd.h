@@ -360,6 +360,20 @@ int64_t mdl_split_gemm_tn_ws_bytes(int64_t T, int Mi, int N);
 int mdl_split_gemm_tn(const void* A, int64_t a_rsb, const float* a_scale, int Mi, const void* B, int64_t b_rsb, const float* b_scale,
                       int N, float* out, int64_t T, void* ws, void* stream);
 
+/* N1 producers that write split images directly (csrc/preattn_act.hip): mdl_ln_gelu_drop_fwd / _bwd with the output tensor as an
+ * image -- the pre-attention activations and their gradients are consumed by contractions only, so no fp32 copy is written (the
+ * forward also writes y when y != NULL: E, which the pooling kernels read).  Scales from rigorous bounds (no pass over the data):
+ *   forward  |y|  <= (max|gamma| sqrt(W-1) + max|beta|) / (1-p)
+ *   backward |dx| <= rstd_max 1.13 max|gamma| max|dy| (2 + sqrt(W)) / (1-p);  dy_absmax = device float with max |dy| (from the producing
+ *            kernel's epilogue) or NULL (one extra pass over dy).  The dx image is followed by 32 zero rows; ws as mdl_ln_gelu_drop_bwd. */
+int mdl_ln_gelu_drop_fwd_split(const float* x, const float* bias, const float* gamma, const float* beta, float* y, void* img, float* scale,
+                               float* mean, float* rstd, int64_t rows, int W, float eps, float p_drop, uint64_t seed, const uint8_t* keep,
+                               void* stream);
+int mdl_ln_gelu_drop_bwd_split(const float* x, const float* bias, const float* gamma, const float* beta, const float* mean,
+                               const float* rstd, const float* dy, const float* dy_absmax, void* dx_img, float* dx_scale, float* dgamma,
+                               float* dbeta, float* dbias, int64_t rows, int W, float p_drop, uint64_t seed, const uint8_t* keep, void* ws,
+                               void* stream);
+
 /* A2 on the split engine (csrc/abmil_gate_split.hip): mdl_abmil_gate_fwd / mdl_abmil_attnpool_bwd(_phases) with E given as a split
  * image (rows of e_rsb bytes holding the H*512 head-major channels, scale e_scale) -- everything else (parameters, scores, saved
  * activations, gradients, dropout, pooling term, `accumulate`) as in the fp32 entry points.  scores == NULL in the backward: no

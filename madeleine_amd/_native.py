@@ -87,6 +87,8 @@ SIGNATURES = {
     "mdl_split_gemm_nt": (i32, [c_p, i64, c_f, c_p, i64, c_f, c_f, i64, i64, i32, i32, c_f, i32, c_f, c_p]),
     "mdl_split_gemm_tn_ws_bytes": (i64, [i64, i32, i32]),
     "mdl_split_gemm_tn": (i32, [c_p, i64, c_f, i32, c_p, i64, c_f, i32, c_f, i64, c_p, c_p]),
+    "mdl_ln_gelu_drop_fwd_split": (i32, [c_f, c_f, c_f, c_f, c_f, c_p, c_f, c_f, c_f, i64, i32, f32, f32, u64, c_p, c_p]),
+    "mdl_ln_gelu_drop_bwd_split": (i32, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_f, c_f, c_f, c_f, i64, i32, f32, u64, c_p, c_p, c_p]),
     "mdl_abmil_gate_fwd_split_ws_bytes": (i64, [i64, i32]),
     "mdl_abmil_gate_fwd_split": (i32, [c_p, i64, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i64, i32, f32, u64, c_p, c_p, c_p, c_p]),
     "mdl_abmil_gate_bwd_split_ws_bytes": (i64, [i64, i32]),

@@ -12,7 +12,7 @@
 // One wave per row: lane L owns columns {4L + 256 i .. +3}, i < W/256 (W = 512 -> 2 float4, 2048 -> 8 float4), so
 // a row is W/256 coalesced 1 KiB loads, the mean/variance are two 64-lane reductions, and in backward the per-
 // column sums for d(gamma), d(beta) accumulate in registers across the rows a wave walks.
-#include "common.hpp"
+#include "split_engine.hpp"
 
 namespace mdl {
 
@@ -153,6 +153,22 @@ __device__ __forceinline__ void group_store(IO* __restrict__ p, int lane, int i,
     }
 }
 
+// split-image store of 4 consecutive columns c .. c + 3 (c % 4 == 0) of an image row: 8 B of the hi plane, 8 B of the lo plane
+__device__ __forceinline__ void img_store4(char* __restrict__ row, int c, const f32x4& v, float s) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    uint32_t h[2], l[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float a0 = v[2 * i] * s, a1 = v[2 * i + 1] * s;
+        const _Float16 h0 = (_Float16)a0, h1 = (_Float16)a1;
+        h[i] = __builtin_bit_cast(uint32_t, h2{h0, h1});
+        l[i] = __builtin_bit_cast(uint32_t, h2{(_Float16)(a0 - (float)h0), (_Float16)(a1 - (float)h1)});
+    }
+    char* p = row + (int64_t)(c >> 5) * 128 + (c & 31) * 2;
+    *reinterpret_cast<u32x2*>(p) = u32x2{h[0], h[1]};
+    *reinterpret_cast<u32x2*>(p + 64) = u32x2{l[0], l[1]};
+}
+
 // Geometry: a 256-thread block = 4 waves.  WPR waves share one row (each owns a 256*NV-column segment), so a block
 // works on 4/WPR rows at a time: W = 512 -> NV 2, WPR 1 (one wave per row); W = 2048 -> NV 2, WPR 4 (one block per
 // row; keeps the backward at ~110 VGPRs = 4 waves/SIMD instead of 256+ = 1 wave/SIMD with a whole row per wave).
@@ -178,14 +194,16 @@ __device__ __forceinline__ void row_allreduce2(float& a, float& b, float (*red)[
     }
 }
 
-template <int NV, int WPR, class IO>
+// IMG: 0 = y only; 1 = split image only (the output feeds contractions of the split engine only); 2 = both (fp32 kernels only)
+template <int NV, int WPR, class IO, int IMG = 0>
 __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_fwd_kernel(const IO* __restrict__ x,
                                                                      const float* __restrict__ bias,
                                                                      const float* __restrict__ gamma,
                                                                      const float* __restrict__ beta,
                                                                      IO* __restrict__ y, float* __restrict__ mean_o,
                                                                      float* __restrict__ rstd_o, int64_t rows, float eps,
-                                                                     ActDrop drop) {
+                                                                     ActDrop drop, char* __restrict__ img = nullptr,
+                                                                     const float* __restrict__ img_sc = nullptr) {
     constexpr int W = NV * 256 * WPR, RPB = 4 / WPR;
     __shared__ float red[1][4][2];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, slot = wv / WPR, seg = wv % WPR;
@@ -246,7 +264,8 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_fwd_kernel(const IO* _
                     const float t = (v[i][e] - mean) * rstd * g[i][e] + b[i][e];
                     o[e] = act_gelu<IO>(t) * kp[e];
                 }
-                group_store<IO, NV>(yr, lane, i, prev, o);
+                if (IMG != 1) group_store<IO, NV>(yr, lane, i, prev, o);
+                if (IMG != 0) img_store4(img + r * (int64_t)(W * 4), ci, o, img_sc[0]);
                 prev = o;
             }
             if (lane == 0 && seg == 0) {
@@ -257,7 +276,8 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_fwd_kernel(const IO* _
     }
 }
 
-template <int NV, int WPR, class IO>
+// IMG: dx is written as a split image (rows of 4 W bytes at `img`, scale img_sc[0]) instead of dx
+template <int NV, int WPR, class IO, bool IMG = false>
 __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_bwd_kernel(const IO* __restrict__ x,
                                                                      const float* __restrict__ bias,
                                                                      const float* __restrict__ gamma,
@@ -265,7 +285,9 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_bwd_kernel(const IO* _
                                                                      const float* __restrict__ mean_i,
                                                                      const float* __restrict__ rstd_i,
                                                                      const IO* __restrict__ dy, IO* __restrict__ dx,
-                                                                     float* __restrict__ part, int64_t rows, ActDrop drop) {
+                                                                     float* __restrict__ part, int64_t rows, ActDrop drop,
+                                                                     char* __restrict__ img = nullptr,
+                                                                     const float* __restrict__ img_sc = nullptr) {
     constexpr int W = NV * 256 * WPR, RPB = 4 / WPR;
     __shared__ float red[1][4][2];
     __shared__ float csum[WPR < 4 ? 3 * W : 1];  // WPR < 4: several waves own the same columns -> merged through LDS
@@ -348,7 +370,8 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_bwd_kernel(const IO* _
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = rstd * (dxh[i][e] - m1 - xh[i][e] * m2);
                 sx[i] += v;
-                group_store<IO, NV>(o, lane, i, prev, v);
+                if (IMG) img_store4(img + r * (int64_t)(W * 4), cb + CM::off(i, lane), v, img_sc[0]);
+                else group_store<IO, NV>(o, lane, i, prev, v);
                 prev = v;
             }
         }
@@ -418,6 +441,39 @@ __global__ __launch_bounds__(256) void ln_reduce_kernel(const float* __restrict_
     }
 }
 
+// Rigorous output bounds -> image scales (one workgroup; W <= 4096).
+//   forward : |GELU(LN(x)) keep| <= (max|gamma| sqrt(W - 1) + max|beta|) / (1 - p)       (|x^_i| <= sqrt(W - 1), |GELU(t)| <= |t|)
+//   backward: |dx_i| = rstd |dh_i - mean(dh) - x^_i mean(dh x^)| <= rstd_max D (2 + sqrt(W)),  D = 1.13 max|gamma| max|dy| / (1 - p)
+//             (|GELU'| <= 1.13, mean|x^| <= 1)
+// sc[0] = scale, sc[1] = the bound.  aux[0] = max rstd, aux[1] = max |dy| (backward only).
+__global__ __launch_bounds__(256) void ln_bound_scale_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, int W,
+                                                             float inv_keep, const float* __restrict__ aux, float* __restrict__ sc) {
+    __shared__ float red[2][4];
+    float g = 0.f, b = 0.f;
+    for (int c = threadIdx.x; c < W; c += 256) {
+        g = fmaxf(g, fabsf(gamma[c]));
+        b = fmaxf(b, fabsf(beta[c]));
+    }
+    g = wave_max(g);
+    b = wave_max(b);
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = g;
+        red[1][threadIdx.x >> 6] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        g = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+        b = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+        const float bound = aux ? aux[0] * (1.13f * g * aux[1] * inv_keep) * (2.f + sqrtf((float)W))
+                                : (g * sqrtf((float)(W - 1)) + b) * inv_keep;
+        sc[1] = bound;
+        sc[0] = sp_scale_for(bound);
+    }
+}
+
+int sp_launch_absmax(const float* X, int64_t ldx, int64_t rows, int K, float* out, hipStream_t s);   // split_gemm.hip
+int sp_launch_absmax_flat(const float* x, int64_t n, float* out, hipStream_t s);
+
 static inline ActDrop make_act_drop(float p, uint64_t seed, const uint8_t* keep) {
     ActDrop d;
     d.on = p > 0.f ? 1 : 0;
@@ -443,7 +499,7 @@ using namespace mdl;
 extern "C" int64_t mdl_ln_gelu_drop_bwd_ws_bytes(int64_t rows, int W) {
     if (rows < 0) return MDL_E_ARG;
     if (!act_width_ok(W)) return MDL_E_UNSUPPORTED;   // 512 * n_heads for n_heads in {1, 2, 4, 8}, and 256
-    return (int64_t)act_blocks(rows, W) * 3 * W * 4 + 64;
+    return (int64_t)act_blocks(rows, W) * 3 * W * 4 + 128;   // + aux floats of the split variant
 }
 
 #define MDL_DISPATCH_W(W, ...)                                                       \
@@ -542,4 +598,95 @@ extern "C" int mdl_ln_gelu_drop_bwd_bf16(const uint16_t* x, const float* bias, c
                                          const uint8_t* keep, void* ws, void* stream) {
     return ln_bwd_launch<bf16_t>((const bf16_t*)x, bias, gamma, beta, mean, rstd, (const bf16_t*)dy, (bf16_t*)dx, dgamma, dbeta,
                                  dbias, rows, W, p_drop, seed, keep, ws, stream);
+}
+
+/* mdl_ln_gelu_drop_fwd whose output is written as a SPLIT IMAGE (rows of 4 W bytes at img; scale[2] = {scale, bound} from the
+ * parameters: |y| <= (max|gamma| sqrt(W-1) + max|beta|) / (1-p)) -- and, when y != NULL, as fp32 as well. */
+extern "C" int mdl_ln_gelu_drop_fwd_split(const float* x, const float* bias, const float* gamma, const float* beta, float* y, void* img,
+                                          float* scale, float* mean, float* rstd, int64_t rows, int W, float eps, float p_drop,
+                                          uint64_t seed, const uint8_t* keep, void* stream) {
+    if (!x || !gamma || !beta || !img || !scale || !mean || !rstd || rows < 0) return MDL_E_ARG;
+    if (!(p_drop >= 0.f && p_drop < 1.f) || !(eps > 0.f)) return MDL_E_ARG;
+    if (!act_width_ok(W) || W > 4096) return MDL_E_UNSUPPORTED;
+    if (!host_aligned16(x) || !host_aligned16(y) || !host_aligned16(img) || !host_aligned16(gamma) || !host_aligned16(beta) ||
+        !host_aligned16(bias))
+        return MDL_E_ALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    const ActDrop d = make_act_drop(p_drop, seed, keep);
+    hipLaunchKernelGGL(ln_bound_scale_kernel, dim3(1), dim3(256), 0, s, gamma, beta, W, d.inv, (const float*)nullptr, scale);
+    MDL_LAUNCH_CHECK();
+    if (rows == 0) return MDL_OK;
+#define MDL_LN_FWD_IMG(NVV, WPRV, NB)                                                                                                    \
+    do {                                                                                                                               \
+        if (y) hipLaunchKernelGGL((ln_gelu_drop_fwd_kernel<NVV, WPRV, float, 2>), dim3((unsigned)(NB)), dim3(ACT_BLOCK), 0, s, x, bias, \
+                                  gamma, beta, y, mean, rstd, rows, eps, d, (char*)img, (const float*)scale);                           \
+        else hipLaunchKernelGGL((ln_gelu_drop_fwd_kernel<NVV, WPRV, float, 1>), dim3((unsigned)(NB)), dim3(ACT_BLOCK), 0, s, x, bias,   \
+                                gamma, beta, y, mean, rstd, rows, eps, d, (char*)img, (const float*)scale);                             \
+    } while (0)
+    if (W == 2048) {
+        int64_t nb = (rows + 3) / 4;
+        if (nb > 2048) nb = 2048;
+        MDL_LN_FWD_IMG(8, 1, nb);
+    } else {
+        MDL_DISPATCH_W(W, { MDL_LN_FWD_IMG(NV, WPR, act_blocks(rows, W)); });
+    }
+#undef MDL_LN_FWD_IMG
+    MDL_LAUNCH_CHECK();
+    return MDL_OK;
+}
+
+/* mdl_ln_gelu_drop_bwd whose dx is written as a SPLIT IMAGE followed by 32 all-zero rows (the B operand of mdl_split_gemm_tn);
+ * dx_scale[2] = {scale, bound} from the rigorous bound rstd_max 1.13 max|gamma| max|dy| (2 + sqrt(W)) / (1-p).  dy_absmax: device
+ * float holding max |dy| (e.g. from the epilogue of the kernel that produced dy), or NULL: computed here by one pass over dy.
+ * ws: mdl_ln_gelu_drop_bwd_ws_bytes(rows, W) + 64 bytes. */
+extern "C" int mdl_ln_gelu_drop_bwd_split(const float* x, const float* bias, const float* gamma, const float* beta, const float* mean,
+                                          const float* rstd, const float* dy, const float* dy_absmax, void* dx_img, float* dx_scale,
+                                          float* dgamma, float* dbeta, float* dbias, int64_t rows, int W, float p_drop, uint64_t seed,
+                                          const uint8_t* keep, void* ws, void* stream) {
+    if (!x || !gamma || !beta || !mean || !rstd || !dy || !dx_img || !dx_scale || !dgamma || !dbeta || !ws || rows < 0) return MDL_E_ARG;
+    if (!(p_drop >= 0.f && p_drop < 1.f)) return MDL_E_ARG;
+    if (!act_width_ok(W) || W > 4096) return MDL_E_UNSUPPORTED;
+    if (!host_aligned16(x) || !host_aligned16(dy) || !host_aligned16(dx_img) || !host_aligned16(gamma) || !host_aligned16(beta) ||
+        !host_aligned16(bias) || !host_aligned16(ws))
+        return MDL_E_ALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    const ActDrop d = make_act_drop(p_drop, seed, keep);
+    int nb = rows > 0 ? act_blocks(rows, W) : 0;
+    if (W == 2048 && nb > 0) {
+        int64_t b2 = (rows + 1) / 2;
+        if (b2 > 2048) b2 = 2048;
+        nb = (int)b2;
+    }
+    float* part = (float*)ws;
+    float* aux = (float*)((char*)ws + (((int64_t)act_blocks(rows, W) * 3 * W * 4 + 15) & ~(int64_t)15));   // [0] max rstd, [1] max |dy|
+    hipError_t e = hipMemsetAsync(aux, 0, 2 * sizeof(float), s);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync((char*)dx_img + rows * (int64_t)W * 4, 0, (size_t)32 * W * 4, s);
+    if (e != hipSuccess) return (int)e;
+    int rc = sp_launch_absmax_flat(rstd, rows, aux, s);
+    if (rc) return rc;
+    if (dy_absmax) {
+        e = hipMemcpyAsync(aux + 1, dy_absmax, sizeof(float), hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) return (int)e;
+    } else {
+        rc = sp_launch_absmax(dy, W, rows, W, aux + 1, s);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(ln_bound_scale_kernel, dim3(1), dim3(256), 0, s, gamma, beta, W, d.inv, (const float*)aux, dx_scale);
+    MDL_LAUNCH_CHECK();
+    if (W == 2048 && nb > 0) {
+        hipLaunchKernelGGL((ln_gelu_drop_bwd_kernel<4, 2, float, true>), dim3(nb), dim3(ACT_BLOCK), 0, s, x, bias, gamma, beta, mean, rstd, dy,
+                           (float*)nullptr, part, rows, d, (char*)dx_img, (const float*)dx_scale);
+        MDL_LAUNCH_CHECK();
+    } else
+    MDL_DISPATCH_W(W, {
+        if (nb > 0) {
+            hipLaunchKernelGGL((ln_gelu_drop_bwd_kernel<NV, WPR, float, true>), dim3(nb), dim3(ACT_BLOCK), 0, s, x, bias, gamma, beta, mean,
+                               rstd, dy, (float*)nullptr, part, rows, d, (char*)dx_img, (const float*)dx_scale);
+            MDL_LAUNCH_CHECK();
+        }
+    });
+    hipLaunchKernelGGL(ln_reduce_kernel, dim3((3 * W + 31) / 32), dim3(256), 0, s, (const float*)part, dgamma, dbeta, dbias, nb, W);
+    MDL_LAUNCH_CHECK();
+    return MDL_OK;
 }

@@ -391,6 +391,104 @@ class SplitLinearFn(torch.autograd.Function):
         return dx, dW, db
 
 
+# max |t| of a gradient tensor, published by the kernel that produced it (epilogue atomics) for the consumer that needs a bound on it
+_ABSMAX = {}
+
+
+def _put_absmax(t, amax):
+    if len(_ABSMAX) > 64:
+        _ABSMAX.clear()
+    _ABSMAX[(t.data_ptr(), t.numel())] = amax
+
+
+def _take_absmax(t):
+    return _ABSMAX.pop((t.data_ptr(), t.numel()), None)
+
+
+class PreAttnBlockFn(torch.autograd.Function):
+    """One block of the pre-attention MLP -- Linear -> LayerNorm -> GELU -> Dropout (Model.py:351-354, :355-358, :359-362) -- as ONE
+    autograd node on the split engine.  The activations between the blocks exist as split images only (consumed by contractions):
+    `x` is either the fp32 input of the first block (x_scale None) or the previous block's image (x_scale = its scale); the block
+    returns (image [T,N] as an opaque float32 tensor, scale [2], fp32 output or an empty tensor).  Gradients travel as ordinary fp32
+    tensors of the images' shape; in backward the LayerNorm kernel writes d(pre-LN) as an image straight away and the dX / dW
+    contractions read it -- no conversion pass anywhere (scales come from rigorous bounds, include/madeleine_amd.h)."""
+
+    @staticmethod
+    def forward(ctx, x, x_scale, W, lin_bias, gamma, beta, eps, p_drop, seed, keep, want_fp32):
+        _require(x, "x")
+        for t_, n_ in ((W, "weight"), (gamma, "gamma"), (beta, "beta")):
+            _require(t_, n_)
+        if lin_bias is not None:
+            _require(lin_bias, "bias")
+        lib = _native.lib()
+        T, K = x.shape
+        N = W.shape[0]
+        dev = x.device
+        xi = SplitImage(x, x_scale, T, K) if x_scale is not None else split_image(x)
+        y = split_gemm_nt(xi, split_image(W), name="linear_fwd")          # pre-LN values (the Linear's bias is added by the LN kernel)
+        img = torch.empty(T, N, device=dev, dtype=torch.float32)
+        scale = torch.empty(2, device=dev, dtype=torch.float32)
+        out = torch.empty(T, N, device=dev, dtype=torch.float32) if want_fp32 else None
+        mean = torch.empty(T, device=dev, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        with _timed("ln_gelu_drop_fwd", ("byte", (3.0 if want_fp32 else 2.0) * T * N * 4)):
+            rc = lib.mdl_ln_gelu_drop_fwd_split(_ptr(y), _ptr(lin_bias), _ptr(gamma), _ptr(beta), _ptr(out), _ptr(img), _ptr(scale),
+                                                _ptr(mean), _ptr(rstd), T, N, float(eps), float(p_drop), int(seed), _ptr(keep), _stream())
+        if rc == -3:
+            raise NotImplementedError("fused LayerNorm-GELU-Dropout supports widths 256/512/1024/2048/4096 (got %d)" % N)
+        _native.check(rc, "mdl_ln_gelu_drop_fwd_split")
+        ctx.save_for_backward(xi.data, xi.scale, W, y, gamma, beta, mean, rstd, lin_bias if lin_bias is not None else torch.empty(0))
+        ctx.cfg = (float(p_drop), int(seed), keep, lin_bias is not None, bool(want_fp32), T, K, N)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(scale)
+        if want_fp32:
+            ctx.mark_non_differentiable(img)      # the gradient arrives on the fp32 output
+            return img, scale, out
+        empty = x.new_empty(0)
+        ctx.mark_non_differentiable(empty)
+        return img, scale, empty
+
+    @staticmethod
+    def backward(ctx, d_img, _d_scale, d_out):
+        xdata, xscale, W, y, gamma, beta, mean, rstd, lin_bias = ctx.saved_tensors
+        p_drop, seed, keep, has_bias, want_fp32, T, K, N = ctx.cfg
+        lin_bias = lin_bias if has_bias else None
+        dy = d_out if want_fp32 else d_img
+        if dy is None:
+            dy = torch.zeros(T, N, device=y.device, dtype=torch.float32)
+        dy = dy.float().contiguous().view(T, N)
+        lib = _native.lib()
+        dev = y.device
+        dximg = torch.empty(T + 32, N, device=dev, dtype=torch.float32)
+        dxscale = torch.empty(2, device=dev, dtype=torch.float32)
+        dg, db = torch.empty_like(gamma), torch.empty_like(beta)
+        dbias = torch.empty_like(lin_bias) if has_bias else None
+        ws = _ws(lib.mdl_ln_gelu_drop_bwd_ws_bytes(T, N), dev)
+        amax = _take_absmax(dy)
+        with _timed("ln_gelu_drop_bwd", ("byte", (3.0 if amax is not None else 4.0) * T * N * 4)):
+            rc = lib.mdl_ln_gelu_drop_bwd_split(_ptr(y), _ptr(lin_bias), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(dy), _ptr(amax),
+                                                _ptr(dximg), _ptr(dxscale), _ptr(dg), _ptr(db), _ptr(dbias), T, N, p_drop, seed, _ptr(keep),
+                                                _ptr(ws), _stream())
+        _native.check(rc, "mdl_ln_gelu_drop_bwd_split")
+        dyi = SplitImage(dximg, dxscale, T, N)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            am = torch.zeros(1, device=dev, dtype=torch.float32)
+            dx = split_gemm_nt(dyi, split_image(W.t().contiguous()), absmax_out=am, name="linear_bwd")
+            _put_absmax(dx, am)
+        dW = split_gemm_tn(SplitImage(xdata, xscale, T, K), dyi, name="linear_bwd")
+        return dx, None, dW, dbias, dg, db, None, None, None, None, None
+
+
+def preattn_block(x, x_scale, W, lin_bias, gamma, beta, eps=1e-5, p_drop=0.0, seed=0, keep=None, want_fp32=False):
+    return PreAttnBlockFn.apply(x, x_scale, W.contiguous(), None if lin_bias is None else lin_bias.contiguous(), gamma.contiguous(),
+                                beta.contiguous(), float(eps), float(p_drop), int(seed), keep, bool(want_fp32))
+
+
+def preattn_split_supported(x2d, K) -> bool:
+    return GEMM_MODE == "split" and x2d.is_cuda and x2d.dtype == torch.float32 and x2d.shape[0] > 256 and K % 32 == 0
+
+
 def linear_fwd_raw(x2d, W, bias):
     """Y = X W^T (+ bias) through mdl_linear_fwd / mdl_linear_fwd_bf16 (by the storage type of x2d)."""
     lib = _native.lib()
@@ -560,7 +658,7 @@ class AttnPoolFn(torch.autograd.Function):
     3 x |E| elementwise pass (3.8 ms per config-3 step); without it the third output is an empty tensor."""
 
     @staticmethod
-    def forward(ctx, E, Wa, ba, Wb, bb, wc, bc, p_drop, seed, keep_a, keep_b, cu_seqlens, max_len, Wtok, btok, *views):
+    def forward(ctx, E, Wa, ba, Wb, bb, wc, bc, p_drop, seed, keep_a, keep_b, cu_seqlens, max_len, Wtok, btok, Eimg, Escale, *views):
         _require_act(E, "E")
         for t, n in ((Wa, "Wa"), (ba, "ba"), (Wb, "Wb"), (bb, "bb"), (wc, "wc"), (bc, "bc")):
             _require(t, n)
@@ -570,10 +668,11 @@ class AttnPoolFn(torch.autograd.Function):
         for v in views:
             _require(v, "view token indices", torch.int32)
         ctx.set_materialize_grads(False)
-        need = any(ctx.needs_input_grad[:7]) or any(ctx.needs_input_grad[13:15])
+        need = any(ctx.needs_input_grad[:7]) or any(ctx.needs_input_grad[13:15])   # (inputs 15, 16 = the image of E: no gradient)
         ctx.Ei = None
         if _split_gate(E2d):
-            Ei = split_image(E2d)
+            # the image of E: written by the producing LayerNorm kernel (Eimg / Escale), else built here (3 passes over E)
+            Ei = SplitImage(Eimg, Escale, E2d.shape[0], E2d.shape[1]) if Eimg is not None else split_image(E2d)
             scores, act_a, act_b = gate_fwd_split_raw(Ei, Wa, ba, Wb, bb, wc, bc, p_drop, seed, keep_a, keep_b, need)
             ctx.Ei = Ei if need else None
         else:
@@ -632,8 +731,11 @@ class AttnPoolFn(torch.autograd.Function):
         if ragged:   # bag index of every packed token row, on the device (no sync)
             row_bag = torch.searchsorted(cu[1:].contiguous(), torch.arange(E2d.shape[0], device=E2d.device), right=True).to(torch.int32)
         if ctx.Ei is not None:
+            am = torch.zeros(1, device=dE.device, dtype=torch.float32) if V == 0 else None   # (views add to dE afterwards)
             dWa, dWb, dba, dbb, dwc, dbc = attnpool_bwd_split_raw(ctx.Ei, Wa, Wb, wc, act_a, act_b, ds, dE, p_drop, seed, keep_a, keep_b,
-                                                                  scores, m, l, d_main, row_bag, N if not ragged else 0, acc_e)
+                                                                  scores, m, l, d_main, row_bag, N if not ragged else 0, acc_e, am)
+            if am is not None:
+                _put_absmax(dE, am)
             ctx.Ei = None
         else:
             dWa, dWb, dba, dbb, dwc, dbc = attnpool_bwd_raw(E2d, Wa, Wb, wc, act_a, act_b, ds, dE, p_drop, seed, keep_a, keep_b,
@@ -641,16 +743,18 @@ class AttnPoolFn(torch.autograd.Function):
         for i in range(V):   # ... and their dE terms are added once dE has been written (no read of E)
             vp, vm, vl = vflat[3 * i:3 * i + 3]
             pool_view_bwd_raw(E2d, scores, vp, vm, vl, d_pooled[:, 1 + i].contiguous(), dE, None, n_bags, N, views[i])
-        return (dE.view(e_shape), dWa, dba, dWb, dbb, dwc, dbc, None, None, None, None, None, None, dWtok, dbtok) + (None,) * V
+        return (dE.view(e_shape), dWa, dba, dWb, dbb, dwc, dbc, None, None, None, None, None, None, dWtok, dbtok, None, None) + (None,) * V
 
 
 def attn_pool(E, Wa, ba, Wb, bb, wc, bc, p_drop=0.0, seed=0, keep_a=None, keep_b=None, cu_seqlens=None, max_len=None, views=(),
-              tok_proj=None):
-    """-> (pooled, raw scores), or (pooled, raw scores, token projections [T,P]) with tok_proj = (Wtok [P,H*512], btok or None)."""
+              tok_proj=None, e_img=None):
+    """-> (pooled, raw scores), or (pooled, raw scores, token projections [T,P]) with tok_proj = (Wtok [P,H*512], btok or None).
+    e_img = (image data, scale) of E when the producing kernel wrote one (split GEMM mode)."""
     Wtok, btok = tok_proj if tok_proj is not None else (None, None)
+    Eimg, Escale = e_img if e_img is not None else (None, None)
     pooled, scores, tok = AttnPoolFn.apply(E, Wa, ba, Wb, bb, wc, bc, float(p_drop), int(seed), keep_a, keep_b, cu_seqlens, max_len,
                                            None if Wtok is None else Wtok.contiguous(), None if btok is None else btok.contiguous(),
-                                           *views)
+                                           Eimg, Escale, *views)
     return (pooled, scores) if tok_proj is None else (pooled, scores, tok)
 
 

@@ -119,12 +119,8 @@ class ABMILEmbedder(nn.Module):
         """Parameter `w` with axis `dim` (length H*512) in head-major order."""
         return _PermuteFn.apply(w, self._perm, self._inv_perm, dim)
 
-    def _act(self, x, ln, blk, perm=None, lin_bias=None):
-        """(+ bias of the preceding Linear) -> LayerNorm -> GELU -> Dropout(.1) of block `blk` in ONE fused HIP pass each
-        way (functional.ln_gelu_drop); the Linear itself runs bias-free."""
-        g, b = (ln.weight, ln.bias) if perm is None else (self.permuted(ln.weight, 0), self.permuted(ln.bias, 0))
-        if lin_bias is not None and perm is not None:
-            lin_bias = self.permuted(lin_bias, 0)
+    def _drop_cfg(self, blk, perm=None):
+        """(p, seed, keep) of block `blk`'s dropout for this forward."""
         p, seed, keep = 0.0, 0, None
         if self.training:
             p = float(self.pre_attn[4 * blk + 3].p)   # the nn.Dropout module of this block (0.1 unless the user changed it)
@@ -138,10 +134,31 @@ class ABMILEmbedder(nn.Module):
                 keep = keep.to(torch.uint8).contiguous()
             else:
                 seed = MF.new_dropout_seed()
+        return p, seed, keep
+
+    def _block_split(self, x, x_scale, blk, perm=None, want_fp32=False):
+        """Linear + LayerNorm + GELU + Dropout of block `blk` as one node on the split engine (functional.PreAttnBlockFn)."""
+        lin, ln = self.pre_attn[4 * blk], self.pre_attn[4 * blk + 1]
+        W, lb, g, b = lin.weight, lin.bias, ln.weight, ln.bias
+        if perm is not None:
+            W, lb, g, b = self.permuted(W, 0), self.permuted(lb, 0), self.permuted(g, 0), self.permuted(b, 0)
+        p, seed, keep = self._drop_cfg(blk, perm)
+        if keep is not None:
+            keep = keep.reshape(-1, keep.shape[-1])
+        return MF.preattn_block(x, x_scale, W, lb, g, b, ln.eps, p, seed, keep, want_fp32)
+
+    def _act(self, x, ln, blk, perm=None, lin_bias=None):
+        """(+ bias of the preceding Linear) -> LayerNorm -> GELU -> Dropout(.1) of block `blk` in ONE fused HIP pass each
+        way (functional.ln_gelu_drop); the Linear itself runs bias-free."""
+        g, b = (ln.weight, ln.bias) if perm is None else (self.permuted(ln.weight, 0), self.permuted(ln.bias, 0))
+        if lin_bias is not None and perm is not None:
+            lin_bias = self.permuted(lin_bias, 0)
+        p, seed, keep = self._drop_cfg(blk, perm)
         return MF.ln_gelu_drop(x if x.dtype == torch.bfloat16 else x.float(), g, b, ln.eps, p, seed, keep, lin_bias)
 
-    def embed_tokens_headmajor(self, bags: torch.Tensor) -> torch.Tensor:
-        """pre_attn(bags) with the 2048 output channels in head-major order: [BM, N, H*512].
+    def embed_tokens_headmajor(self, bags: torch.Tensor, return_image: bool = False):
+        """pre_attn(bags) with the 2048 output channels in head-major order: [BM, N, H*512]  (with return_image: (E, image of E or
+        None) -- in the split GEMM mode the last block's kernel writes the split image the gate contractions read).
 
         Under torch.autocast(bfloat16) -- the reference's `precision: bfloat16` runs (trainer.py:101-103) -- the
         activations are kept in bf16 end to end (Linear outputs, the fused LayerNorm-GELU-Dropout input/output and E):
@@ -153,10 +170,20 @@ class ABMILEmbedder(nn.Module):
                 bf = torch.bfloat16
                 x = self._act(MF.linear(bags.to(bf), pa[0].weight), pa[1], 0, None, pa[0].bias)
                 x = self._act(MF.linear(x, pa[4].weight), pa[5], 1, None, pa[4].bias)
-                return self._act(MF.linear(x, self.permuted(pa[8].weight, 0)), pa[9], 2, perm, pa[8].bias)
+                E = self._act(MF.linear(x, self.permuted(pa[8].weight, 0)), pa[9], 2, perm, pa[8].bias)
+                return (E, None) if return_image else E
+        x2d = bags.reshape(-1, bags.shape[-1])
+        if MF.preattn_split_supported(x2d.float(), x2d.shape[-1]) and pa[0].weight.shape[0] % 32 == 0:
+            # split GEMM mode: three fused blocks; the activations between them exist as split images only
+            img, sc, _ = self._block_split(x2d.float().contiguous(), None, 0)
+            img, sc, _ = self._block_split(img, sc, 1)
+            img, sc, E = self._block_split(img, sc, 2, perm, want_fp32=True)
+            E = E.view(*bags.shape[:-1], E.shape[-1])
+            return (E, (img, sc)) if return_image else E
         x = self._act(MF.linear(bags.float(), pa[0].weight), pa[1], 0, None, pa[0].bias)
         x = self._act(MF.linear(x, pa[4].weight), pa[5], 1, None, pa[4].bias)
-        return self._act(MF.linear(x, self.permuted(pa[8].weight, 0)), pa[9], 2, perm, pa[8].bias)
+        E = self._act(MF.linear(x, self.permuted(pa[8].weight, 0)), pa[9], 2, perm, pa[8].bias)
+        return (E, None) if return_image else E
 
     def gate_params_stacked(self):
         ps = [h.gate_params() for h in self.attn]
@@ -176,7 +203,7 @@ class ABMILEmbedder(nn.Module):
                 kb.reshape(T, self.n_heads, MF.HID).to(torch.uint8).contiguous()
         return p, MF.new_dropout_seed(), None, None
 
-    def pool_headmajor(self, E_hm: torch.Tensor, views=(), tok_proj=None):
+    def pool_headmajor(self, E_hm: torch.Tensor, views=(), tok_proj=None, e_img=None):
         """E_hm [BM,N,H*512] -> (pooled_hm [BM,(1+V,)H*512], raw scores [BM,N,H]) through the fused HIP path; `views` = V int32
         token-index lists pooled in the same autograd node (no index_select copies of E).  tok_proj = (W [P,H*512] head-major
         columns, bias): the token projection [BM,N,P] comes out of the same node (third result), see functional.AttnPoolFn."""
@@ -185,12 +212,12 @@ class ABMILEmbedder(nn.Module):
         BM, N, _ = E_hm.shape
         wa, ba, wb, bb, wc, bc = self.gate_params_stacked()
         p, seed, ka, kb = self._gate_dropout((BM, N))
-        out = MF.attn_pool(E_hm, wa, ba, wb, bb, wc, bc, p, seed, ka, kb, views=views, tok_proj=tok_proj)
+        out = MF.attn_pool(E_hm, wa, ba, wb, bb, wc, bc, p, seed, ka, kb, views=views, tok_proj=tok_proj, e_img=e_img)
         if tok_proj is None:
             return out[0], out[1].view(BM, N, self.n_heads)
         return out[0], out[1].view(BM, N, self.n_heads), out[2].view(BM, N, -1)
 
-    def pool_headmajor_ragged(self, E_hm: torch.Tensor, cu_seqlens: torch.Tensor, max_len: int):
+    def pool_headmajor_ragged(self, E_hm: torch.Tensor, cu_seqlens: torch.Tensor, max_len: int, e_img=None):
         """Packed E_hm [T,H*512] + cu_seqlens int64 [n_bags+1] -> (pooled_hm [n_bags,H*512], raw scores [T,H])."""
         for h in self.attn:
             h._check_geometry()
@@ -198,7 +225,7 @@ class ABMILEmbedder(nn.Module):
             raise NotImplementedError("ragged bags are supported for activation='softmax' (the reference's scripts)")
         wa, ba, wb, bb, wc, bc = self.gate_params_stacked()
         p, seed, ka, kb = self._gate_dropout((E_hm.shape[0], 1))
-        return MF.attn_pool(E_hm, wa, ba, wb, bb, wc, bc, p, seed, ka, kb, cu_seqlens, max_len)
+        return MF.attn_pool(E_hm, wa, ba, wb, bb, wc, bc, p, seed, ka, kb, cu_seqlens, max_len, e_img=e_img)
 
     def _scores_only(self, E_hm):
         BM, N, _ = E_hm.shape
@@ -219,18 +246,18 @@ class ABMILEmbedder(nn.Module):
         of a Linear over the head-major token embeddings (MADELEINE's token_projector), its output [BM,N,P] as a fourth result."""
         if self.agg_type != 'regular':
             raise NotImplementedError('Agg type not supported. Options are "regular".')
-        E = self.embed_tokens_headmajor(bags)
+        E, e_img = self.embed_tokens_headmajor(bags, return_image=True)
         act = self.attn[0].activation
         if tok_proj is not None:
             if act == 'softmax' and n_views == 1:
-                pooled, scores, tok = self.pool_headmajor(E, tok_proj=tok_proj)      # one autograd node for both consumers of E
+                pooled, scores, tok = self.pool_headmajor(E, tok_proj=tok_proj, e_img=e_img)   # one autograd node for both consumers of E
                 return pooled, E, scores, tok
             with torch.autocast(device_type="cuda", enabled=False):
                 tok = MF.linear(E, tok_proj[0], tok_proj[1])
-            return self.forward_headmajor_from_tokens(E, n_views) + (tok,)
-        return self.forward_headmajor_from_tokens(E, n_views)
+            return self.forward_headmajor_from_tokens(E, n_views, e_img) + (tok,)
+        return self.forward_headmajor_from_tokens(E, n_views, e_img)
 
-    def forward_headmajor_from_tokens(self, E, n_views=1):
+    def forward_headmajor_from_tokens(self, E, n_views=1, e_img=None):
         act = self.attn[0].activation
         if act == 'softmax' and n_views != 1:
             # intra-modality views (Model.py:419-440): two random halves of the token axis (numpy RNG, as the reference),
@@ -239,10 +266,10 @@ class ABMILEmbedder(nn.Module):
             np.random.shuffle(all_indices)
             mid = len(all_indices) // 2
             views = tuple(torch.as_tensor(idx, dtype=torch.int32).to(E.device) for idx in (all_indices[:mid], all_indices[mid:]))
-            pooled, scores = self.pool_headmajor(E, views)
+            pooled, scores = self.pool_headmajor(E, views, e_img=e_img)
             return pooled, E, scores
         if act == 'softmax':
-            pooled, scores = self.pool_headmajor(E)
+            pooled, scores = self.pool_headmajor(E, e_img=e_img)
         else:
             # non-default activations (abmil.py:56-61): scores from the HIP gate kernel, the elementwise activation in torch,
             # the un-normalised weighted pooling in the HIP pool kernels' linear mode (mdl_abmil_wpool_*)
@@ -385,9 +412,9 @@ class MADELEINE(nn.Module):
             tok_stain = torch.repeat_interleave(row_stain, torch.tensor(lens)).to(device)
             x = torch.cat([x, self.embedding(tok_stain).to(x.dtype)], dim=-1)
         emb = self.wsi_embedders
-        E = emb.embed_tokens_headmajor(x)                                       # [T, H*512]
+        E, e_img = emb.embed_tokens_headmajor(x, return_image=True)             # [T, H*512]
         cu_d = cu.to(device)
-        pooled, _ = emb.pool_headmajor_ragged(E, cu_d, max(lens))
+        pooled, _ = emb.pool_headmajor_ragged(E, cu_d, max(lens), e_img=e_img)
         slide = self._project_slide(pooled).view(bs, n_mod, 1, -1)              # [B,M,1,512]
         head = (cu[:-1].unsqueeze(1) + torch.arange(n_loss_tokens).unsqueeze(0)).reshape(-1).to(device)
         tok = self._project_tokens(E.index_select(0, head)).view(bs, n_mod, n_loss_tokens, -1)   # [B,M,n,128]
