@@ -199,14 +199,21 @@ def secondary_c3_leg(dev, D, MF, InfoNCE, MADELEINE, steps=5, warmup=2):
             "workload": f"c3: {B} slides x {M} stains (cases per stain {k}) x {N} x {Dm}, InfoNCE + GOT, train mode, AdamW",
             "final_loss": float(loss.detach()),
             "kernel_ms": {n: round(v[0], 4) for n, v in prof.items()}, "kernel_calls_per_step": {n: v[1] // steps for n, v in prof.items()},
-            "kernel_roofline": kernel_rooflines(prof, work)}
+            "kernel_roofline": kernel_rooflines(prof, work, "float32", MF.gemm_mode())}
 
 
-def kernel_rooflines(prof, work, precision="float32"):
+F16_MFMA_PEAK_TF = 2500.0   # MI355X_MICROARCH.md: dense fp16 / bf16 matrix peak (v_mfma_f32_32x32x16_f16 / _bf16)
+
+
+def kernel_rooflines(prof, work, precision="float32", gemm_mode="fp32"):
     """Achieved rate of every kernel family that declared its algorithmic work (functional.KernelTimer.work): TFLOP/s against the
     dense MFMA peak of the dtype for the contractions, GB/s against the 8 TB/s HBM3E peak for the bandwidth-bound passes.  Event
     times are un-profiled clocks (rocprofv3 lowers the clocks: the durations in profiles/ are 7-12 % longer)."""
-    mpeak = F32_MFMA_PEAK_TF if precision == "float32" else 2500.0
+    # split GEMM mode (fp32 precision): every algorithmic fp32 FLOP costs three fp16 MFMA FLOPs (ah bh + ah bl + al bh): `achieved` stays
+    # algorithmic (fp32-equivalent), `frac` = 3 x achieved / the fp16 matrix peak = the matrix-core utilisation of the kernels
+    split = precision == "float32" and gemm_mode == "split"
+    mpeak = (F16_MFMA_PEAK_TF if split else F32_MFMA_PEAK_TF) if precision == "float32" else 2500.0
+    mult = 3.0 if split else 1.0
     out = {}
     for name, (kind, per_call) in sorted(work.items()):
         if name not in prof or prof[name][0] <= 0:
@@ -215,7 +222,9 @@ def kernel_rooflines(prof, work, precision="float32"):
         if kind == "flop":
             ach = per_call / (ms * 1e-3) / 1e12
             out[name] = {"bound": "mfma", "avg_ms": round(ms, 4), "achieved": round(ach, 1), "unit": "TFLOP/s", "peak": mpeak,
-                         "frac": round(ach / mpeak, 4)}
+                         "frac": round(mult * ach / mpeak, 4)}
+            if split:
+                out[name]["raw_mfma_tflops"] = round(mult * ach, 1)
         else:
             ach = per_call / (ms * 1e-3) / 1e9
             out[name] = {"bound": "hbm", "avg_ms": round(ms, 4), "achieved": round(ach, 1), "unit": "GB/s", "peak": HBM_PEAK_GBS,
@@ -480,6 +489,30 @@ def main():
                              "(torch.autocast(bfloat16), the reference's `precision: bfloat16`)",
                     "final_loss": float(lb.detach()), "kernel_ms": {k: round(v[0], 4) for k, v in pb.items()},
                     "kernel_roofline": kernel_rooflines(pb, wb, "bfloat16")}
+    f32_leg = None
+    if a.precision == "float32" and world == 1 and not a.no_bf16_leg and host_iter is None and MF.gemm_mode() == "split":
+        # the same step with every contraction on the exact-fp32 matrix-core kernels (v_mfma_f32_32x32x2_f32): the 'fp32' GEMM mode
+        MF.set_gemm_mode("fp32")
+        try:
+            for _ in range(2):
+                step()
+            fence()
+            MF.TIMER = MF.KernelTimer()
+            nf = max(3, min(10, a.steps))
+            tf0 = time.perf_counter()
+            for _ in range(nf):
+                lf = step()
+            fence()
+            ef = time.perf_counter() - tf0
+            pf, wf = MF.TIMER.report(), MF.TIMER.work()
+            MF.TIMER = None
+            f32_leg = {"value": round(B * nf / ef, 3), "unit": "slides/s", "ms_per_step": round(1e3 * ef / nf, 3), "steps": nf,
+                       "dtype": "f32 on v_mfma_f32_32x32x2_f32 (MADELEINE_GEMM=fp32): the round-1/2 engine, 157.3 TFLOP/s peak",
+                       "final_loss": float(lf.detach()), "kernel_ms": {k: round(v[0], 4) for k, v in pf.items()},
+                       "kernel_roofline": kernel_rooflines(pf, wf, "float32", "fp32")}
+        finally:
+            MF.TIMER = None
+            MF.set_gemm_mode("split")
     if host_iter is not None:
         host_iter.close()   # stops and joins the stager thread
 
@@ -510,7 +543,10 @@ def main():
             "metric": "slides/sec (pretrain step) at B=32 N=4096 d=512; 1/2/4/8 GPU",
             "value": round(value, 3), "unit": "slides/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if a.precision == "float32" else "bf16 (storage + MFMA operands; fp32 accumulate)",
+            "dtype": (("f32 (values, accumulation and epilogues fp32; contractions as 3-term split-fp16 products ah bh + ah bl + al bh on "
+                       "v_mfma_f32_32x32x16_f16 -- error below an fp32 fmaf chain, tests/test_split_gpu.py; MADELEINE_GEMM=fp32 selects "
+                       "v_mfma_f32_32x32x2_f32, see fp32_mfma_mode)") if MF.gemm_mode() == "split" else "f32")
+                      if a.precision == "float32" else "bf16 (storage + MFMA operands; fp32 accumulate)",
             "data": ("synthetic (HOST-resident randn bags through the pinned double-buffered H2D stager, PCIe-inclusive)"
                      if host_iter is not None else
                      "synthetic (device-resident randn bags, random-init weights, manual_seed 42)"),
@@ -553,11 +589,16 @@ def main():
             tf_f = flop_f / (msf * 1e-3) / 1e12
             tf_b = 2 * flop_f / (msb * 1e-3) / 1e12
             tf = 3 * flop_f / ((msf + msb) * 1e-3) / 1e12
-            mpeak = F32_MFMA_PEAK_TF if a.precision == "float32" else 2500.0
-            out["roofline_mfma"] = {"kernel": "abmil_gate fwd + bwd contractions (dX, dW) on " + ("v_mfma_f32_32x32x2_f32" if a.precision == "float32"
-                                                                                                  else "v_mfma_f32_32x32x16_bf16"), "bound": "mfma",
-                                    "achieved": round(tf, 2), "peak": mpeak, "unit": "TFLOP/s",
-                                    "frac": round(tf / mpeak, 4), "fwd_tflops": round(tf_f, 2),
+            splitm = a.precision == "float32" and MF.gemm_mode() == "split"
+            mpeak = (F16_MFMA_PEAK_TF if splitm else F32_MFMA_PEAK_TF) if a.precision == "float32" else 2500.0
+            mult = 3.0 if splitm else 1.0   # fp16 MFMA FLOPs issued per algorithmic fp32 FLOP
+            instr = "v_mfma_f32_32x32x16_bf16" if a.precision != "float32" else ("v_mfma_f32_32x32x16_f16 (3-term split products)" if splitm
+                                                                                  else "v_mfma_f32_32x32x2_f32")
+            out["roofline_mfma"] = {"kernel": "abmil_gate fwd + bwd contractions (dX, dW) on " + instr, "bound": "mfma",
+                                    "achieved": round(mult * tf, 2), "peak": mpeak, "unit": "TFLOP/s",
+                                    "frac": round(mult * tf / mpeak, 4),
+                                    "algorithmic_fp32_tflops": round(tf, 2), "algorithmic_over_fp32_mfma_peak": round(tf / F32_MFMA_PEAK_TF, 4),
+                                    "fwd_tflops": round(tf_f, 2),
                                     "bwd_contractions_tflops": round(tf_b, 2), "fwd_ms": round(msf, 3),
                                     "bwd_contractions_ms": round(msb, 3), "bwd_includes_dz_pass": not split,
                                     # the same FLOPs over forward + the WHOLE backward (dz pass included): comparable across rounds
@@ -573,9 +614,12 @@ def main():
                                                    "frac": round(dz_bytes / (msz * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         out["kernel_ms"] = {k: round(v[0], 4) for k, v in prof.items()}
         out["kernel_calls_per_step"] = {k: v[1] // a.steps for k, v in prof.items()}
-        out["kernel_roofline"] = kernel_rooflines(prof, work, a.precision)
+        out["kernel_roofline"] = kernel_rooflines(prof, work, a.precision, MF.gemm_mode())
+        out["config"]["gemm_mode"] = MF.gemm_mode() if a.precision == "float32" else "bf16"
         if bf16_leg is not None:
             out["bf16_mode"] = bf16_leg
+        if f32_leg is not None:
+            out["fp32_mfma_mode"] = f32_leg
         if c3_leg is not None:
             out["c3_mode"] = c3_leg
         if infer_leg is not None:

@@ -102,3 +102,34 @@ def test_split_linear_autograd_matches_fp32_mode(dev):
             assert rel_err(xd.grad, x64.grad) < 1e-6 and rel_err(Wd.grad, W64.grad) < 1e-6 and rel_err(bd.grad, b64.grad) < 1e-6, mode
     finally:
         MF.set_gemm_mode(old)
+
+
+def test_parity_suite_in_fp32_gemm_mode(dev):
+    """The default GEMM mode is 'split' (what every other -m gpu test exercises).  The exact-fp32 matrix-core kernels
+    (v_mfma_f32_32x32x2_f32, MADELEINE_GEMM=fp32) stay in the product as the second mode: the encoder goldens with every parameter
+    gradient, the gate kernels on the multi-split path against the CPU oracle, the full train step golden and the ragged config-5
+    backward run here once more in that mode."""
+    from madeleine_amd import functional as MF
+    from tests import test_bench_path_gpu as TB
+    from tests import test_model_gpu as TM
+    old = MF.gemm_mode()
+    MF.set_gemm_mode("fp32")
+    try:
+        TM.test_encoder_eval_and_grads(dev)
+        TB.test_gate_split_path_vs_oracle(dev, 0.25)
+        TB.test_full_step_dp_w1_matches_reference_golden(dev)
+        TM.test_forward_ragged_unequal_backward_vs_oracle(dev, False)
+    finally:
+        MF.set_gemm_mode(old)
+
+
+def test_gemm_mode_switch():
+    from madeleine_amd import functional as MF
+    old = MF.gemm_mode()
+    try:
+        MF.set_gemm_mode("fp32")
+        assert MF.gemm_mode() == "fp32"
+        with pytest.raises(ValueError):
+            MF.set_gemm_mode("bf16")
+    finally:
+        MF.set_gemm_mode(old)

@@ -48,7 +48,7 @@ __device__ __forceinline__ f32x16 mfma16(const u32x4& a, const u32x4& b, const f
 // One chunk = one K block (KB logical k).  LDS row = 8 chunks of 16 B: chunk index = ks * 2 + kh with
 //   NP = 2: ks = plane * 2 + s   (s = 16-k half of the 32-k block)      sets: (s | hi,hi) (s | hi,lo) (s | lo,hi), s = 0, 1
 //   NP = 3: ks = plane (0..2; 3 = pad)                                  sets: (0,0) (0,1) (1,0) (0,2) (1,1) (2,0)
-template <int NP, int EPI>
+template <int NP, int EPI, int PF>
 __device__ __forceinline__ void split_body(const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, float* __restrict__ C,
                                            int64_t ldc, int64_t M, int N, int nblk, SmemP& sm) {
     const int tid = threadIdx.x, lane = tid & 63;
@@ -117,7 +117,7 @@ __device__ __forceinline__ void split_body(const uint16_t* __restrict__ A, const
     SB();
     // the set whose stage reads are all requested: barrier first, then the next chunk's first fragments + DMA between its MFMAs
 #define LASTSET(FA, FB, NEXTLOADS)                                              \
-    DMA_WAIT();                                                                 \
+    if (PF) asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); else DMA_WAIT();   \
     __syncthreads();                                                            \
     NEXTLOADS;                                                                  \
     SB();                                                                       \
@@ -129,8 +129,26 @@ __device__ __forceinline__ void split_body(const uint16_t* __restrict__ A, const
             dma(st, f, m);                                                      \
             SB();                                                               \
         }                                                                       \
+        if (PF) {   /* touch the lines of block ch + PF (one 128-B line per thread: 256 A rows, 256 B rows) -> L2 */ \
+            const int fp = (ch + PF < nblk) ? ch + PF : nblk - 1;               \
+            asm volatile("global_load_dword %0, %1, %2" : "+v"(pfreg) : "v"(pfoff), "s"(pfbase + (int64_t)fp * 128) : "memory"); \
+        }                                                                       \
     }
     u32x4 a0[4], a1[4], a2[4], b0[2], b1[2], b2[2];
+    // prefetch addressing: thread t < 256 touches A row t, t >= 256 touches B row t - 256 (uniform base = A image start)
+    uint32_t pfreg = 0;
+    // waves 0-3 touch the 256 A rows of the block, waves 4-7 the 256 B rows (wave-uniform base, one 128-B line per thread)
+    const char* pfbase;
+    uint32_t pfoff;
+    {
+        int64_t ra = (tid & 255);
+        if (wave < 4) { if (m0 + ra > M - 1) ra = M - 1 - m0; pfbase = baseA; pfoff = (uint32_t)(ra * row_bytes); }
+        else { pfbase = baseB; pfoff = (uint32_t)(ra * row_bytes); }
+        const uint64_t v = reinterpret_cast<uint64_t>(pfbase);
+        const uint32_t plo = __builtin_amdgcn_readfirstlane((uint32_t)v), phi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+        pfbase = reinterpret_cast<const char*>(((uint64_t)phi << 32) | plo);
+    }
+    if (PF) asm volatile("global_load_dword %0, %1, %2" : "+v"(pfreg) : "v"(pfoff), "s"(pfbase) : "memory");
 #pragma unroll
     for (int p = 0; p < 8; ++p) dma(0, 0, p);
     DMA_WAIT();
@@ -164,6 +182,7 @@ __device__ __forceinline__ void split_body(const uint16_t* __restrict__ A, const
     }
     DMA_WAIT();
     __syncthreads();
+    if (PF && pfreg == 0x12345678u && M < 0) C[0] = 1.f;   // keeps the prefetch register allocated to the end
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
@@ -175,11 +194,11 @@ __device__ __forceinline__ void split_body(const uint16_t* __restrict__ A, const
             }
         }
 }
-template <int NP, int EPI>
+template <int NP, int EPI, int PF = 0>
 __global__ __launch_bounds__(512) void split_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, float* __restrict__ C,
                                                     int64_t ldc, int64_t M, int N, int nblk) {
     __shared__ __attribute__((aligned(16))) SmemP sm;
-    split_body<NP, EPI>(A, B, C, ldc, M, N, nblk, sm);
+    split_body<NP, EPI, PF>(A, B, C, ldc, M, N, nblk, sm);
 }
 
 // ---- host-side splitting -------------------------------------------------------------------------------------------------------
@@ -286,6 +305,23 @@ int main(int argc, char** argv) {
                 hipEventElapsedTime(&ms, e0, e1);
                 if (rd > 0) { if (epi == 0) { sum += ms; if (ms < best) best = ms; } else sum_ne += ms; }
             }
+        if (NP == 2) {
+            for (int pf = 2; pf <= 4; ++pf) {
+                double sp = 0;
+                for (int rd = 0; rd < rounds; ++rd) {
+                    hipEventRecord(e0);
+                    if (pf == 2) hipLaunchKernelGGL((split_kernel<2, 0, 2>), dim3(tiles), dim3(512), 0, 0, A, B, C, (int64_t)N, M, N, nblk);
+                    if (pf == 3) hipLaunchKernelGGL((split_kernel<2, 0, 3>), dim3(tiles), dim3(512), 0, 0, A, B, C, (int64_t)N, M, N, nblk);
+                    if (pf == 4) hipLaunchKernelGGL((split_kernel<2, 0, 4>), dim3(tiles), dim3(512), 0, 0, A, B, C, (int64_t)N, M, N, nblk);
+                    hipEventRecord(e1);
+                    hipEventSynchronize(e1);
+                    float ms;
+                    hipEventElapsedTime(&ms, e0, e1);
+                    if (rd > 0) sp += ms;
+                }
+                printf("   L2 touch-prefetch %d blocks ahead: mean %.3f ms = %.0f TF\n", pf, sp / (rounds - 1), 2.0 * M * N * K / (sp / (rounds - 1)) / 1e9);
+            }
+        }
         const double fl = 2.0 * M * N * K, mean = sum / (rounds - 1), mean_ne = sum_ne / (rounds - 1);
         printf("   M=%lld N=%d K=%d: mean %.3f ms = %.0f TF fp32-equivalent (raw MFMA %.2f PF); best %.3f ms (%.0f TF);  no C store: %.3f ms (%.0f TF)\n",
                (long long)M, N, K, mean, fl / mean / 1e9, fl * (NP == 2 ? 3 : 6) / mean / 1e12, best, fl / best / 1e9, mean_ne, fl / mean_ne / 1e9);
