@@ -670,6 +670,7 @@ class AttnPoolFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         need = any(ctx.needs_input_grad[:7]) or any(ctx.needs_input_grad[13:15])   # (inputs 15, 16 = the image of E: no gradient)
         ctx.Ei = None
+        Ei = None
         if _split_gate(E2d):
             # the image of E: written by the producing LayerNorm kernel (Eimg / Escale), else built here (3 passes over E)
             Ei = SplitImage(Eimg, Escale, E2d.shape[0], E2d.shape[1]) if Eimg is not None else split_image(E2d)
@@ -683,7 +684,12 @@ class AttnPoolFn(torch.autograd.Function):
             _require(Wtok, "token_projector weight")
             if btok is not None:
                 _require(btok, "token_projector bias")
-            tok = linear_fwd_raw(E2d, Wtok, btok)
+            if Ei is not None and split_linear_supported(E2d.shape[0], Wtok.shape[0], Wtok.shape[1]):
+                # split engine on the image of E the gate forward used (N = 128: half of the 256-wide tile idles, still faster than
+                # the fp32 tall tile)
+                tok = split_gemm_nt(Ei, split_image(Wtok), btok, name="linear_fwd")
+            else:
+                tok = linear_fwd_raw(E2d, Wtok, btok)
         else:
             tok = E2d.new_empty(0)
             ctx.mark_non_differentiable(tok)
@@ -720,7 +726,14 @@ class AttnPoolFn(torch.autograd.Function):
         dWtok = dbtok = None
         acc_e = 0
         if has_tok and d_tok is not None:
-            dWtok, dbtok = linear_bwd_raw(E2d, Wtok, d_tok.to(E2d.dtype).contiguous(), dE, has_btok)
+            if ctx.Ei is not None and split_linear_supported(E2d.shape[0], Wtok.shape[0], Wtok.shape[1]):
+                d_tok = d_tok.float().contiguous()
+                dti = split_image(d_tok, pad_rows=32)
+                split_gemm_nt(dti, split_image(Wtok.t().contiguous()), out=dE, name="linear_bwd")        # dX straight into dE
+                dWtok = split_gemm_tn(ctx.Ei, dti, name="linear_bwd")
+                dbtok = d_tok.sum(0) if has_btok else None
+            else:
+                dWtok, dbtok = linear_bwd_raw(E2d, Wtok, d_tok.to(E2d.dtype).contiguous(), dE, has_btok)
             acc_e = 1
         # scores-only pooling backward (one read of E), then the gate backward whose dX epilogue adds the pooling term
         pool_bwd_raw(E2d, scores, pooled, m, l, d_main, None, 0, ds, acc_s, n_bags, N, cu, max_len)
