@@ -2,9 +2,10 @@
 (reference madeleine/models/abmil.py:8-68): same constructor, same sub-module names (hence the same
 state_dict keys attention_a.0.*, attention_b.0.*, attention_c.*), same forward contract.
 
-The arithmetic runs in libmadeleine_amd.so (mdl_abmil_gate_fwd/bwd); the kernels are specialised for
-the geometry the MADELEINE encoder hard-wires (input_dim = hidden_dim = 512, n_classes = 1,
-Model.py:64-77).  Other geometries raise NotImplementedError: there is no eager fallback.
+The arithmetic runs in libmadeleine_amd.so: the fused gate kernels (mdl_abmil_gate_fwd/bwd and their split-engine siblings) are
+specialised for the geometry the MADELEINE encoder hard-wires (input_dim = hidden_dim = 512, n_classes = 1, Model.py:64-77);
+any other geometry -- including the class defaults 1024 / 256 / 1 -- runs its two Linears on the HIP Linear kernels with elementwise
+activations (`_forward_generic`).  Inside ABMILEmbedder only the fused geometry is accepted.
 """
 import torch
 import torch.nn.functional as F
@@ -52,11 +53,38 @@ class BatchedABMIL(nn.Module):
             raise NotImplementedError("madeleine_amd.BatchedABMIL: the gate kernels take one dropout rate for both branches")
         return pa
 
+    def _is_fused_geometry(self):
+        return self.input_dim == MF.HID and self.hidden_dim == MF.HID and self.n_classes == 1
+
+    def _forward_generic(self, x, return_raw_attention):
+        """Any other geometry -- e.g. the class defaults input_dim = 1024, hidden_dim = 256 (abmil.py:10): the two gate Linears run on
+        the HIP Linear kernels (functional.linear: split-fp16 / fp32 matrix-core engine, forward + dX + dW), the tanh / sigmoid / dropout
+        and the hidden -> n_classes product (a reduction over <= hidden_dim channels per class) are elementwise torch ops."""
+        B, N, D = x.shape
+        if D != self.input_dim:
+            raise ValueError("BatchedABMIL: expected input dim %d, got %d" % (self.input_dim, D))
+        x2 = x.float().contiguous().view(B * N, D)
+        a = torch.tanh(MF.linear(x2, self.attention_a[0].weight, self.attention_a[0].bias))
+        b = torch.sigmoid(MF.linear(x2, self.attention_b[0].weight, self.attention_b[0].bias))
+        p = self.dropout_p()
+        if p > 0:
+            if self._injected_keep is not None:
+                ka, kb = (k.reshape(B * N, self.hidden_dim).to(a.dtype) for k in self._injected_keep)
+                a, b = a * ka / (1.0 - p), b * kb / (1.0 - p)
+            else:
+                a, b = F.dropout(a, p, True), F.dropout(b, p, True)
+        ab = a * b
+        A = torch.stack([(ab * self.attention_c.weight[c]).sum(-1) + self.attention_c.bias[c] for c in range(self.n_classes)], dim=-1)
+        A = A.view(B, N, self.n_classes)
+        activated = activate(A, self.activation)
+        return (activated, A) if return_raw_attention else activated
+
     def forward(self, x, return_raw_attention=False):
-        """x [B, N, 512] -> activated attention [B, N, 1] (and the raw scores when asked)."""
-        self._check_geometry()
+        """x [B, N, input_dim] -> activated attention [B, N, n_classes] (and the raw scores when asked)."""
         if x.dim() != 3:
             raise ValueError("BatchedABMIL expects x of shape [batch, tokens, dim]")
+        if not self._is_fused_geometry():
+            return self._forward_generic(x, return_raw_attention)
         B, N, D = x.shape
         wa, ba, wb, bb, wc, bc = self.gate_params()
         p = self.dropout_p()

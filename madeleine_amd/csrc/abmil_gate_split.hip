@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void sp_gate_dz_kernel(const float* __restrict
                                                          const float* __restrict__ act_b, const float* __restrict__ d_scores,
                                                          char* __restrict__ dzi, const float* __restrict__ dz_sc,
                                                          float* __restrict__ slabV, int64_t T, int H, DropCfg drop) {
-    constexpr int VEC = 4, NQ = HID / VEC, PH = 256 / NQ;   // 128 column groups x 2 row phases
+    constexpr int VEC = 8, NQ = HID / VEC, PH = 256 / NQ;   // 64 groups of 8 columns (16-B image stores) x 4 row phases
     __shared__ float red[PH - 1][NQ][3 * VEC + 1];
     const int tid = threadIdx.x, q = tid % NQ, ph = tid / NQ, c = blockIdx.y;
     const int64_t r0 = (int64_t)blockIdx.x * DZ_ROWS;
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void sp_gate_dz_kernel(const float* __restrict
     }
     float sds = 0.f;
     const int64_t offa = sp_img_off(q * VEC, 0), offb = sp_img_off(HID + q * VEC, 0);
-    constexpr int UNR = 4;
+    constexpr int UNR = 2;   // 2 rows x (a, b) x 2 x 16 B = 8 loads in flight per thread
     for (int64_t rb = r0 + ph; rb < r1; rb += PH * UNR) {
         float va[UNR][VEC], vb[UNR][VEC], ds[UNR];
 #pragma unroll
@@ -200,8 +200,14 @@ __global__ __launch_bounds__(256) void sp_gate_dz_kernel(const float* __restrict
             const int64_t r = rb + PH * u;
             const bool ok = r < r1;
             const int64_t o = ((ok ? r : rb) * H + c) * HID + q * VEC;
-            ldv<float>(act_a + o, va[u]);
-            ldv<float>(act_b + o, vb[u]);
+            const f32x4 a0 = ld4_nt(act_a + o), a1 = ld4_nt(act_a + o + 4), b0 = ld4_nt(act_b + o), b1 = ld4_nt(act_b + o + 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                va[u][i] = a0[i];
+                va[u][4 + i] = a1[i];
+                vb[u][i] = b0[i];
+                vb[u][4 + i] = b1[i];
+            }
             ds[u] = ok ? d_scores[r * H + c] : 0.f;
         }
 #pragma unroll
@@ -209,9 +215,7 @@ __global__ __launch_bounds__(256) void sp_gate_dz_kernel(const float* __restrict
             const int64_t r = rb + PH * u;
             if (r < r1) {
                 const int64_t o = (r * H + c) * HID + q * VEC;
-                const uint32_t rkey = drop_row_key(drop, o);
-                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-                uint32_t ha[2], la[2], hb[2], lb[2];
+                const uint32_t rkey = drop_row_key(drop, o);   // the 8 elements share the high word (o % 512 + i < 512)
                 float za[VEC], zb[VEC];
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) {
@@ -220,22 +224,18 @@ __global__ __launch_bounds__(256) void sp_gate_dz_kernel(const float* __restrict
                     sw[i] += w;
                     sa[i] += za[i];
                     sb[i] += zb[i];
-                }
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const float a0 = za[2 * i] * s, a1 = za[2 * i + 1] * s, b0 = zb[2 * i] * s, b1 = zb[2 * i + 1] * s;
-                    const _Float16 ha0 = (_Float16)a0, ha1 = (_Float16)a1, hb0 = (_Float16)b0, hb1 = (_Float16)b1;
-                    ha[i] = __builtin_bit_cast(uint32_t, h2{ha0, ha1});
-                    hb[i] = __builtin_bit_cast(uint32_t, h2{hb0, hb1});
-                    la[i] = __builtin_bit_cast(uint32_t, h2{(_Float16)(a0 - (float)ha0), (_Float16)(a1 - (float)ha1)});
-                    lb[i] = __builtin_bit_cast(uint32_t, h2{(_Float16)(b0 - (float)hb0), (_Float16)(b1 - (float)hb1)});
+                    za[i] *= s;
+                    zb[i] *= s;
                 }
                 sds += ds[u];
+                u32x4 ha, la, hb, lb;
+                sp_split8(za, ha, la);
+                sp_split8(zb, hb, lb);
                 char* row = dzi + (r * H + c) * (int64_t)(1024 * 4);
-                *reinterpret_cast<u32x2*>(row + offa) = u32x2{ha[0], ha[1]};
-                *reinterpret_cast<u32x2*>(row + offa + 64) = u32x2{la[0], la[1]};
-                *reinterpret_cast<u32x2*>(row + offb) = u32x2{hb[0], hb[1]};
-                *reinterpret_cast<u32x2*>(row + offb + 64) = u32x2{lb[0], lb[1]};
+                *reinterpret_cast<u32x4*>(row + offa) = ha;
+                *reinterpret_cast<u32x4*>(row + offa + 64) = la;
+                *reinterpret_cast<u32x4*>(row + offb) = hb;
+                *reinterpret_cast<u32x4*>(row + offb + 64) = lb;
             }
         }
     }

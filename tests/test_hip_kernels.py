@@ -654,3 +654,34 @@ def test_linear_and_ln_c3_size_vs_library(dev):
     dropped = (tail_d == 0) & (tail_0 != 0)
     assert abs(float(dropped.float().mean()) - 0.1) < 0.005
     assert rel_err(tail_d[~dropped], (tail_0 / 0.9)[~dropped]) < 1e-6
+
+
+@pytest.mark.parametrize("din,hid,ncls,N", [(1024, 256, 1, 700), (1024, 256, 1, 40), (768, 512, 2, 300)])
+def test_batched_abmil_other_geometries_vs_oracle(dev, din, hid, ncls, N):
+    """BatchedABMIL outside the 512 / 512 / 1 geometry MADELEINE hard-wires -- first of all the reference class's own defaults
+    input_dim = 1024, hidden_dim = 256 (madeleine/models/abmil.py:10; VERDICT round 2, missing #4): values, the softmax over the patch
+    axis and every gradient against the oracle (abmil.py:41-68), train mode with injected dropout masks."""
+    from madeleine_amd import BatchedABMIL
+    from oracle import recipe
+    B = 2
+    m = BatchedABMIL(input_dim=din, hidden_dim=hid, dropout=True, n_classes=ncls).to(dev).train()
+    sd = {k: torch.from_numpy(v) for k, v in recipe.state_dict_recipe({k: tuple(v.shape) for k, v in m.state_dict().items()}, "abg").items()}
+    m.load_state_dict(sd)
+    x = t((B, N, din), f"abg:x{din}{N}")
+    ka = torch.from_numpy(recipe.bernoulli((B, N, hid), "abg:ka", 0.75))
+    kb = torch.from_numpy(recipe.bernoulli((B, N, hid), "abg:kb", 0.75))
+    gout = t((B, N, ncls), "abg:g")
+    ref_p = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    xr = x.clone().requires_grad_()
+    raw_ref = R.gate_scores(xr, ref_p["attention_a.0.weight"], ref_p["attention_a.0.bias"], ref_p["attention_b.0.weight"],
+                            ref_p["attention_b.0.bias"], ref_p["attention_c.weight"], ref_p["attention_c.bias"], ka, kb)
+    att_ref = torch.softmax(raw_ref, dim=1)
+    ((att_ref * gout).sum() + 0.3 * (raw_ref * gout).sum()).backward()   # (the raw term: softmax alone is shift-invariant in bc)
+    m._injected_keep = (ka.to(dev), kb.to(dev))
+    xd = x.to(dev).requires_grad_()
+    att, raw = m(xd, return_raw_attention=True)
+    ((att * gout.to(dev)).sum() + 0.3 * (raw * gout.to(dev)).sum()).backward()
+    assert rel_err(raw, raw_ref) < 1e-5 and rel_err(att, att_ref) < 1e-5
+    assert rel_err(xd.grad, xr.grad) < 1e-4
+    for k, p in m.named_parameters():
+        assert rel_err(p.grad, ref_p[k].grad) < 1e-4, k
