@@ -12,6 +12,8 @@
 //             per backward: 1.3 ms of HBM-bound passes at config 2).  fp32 slabs over token splits, reduced by gate_reduce_w.
 // Operands reach LDS by LDS-DMA (global_load_lds_dwordx4) into the same XOR-swizzled 64-B row image the fp32 kernels
 // use (16-B chunk kq of row r is stored at slot kq ^ ((r >> 2) & 3)), read back with conflict-free ds_read_b128.
+#include <cstdlib>
+
 #include "tile_engine_bf16.hpp"
 
 namespace mdl {
@@ -171,6 +173,104 @@ __global__ __launch_bounds__(256, 2) void gate_fwd_bf16_kernel(const bf16_t* __r
         const int64_t t = t0 + tid;
         const float* sr = reinterpret_cast<const float*>(&sm) + 4 * (32 * 64);
         if (t < T) part[(t * H + c) * GATE_JT + jt] = sr[tid] + sr[BBM + tid];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Round 3: the forward on the 256 x 256 x 64 tile (nt256_mainloop: whole 128-B lines per row and chunk, 8 waves as 2 x 4, 128 x 64 per
+// wave) for T >= 4096.  Tile = 256 tokens x (128 a | 128 b) gate columns; tile column n = wn * 64 + ct * 32 + l: ct = 0 -> a column
+// j0 + wn * 32 + l, ct = 1 -> the b column of the same j, so a wave holds za and zb of the same (token, j) in acc[rt][0] / acc[rt][1]
+// (the layout of abmil_gate_split.hip).  Epilogue as above: 4 passes of 32 rows x (32 a | 32 b) through the wave's LDS tile.
+// ------------------------------------------------------------------------------------------------
+template <int DM, bool SAVE>
+__global__ __launch_bounds__(512) void gate_fwd256_bf16_kernel(const bf16_t* __restrict__ E, int64_t ldE, const bf16_t* __restrict__ WK,
+                                                               const float* __restrict__ ba, const float* __restrict__ bb,
+                                                               const float* __restrict__ wc, float* __restrict__ part,
+                                                               bf16_t* __restrict__ act_a, bf16_t* __restrict__ act_b, int64_t T, int H,
+                                                               int n_ttiles, DropCfg drop) {
+    __shared__ SmemQ sm;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const XcdHead xh = xcd_head(blockIdx.x, H);
+    const int jt = xh.li % GATE_JT, c = xh.c, tt = (xh.li / GATE_JT) * xh.nshare + xh.share;
+    if (tt >= n_ttiles) return;  // block-uniform
+    const int64_t t0 = (int64_t)tt * QM;
+    const int j0 = jt * 128;
+
+    const char* baseA = reinterpret_cast<const char*>(E + t0 * ldE + (int64_t)c * HID);
+    const char* baseB = reinterpret_cast<const char*>(WK + (int64_t)c * 1024 * HID);
+    uint32_t voA[4], voB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int row, ch;
+        nt256_slot(wave, i, lane, row, ch);
+        int64_t ra = row;
+        if (t0 + ra > T - 1) ra = T - 1 - t0;
+        voA[i] = (uint32_t)(ra * ldE * 2 + ch * 16);
+        const int wrow = ((row >> 5) & 1) * HID + j0 + (row >> 6) * 32 + (row & 31);
+        voB[i] = (uint32_t)(wrow * (HID * 2) + ch * 16);
+    }
+    f32x16 acc[4][2];
+    nt256_mainloop(sm, acc, HID / QK, wm, wn, lane, [&](int st, int64_t f, int piece) {
+        const int i = piece & 3;
+        if (piece < 4) glds16_s(voA[i], baseA + f * (QK * 2), lds_addr_of(&sm.A[st][(wave * 4 + i) * 1024]));
+        else glds16_s(voB[i], baseB + f * (QK * 2), lds_addr_of(&sm.B[st][(wave * 4 + i) * 1024]));
+    });
+
+    const int l32 = lane & 31;
+    float* tile = reinterpret_cast<float*>(&sm) + wave * (32 * 64);
+    float* sred = reinterpret_cast<float*>(&sm) + 8 * (32 * 64) + wn * QM + wm * 128;   // [4 (wn)][256 rows]
+    const int g4 = lane & 3, r16 = lane >> 2;
+    const int jc = j0 + wn * 32;
+    const float bav = ba[c * HID + jc + l32], bbv = bb[c * HID + jc + l32];
+    const f32x4 wlo = *reinterpret_cast<const f32x4*>(wc + c * HID + jc + g4 * 8);
+    const f32x4 whi = *reinterpret_cast<const f32x4*>(wc + c * HID + jc + g4 * 8 + 4);
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            tile[acc_row(r, lane) * 64 + l32] = (float)(bf16_t)fast_tanh(acc[rt][0][r] + bav);
+            tile[acc_row(r, lane) * 64 + 32 + l32] = (float)(bf16_t)fast_sigmoid(acc[rt][1][r] + bbv);
+            if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = i * 16 + r16;
+            const f32x4 alo = *reinterpret_cast<const f32x4*>(&tile[row * 64 + g4 * 8]);
+            const f32x4 ahi = *reinterpret_cast<const f32x4*>(&tile[row * 64 + g4 * 8 + 4]);
+            const f32x4 blo = *reinterpret_cast<const f32x4*>(&tile[row * 64 + 32 + g4 * 8]);
+            const f32x4 bhi = *reinterpret_cast<const f32x4*>(&tile[row * 64 + 32 + g4 * 8 + 4]);
+            float sum = 0.f;
+            if (t0 + wm * 128 + rt * 32 + row < T) {
+                const int64_t idx = ((t0 + wm * 128 + rt * 32) * H + c) * HID + jc + (uint32_t)(row * H * HID + g4 * 8);
+                const uint32_t rkey = drop_row_key(drop, idx);
+                if (SAVE) {
+                    st8_bf16(act_a + idx, alo, ahi);
+                    st8_bf16(act_b + idx, blo, bhi);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    bool keep_a, keep_b;
+                    fwd_keep2_bf16<DM>(drop, idx + e, rkey, keep_a, keep_b);
+                    const float a = e < 4 ? alo[e & 3] : ahi[e & 3], b = e < 4 ? blo[e & 3] : bhi[e & 3];
+                    const float w = e < 4 ? wlo[e & 3] : whi[e & 3];
+                    const float ad = keep_a ? a * drop.inv : 0.f;
+                    const float bd = keep_b ? b * drop.inv : 0.f;
+                    sum += ad * bd * w;
+                }
+            }
+            sum += __shfl_xor(sum, 1, 64);
+            sum += __shfl_xor(sum, 2, 64);
+            if (g4 == 0) sred[rt * 32 + row] = sum;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    __syncthreads();
+    if (tid < QM) {
+        const int64_t t = t0 + tid;
+        const float* sr = reinterpret_cast<const float*>(&sm) + 8 * (32 * 64);
+        if (t < T) part[(t * H + c) * GATE_JT + jt] = ((sr[tid] + sr[QM + tid]) + sr[2 * QM + tid]) + sr[3 * QM + tid];
     }
 }
 
@@ -442,7 +542,23 @@ extern "C" int mdl_abmil_gate_fwd_bf16(const uint16_t* E, int64_t ldE, const flo
 #define MDL_GATE_FWD16(DM, SAVE)                                                                                                   \
     hipLaunchKernelGGL((gate_fwd_bf16_kernel<DM, SAVE>), dim3((unsigned)grid), dim3(256), 0, s, (const bf16_t*)E, ldE, (const bf16_t*)WK, \
                        ba, bb, wc, part, (bf16_t*)act_a, (bf16_t*)act_b, T, H, (int)n_tt, d)
-    if (act_a) {
+    const int64_t n_tt256 = (T + QM - 1) / QM;
+    const int64_t grid256 = xcd_head_grid(n_tt256, GATE_JT, H);
+#define MDL_GATE_FWD256(DM, SAVE)                                                                                                  \
+    hipLaunchKernelGGL((gate_fwd256_bf16_kernel<DM, SAVE>), dim3((unsigned)grid256), dim3(512), 0, s, (const bf16_t*)E, ldE,       \
+                       (const bf16_t*)WK, ba, bb, wc, part, (bf16_t*)act_a, (bf16_t*)act_b, T, H, (int)n_tt256, d)
+    const bool big = T >= 4096 && !getenv("MADELEINE_BF16_GATE128");
+    if (big) {   // 256 x 256 x 64 tile
+        if (act_a) {
+            if (dm == 0) MDL_GATE_FWD256(0, true);
+            else if (dm == 1) MDL_GATE_FWD256(1, true);
+            else MDL_GATE_FWD256(2, true);
+        } else {
+            if (dm == 0) MDL_GATE_FWD256(0, false);
+            else if (dm == 1) MDL_GATE_FWD256(1, false);
+            else MDL_GATE_FWD256(2, false);
+        }
+    } else if (act_a) {
         if (dm == 0) MDL_GATE_FWD16(0, true);
         else if (dm == 1) MDL_GATE_FWD16(1, true);
         else MDL_GATE_FWD16(2, true);
@@ -451,6 +567,7 @@ extern "C" int mdl_abmil_gate_fwd_bf16(const uint16_t* E, int64_t ldE, const flo
         else if (dm == 1) MDL_GATE_FWD16(1, false);
         else MDL_GATE_FWD16(2, false);
     }
+#undef MDL_GATE_FWD256
 #undef MDL_GATE_FWD16
     MDL_LAUNCH_CHECK();
     return gate_launch_finalize(part, bc, scores, T * H, H, s);
