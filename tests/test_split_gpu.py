@@ -133,3 +133,62 @@ def test_gemm_mode_switch():
             MF.set_gemm_mode("bf16")
     finally:
         MF.set_gemm_mode(old)
+
+
+@pytest.mark.parametrize("T,K,N,want_fp32,mode", [(1000, 512, 512, False, "eval"), (700, 800, 512, False, "mask"), (515, 512, 2048, True, "mask"),
+                                                   (300, 64, 1024, True, "eval")])
+def test_preattn_block_vs_torch_fp64(dev, T, K, N, want_fp32, mode):
+    """One pre-attention block (Linear -> LayerNorm -> GELU -> Dropout, reference madeleine/models/Model.py:351-354) as the fused split
+    node: the image it emits decodes to the fp64 result, the optional fp32 copy equals it, and x / W / bias / gamma / beta gradients
+    match fp64 autograd -- the LayerNorm kernels write split images straight away (forward: scale from the parameter bound; backward:
+    from rstd_max, max|dy|), so this also checks those bounds leave the values well inside the fp16 range."""
+    import torch.nn.functional as F
+    from madeleine_amd import functional as MF
+    from oracle import recipe
+    x = t((T, K), f"pb:x{T}{K}") * 2
+    W = 0.05 * t((N, K), f"pb:w{N}{K}")
+    lb, g, b = 0.3 * t((N,), f"pb:lb{N}"), 1 + 0.2 * t((N,), f"pb:g{N}"), 0.3 * t((N,), f"pb:b{N}")
+    dy = t((T, N), f"pb:dy{T}{N}") * torch.logspace(0, -2, T).unsqueeze(1)
+    keep = torch.from_numpy(recipe.bernoulli((T, N), f"pb:k{T}{N}", 0.9)) if mode == "mask" else None
+    p = 0.1 if keep is not None else 0.0
+    leaves = [v.double().requires_grad_() for v in (x, W, lb, g, b)]
+    ref = F.gelu(F.layer_norm(leaves[0] @ leaves[1].t() + leaves[2], (N,), leaves[3], leaves[4], 1e-5))
+    if keep is not None:
+        ref = ref * keep.double() / 0.9
+    ref.backward(dy.double())
+    dl = [v.to(dev).requires_grad_() for v in (x, W, lb, g, b)]
+    img, sc, out = MF.preattn_block(dl[0], None, dl[1], dl[2], dl[3], dl[4], 1e-5, p, 0,
+                                    None if keep is None else keep.to(torch.uint8).to(dev), want_fp32)
+    dec = _decode(MF.SplitImage(img.detach(), sc, T, N), T, N)
+    assert rel_err(dec, ref) < 1e-5
+    bound = float(sc[1])
+    assert float(ref.abs().max()) <= bound < 2 ** 9 * float(ref.abs().max()) and 2 ** 13 <= bound * float(sc[0]) < 2 ** 14
+    if want_fp32:
+        assert rel_err(out, ref) < 1e-5
+        out.backward(dy.to(dev))
+    else:
+        img.backward(dy.to(dev))
+    for name, a, r in zip(("x", "W", "lin_bias", "gamma", "beta"), dl, leaves):
+        assert rel_err(a.grad, r.grad) < 2e-5, name
+
+
+def test_preattn_blocks_chain_on_images(dev):
+    """Two chained blocks: the second consumes the first's IMAGE (no fp32 activation in between); gradients flow back as fp32."""
+    import torch.nn.functional as F
+    from madeleine_amd import functional as MF
+    T, K, N1, N2 = 900, 512, 512, 2048
+    x = t((T, K), "pbc:x")
+    W1, W2 = 0.05 * t((N1, K), "pbc:w1"), 0.05 * t((N2, N1), "pbc:w2")
+    g1, b1, g2, b2 = 1 + 0.1 * t((N1,), "pbc:g1"), 0.1 * t((N1,), "pbc:b1"), 1 + 0.1 * t((N2,), "pbc:g2"), 0.1 * t((N2,), "pbc:b2")
+    dy = t((T, N2), "pbc:dy")
+    lv = [v.double().requires_grad_() for v in (x, W1, g1, b1, W2, g2, b2)]
+    h = F.gelu(F.layer_norm(lv[0] @ lv[1].t(), (N1,), lv[2], lv[3], 1e-5))
+    ref = F.gelu(F.layer_norm(h @ lv[4].t(), (N2,), lv[5], lv[6], 1e-5))
+    ref.backward(dy.double())
+    dl = [v.to(dev).requires_grad_() for v in (x, W1, g1, b1, W2, g2, b2)]
+    i1, s1, _ = MF.preattn_block(dl[0], None, dl[1], None, dl[2], dl[3])
+    i2, s2, out = MF.preattn_block(i1, s1, dl[4], None, dl[5], dl[6], want_fp32=True)
+    assert rel_err(out, ref) < 1e-5
+    out.backward(dy.to(dev))
+    for name, a, r in zip(("x", "W1", "g1", "b1", "W2", "g2", "b2"), dl, lv):
+        assert rel_err(a.grad, r.grad) < 2e-5, name
