@@ -424,6 +424,8 @@ class PreAttnBlockFn(torch.autograd.Function):
         T, K = x.shape
         N = W.shape[0]
         dev = x.device
+        if x_scale is None:
+            _ABSMAX.clear()      # first block of an encoder forward: no published maximum outlives a step
         xi = SplitImage(x, x_scale, T, K) if x_scale is not None else split_image(x)
         y = split_gemm_nt(xi, split_image(W), name="linear_fwd")          # pre-LN values (the Linear's bias is added by the LN kernel)
         img = torch.empty(T, N, device=dev, dtype=torch.float32)
@@ -438,7 +440,7 @@ class PreAttnBlockFn(torch.autograd.Function):
             raise NotImplementedError("fused LayerNorm-GELU-Dropout supports widths 256/512/1024/2048/4096 (got %d)" % N)
         _native.check(rc, "mdl_ln_gelu_drop_fwd_split")
         ctx.save_for_backward(xi.data, xi.scale, W, y, gamma, beta, mean, rstd, lin_bias if lin_bias is not None else torch.empty(0))
-        ctx.cfg = (float(p_drop), int(seed), keep, lin_bias is not None, bool(want_fp32), T, K, N)
+        ctx.cfg = (float(p_drop), int(seed), keep, lin_bias is not None, bool(want_fp32), T, K, N, x_scale is not None)
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(scale)
         if want_fp32:
@@ -451,7 +453,7 @@ class PreAttnBlockFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_img, _d_scale, d_out):
         xdata, xscale, W, y, gamma, beta, mean, rstd, lin_bias = ctx.saved_tensors
-        p_drop, seed, keep, has_bias, want_fp32, T, K, N = ctx.cfg
+        p_drop, seed, keep, has_bias, want_fp32, T, K, N, x_is_image = ctx.cfg
         lin_bias = lin_bias if has_bias else None
         dy = d_out if want_fp32 else d_img
         if dy is None:
@@ -475,7 +477,8 @@ class PreAttnBlockFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             am = torch.zeros(1, device=dev, dtype=torch.float32)
             dx = split_gemm_nt(dyi, split_image(W.t().contiguous()), absmax_out=am, name="linear_bwd")
-            _put_absmax(dx, am)
+            if x_is_image:       # the consumer is the previous block's LayerNorm backward (this node's input was its image)
+                _put_absmax(dx, am)
         dW = split_gemm_tn(SplitImage(xdata, xscale, T, K), dyi, name="linear_bwd")
         return dx, None, dW, dbias, dg, db, None, None, None, None, None
 
