@@ -76,10 +76,11 @@ __device__ __forceinline__ void sp_keep2(const DropCfg& d, int64_t idx, uint32_t
     }
 }
 
-// Tile: 256 tokens x (128 a | 128 b) gate columns j0 .. j0 + 127 of head c.  Tile column n = wn * 64 + ct * 32 + l: ct = 0 -> a column
-// j0 + wn * 32 + l, ct = 1 -> b column j0 + wn * 32 + l, so that a wave holds za and zb of the same (token, j) in acc[rt][0] / [rt][1].
+// Tile: 256 tokens x (128 a | 128 b) gate columns j0 .. j0 + 127 of head c.  Tile column n = wn * SP_WCOLS + ct * 32 + l with the first
+// SPNCT / 2 column tiles of a wave = a columns j0 + wn * (16 SPNCT) + ct * 32 + l and the second half = the b columns of the same j, so that
+// a wave holds za and zb of the same (token, j) in acc[rt][cp] / acc[rt][SPNCT / 2 + cp].
 template <int DM, bool SAVE>
-__global__ __launch_bounds__(512) void sp_gate_fwd_kernel(const char* __restrict__ Ei, int64_t e_rsb, const float* __restrict__ e_sc,
+__global__ __launch_bounds__(SP_THREADS) void sp_gate_fwd_kernel(const char* __restrict__ Ei, int64_t e_rsb, const float* __restrict__ e_sc,
                                                           const char* __restrict__ WK, const float* __restrict__ w_sc,
                                                           const float* __restrict__ ba, const float* __restrict__ bb,
                                                           const float* __restrict__ wc, float* __restrict__ part,
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(512) void sp_gate_fwd_kernel(const char* __restrict
     __shared__ SmemSP sm;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave / SP_WN, wn = wave % SP_WN;
     const XcdHead xh = xcd_head(blockIdx.x, H);
     const int jt = xh.li % GATE_JT, c = xh.c, tt = (xh.li / GATE_JT) * xh.nshare + xh.share;
     if (tt >= n_ttiles) return;  // block-uniform
@@ -97,76 +98,87 @@ __global__ __launch_bounds__(512) void sp_gate_fwd_kernel(const char* __restrict
 
     const char* baseA = Ei + t0 * e_rsb + (int64_t)c * (HID * 4);
     const char* baseB = WK + (int64_t)c * 1024 * (HID * 4);
-    uint32_t voA[4], voB[4];
+    constexpr int HALF = SPNCT / 2;   // a (= b) column tiles per wave
+    uint32_t voA[SP_PW], voB[SP_PW];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < SP_PW; ++i) {
         int row, ch;
         sp_nt_slot(wave, i, lane, row, ch);
         int64_t ra = row;
         if (t0 + ra > T - 1) ra = T - 1 - t0;
         voA[i] = (uint32_t)(ra * e_rsb + ch * 16);
-        const int wrow = ((row >> 5) & 1) * HID + j0 + (row >> 6) * 32 + (row & 31);   // tile row -> row of the head's [a | b] block
+        // tile row (= tile column of the product) -> row of the head's [a | b] weight block
+        const int wv = row / SP_WCOLS, ct = (row >> 5) % SPNCT;
+        const int wrow = (ct / HALF) * HID + j0 + wv * (32 * HALF) + (ct % HALF) * 32 + (row & 31);
         voB[i] = (uint32_t)(wrow * (HID * 4) + ch * 16);
     }
-    f32x16 acc[4][2];
+    SpAcc acc;
     sp_zero(acc);
     sp_nt_mainloop(sm, acc, HID / 32, wm, wn, lane, [&](int st, int f, int piece) {
-        const int i = piece & 3;
-        if (piece < 4) glds16_s(voA[i], sp_uniform(baseA + (int64_t)f * 128), lds_addr_of(&sm.A[st][(wave * 4 + i) * 1024]));
-        else glds16_s(voB[i], sp_uniform(baseB + (int64_t)f * 128), lds_addr_of(&sm.B[st][(wave * 4 + i) * 1024]));
+        const int i = piece % SP_PW;
+        if (piece < SP_PW) glds16_s(voA[i], sp_uniform(baseA + (int64_t)f * 128), lds_addr_of(&sm.A[st][(wave * SP_PW + i) * 1024]));
+        else glds16_s(voB[i], sp_uniform(baseB + (int64_t)f * 128), lds_addr_of(&sm.B[st][(wave * SP_PW + i) * 1024]));
     });
 
-    // ---- epilogue: 4 passes (rt) of a 32-row x (32 a | 32 b)-column block through the wave's LDS tile (as abmil_gate.hip)
+    // ---- epilogue: 4 x HALF passes (rt, cp) of a 32-row x (32 a | 32 b)-column block through the wave's LDS tile (as abmil_gate.hip)
     const float inv = 1.f / (e_sc[0] * w_sc[0]);
     const int l32 = lane & 31;
     float* tile = reinterpret_cast<float*>(&sm) + wave * (32 * 64);
-    float* sred = reinterpret_cast<float*>(&sm) + 8 * (32 * 64) + wn * SPM + wm * 128;   // [4 (wn)][256 rows]
+    float* sred = reinterpret_cast<float*>(&sm) + SP_WAVES * (32 * 64) + wn * SPM + wm * 128;   // [SP_WN][256 rows]
     const int g8 = lane & 7, r8 = lane >> 3;
-    const int jc = j0 + wn * 32;   // first gate column of this wave
-    const float bav = ba[c * HID + jc + l32], bbv = bb[c * HID + jc + l32];
-    const f32x4 wc4 = *reinterpret_cast<const f32x4*>(wc + c * HID + jc + g8 * 4);
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {
+    for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            tile[acc_row(r, lane) * 64 + l32] = fast_tanh(fmaf(acc[rt][0][r], inv, bav));
-            tile[acc_row(r, lane) * 64 + 32 + l32] = fast_sigmoid(fmaf(acc[rt][1][r], inv, bbv));
-            if ((r & 3) == 3) SP_SB();
-        }
+        for (int cp = 0; cp < HALF; ++cp) {
+            const int jc = j0 + wn * (32 * HALF) + cp * 32;   // first gate column of this pass
+            const float bav = ba[c * HID + jc + l32], bbv = bb[c * HID + jc + l32];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = i * 8 + r8;
-            const f32x4 a4 = *reinterpret_cast<const f32x4*>(&tile[row * 64 + g8 * 4]);
-            const f32x4 b4 = *reinterpret_cast<const f32x4*>(&tile[row * 64 + 32 + g8 * 4]);
-            float sum = 0.f;
-            if (t0 + wm * 128 + rt * 32 + row < T) {
-                const int64_t idx = ((t0 + wm * 128 + rt * 32) * H + c) * HID + jc + (uint32_t)(row * H * HID + g8 * 4);
-                const uint32_t rkey = drop_row_key(drop, idx);   // idx % 4 == 0: the 4 elements share the high word
-                if (SAVE) {
-                    *reinterpret_cast<f32x4*>(act_a + idx) = a4;
-                    *reinterpret_cast<f32x4*>(act_b + idx) = b4;
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    bool keep_a, keep_b;
-                    sp_keep2<DM>(drop, idx + e, rkey, keep_a, keep_b);
-                    const float ad = keep_a ? a4[e] * drop.inv : 0.f;
-                    const float bd = keep_b ? b4[e] * drop.inv : 0.f;
-                    sum += ad * bd * wc4[e];
-                }
+            for (int r = 0; r < 16; ++r) {
+                tile[acc_row(r, lane) * 64 + l32] = fast_tanh(fmaf(acc[rt][cp][r], inv, bav));
+                tile[acc_row(r, lane) * 64 + 32 + l32] = fast_sigmoid(fmaf(acc[rt][HALF + cp][r], inv, bbv));
+                if ((r & 3) == 3) SP_SB();
             }
-            sum += __shfl_xor(sum, 1, 64);
-            sum += __shfl_xor(sum, 2, 64);
-            sum += __shfl_xor(sum, 4, 64);
-            if (g8 == 0) sred[rt * 32 + row] = sum;
-            SP_SB();
+            const f32x4 wc4 = *reinterpret_cast<const f32x4*>(wc + c * HID + jc + g8 * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = i * 8 + r8;
+                const f32x4 a4 = *reinterpret_cast<const f32x4*>(&tile[row * 64 + g8 * 4]);
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(&tile[row * 64 + 32 + g8 * 4]);
+                float sum = 0.f;
+                if (t0 + wm * 128 + rt * 32 + row < T) {
+                    const int64_t idx = ((t0 + wm * 128 + rt * 32) * H + c) * HID + jc + (uint32_t)(row * H * HID + g8 * 4);
+                    const uint32_t rkey = drop_row_key(drop, idx);   // idx % 4 == 0: the 4 elements share the high word
+                    if (SAVE) {
+                        *reinterpret_cast<f32x4*>(act_a + idx) = a4;
+                        *reinterpret_cast<f32x4*>(act_b + idx) = b4;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        bool keep_a, keep_b;
+                        sp_keep2<DM>(drop, idx + e, rkey, keep_a, keep_b);
+                        const float ad = keep_a ? a4[e] * drop.inv : 0.f;
+                        const float bd = keep_b ? b4[e] * drop.inv : 0.f;
+                        sum += ad * bd * wc4[e];
+                    }
+                }
+                sum += __shfl_xor(sum, 1, 64);
+                sum += __shfl_xor(sum, 2, 64);
+                sum += __shfl_xor(sum, 4, 64);
+                if (g8 == 0) {
+                    if (cp == 0) sred[rt * 32 + row] = sum;
+                    else sred[rt * 32 + row] += sum;
+                }
+                SP_SB();
+            }
         }
-    }
     __syncthreads();
-    if (tid < SPM) {
-        const int64_t t = t0 + tid;
-        const float* sr = reinterpret_cast<const float*>(&sm) + 8 * (32 * 64);
-        if (t < T) part[(t * H + c) * GATE_JT + jt] = ((sr[tid] + sr[SPM + tid]) + sr[2 * SPM + tid]) + sr[3 * SPM + tid];
+    for (int rr = tid; rr < SPM; rr += SP_THREADS) {
+        const int64_t t = t0 + rr;
+        const float* sr = reinterpret_cast<const float*>(&sm) + SP_WAVES * (32 * 64);
+        float v = sr[rr];
+#pragma unroll
+        for (int w = 1; w < SP_WN; ++w) v += sr[w * SPM + rr];
+        if (t < T) part[(t * H + c) * GATE_JT + jt] = v;
     }
 }
 
@@ -274,14 +286,14 @@ __global__ __launch_bounds__(256) void sp_gate_dz_kernel(const float* __restrict
 // ================================================================================================
 // backward, stage 2: dE[t, c, n0 + n] (+)= sum_j dz[t, c, j] WN[c][n0 + n][j]  (+ pooling term), K = 1024
 // ================================================================================================
-__global__ __launch_bounds__(512) void sp_gate_dx_kernel(const char* __restrict__ dzi, const float* __restrict__ dz_sc,
+__global__ __launch_bounds__(SP_THREADS) void sp_gate_dx_kernel(const char* __restrict__ dzi, const float* __restrict__ dz_sc,
                                                          const char* __restrict__ WN, const float* __restrict__ w_sc,
                                                          float* __restrict__ dE, int64_t ldE, int accumulate, int64_t T, int H,
                                                          PoolTerm pt, float* __restrict__ absmax_out) {
     __shared__ SmemSP sm;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave / SP_WN, wn = wave % SP_WN;
     const XcdHead xh = xcd_head(blockIdx.x, H);
     const int nt = xh.li % 2, c = xh.c, tt = (xh.li / 2) * xh.nshare + xh.share;
     const int64_t t0 = (int64_t)tt * SPM;
@@ -291,9 +303,9 @@ __global__ __launch_bounds__(512) void sp_gate_dx_kernel(const char* __restrict_
     const uint32_t rowA = (uint32_t)H * 4096u;
     const char* baseA = dzi + (t0 * H + c) * (int64_t)4096;
     const char* baseB = WN + ((int64_t)c * HID + n0) * 4096;
-    uint32_t voA[4], voB[4];
+    uint32_t voA[SP_PW], voB[SP_PW];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < SP_PW; ++i) {
         int row, ch;
         sp_nt_slot(wave, i, lane, row, ch);
         int64_t ra = row;
@@ -301,12 +313,12 @@ __global__ __launch_bounds__(512) void sp_gate_dx_kernel(const char* __restrict_
         voA[i] = (uint32_t)ra * rowA + ch * 16;
         voB[i] = (uint32_t)row * 4096u + ch * 16;
     }
-    f32x16 acc[4][2];
+    SpAcc acc;
     sp_zero(acc);
     sp_nt_mainloop(sm, acc, 1024 / 32, wm, wn, lane, [&](int st, int f, int piece) {
-        const int i = piece & 3;
-        if (piece < 4) glds16_s(voA[i], sp_uniform(baseA + (int64_t)f * 128), lds_addr_of(&sm.A[st][(wave * 4 + i) * 1024]));
-        else glds16_s(voB[i], sp_uniform(baseB + (int64_t)f * 128), lds_addr_of(&sm.B[st][(wave * 4 + i) * 1024]));
+        const int i = piece % SP_PW;
+        if (piece < SP_PW) glds16_s(voA[i], sp_uniform(baseA + (int64_t)f * 128), lds_addr_of(&sm.A[st][(wave * SP_PW + i) * 1024]));
+        else glds16_s(voB[i], sp_uniform(baseB + (int64_t)f * 128), lds_addr_of(&sm.B[st][(wave * SP_PW + i) * 1024]));
     });
     const float inv = 1.f / (dz_sc[0] * w_sc[0]);
     float amax = 0.f;
@@ -334,14 +346,14 @@ __global__ __launch_bounds__(512) void sp_gate_dx_kernel(const char* __restrict_
 // ================================================================================================
 // backward, stage 3: slabW[sp][c][k' 512][1024: a | b] = sum_{t in split} E[t, c, k'] dz[t, c, n]      (TN over tokens)
 // ================================================================================================
-__global__ __launch_bounds__(512) void sp_gate_dw_kernel(const char* __restrict__ Ei, int64_t e_rsb, const float* __restrict__ e_sc,
+__global__ __launch_bounds__(SP_THREADS) void sp_gate_dw_kernel(const char* __restrict__ Ei, int64_t e_rsb, const float* __restrict__ e_sc,
                                                          const char* __restrict__ dzi, const float* __restrict__ dz_sc,
                                                          float* __restrict__ slabW, int64_t T, int H, int64_t tok_per_split,
                                                          int n_splits) {
     __shared__ SmemSP sm;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave / SP_WN, wn = wave % SP_WN;
     const XcdHead xh = xcd_head(blockIdx.x, H);
     const int kt = xh.li % 2, ntile = (xh.li / 2) % 4, c = xh.c, sp = (xh.li / 8) * xh.nshare + xh.share;
     if (sp >= n_splits) return;  // block-uniform
@@ -351,10 +363,10 @@ __global__ __launch_bounds__(512) void sp_gate_dw_kernel(const char* __restrict_
     if (te > T) te = T;
     const int64_t nch = (te > ts) ? (te - ts + SPK - 1) / SPK : 0;
 
-    uint32_t tokq[4], coA[4], coB[4];
+    uint32_t tokq[SP_PW], coA[SP_PW], coB[SP_PW];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int kr = (wave * 4 + q) * 2 + (lane >> 5), p = kr >> 5, src = (lane & 31) ^ ((kr & 3) << 2);
+    for (int q = 0; q < SP_PW; ++q) {
+        const int kr = (wave * SP_PW + q) * 2 + (lane >> 5), p = kr >> 5, src = (lane & 31) ^ ((kr & 3) << 2);
         tokq[q] = kr & 31;
         coA[q] = (uint32_t)sp_img_off(i0 + src * 8, p);
         coB[q] = (uint32_t)sp_img_off(n0 + src * 8, p);
@@ -362,17 +374,17 @@ __global__ __launch_bounds__(512) void sp_gate_dw_kernel(const char* __restrict_
     const uint32_t rowB = (uint32_t)H * 4096u;
     const char* baseA = Ei + ts * e_rsb + (int64_t)c * (HID * 4);
     const char* baseB = dzi + (ts * H + c) * (int64_t)4096;
-    f32x16 acc[4][2];
+    SpAcc acc;
     sp_zero(acc);
     sp_tn_mainloop(sm, acc, nch, wm, wn, lane, [&](int st, int64_t f, int piece) {
-        const int q = piece & 3;
-        if (piece < 4) {   // E rows past T - 1 re-read row T - 1: their dz rows are the zero pad
+        const int q = piece % SP_PW;
+        if (piece < SP_PW) {   // E rows past T - 1 re-read row T - 1: their dz rows are the zero pad
             uint32_t tk = tokq[q];
             const int64_t left = T - 1 - (ts + f * SPK);
             if (left < SPK) tk = tk < (uint32_t)left ? tk : (uint32_t)left;
-            glds16_s(tk * (uint32_t)e_rsb + coA[q], sp_uniform(baseA + f * SPK * e_rsb), lds_addr_of(&sm.A[st][(wave * 4 + q) * 1024]));
+            glds16_s(tk * (uint32_t)e_rsb + coA[q], sp_uniform(baseA + f * SPK * e_rsb), lds_addr_of(&sm.A[st][(wave * SP_PW + q) * 1024]));
         } else {
-            glds16_s(tokq[q] * rowB + coB[q], sp_uniform(baseB + f * SPK * (int64_t)rowB), lds_addr_of(&sm.B[st][(wave * 4 + q) * 1024]));
+            glds16_s(tokq[q] * rowB + coB[q], sp_uniform(baseB + f * SPK * (int64_t)rowB), lds_addr_of(&sm.B[st][(wave * SP_PW + q) * 1024]));
         }
     });
     const float inv = 1.f / (e_sc[0] * dz_sc[0]);
@@ -455,7 +467,7 @@ extern "C" int mdl_abmil_gate_fwd_split(const void* E_img, int64_t e_rsb, const 
     MDL_LAUNCH_CHECK();
     const int dm = !d.on ? 0 : (d.ka ? 2 : 1);
 #define MDL_GATE_FWD_SP(DM, SAVE)                                                                                                     \
-    hipLaunchKernelGGL((sp_gate_fwd_kernel<DM, SAVE>), dim3((unsigned)grid), dim3(512), 0, s, (const char*)E_img, e_rsb, e_scale,     \
+    hipLaunchKernelGGL((sp_gate_fwd_kernel<DM, SAVE>), dim3((unsigned)grid), dim3(SP_THREADS), 0, s, (const char*)E_img, e_rsb, e_scale, \
                        (const char*)WK, (const float*)sc, ba, bb, wc, part, act_a, act_b, T, H, (int)n_tt, d)
     if (act_a) {
         if (dm == 0) MDL_GATE_FWD_SP(0, true);
@@ -542,11 +554,11 @@ extern "C" int mdl_abmil_attnpool_bwd_split(const void* E_img, int64_t e_rsb, co
             const int64_t n_tt = (T + SPM - 1) / SPM;
             const int64_t grid = xcd_head_grid(n_tt, 2, H);
             if (grid > 0x7fffffff) return MDL_E_UNSUPPORTED;
-            hipLaunchKernelGGL(sp_gate_dx_kernel, dim3((unsigned)grid), dim3(512), 0, s, (const char*)dzi, (const float*)(sc + 4),
+            hipLaunchKernelGGL(sp_gate_dx_kernel, dim3((unsigned)grid), dim3(SP_THREADS), 0, s, (const char*)dzi, (const float*)(sc + 4),
                                (const char*)WN, (const float*)sc, dE, ldE, accumulate, T, H, pt, dE_absmax);
             MDL_LAUNCH_CHECK();
         }
-        hipLaunchKernelGGL(sp_gate_dw_kernel, dim3((unsigned)xcd_head_grid(L.S, 8, H)), dim3(512), 0, s, (const char*)E_img, e_rsb, e_scale,
+        hipLaunchKernelGGL(sp_gate_dw_kernel, dim3((unsigned)xcd_head_grid(L.S, 8, H)), dim3(SP_THREADS), 0, s, (const char*)E_img, e_rsb, e_scale,
                            (const char*)dzi, (const float*)(sc + 4), slabW, T, H, L.tps, L.S);
         MDL_LAUNCH_CHECK();
         const int rc = gate_launch_reduce_w(slabW, dWa, dWb, H, L.S, s);

@@ -18,8 +18,8 @@
 // cache line: hi plane | lo plane), i.e. exactly the bytes of the fp32 row.  One image serves both operand roles:
 //   NT  C[m][n] = sum_k A[m][k] B[n][k]   rows of both images are K-contiguous          (forward products, dX)
 //   TN  C[m][n] = sum_t A[t][m] B[t][n]   rows of both images are the contraction index  (dW; fragments by ds_read_b64_tr_b16)
-// Tile: 256 x 256 per 512-thread workgroup (8 waves as 2 x 4, 128 x 64 = 4 x 2 MFMA tiles per wave), one chunk = one 32-k block of
-// both operands = 2 x 32 KiB by LDS-DMA, two stages (128 KiB, one workgroup per CU), 48 MFMAs per wave and chunk, the in-wave
+// Tile: 256 x 256 per workgroup (4 waves as 2 x 2, 128 x 128 = 4 x 4 MFMA tiles per wave, 256 accumulators in AGPRs; see SPNCT), one chunk =
+// one 32-k block of both operands = 2 x 32 KiB by LDS-DMA, two stages (128 KiB, one workgroup per CU), 96 MFMAs per wave and chunk, the in-wave
 // software pipeline of the other engines (fragments of the next MFMA set requested behind the first MFMA of the current one, one
 // barrier per chunk before its last set, the next-but-one chunk's DMA between that set's MFMAs).
 #pragma once
@@ -33,6 +33,21 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int SPM = 256, SPN = 256, SPK = 32;
 constexpr int SP_STAGE = 256 * 128;   // bytes per operand per stage
+// Wave layout of the 256 x 256 tile: 2 x SP_WN waves, each 128 rows x (32 SPNCT) columns = 4 x SPNCT MFMA tiles.
+//   SPNCT = 2: 8 waves x 128 x 64  (128 accumulator registers, two waves per SIMD)  -- shipped
+//   SPNCT = 4: 4 waves x 128 x 128 (256 accumulators in AGPRs, ONE wave per SIMD): 8 fragment reads per 16 MFMAs instead of 6 per 8, a
+//              third less LDS read traffic per MFMA.  +12-17 % in tools/micro/split_lab.hip (L2-resident A operand, plain epilogue), but
+//              SLOWER in the product (Linears -7 %, gate dX / dW -8 %; the fused gate epilogues spill with 256 live accumulators):
+//              with HBM-streamed operands and the LDS-transposed epilogues a single wave per SIMD has nothing to hide its stalls behind.
+//              The kernels are written against these constants, so the A/B is this one line.
+constexpr int SPNCT = 2;
+constexpr int SP_WN = 8 / SPNCT;            // wave columns
+constexpr int SP_WAVES = 2 * SP_WN;
+constexpr int SP_THREADS = 64 * SP_WAVES;
+constexpr int SP_PW = 32 / SP_WAVES;        // LDS-DMA pieces (1 KiB) per wave, operand and stage
+constexpr int SP_NP = 2 * SP_PW;            // pieces per wave and chunk = MFMAs of one set = 4 SPNCT
+constexpr int SP_WCOLS = 32 * SPNCT;        // columns per wave
+typedef f32x16 SpAcc[4][SPNCT];
 struct __attribute__((aligned(16))) SmemSP {
     char A[2][SP_STAGE];
     char B[2][SP_STAGE];
@@ -48,11 +63,11 @@ __device__ __forceinline__ const char* sp_uniform(const char* p) {
 #define SP_SB() __builtin_amdgcn_sched_barrier(0)
 #define SP_DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
-__device__ __forceinline__ void sp_zero(f32x16 (&acc)[4][2]) {
+__device__ __forceinline__ void sp_zero(SpAcc& acc) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < SPNCT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 }
@@ -63,36 +78,37 @@ __device__ __forceinline__ f32x16 sp_mfma(const u32x4& a, const u32x4& b, const 
 // ---- NT ---------------------------------------------------------------------------------------------------------------------------
 // LDS stage row = 128 B = 8 chunks of 16 B; chunk index = ks * 2 + kh with ks = plane * 2 + s (s = 16-k half of the block); 16-B
 // chunk c of tile row r is stored at chunk position c ^ ((r >> 1) & 7) (conflict-free ds_read_b128 on 128-B rows).
-// DMA piece i (0..3) of wave w for one operand: rows (4w + i) * 8 .. + 7; this lane deposits global chunk c of row `row`.
-__device__ __forceinline__ void sp_nt_slot(int wave, int i, int lane, int& row, int& c) {
-    row = (wave * 4 + i) * 8 + (lane >> 3);
+// DMA piece i (< SP_PW) of wave w for one operand: rows (SP_PW w + i) * 8 .. + 7 -> LDS bytes (SP_PW w + i) * 1024 ..; this lane
+// deposits global chunk c of row `row`.
+__device__ __forceinline__ void sp_nt_slot(int wave, int i, int lane, int& row, int& c) {   // i < SP_PW
+    row = (wave * SP_PW + i) * 8 + (lane >> 3);
     c = (lane & 7) ^ ((row >> 1) & 7);
 }
-// dma(stage, block, piece): piece 0..3 = this wave's A row groups, 4..7 = its B row groups (glds16_s).
+// dma(stage, block, piece): piece < SP_PW = this wave's A row groups, SP_PW .. SP_NP - 1 = its B row groups (glds16_s).
 template <class Dma>
-__device__ __forceinline__ void sp_nt_mainloop(SmemSP& sm, f32x16 (&acc)[4][2], int nblk, int wm, int wn, int lane, Dma&& dma) {
+__device__ __forceinline__ void sp_nt_mainloop(SmemSP& sm, SpAcc& acc, int nblk, int wm, int wn, int lane, Dma&& dma) {
     const int l32 = lane & 31, kh = lane >> 5;
-    uint32_t offA[4], offB[2];
+    uint32_t offA[4], offB[SPNCT];
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) {
         const int r = wm * 128 + rt * 32 + l32;
         offA[rt] = r * 128 + ((kh ^ ((r >> 1) & 7)) << 4);
     }
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-        const int r = wn * 64 + ct * 32 + l32;
+    for (int ct = 0; ct < SPNCT; ++ct) {
+        const int r = wn * SP_WCOLS + ct * 32 + l32;
         offB[ct] = r * 128 + ((kh ^ ((r >> 1) & 7)) << 4);
     }
     auto ldA = [&](u32x4 (&fa)[4], int st, int ks) {
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) fa[rt] = *reinterpret_cast<const u32x4*>(&sm.A[st][offA[rt] ^ (ks << 5)]);
     };
-    auto ldB = [&](u32x4 (&fb)[2], int st, int ks) {
+    auto ldB = [&](u32x4 (&fb)[SPNCT], int st, int ks) {
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) fb[ct] = *reinterpret_cast<const u32x4*>(&sm.B[st][offB[ct] ^ (ks << 5)]);
+        for (int ct = 0; ct < SPNCT; ++ct) fb[ct] = *reinterpret_cast<const u32x4*>(&sm.B[st][offB[ct] ^ (ks << 5)]);
     };
-    auto mma1 = [&](const u32x4 (&fa)[4], const u32x4 (&fb)[2], int m) {
-        const int rt = m >> 1, ct = m & 1;
+    auto mma1 = [&](const u32x4 (&fa)[4], const u32x4 (&fb)[SPNCT], int m) {
+        const int rt = m / SPNCT, ct = m % SPNCT;
         acc[rt][ct] = sp_mfma(fa[rt], fb[ct], acc[rt][ct]);
     };
 #define SP_SET(FA, FB, LOADS)                                                   \
@@ -100,18 +116,18 @@ __device__ __forceinline__ void sp_nt_mainloop(SmemSP& sm, f32x16 (&acc)[4][2], 
     SP_SB();                                                                    \
     LOADS;                                                                      \
     SP_SB();                                                                    \
-    _Pragma("unroll") for (int m = 1; m < 8; ++m) mma1(FA, FB, m);              \
+    _Pragma("unroll") for (int m = 1; m < SP_NP; ++m) mma1(FA, FB, m);          \
     SP_SB();
     if (nblk <= 0) return;
-    u32x4 a0[4], a1[4], a2[4], b0[2], b1[2], b2[2];
+    u32x4 a0[4], a1[4], a2[4], b0[SPNCT], b1[SPNCT], b2[SPNCT];
 #pragma unroll
-    for (int p = 0; p < 8; ++p) dma(0, 0, p);
+    for (int p = 0; p < SP_NP; ++p) dma(0, 0, p);
     SP_DMA_WAIT();
     __syncthreads();
     {
         const int f = nblk > 1 ? 1 : 0;
 #pragma unroll
-        for (int p = 0; p < 8; ++p) dma(1, f, p);
+        for (int p = 0; p < SP_NP; ++p) dma(1, f, p);
     }
     ldA(a0, 0, 0);
     ldB(b0, 0, 0);
@@ -132,7 +148,7 @@ __device__ __forceinline__ void sp_nt_mainloop(SmemSP& sm, f32x16 (&acc)[4][2], 
         SP_SB();
         const int f = (ch + 2 < nblk) ? ch + 2 : nblk - 1;
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
+        for (int m = 0; m < SP_NP; ++m) {
             mma1(a1, b2, m);                             // lo hi, s1
             SP_SB();
             dma(st, f, m);
@@ -148,7 +164,7 @@ __device__ __forceinline__ void sp_nt_mainloop(SmemSP& sm, f32x16 (&acc)[4][2], 
 // LDS stage image of one operand: [64 kr][256 columns] fp16, kr = plane * 32 + token of the 32-token chunk, 512 B per kr row, 64-B
 // unit u of row kr stored at unit u ^ (kr & 3).  Fragments (8 consecutive tokens of the lane's output row / column) are gathered by
 // ds_read_b64_tr_b16 (lane mapping: tile_engine_bf16.hpp).  k-step KS = plane * 2 + s: + KS * 16 kr rows = KS * 8192 B.
-// DMA piece q (0..3) of wave w for one operand: kr rows (4w + q) * 2 + (lane >> 5); stored 16-B chunk position lane & 31 holds the
+// DMA piece q (< SP_PW) of wave w for one operand: kr rows (SP_PW w + q) * 2 + (lane >> 5); stored 16-B chunk position lane & 31 holds the
 // global chunk (lane & 31) ^ ((kr & 3) << 2)  (8 columns each).
 template <int OFF>
 __device__ __forceinline__ u32x2 sp_tr16(uint32_t lds_byte_addr) {
@@ -160,7 +176,7 @@ struct SpFragA {
     u32x2 v[4][2];
 };
 struct SpFragB {
-    u32x2 v[2][2];
+    u32x2 v[SPNCT][2];
 };
 template <int KS>
 __device__ __forceinline__ void sp_tn_ldA(SpFragA& f, const uint32_t (&a)[4]) {
@@ -171,41 +187,41 @@ __device__ __forceinline__ void sp_tn_ldA(SpFragA& f, const uint32_t (&a)[4]) {
     }
 }
 template <int KS>
-__device__ __forceinline__ void sp_tn_ldB(SpFragB& f, const uint32_t (&b)[2]) {
+__device__ __forceinline__ void sp_tn_ldB(SpFragB& f, const uint32_t (&b)[SPNCT]) {
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
+    for (int ct = 0; ct < SPNCT; ++ct) {
         f.v[ct][0] = sp_tr16<KS * 8192>(b[ct]);
         f.v[ct][1] = sp_tr16<KS * 8192 + 2048>(b[ct]);
     }
 }
-__device__ __forceinline__ void sp_tn_mma(f32x16 (&acc)[4][2], const SpFragA& fa, const SpFragB& fb, int m) {
-    const int rt = m >> 1, ct = m & 1;
+__device__ __forceinline__ void sp_tn_mma(SpAcc& acc, const SpFragA& fa, const SpFragB& fb, int m) {
+    const int rt = m / SPNCT, ct = m % SPNCT;
     const u32x4 av = {fa.v[rt][0].x, fa.v[rt][0].y, fa.v[rt][1].x, fa.v[rt][1].y};
     const u32x4 bv = {fb.v[ct][0].x, fb.v[ct][0].y, fb.v[ct][1].x, fb.v[ct][1].y};
     acc[rt][ct] = sp_mfma(av, bv, acc[rt][ct]);
 }
 #define SP_LGKM_WAIT() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-// acc[rt][ct] += sum over nch chunks of 32 tokens of A[t][wm*128 + rt*32 ..] B[t][wn*64 + ct*32 ..];  dma(stage, chunk, piece 0..7)
+// acc[rt][ct] += sum over nch chunks of 32 tokens of A[t][wm*128 + rt*32 ..] B[t][wn*SP_WCOLS + ct*32 ..];  dma(stage, chunk, piece < SP_NP)
 template <class Dma>
-__device__ __forceinline__ void sp_tn_mainloop(SmemSP& sm, f32x16 (&acc)[4][2], int64_t nch, int wm, int wn, int lane, Dma&& dma) {
+__device__ __forceinline__ void sp_tn_mainloop(SmemSP& sm, SpAcc& acc, int64_t nch, int wm, int wn, int lane, Dma&& dma) {
     const int g = lane >> 4, r = lane & 15;
     const int kb = (g >> 1) * 8 + (r >> 2);
-    uint32_t a_0[4], b_0[2];
+    uint32_t a_0[4], b_0[SPNCT];
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt)
         a_0[rt] = lds_addr_of(&sm.A[0][0]) + kb * 512 + (((wm * 128 + rt * 32 + (g & 1) * 16 + (r & 3) * 4) * 2) ^ ((kb & 3) << 6));
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-        b_0[ct] = lds_addr_of(&sm.B[0][0]) + kb * 512 + (((wn * 64 + ct * 32 + (g & 1) * 16 + (r & 3) * 4) * 2) ^ ((kb & 3) << 6));
+    for (int ct = 0; ct < SPNCT; ++ct)
+        b_0[ct] = lds_addr_of(&sm.B[0][0]) + kb * 512 + (((wn * SP_WCOLS + ct * 32 + (g & 1) * 16 + (r & 3) * 4) * 2) ^ ((kb & 3) << 6));
     if (nch <= 0) return;
 #pragma unroll
-    for (int p = 0; p < 8; ++p) dma(0, (int64_t)0, p);
+    for (int p = 0; p < SP_NP; ++p) dma(0, (int64_t)0, p);
     SP_DMA_WAIT();
     __syncthreads();
     {
         const int64_t f = nch > 1 ? 1 : 0;
 #pragma unroll
-        for (int p = 0; p < 8; ++p) dma(1, f, p);
+        for (int p = 0; p < SP_NP; ++p) dma(1, f, p);
     }
     SpFragA a0, a1, a2;
     SpFragB b0, b1, b2;
@@ -218,20 +234,20 @@ __device__ __forceinline__ void sp_tn_mainloop(SmemSP& sm, f32x16 (&acc)[4][2], 
     SP_SB();                                                                    \
     LOADS;                                                                      \
     SP_SB();                                                                    \
-    _Pragma("unroll") for (int m = 1; m < 8; ++m) sp_tn_mma(acc, FA, FB, m);    \
+    _Pragma("unroll") for (int m = 1; m < SP_NP; ++m) sp_tn_mma(acc, FA, FB, m); \
     SP_SB();                                                                    \
     SP_LGKM_WAIT();                                                             \
     SP_SB();
     for (int64_t ch = 0; ch < nch; ++ch) {
         const int st = (int)(ch & 1);
-        uint32_t aA[4], aB[2], nA[4], nB[2];
+        uint32_t aA[4], aB[SPNCT], nA[4], nB[SPNCT];
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) {
             aA[rt] = a_0[rt] + st * SP_STAGE;
             nA[rt] = a_0[rt] + (st ^ 1) * SP_STAGE;
         }
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
+        for (int ct = 0; ct < SPNCT; ++ct) {
             aB[ct] = b_0[ct] + st * SP_STAGE;
             nB[ct] = b_0[ct] + (st ^ 1) * SP_STAGE;
         }
@@ -248,7 +264,7 @@ __device__ __forceinline__ void sp_tn_mainloop(SmemSP& sm, f32x16 (&acc)[4][2], 
         SP_SB();
         const int64_t f = (ch + 2 < nch) ? ch + 2 : nch - 1;
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
+        for (int m = 0; m < SP_NP; ++m) {
             sp_tn_mma(acc, a1, b2, m);                                 // lo hi, s1
             SP_SB();
             dma(st, f, m);
@@ -263,34 +279,36 @@ __device__ __forceinline__ void sp_tn_mainloop(SmemSP& sm, f32x16 (&acc)[4][2], 
 }
 
 // ---- epilogue through LDS ---------------------------------------------------------------------------------------------------------
-// Hands the wave's 128 x 64 sub-tile to emit(row, col, v) as row-contiguous float4s: columns col .. col + 3 of tile row `row` (tile
+// Hands the wave's 128 x SP_WCOLS sub-tile to emit(row, col, v) as row-contiguous float4s: columns col .. col + 3 of tile row `row` (tile
 // coordinates); 16 lanes cover 256 contiguous bytes of a row.  FULL = false skips rows >= rows_valid.  Call after the main loop
-// returned (staging memory free); wave-private LDS regions, no block barrier inside.
+// returned (staging memory free); wave-private LDS regions ([32][64] floats per wave), no block barrier inside.
 template <bool FULL, int INFLIGHT = 4, class Emit>
-__device__ __forceinline__ void sp_epilogue_rows(const f32x16 (&acc)[4][2], SmemSP& sm, int wave, int wm, int wn, int lane,
-                                                 int rows_valid, Emit&& emit) {
+__device__ __forceinline__ void sp_epilogue_rows(const SpAcc& acc, SmemSP& sm, int wave, int wm, int wn, int lane, int rows_valid,
+                                                 Emit&& emit) {
     float* tile = reinterpret_cast<float*>(&sm) + wave * (32 * 64);
     const int l32 = lane & 31, rl = lane >> 4, c4 = lane & 15;
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {
+    for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
+        for (int cp = 0; cp < SPNCT / 2; ++cp) {
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct) tile[acc_row(r, lane) * 64 + ct * 32 + l32] = acc[rt][ct][r];
+            for (int r = 0; r < 16; ++r)
 #pragma unroll
-        for (int h = 0; h < 8 / INFLIGHT; ++h) {   // INFLIGHT reads in flight, then their consumers (bounds the VGPRs)
-            f32x4 v[INFLIGHT];
+                for (int c2 = 0; c2 < 2; ++c2) tile[acc_row(r, lane) * 64 + c2 * 32 + l32] = acc[rt][cp * 2 + c2][r];
 #pragma unroll
-            for (int j = 0; j < INFLIGHT; ++j)
-                v[j] = *reinterpret_cast<const f32x4*>(&tile[((h * INFLIGHT + j) * 4 + rl) * 64 + c4 * 4]);
+            for (int h = 0; h < 8 / INFLIGHT; ++h) {   // INFLIGHT reads in flight, then their consumers (bounds the VGPRs)
+                f32x4 v[INFLIGHT];
 #pragma unroll
-            for (int j = 0; j < INFLIGHT; ++j) {
-                const int row = wm * 128 + rt * 32 + (h * INFLIGHT + j) * 4 + rl;
-                if (FULL || row < rows_valid) emit(row, wn * 64 + c4 * 4, v[j]);
+                for (int j = 0; j < INFLIGHT; ++j)
+                    v[j] = *reinterpret_cast<const f32x4*>(&tile[((h * INFLIGHT + j) * 4 + rl) * 64 + c4 * 4]);
+#pragma unroll
+                for (int j = 0; j < INFLIGHT; ++j) {
+                    const int row = wm * 128 + rt * 32 + (h * INFLIGHT + j) * 4 + rl;
+                    if (FULL || row < rows_valid) emit(row, wn * SP_WCOLS + cp * 64 + c4 * 4, v[j]);
+                }
+                SP_SB();
             }
-            SP_SB();
         }
-    }
 }
 
 // absmax bookkeeping: non-negative floats order like their bit patterns

@@ -76,14 +76,14 @@ __global__ __launch_bounds__(256) void sp_convert_kernel(const float* __restrict
 
 // ---- NT -------------------------------------------------------------------------------------------------------------------------------
 // C[m][n] (+)= inv * sum_k A[m][k] B[n][k] (+ bias[n]);  rows m >= M / n >= N re-read the last valid row (discarded).
-__global__ __launch_bounds__(512) void sp_nt_kernel(const char* __restrict__ A, int64_t a_rsb, const float* __restrict__ a_sc,
+__global__ __launch_bounds__(SP_THREADS) void sp_nt_kernel(const char* __restrict__ A, int64_t a_rsb, const float* __restrict__ a_sc,
                                                     const char* __restrict__ B, int64_t b_rsb, const float* __restrict__ b_sc,
                                                     float* __restrict__ C, int64_t ldc, int64_t M, int N, int nblk, int n_tiles,
                                                     const float* __restrict__ bias, int accumulate, float* __restrict__ absmax_out) {
     __shared__ SmemSP sm;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave / SP_WN, wn = wave % SP_WN;
     const int ncol = (N + SPN - 1) / SPN;
     const int lid = xcd_remap(blockIdx.x, n_tiles);
     const int nt = lid % ncol;
@@ -92,9 +92,9 @@ __global__ __launch_bounds__(512) void sp_nt_kernel(const char* __restrict__ A, 
 
     const char* baseA = A + m0 * a_rsb;
     const char* baseB = B + (int64_t)n0 * b_rsb;
-    uint32_t voA[4], voB[4];
+    uint32_t voA[SP_PW], voB[SP_PW];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < SP_PW; ++i) {
         int row, c;
         sp_nt_slot(wave, i, lane, row, c);
         int64_t ra = row, rb = row;
@@ -103,12 +103,12 @@ __global__ __launch_bounds__(512) void sp_nt_kernel(const char* __restrict__ A, 
         voA[i] = (uint32_t)(ra * a_rsb + c * 16);
         voB[i] = (uint32_t)(rb * b_rsb + c * 16);
     }
-    f32x16 acc[4][2];
+    SpAcc acc;
     sp_zero(acc);
     sp_nt_mainloop(sm, acc, nblk, wm, wn, lane, [&](int st, int f, int piece) {
-        const int i = piece & 3;
-        if (piece < 4) glds16_s(voA[i], baseA + (int64_t)f * 128, lds_addr_of(&sm.A[st][(wave * 4 + i) * 1024]));
-        else glds16_s(voB[i], baseB + (int64_t)f * 128, lds_addr_of(&sm.B[st][(wave * 4 + i) * 1024]));
+        const int i = piece % SP_PW;
+        if (piece < SP_PW) glds16_s(voA[i], sp_uniform(baseA + (int64_t)f * 128), lds_addr_of(&sm.A[st][(wave * SP_PW + i) * 1024]));
+        else glds16_s(voB[i], sp_uniform(baseB + (int64_t)f * 128), lds_addr_of(&sm.B[st][(wave * SP_PW + i) * 1024]));
     });
     const float inv = 1.f / (a_sc[0] * b_sc[0]);
     float amax = 0.f;
@@ -132,13 +132,13 @@ __global__ __launch_bounds__(512) void sp_nt_kernel(const char* __restrict__ A, 
 // ---- TN -------------------------------------------------------------------------------------------------------------------------------
 // slab[sp][m][n] = inv * sum_{t in split sp} A[t][m] B[t][n].  A rows t >= T re-read row T - 1; the B image must continue with >= 32
 // all-zero rows after row T - 1 (their products vanish).  Columns >= Mi / >= N fetch column 0 (discarded).
-__global__ __launch_bounds__(512) void sp_tn_kernel(const char* __restrict__ A, int64_t a_rsb, const float* __restrict__ a_sc, int Mi,
+__global__ __launch_bounds__(SP_THREADS) void sp_tn_kernel(const char* __restrict__ A, int64_t a_rsb, const float* __restrict__ a_sc, int Mi,
                                                     const char* __restrict__ B, int64_t b_rsb, const float* __restrict__ b_sc, int N,
                                                     float* __restrict__ slab, int64_t T, int64_t tok_per_split, int n_tiles) {
     __shared__ SmemSP sm;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave / SP_WN, wn = wave % SP_WN;
     const int nmt = (Mi + SPM - 1) / SPM, nnt = (N + SPN - 1) / SPN;
     const int lid = xcd_remap(blockIdx.x, n_tiles);
     const int mt = lid % nmt, nt = (lid / nmt) % nnt, sp = lid / (nmt * nnt);
@@ -149,10 +149,10 @@ __global__ __launch_bounds__(512) void sp_tn_kernel(const char* __restrict__ A, 
     const int64_t nch = (te > ts) ? (te - ts + SPK - 1) / SPK : 0;
 
     // per piece q: kr = (4w + q) * 2 + (lane >> 5): plane = kr >> 5, token = kr & 31; global chunk src = (lane & 31) ^ ((kr & 3) << 2)
-    uint32_t tokq[4], coA[4], coB[4];
+    uint32_t tokq[SP_PW], coA[SP_PW], coB[SP_PW];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int kr = (wave * 4 + q) * 2 + (lane >> 5), p = kr >> 5, src = (lane & 31) ^ ((kr & 3) << 2);
+    for (int q = 0; q < SP_PW; ++q) {
+        const int kr = (wave * SP_PW + q) * 2 + (lane >> 5), p = kr >> 5, src = (lane & 31) ^ ((kr & 3) << 2);
         tokq[q] = kr & 31;
         const int ca = i0 + src * 8, cbn = n0 + src * 8;
         coA[q] = (uint32_t)sp_img_off(ca < Mi ? ca : 0, p);
@@ -160,17 +160,17 @@ __global__ __launch_bounds__(512) void sp_tn_kernel(const char* __restrict__ A, 
     }
     const char* baseA = A + ts * a_rsb;
     const char* baseB = B + ts * b_rsb;
-    f32x16 acc[4][2];
+    SpAcc acc;
     sp_zero(acc);
     sp_tn_mainloop(sm, acc, nch, wm, wn, lane, [&](int st, int64_t f, int piece) {
-        const int q = piece & 3;
-        if (piece < 4) {
+        const int q = piece % SP_PW;
+        if (piece < SP_PW) {
             uint32_t tk = tokq[q];
             const int64_t left = T - 1 - (ts + f * SPK);   // >= 0
             if (left < SPK) tk = tk < (uint32_t)left ? tk : (uint32_t)left;   // uniform branch: only the chunk at the end of A
-            glds16_s(tk * (uint32_t)a_rsb + coA[q], baseA + f * SPK * a_rsb, lds_addr_of(&sm.A[st][(wave * 4 + q) * 1024]));
+            glds16_s(tk * (uint32_t)a_rsb + coA[q], sp_uniform(baseA + f * SPK * a_rsb), lds_addr_of(&sm.A[st][(wave * SP_PW + q) * 1024]));
         } else {
-            glds16_s(tokq[q] * (uint32_t)b_rsb + coB[q], baseB + f * SPK * b_rsb, lds_addr_of(&sm.B[st][(wave * 4 + q) * 1024]));
+            glds16_s(tokq[q] * (uint32_t)b_rsb + coB[q], sp_uniform(baseB + f * SPK * b_rsb), lds_addr_of(&sm.B[st][(wave * SP_PW + q) * 1024]));
         }
     });
     const float inv = 1.f / (a_sc[0] * b_sc[0]);
@@ -236,7 +236,7 @@ extern "C" int mdl_split_gemm_nt(const void* A, int64_t a_rsb, const float* a_sc
     if (M == 0) return MDL_OK;
     const int64_t tiles = ((M + SPM - 1) / SPM) * ((N + SPN - 1) / SPN);
     if (tiles > 0x7fffffff || a_rsb * SPM > 0x7fffffff || b_rsb * SPN > 0x7fffffff) return MDL_E_UNSUPPORTED;
-    hipLaunchKernelGGL(sp_nt_kernel, dim3((unsigned)tiles), dim3(512), 0, (hipStream_t)stream, (const char*)A, a_rsb, a_scale,
+    hipLaunchKernelGGL(sp_nt_kernel, dim3((unsigned)tiles), dim3(SP_THREADS), 0, (hipStream_t)stream, (const char*)A, a_rsb, a_scale,
                        (const char*)B, b_rsb, b_scale, C, ldc, M, N, K / 32, (int)tiles, bias, accumulate, absmax_out);
     MDL_LAUNCH_CHECK();
     return MDL_OK;
@@ -259,7 +259,7 @@ extern "C" int mdl_split_gemm_tn(const void* A, int64_t a_rsb, const float* a_sc
     const int S = sp_tn_splits(T, Mi, N);
     const int64_t tps = sp_tn_tps(T, S);
     const int tiles = ((Mi + SPM - 1) / SPM) * ((N + SPN - 1) / SPN) * S;
-    hipLaunchKernelGGL(sp_tn_kernel, dim3(tiles), dim3(512), 0, s, (const char*)A, a_rsb, a_scale, Mi, (const char*)B, b_rsb, b_scale, N,
+    hipLaunchKernelGGL(sp_tn_kernel, dim3(tiles), dim3(SP_THREADS), 0, s, (const char*)A, a_rsb, a_scale, Mi, (const char*)B, b_rsb, b_scale, N,
                        (float*)ws, T, tps, tiles);
     MDL_LAUNCH_CHECK();
     return lin_launch_reduce((const float*)ws, out, Mi, N, S, s);
