@@ -192,3 +192,42 @@ def test_preattn_blocks_chain_on_images(dev):
     out.backward(dy.to(dev))
     for name, a, r in zip(("x", "W1", "g1", "b1", "W2", "g2", "b2"), dl, lv):
         assert rel_err(a.grad, r.grad) < 2e-5, name
+
+
+@pytest.mark.parametrize("in_scale,loss_scale", [(1.0, 1.0), (3e3, 1e-7), (1e-3, 1e6)])
+def test_split_mode_is_scale_robust(dev, in_scale, loss_scale):
+    """fp16 has five exponent bits: the split engine relies on per-tensor power-of-two scales (exact absmax for inputs and weights,
+    rigorous bounds for the LayerNorm / dz outputs).  A whole encoder + pooling + projector forward / backward with the inputs and the
+    loss scaled over ten orders of magnitude gives the same slide embeddings and parameter gradients as the exact-fp32 matrix-core mode."""
+    from types import SimpleNamespace
+    from madeleine_amd import MADELEINE
+    from madeleine_amd import functional as MF
+    from oracle import recipe
+    mods = ["HE", "HER2", "ER"]
+    cfg = SimpleNamespace(MODALITIES=mods, wsi_encoder="abmil", patch_embedding_dim=64, wsi_encoder_hidden_dim=512, activation="softmax",
+                          n_heads=4)
+    model = MADELEINE(cfg)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in recipe.state_dict_recipe(shapes, "scl").items()})
+    model = model.to(dev).eval()
+    feats = t((3, 3, 200, 64), "scl:feats") * in_scale
+    w_e, w_t = t((3, 1, 512), "scl:we").to(dev), t((3, 200, 128), "scl:wt").to(dev)
+    res = {}
+    old = MF.gemm_mode()
+    try:
+        for mode in ("fp32", "split"):
+            MF.set_gemm_mode(mode)
+            model.zero_grad()
+            embs, toks = model({"feats": feats}, device=dev, train=True)
+            obj = loss_scale * (sum((embs[k] * (w_e if k != "HE" else w_e.unsqueeze(3))).sum() for k in mods)
+                                + 0.01 * sum((toks[k] * (w_t if k != "HE" else w_t.unsqueeze(3))).sum() for k in mods))
+            obj.backward()
+            res[mode] = (embs["ER"].detach().clone(), {k: p.grad.detach().clone() for k, p in model.named_parameters()})
+    finally:
+        MF.set_gemm_mode(old)
+    assert rel_err(res["split"][0], res["fp32"][0]) < 1e-5
+    top = max(float(g.norm()) for g in res["fp32"][1].values())
+    assert np.isfinite(top) and top > 0
+    for k, g in res["fp32"][1].items():
+        assert torch.isfinite(res["split"][1][k]).all(), k
+        assert float((res["split"][1][k] - g).norm()) <= 1e-4 * float(g.norm()) + 1e-6 * top, k
