@@ -54,7 +54,7 @@ const char* mdl_version(void);
 /* ABI revision of this header: bumped whenever an entry point's argument list changes.  A binding compares
  * mdl_abi_version() with the MDL_ABI_VERSION it was written against BEFORE calling anything else, so that a stale
  * shared object fails loudly instead of being called with shifted arguments. */
-#define MDL_ABI_VERSION 9
+#define MDL_ABI_VERSION 10
 int mdl_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -354,8 +354,12 @@ int mdl_abmil_attnpool_bwd_bf16(const uint16_t* E, int64_t ldE, const float* Wa,
  */
 int mdl_split_image(const float* X, int64_t ldx, int64_t rows, int K, void* img, int64_t rsb, int64_t pad_rows, float* scale,
                     void* stream);
+/* row_gate (device float[ceil(M / 256)], may be NULL; only with accumulate != 0 and bias == NULL): output tiles whose entry is 0 are
+ * skipped -- mdl_split_tile_absmax(X, ...) fills it with the per-256-row maxima of |X| for A = image(X). */
+int mdl_split_tile_absmax(const float* X, int64_t ldx, int64_t rows, int K, float* gate, void* stream);
 int mdl_split_gemm_nt(const void* A, int64_t a_rsb, const float* a_scale, const void* B, int64_t b_rsb, const float* b_scale, float* C,
-                      int64_t ldc, int64_t M, int N, int K, const float* bias, int accumulate, float* absmax_out, void* stream);
+                      int64_t ldc, int64_t M, int N, int K, const float* bias, int accumulate, float* absmax_out, const float* row_gate,
+                      void* stream);
 int64_t mdl_split_gemm_tn_ws_bytes(int64_t T, int Mi, int N);
 int mdl_split_gemm_tn(const void* A, int64_t a_rsb, const float* a_scale, int Mi, const void* B, int64_t b_rsb, const float* b_scale,
                       int N, float* out, int64_t T, void* ws, void* stream);

@@ -74,12 +74,33 @@ __global__ __launch_bounds__(256) void sp_convert_kernel(const float* __restrict
     *reinterpret_cast<u32x4*>(row + sp_img_off(k, 1)) = lo;
 }
 
+// gate[i] = max |X[256 i .. 256 i + 255][:]|: lets mdl_split_gemm_nt skip the output tiles whose A rows are all zero (the
+// token_projector's dX in the fused A2 + A3 backward: the local loss reads the first <= 256 tokens of a bag, the rest of d_tok is 0)
+__global__ __launch_bounds__(256) void sp_tile_absmax_kernel(const float* __restrict__ X, int64_t ldx, int64_t rows, int K,
+                                                             float* __restrict__ gate) {
+    __shared__ float red[4];
+    const int64_t r0 = (int64_t)blockIdx.x * SPM;
+    int64_t r1 = r0 + SPM;
+    if (r1 > rows) r1 = rows;
+    const int g = K / 4;
+    float m = 0.f;
+    for (int64_t i = threadIdx.x; i < (r1 - r0) * g; i += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(X + (r0 + i / g) * ldx + (i % g) * 4);
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) gate[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
 // ---- NT -------------------------------------------------------------------------------------------------------------------------------
 // C[m][n] (+)= inv * sum_k A[m][k] B[n][k] (+ bias[n]);  rows m >= M / n >= N re-read the last valid row (discarded).
 __global__ __launch_bounds__(SP_THREADS) void sp_nt_kernel(const char* __restrict__ A, int64_t a_rsb, const float* __restrict__ a_sc,
                                                     const char* __restrict__ B, int64_t b_rsb, const float* __restrict__ b_sc,
                                                     float* __restrict__ C, int64_t ldc, int64_t M, int N, int nblk, int n_tiles,
-                                                    const float* __restrict__ bias, int accumulate, float* __restrict__ absmax_out) {
+                                                    const float* __restrict__ bias, int accumulate, float* __restrict__ absmax_out,
+                                                    const float* __restrict__ row_gate) {
     __shared__ SmemSP sm;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -87,6 +108,7 @@ __global__ __launch_bounds__(SP_THREADS) void sp_nt_kernel(const char* __restric
     const int ncol = (N + SPN - 1) / SPN;
     const int lid = xcd_remap(blockIdx.x, n_tiles);
     const int nt = lid % ncol;
+    if (row_gate && row_gate[lid / ncol] == 0.f) return;   // block-uniform: the 256 A rows of this tile are all zero (accumulate mode)
     const int64_t m0 = (int64_t)(lid / ncol) * SPM;
     const int n0 = nt * SPN;
 
@@ -227,9 +249,19 @@ extern "C" int mdl_split_image(const float* X, int64_t ldx, int64_t rows, int K,
 /* C [M, N] (row stride ldc floats) (+)= sum_k A[m][k] B[n][k] (+ bias[n]) on the split images A (M rows) and B (N rows) of K columns;
  * a_scale / b_scale: device floats, the images' scales.  absmax_out (device float, may be NULL): atomically raised to max |C|
  * (the caller zeroes it).  N % 4 == 0, K % 32 == 0. */
+extern "C" int mdl_split_tile_absmax(const float* X, int64_t ldx, int64_t rows, int K, float* gate, void* stream) {
+    if (!X || !gate || rows < 0 || K < 4 || (K & 3) || ldx < K || (ldx & 3)) return MDL_E_ARG;
+    if (!host_aligned16(X)) return MDL_E_ALIGN;
+    if (rows == 0) return MDL_OK;
+    hipLaunchKernelGGL(sp_tile_absmax_kernel, dim3((unsigned)((rows + SPM - 1) / SPM)), dim3(256), 0, (hipStream_t)stream, X, ldx, rows, K, gate);
+    MDL_LAUNCH_CHECK();
+    return MDL_OK;
+}
+
 extern "C" int mdl_split_gemm_nt(const void* A, int64_t a_rsb, const float* a_scale, const void* B, int64_t b_rsb, const float* b_scale,
                                  float* C, int64_t ldc, int64_t M, int N, int K, const float* bias, int accumulate, float* absmax_out,
-                                 void* stream) {
+                                 const float* row_gate, void* stream) {
+    if (row_gate && (!accumulate || bias)) return MDL_E_ARG;   // skipping a tile is only the identity when it would add zeros
     if (!A || !B || !C || !a_scale || !b_scale || M < 0 || N < 4 || (N & 3) || K < 32 || (K % 32) || ldc < N || (ldc & 3)) return MDL_E_ARG;
     if (a_rsb < (int64_t)K * 4 || b_rsb < (int64_t)K * 4 || (a_rsb & 15) || (b_rsb & 15)) return MDL_E_ARG;
     if (!host_aligned16(A) || !host_aligned16(B) || !host_aligned16(C) || !host_aligned16(bias)) return MDL_E_ALIGN;
@@ -237,7 +269,7 @@ extern "C" int mdl_split_gemm_nt(const void* A, int64_t a_rsb, const float* a_sc
     const int64_t tiles = ((M + SPM - 1) / SPM) * ((N + SPN - 1) / SPN);
     if (tiles > 0x7fffffff || a_rsb * SPM > 0x7fffffff || b_rsb * SPN > 0x7fffffff) return MDL_E_UNSUPPORTED;
     hipLaunchKernelGGL(sp_nt_kernel, dim3((unsigned)tiles), dim3(SP_THREADS), 0, (hipStream_t)stream, (const char*)A, a_rsb, a_scale,
-                       (const char*)B, b_rsb, b_scale, C, ldc, M, N, K / 32, (int)tiles, bias, accumulate, absmax_out);
+                       (const char*)B, b_rsb, b_scale, C, ldc, M, N, K / 32, (int)tiles, bias, accumulate, absmax_out, row_gate);
     MDL_LAUNCH_CHECK();
     return MDL_OK;
 }

@@ -320,8 +320,18 @@ def split_image(x2d, pad_rows=0) -> SplitImage:
     return SplitImage(data, scale, rows, K)
 
 
-def split_gemm_nt(A: SplitImage, B: SplitImage, bias=None, out=None, accumulate=False, absmax_out=None, name="split_nt"):
-    """C [A.rows, B.rows] (+)= A B^T (+ bias) on two images with the same K."""
+def split_tile_absmax(x2d):
+    """max |x| of every block of 256 rows (the row gate of split_gemm_nt)."""
+    lib = _native.lib()
+    rows, K = x2d.shape
+    gate = torch.empty((rows + 255) // 256, device=x2d.device, dtype=torch.float32)
+    _native.check(lib.mdl_split_tile_absmax(_ptr(x2d), x2d.stride(0), rows, K, _ptr(gate), _stream()), "mdl_split_tile_absmax")
+    return gate
+
+
+def split_gemm_nt(A: SplitImage, B: SplitImage, bias=None, out=None, accumulate=False, absmax_out=None, name="split_nt", row_gate=None):
+    """C [A.rows, B.rows] (+)= A B^T (+ bias) on two images with the same K.  row_gate (accumulate mode only): per-256-row maxima of
+    the tensor A is the image of; output tiles of all-zero A rows are skipped."""
     lib = _native.lib()
     M, N, K = A.rows, B.rows, A.K
     if B.K != K:
@@ -329,7 +339,7 @@ def split_gemm_nt(A: SplitImage, B: SplitImage, bias=None, out=None, accumulate=
     C = out if out is not None else torch.empty(M, N, device=A.data.device, dtype=torch.float32)
     with _timed(name, ("flop", 2.0 * M * N * K)):
         rc = lib.mdl_split_gemm_nt(_ptr(A.data), K * 4, _ptr(A.scale), _ptr(B.data), K * 4, _ptr(B.scale), _ptr(C), C.stride(0), M, N, K,
-                                   _ptr(bias), int(accumulate), _ptr(absmax_out), _stream())
+                                   _ptr(bias), int(accumulate), _ptr(absmax_out), _ptr(row_gate), _stream())
     _native.check(rc, "mdl_split_gemm_nt")
     return C
 
@@ -725,18 +735,15 @@ class AttnPoolFn(torch.autograd.Function):
             d_pooled = torch.zeros(n_bags, 1 + V, pooled.shape[-1], device=pooled.device) if V else torch.zeros_like(pooled)
         d_pooled = d_pooled.float().contiguous()
         d_main = d_pooled[:, 0].contiguous() if V else d_pooled
-        # the other consumer of E first: the token_projector's dX goes straight into dE (no separate gradient tensor, no add pass)
+        # the other consumer of E, the token_projector: its dX is accumulated into the same dE buffer (no separate gradient tensor, no
+        # add pass).  Split engine: AFTER the gate backward, and only on the 256-token tiles where d_tok is not identically zero (the
+        # local loss reads the first <= 256 tokens of a bag, so d_tok is zero on ~94 % of the tiles at N = 4096); the other engines:
+        # before it (the gate dX epilogue then accumulates).
         dWtok = dbtok = None
         acc_e = 0
-        if has_tok and d_tok is not None:
-            if ctx.Ei is not None and split_linear_supported(E2d.shape[0], Wtok.shape[0], Wtok.shape[1]):
-                d_tok = d_tok.float().contiguous()
-                dti = split_image(d_tok, pad_rows=32)
-                split_gemm_nt(dti, split_image(Wtok.t().contiguous()), out=dE, name="linear_bwd")        # dX straight into dE
-                dWtok = split_gemm_tn(ctx.Ei, dti, name="linear_bwd")
-                dbtok = d_tok.sum(0) if has_btok else None
-            else:
-                dWtok, dbtok = linear_bwd_raw(E2d, Wtok, d_tok.to(E2d.dtype).contiguous(), dE, has_btok)
+        tok_after = has_tok and d_tok is not None and ctx.Ei is not None and split_linear_supported(E2d.shape[0], Wtok.shape[0], Wtok.shape[1])
+        if has_tok and d_tok is not None and not tok_after:
+            dWtok, dbtok = linear_bwd_raw(E2d, Wtok, d_tok.to(E2d.dtype).contiguous(), dE, has_btok)
             acc_e = 1
         # scores-only pooling backward (one read of E), then the gate backward whose dX epilogue adds the pooling term
         pool_bwd_raw(E2d, scores, pooled, m, l, d_main, None, 0, ds, acc_s, n_bags, N, cu, max_len)
@@ -750,6 +757,13 @@ class AttnPoolFn(torch.autograd.Function):
             am = torch.zeros(1, device=dE.device, dtype=torch.float32) if V == 0 else None   # (views add to dE afterwards)
             dWa, dWb, dba, dbb, dwc, dbc = attnpool_bwd_split_raw(ctx.Ei, Wa, Wb, wc, act_a, act_b, ds, dE, p_drop, seed, keep_a, keep_b,
                                                                   scores, m, l, d_main, row_bag, N if not ragged else 0, acc_e, am)
+            if tok_after:
+                d_tok = d_tok.float().contiguous()
+                dti = split_image(d_tok, pad_rows=32)
+                split_gemm_nt(dti, split_image(Wtok.t().contiguous()), out=dE, accumulate=True, absmax_out=am, name="linear_bwd",
+                              row_gate=split_tile_absmax(d_tok))
+                dWtok = split_gemm_tn(ctx.Ei, dti, name="linear_bwd")
+                dbtok = d_tok.sum(0) if has_btok else None
             if am is not None:
                 _put_absmax(dE, am)
             ctx.Ei = None

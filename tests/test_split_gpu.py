@@ -231,3 +231,22 @@ def test_split_mode_is_scale_robust(dev, in_scale, loss_scale):
     for k, g in res["fp32"][1].items():
         assert torch.isfinite(res["split"][1][k]).all(), k
         assert float((res["split"][1][k] - g).norm()) <= 1e-4 * float(g.norm()) + 1e-6 * top, k
+
+
+def test_split_gemm_nt_row_gate(dev):
+    """Accumulate-mode product with the row gate: tiles of 256 all-zero A rows are skipped and the result equals the ungated one."""
+    from madeleine_amd import functional as MF
+    M, N, K = 1300, 2048, 128
+    a = t((M, K), "spg:a")
+    a[100:1000] = 0                      # tiles 1 and 2 (rows 256..767) are entirely zero, tiles 0 and 3 partly
+    b = 0.05 * t((N, K), "spg:b")
+    c0 = t((M, N), "spg:c")
+    A, B = MF.split_image(a.to(dev)), MF.split_image(b.to(dev))
+    gate = MF.split_tile_absmax(a.to(dev))
+    assert gate.cpu().tolist()[1:3] == [0.0, 0.0] and float(gate[0]) > 0 and float(gate[5]) > 0
+    out_g = MF.split_gemm_nt(A, B, out=c0.to(dev).clone(), accumulate=True, row_gate=gate)
+    out_u = MF.split_gemm_nt(A, B, out=c0.to(dev).clone(), accumulate=True)
+    assert torch.equal(out_g, out_u)
+    assert rel_err(out_g, c0.double() + a.double() @ b.double().t()) < 1e-6
+    with pytest.raises(RuntimeError):
+        MF.split_gemm_nt(A, B, out=c0.to(dev).clone(), accumulate=False, row_gate=gate)
