@@ -396,10 +396,16 @@ def calculate_losses_dp(STAINS, loss_fn_interMod, got_impl, wsi_embs, token_embs
             if int(tok_idx.max()) >= token_embs["HE"].shape[1]:
                 raise ValueError("GOT sub-samples token indices randperm(k)[:%d] with k = %d participating cases, but the bags "
                                  "carry only %d tokens (reference quirk, loss.py:282)" % (subsample, k_g, token_embs["HE"].shape[1]))
-            tok_idx = tok_idx.to(dev, non_blocking=True)
             rows = labels_l[:, s_idx].bool().nonzero(as_tuple=True)[0].to(dev, non_blocking=True)
-            he = token_embs["HE"][:, :, :, s_idx].index_select(0, rows).index_select(1, tok_idx)
-            st = token_embs[stain].index_select(0, rows).index_select(1, tok_idx)
+            he, st = token_embs["HE"][:, :, :, s_idx], token_embs[stain]
+            # token axis first (a view when the indices are the first k_g tokens -- the common case), then the participating cases:
+            # the gathers and their backward then touch [B, n, 128] instead of [B, N, 128]
+            if k_g <= subsample:
+                he, st = he[:, :k_g], st[:, :k_g]
+            else:
+                tok_idx = tok_idx.to(dev, non_blocking=True)
+                he, st = he.index_select(1, tok_idx), st.index_select(1, tok_idx)
+            he, st = he.index_select(0, rows), st.index_select(0, rows)
             problems.append((he if he.dtype == torch.float64 else he.float(), st if st.dtype == torch.float64 else st.float()))
     ext_local = got_local_extrema(problems, got_impl) if problems else None
 

@@ -15,6 +15,8 @@ from typing import Dict, List, NamedTuple, Optional
 import numpy as np
 import torch
 
+from .loss import GOT as _GOT
+
 from .loss import InfoNCE as _HipInfoNCE
 from .utils import set_model_precision, smooth_rank_measure
 
@@ -87,8 +89,14 @@ def calculate_losses(STAINS, loss_fn_interMod, loss_fn_interMod_local, loss_fn_i
                 he, st = _pair(wsi_embs, part, rows, WHOLE_VIEW_POSITION)
                 terms.append(loss_fn_interMod(query=he, positive_key=st, symmetric=args.symmetric_cl))
         if loss_fn_interMod_local:                               # local: token-level GOT, 256 sub-sampled tokens
-            he_tok = token_embs["HE"][:, :, :, part.column].index_select(0, rows)
-            st_tok = token_embs[part.name].squeeze().index_select(0, rows)   # .squeeze() as in trainer.py:43
+            he_src, st_src = token_embs["HE"][:, :, :, part.column], token_embs[part.name].squeeze()   # .squeeze() as in trainer.py:43
+            if loss_fn_interMod_local is _GOT and st_src.dim() == 3:
+                # our GOT reads token indices randperm(k)[:256] < k = the number of participating cases (the reference's quirk,
+                # loss.py:282): narrowing to the first k tokens BEFORE the row gather is exact and keeps the gathers and their
+                # backward at [B, k, 128] instead of [B, N, 128]
+                kk = min(int(rows.numel()), he_src.shape[1])
+                he_src, st_src = he_src[:, :kk], st_src[:, :kk]
+            he_tok, st_tok = he_src.index_select(0, rows), st_src.index_select(0, rows)
             terms.append(loss_fn_interMod_local(he_tok, st_tok, subsample=256) * args.local_loss_weight)
         if loss_fn_intraMod:                                     # intra: the two half-bag views of each modality
             he1, st1 = _pair(wsi_embs, part, rows, 1)
