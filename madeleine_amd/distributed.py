@@ -352,6 +352,16 @@ def got_multi(problems, impl=None, group=None, extrema=None) -> torch.Tensor:
 _STEP = [0]
 
 
+def _shared_he_tokens(he_all):
+    """MADELEINE returns the H&E tokens as an expand() over the stain axis (Model.py:153-155 repeats them): every slice
+    [:, :, :, s_idx] is the same memory.  ONE select shared by all stains -- otherwise each stain's backward materialises a zero
+    [B,N,128,M-1] tensor and the expand's backward sums them (dozens of dense fills / adds per step at 5 stains).  None when the
+    tensor is not such a view."""
+    if he_all.dim() == 4 and he_all.stride(3) == 0:
+        return he_all.select(3, 0)
+    return None
+
+
 def calculate_losses_dp(STAINS, loss_fn_interMod, got_impl, wsi_embs, token_embs, modality_labels_withoutHE, args,
                         labels_global_withoutHE=None, group=None, subsample=256, shared_seed=0, use_local_loss=True,
                         loss_fn_intraMod=None):
@@ -381,6 +391,7 @@ def calculate_losses_dp(STAINS, loss_fn_interMod, got_impl, wsi_embs, token_embs
 
     # the local (GOT) problems of this step: fixed by the HOST copy of the global labels, identical on every rank
     problems = []
+    he_shared, first_local = None, -1
     if use_local_loss and got_impl is not None and any(int(labels_g[:, s].bool().sum()) > 1 for s in range(len(STAINS))):
         _STEP[0] += 1
         for s_idx, stain in enumerate(STAINS):
@@ -397,7 +408,10 @@ def calculate_losses_dp(STAINS, loss_fn_interMod, got_impl, wsi_embs, token_embs
                 raise ValueError("GOT sub-samples token indices randperm(k)[:%d] with k = %d participating cases, but the bags "
                                  "carry only %d tokens (reference quirk, loss.py:282)" % (subsample, k_g, token_embs["HE"].shape[1]))
             rows = labels_l[:, s_idx].bool().nonzero(as_tuple=True)[0].to(dev, non_blocking=True)
-            he, st = token_embs["HE"][:, :, :, s_idx], token_embs[stain]
+            if first_local < 0:
+                first_local, he_shared = s_idx, _shared_he_tokens(token_embs["HE"])
+            he = he_shared if he_shared is not None else token_embs["HE"][:, :, :, s_idx]
+            st = token_embs[stain]
             # token axis first (a view when the indices are the first k_g tokens -- the common case), then the participating cases:
             # the gathers and their backward then touch [B, n, 128] instead of [B, N, 128]
             if k_g <= subsample:
