@@ -151,12 +151,47 @@ __global__ __launch_bounds__(SP_THREADS) void sp_nt_kernel(const char* __restric
     if (absmax_out) sp_atomic_absmax(absmax_out, amax);
 }
 
+// Chunk lists for the TN loop: list[sp][0 .. count[sp]) = the 32-row chunks of split sp in which X (the fp32 tensor the B image was built
+// from) is not identically zero, in ascending order.  One workgroup per split; flags in LDS, serial compaction by thread 0.
+constexpr int SP_MAX_LIST = 2048;
+__global__ __launch_bounds__(256) void sp_chunk_list_kernel(const float* __restrict__ X, int64_t ldx, int64_t T, int K, int64_t tok_per_split,
+                                                            int32_t* __restrict__ list, int32_t* __restrict__ count, int stride) {
+    __shared__ uint8_t flag[SP_MAX_LIST];
+    const int sp = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t ts = (int64_t)sp * tok_per_split;
+    int64_t te = ts + tok_per_split;
+    if (te > T) te = T;
+    const int nc = te > ts ? (int)((te - ts + SPK - 1) / SPK) : 0;
+    const int g = K / 4;
+    for (int c = wave; c < nc; c += 4) {   // one wave per chunk
+        const int64_t r0 = ts + (int64_t)c * SPK;
+        int64_t r1 = r0 + SPK;
+        if (r1 > T) r1 = T;
+        float m = 0.f;
+        for (int64_t i = lane; i < (r1 - r0) * g; i += 64) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(X + (r0 + i / g) * ldx + (i % g) * 4);
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        }
+        m = wave_max(m);
+        if (lane == 0) flag[c] = m != 0.f;   // (NaN counts as non-zero)
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int n = 0;
+        for (int c = 0; c < nc; ++c)
+            if (flag[c]) list[(int64_t)sp * stride + n++] = c;
+        count[sp] = n;
+    }
+}
+
 // ---- TN -------------------------------------------------------------------------------------------------------------------------------
 // slab[sp][m][n] = inv * sum_{t in split sp} A[t][m] B[t][n].  A rows t >= T re-read row T - 1; the B image must continue with >= 32
 // all-zero rows after row T - 1 (their products vanish).  Columns >= Mi / >= N fetch column 0 (discarded).
 __global__ __launch_bounds__(SP_THREADS) void sp_tn_kernel(const char* __restrict__ A, int64_t a_rsb, const float* __restrict__ a_sc, int Mi,
                                                     const char* __restrict__ B, int64_t b_rsb, const float* __restrict__ b_sc, int N,
-                                                    float* __restrict__ slab, int64_t T, int64_t tok_per_split, int n_tiles) {
+                                                    float* __restrict__ slab, int64_t T, int64_t tok_per_split, int n_tiles,
+                                                    const int32_t* __restrict__ chunk_list, const int32_t* __restrict__ chunk_count,
+                                                    int list_stride) {
     __shared__ SmemSP sm;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -168,7 +203,9 @@ __global__ __launch_bounds__(SP_THREADS) void sp_tn_kernel(const char* __restric
     const int64_t ts = (int64_t)sp * tok_per_split;
     int64_t te = ts + tok_per_split;
     if (te > T) te = T;
-    const int64_t nch = (te > ts) ? (te - ts + SPK - 1) / SPK : 0;
+    // with a chunk list only the chunks in which the B operand is not identically zero are visited (logical index -> chunk of the split)
+    const int32_t* __restrict__ clist = chunk_list ? chunk_list + (int64_t)sp * list_stride : nullptr;
+    const int64_t nch = clist ? chunk_count[sp] : ((te > ts) ? (te - ts + SPK - 1) / SPK : 0);
 
     // per piece q: kr = (4w + q) * 2 + (lane >> 5): plane = kr >> 5, token = kr & 31; global chunk src = (lane & 31) ^ ((kr & 3) << 2)
     uint32_t tokq[SP_PW], coA[SP_PW], coB[SP_PW];
@@ -184,8 +221,9 @@ __global__ __launch_bounds__(SP_THREADS) void sp_tn_kernel(const char* __restric
     const char* baseB = B + ts * b_rsb;
     SpAcc acc;
     sp_zero(acc);
-    sp_tn_mainloop(sm, acc, nch, wm, wn, lane, [&](int st, int64_t f, int piece) {
+    sp_tn_mainloop(sm, acc, nch, wm, wn, lane, [&](int st, int64_t fl, int piece) {
         const int q = piece % SP_PW;
+        const int64_t f = clist ? (int64_t)clist[fl] : fl;
         if (piece < SP_PW) {
             uint32_t tk = tokq[q];
             const int64_t left = T - 1 - (ts + f * SPK);   // >= 0
@@ -276,13 +314,16 @@ extern "C" int mdl_split_gemm_nt(const void* A, int64_t a_rsb, const float* a_sc
 
 extern "C" int64_t mdl_split_gemm_tn_ws_bytes(int64_t T, int Mi, int N) {
     if (T < 0 || Mi < 32 || N < 32) return MDL_E_ARG;
-    return (int64_t)sp_tn_splits(T, Mi, N) * Mi * N * 4 + 64;
+    const int S = sp_tn_splits(T, Mi, N);
+    // slabs | chunk lists [S][tps / 32] + counts [S]
+    return (((int64_t)S * Mi * N * 4 + 15) & ~(int64_t)15) + (int64_t)S * (sp_tn_tps(T, S) / SPK + 1) * 4 + 64;
 }
 
 /* out [N][Mi] (contiguous: a Linear's dW with A = image(X), B = image(dY)) = sum_t B[t][n] A[t][m] over the T rows of the two
  * token-major images (Mi / N columns).  The B image must be followed by >= 32 all-zero rows.  Mi % 32 == 0, N % 32 == 0. */
 extern "C" int mdl_split_gemm_tn(const void* A, int64_t a_rsb, const float* a_scale, int Mi, const void* B, int64_t b_rsb,
-                                 const float* b_scale, int N, float* out, int64_t T, void* ws, void* stream) {
+                                 const float* b_scale, int N, float* out, int64_t T, const float* b_src, int64_t b_src_ld, void* ws,
+                                 void* stream) {
     if (!A || !B || !out || !ws || !a_scale || !b_scale || T < 0 || Mi < 32 || (Mi % 32) || N < 32 || (N % 32)) return MDL_E_ARG;
     if (a_rsb < (int64_t)Mi * 4 || b_rsb < (int64_t)N * 4 || (a_rsb & 15) || (b_rsb & 15) || a_rsb * 32 > 0x7fffffff || b_rsb * 32 > 0x7fffffff)
         return MDL_E_ARG;
@@ -291,8 +332,18 @@ extern "C" int mdl_split_gemm_tn(const void* A, int64_t a_rsb, const float* a_sc
     const int S = sp_tn_splits(T, Mi, N);
     const int64_t tps = sp_tn_tps(T, S);
     const int tiles = ((Mi + SPM - 1) / SPM) * ((N + SPN - 1) / SPN) * S;
+    const int stride = (int)(tps / SPK);
+    int32_t* list = nullptr;
+    int32_t* count = nullptr;
+    if (b_src && stride <= SP_MAX_LIST && T > 0) {   // skip the 32-row chunks in which b_src (the tensor B is the image of) is all zero
+        if (b_src_ld < N || (b_src_ld & 3) || !host_aligned16(b_src)) return MDL_E_ARG;
+        list = (int32_t*)((char*)ws + (((int64_t)S * Mi * N * 4 + 15) & ~(int64_t)15));
+        count = list + (int64_t)S * stride;
+        hipLaunchKernelGGL(sp_chunk_list_kernel, dim3(S), dim3(256), 0, s, b_src, b_src_ld, T, N, tps, list, count, stride);
+        MDL_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(sp_tn_kernel, dim3(tiles), dim3(SP_THREADS), 0, s, (const char*)A, a_rsb, a_scale, Mi, (const char*)B, b_rsb, b_scale, N,
-                       (float*)ws, T, tps, tiles);
+                       (float*)ws, T, tps, tiles, (const int32_t*)list, (const int32_t*)count, stride);
     MDL_LAUNCH_CHECK();
     return lin_launch_reduce((const float*)ws, out, Mi, N, S, s);
 }

@@ -344,8 +344,9 @@ def split_gemm_nt(A: SplitImage, B: SplitImage, bias=None, out=None, accumulate=
     return C
 
 
-def split_gemm_tn(A: SplitImage, B: SplitImage, name="split_tn"):
-    """out [B.K, A.K] = B^T A summed over the rows (tokens) of the two images; B must carry >= 32 zero pad rows."""
+def split_gemm_tn(A: SplitImage, B: SplitImage, name="split_tn", b_src=None):
+    """out [B.K, A.K] = B^T A summed over the rows (tokens) of the two images; B must carry >= 32 zero pad rows.  b_src: the fp32
+    tensor B is the image of -- its all-zero 32-row chunks are skipped."""
     lib = _native.lib()
     T, Mi, N = A.rows, A.K, B.K
     if B.rows != T or B.data.shape[0] < T + 32:
@@ -353,8 +354,8 @@ def split_gemm_tn(A: SplitImage, B: SplitImage, name="split_tn"):
     out = torch.empty(N, Mi, device=A.data.device, dtype=torch.float32)
     ws = _ws(lib.mdl_split_gemm_tn_ws_bytes(T, Mi, N), A.data.device)
     with _timed(name, ("flop", 2.0 * T * Mi * N)):
-        rc = lib.mdl_split_gemm_tn(_ptr(A.data), Mi * 4, _ptr(A.scale), Mi, _ptr(B.data), N * 4, _ptr(B.scale), N, _ptr(out), T, _ptr(ws),
-                                   _stream())
+        rc = lib.mdl_split_gemm_tn(_ptr(A.data), Mi * 4, _ptr(A.scale), Mi, _ptr(B.data), N * 4, _ptr(B.scale), N, _ptr(out), T, _ptr(b_src),
+                                   0 if b_src is None else b_src.stride(0), _ptr(ws), _stream())
     _native.check(rc, "mdl_split_gemm_tn")
     return out
 
@@ -762,7 +763,7 @@ class AttnPoolFn(torch.autograd.Function):
                 dti = split_image(d_tok, pad_rows=32)
                 split_gemm_nt(dti, split_image(Wtok.t().contiguous()), out=dE, accumulate=True, absmax_out=am, name="linear_bwd",
                               row_gate=split_tile_absmax(d_tok))
-                dWtok = split_gemm_tn(ctx.Ei, dti, name="linear_bwd")
+                dWtok = split_gemm_tn(ctx.Ei, dti, name="linear_bwd", b_src=d_tok)
                 dbtok = d_tok.sum(0) if has_btok else None
             if am is not None:
                 _put_absmax(dE, am)

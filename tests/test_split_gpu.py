@@ -250,3 +250,20 @@ def test_split_gemm_nt_row_gate(dev):
     assert rel_err(out_g, c0.double() + a.double() @ b.double().t()) < 1e-6
     with pytest.raises(RuntimeError):
         MF.split_gemm_nt(A, B, out=c0.to(dev).clone(), accumulate=False, row_gate=gate)
+
+
+def test_split_gemm_tn_chunk_gate(dev):
+    """TN product with the chunk list: 32-row chunks in which the B source is identically zero are skipped; the result is unchanged."""
+    from madeleine_amd import functional as MF
+    T, Mi, N = 9000, 512, 128
+    x = t((T, Mi), "spc:x")
+    dy = t((T, N), "spc:dy")
+    dy[40:5000] = 0
+    dy[5100:8990] = 0
+    ref = dy.double().t() @ x.double()
+    A, B = MF.split_image(x.to(dev)), MF.split_image(dy.to(dev), pad_rows=32)
+    out_g = MF.split_gemm_tn(A, B, b_src=dy.to(dev))
+    out_u = MF.split_gemm_tn(A, B)
+    assert rel_err(out_g, ref) < 1e-6 and rel_err(out_u, ref) < 1e-6
+    z = MF.split_gemm_tn(A, MF.split_image(torch.zeros(T, N, device=dev), pad_rows=32), b_src=torch.zeros(T, N, device=dev))
+    assert float(z.abs().max()) == 0.0
