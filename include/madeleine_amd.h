@@ -252,7 +252,9 @@ int mdl_linear_bwd(const float* X, int64_t ldx, const float* W, const float* dY,
  * (:179-207, 30 iterations, beta .5) + Gromov-Wasserstein (:236-275, 5 x 20 IPOT iterations,
  * beta .1) with cos_batch_torch intra costs (:210-233).  Called from trainer.py:42-45.
  *
- * V,Q [k,n,d]: the (already sub-sampled, loss.py:281-284) token sets of k cases; n <= 256, d <= 128.
+ * V,Q [k,n,d]: the (already sub-sampled, loss.py:281-284) token sets of k cases; n <= 512, d <= 128
+ * (n <= 256 -- what trainer.py:44 produces -- keeps the transport plans in registers / one matrix-core panel; 256 < n <= 512 keeps
+ * them in the workspace and walks 256 x 256 output blocks).
  * out [2]: out[0] = sum_b WD_b, out[1] = sum_b GWD_b   (GOT returns out[1] + out[0], a SUM over cases).
  * Thresholds thr = min + .1 (max - min): the reference takes min/max over the WHOLE batch tensor for each of
  * the three cost tensors (cross, intra-V, intra-Q).  minmax_out float[6] (may be NULL) receives this call's

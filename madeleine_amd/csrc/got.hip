@@ -15,7 +15,7 @@ namespace mdl {
     }
 MDL_GOT_DECL(got1024)
 #undef MDL_GOT_DECL
-constexpr int GOT_MAXN = 256;
+constexpr int GOT_MAXN = 512;   // 256 < n <= 512: the workspace-resident class of got_impl.inc
 constexpr int GOT_MAXD = 128;
 }  // namespace mdl
 

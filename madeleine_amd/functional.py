@@ -1007,7 +1007,7 @@ class GOTFn(torch.autograd.Function):
         k, n, d = V.shape
         nbytes = lib.mdl_got_ws_bytes(k, n, d)
         if nbytes == -3:
-            raise NotImplementedError("madeleine_amd.GOT supports n <= 256 tokens per bag and d <= 128 (got n=%d, d=%d); "
+            raise NotImplementedError("madeleine_amd.GOT supports n <= 512 tokens per bag and d <= 128 (got n=%d, d=%d); "
                                       "the reference calls it with subsample=256 (trainer.py:44)" % (n, d))
         ws = _ws(nbytes, V.device)
         out = torch.empty(2, device=V.device, dtype=torch.float32)
@@ -1073,7 +1073,7 @@ class HipGotImpl:
         k, n, d = V.shape
         nbytes = lib.mdl_got_ws_bytes(k, n, d)
         if nbytes == -3:
-            raise NotImplementedError("madeleine_amd.GOT supports n <= 256 tokens per bag and d <= 128 (got n=%d, d=%d)" % (n, d))
+            raise NotImplementedError("madeleine_amd.GOT supports n <= 512 tokens per bag and d <= 128 (got n=%d, d=%d)" % (n, d))
         ws = _ws(nbytes, V.device)
         out = torch.empty(2, device=V.device, dtype=torch.float32)
         mm = minmax.contiguous()

@@ -415,10 +415,10 @@ def test_got_pieces_and_fp64_oracle(dev):
     assert rel_err(vd.grad, v64.grad) < TOL and rel_err(qd.grad, q64.grad) < TOL
 
 
-@pytest.mark.parametrize("k,n", [(2, 70), (3, 130), (2, 200), (2, 256)])
+@pytest.mark.parametrize("k,n", [(2, 70), (3, 130), (2, 200), (2, 256), (2, 257), (2, 384), (1, 512)])
 def test_got_large_n_vs_fp64_oracle(dev, k, n):
-    """The register-resident IPOT / matrix-core paths of every n-class (n <= 64, <= 128, <= 256; 1024- and 512-thread
-    builds) against an fp64 evaluation of the oracle: both distances and the token gradients."""
+    """The IPOT / matrix-core paths of every n-class (n <= 64, <= 128, <= 256 register-resident plans; 256 < n <= 512 plans in
+    the workspace, blocked products) against an fp64 evaluation of the oracle: both distances and the token gradients."""
     from madeleine_amd import functional as MF
     v = t((k, n, 128), f"got:big:v{n}:0")
     q = t((k, n, 128), f"got:big:q{n}:0") + 0.7 * v
@@ -432,9 +432,26 @@ def test_got_large_n_vs_fp64_oracle(dev, k, n):
     assert rel_err(vd.grad, v64.grad) < TOL and rel_err(qd.grad, q64.grad) < TOL
 
 
+def test_got_api_without_subsample(dev):
+    """GOT(v, q, subsample=None) (loss.py:278: every token of the bag enters the transport problem) with more tokens than the
+    training loop's sub-sample: value and gradients against the fp64 oracle."""
+    from madeleine_amd import GOT
+    k, n = 2, 300
+    v = t((k, n, 128), "got:api:v")
+    q = t((k, n, 128), "got:api:q") + 0.7 * v
+    v64, q64 = v.double().requires_grad_(), q.double().requires_grad_()
+    ref = R.got(v64, q64, subsample=None)
+    ref.backward()
+    vd, qd = v.to(dev).requires_grad_(), q.to(dev).requires_grad_()
+    loss = GOT(vd, qd, subsample=None)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(ref)) < TOL * abs(float(ref))
+    assert rel_err(vd.grad, v64.grad) < TOL and rel_err(qd.grad, q64.grad) < TOL
+
+
 def test_got_external_thresholds_and_limits(dev):
     """minmax_in = the batch's own extrema reproduces the local result (value and gradient); two half-batches with the
-    global extrema sum to the full batch (the data-parallel decomposition); n > 256 is refused loudly."""
+    global extrema sum to the full batch (the data-parallel decomposition); n > 512 is refused loudly."""
     from madeleine_amd import functional as MF
     k, n = 6, 12
     v = t((k, n, 128), "got:ext:v").to(dev)
@@ -463,7 +480,7 @@ def test_got_external_thresholds_and_limits(dev):
     assert rel_err(torch.cat([grads[0][0], grads[1][0]]), v1.grad) < 1e-4
     assert rel_err(torch.cat([grads[0][1], grads[1][1]]), q1.grad) < 1e-4
     with pytest.raises(NotImplementedError):
-        MF.got(torch.zeros(1, 300, 128, device=dev), torch.zeros(1, 300, 128, device=dev))
+        MF.got(torch.zeros(1, 600, 128, device=dev), torch.zeros(1, 600, 128, device=dev))
 
 
 # ---------------------------------------------------------------------------------------------- N1 fused LN-GELU-Dropout
