@@ -54,7 +54,7 @@ const char* mdl_version(void);
 /* ABI revision of this header: bumped whenever an entry point's argument list changes.  A binding compares
  * mdl_abi_version() with the MDL_ABI_VERSION it was written against BEFORE calling anything else, so that a stale
  * shared object fails loudly instead of being called with shifted arguments. */
-#define MDL_ABI_VERSION 11
+#define MDL_ABI_VERSION 12
 int mdl_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -220,10 +220,14 @@ int64_t mdl_infonce_ws_bytes(int S, int Kmax, int D);
  * 0.5 CE_i + 0.5 CE'_i); rows >= cnt[s] are zeroed. */
 int mdl_infonce_fwd(const float* Q, const float* P, const int32_t* cnt, float* loss, float* row_loss, int S, int Kmax,
                     int D, float temperature, int symmetric, void* ws, void* stream);
-/* d_loss [S] incoming gradient of the mean losses -- or, when d_row_loss [S,Kmax] != NULL, the gradients of the per-sample
- * losses (d_loss is then ignored and may be NULL); dQ,dP [S,Kmax,D] (rows >= cnt[s] are zeroed).  ws must be the forward's. */
-int mdl_infonce_bwd(const float* d_loss, const float* d_row_loss, const int32_t* cnt, float* dQ, float* dP, int S, int Kmax, int D,
-                    float temperature, int symmetric, void* ws, void* stream);
+/* Q,P: the forward's inputs (the fused path keeps no normalised copies).  d_loss [S] incoming gradient of the mean losses -- or, when
+ * d_row_loss [S,Kmax] != NULL, the gradients of the per-sample losses (d_loss is then ignored and may be NULL); dQ,dP [S,Kmax,D] (rows
+ * >= cnt[s] are zeroed).  ws must be the forward's.
+ * Kmax <= 256 and D <= 512 (every configuration of the training loop): ONE launch forward (similarity on the raw rows scaled by the
+ * reciprocal norms of the same streaming pass, row / column log-sum-exp, losses; "batched InfoNCE similarity + logsumexp" of the
+ * north star) and ONE launch backward (coefficients, both gradient products, normalize() backward). */
+int mdl_infonce_bwd(const float* Q, const float* P, const float* d_loss, const float* d_row_loss, const int32_t* cnt, float* dQ,
+                    float* dP, int S, int Kmax, int D, float temperature, int symmetric, void* ws, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * N1 -- every Linear of the encoder as an exact-fp32 contraction in hand-written kernels: the three

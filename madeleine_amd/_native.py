@@ -13,7 +13,7 @@ from . import _build
 
 _LOCK = threading.Lock()
 _LIB = None
-ABI_VERSION = 11   # == MDL_ABI_VERSION of include/madeleine_amd.h this file's SIGNATURES were written against
+ABI_VERSION = 12   # == MDL_ABI_VERSION of include/madeleine_amd.h this file's SIGNATURES were written against
 
 c_f = ctypes.c_void_p  # float* (device)
 c_p = ctypes.c_void_p
@@ -54,7 +54,7 @@ SIGNATURES = {
     "mdl_linear_bwd": (i32, [c_f, i64, c_f, c_f, i64, c_f, i64, c_f, c_f, i64, i32, i32, c_p, c_p]),
     "mdl_infonce_ws_bytes": (i64, [i32, i32, i32]),
     "mdl_infonce_fwd": (i32, [c_f, c_f, c_p, c_f, c_f, i32, i32, i32, f32, i32, c_p, c_p]),
-    "mdl_infonce_bwd": (i32, [c_f, c_f, c_p, c_f, c_f, i32, i32, i32, f32, i32, c_p, c_p]),
+    "mdl_infonce_bwd": (i32, [c_f, c_f, c_f, c_f, c_p, c_f, c_f, i32, i32, i32, f32, i32, c_p, c_p]),
     "mdl_got_ws_bytes": (i64, [i32, i32, i32]),
     "mdl_got_fwd": (i32, [c_f, c_f, c_f, c_f, c_f, i32, i32, i32, c_p, c_p]),
     "mdl_got_extrema": (i32, [c_f, c_f, c_f, i32, i32, i32, c_p, c_p]),

@@ -7,16 +7,21 @@
 // of launches.  At temperature 0.001 the logits are cosines x 1000, so the similarity contraction runs on
 // the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) and every logsumexp is max-subtracted.
 //
+// Two paths: Kp <= 256 and D <= 512 (every configuration of the training loop) -> the fused kernels at the end of this file, one
+// launch forward and one backward; anything larger -> the staged kernels (normalise | logits | lse | loss ; coef | grad | norm-bwd).
 // Workspace (floats; Kp = Kmax rounded up to 32):
 //   Qn,Pn [S,Kp,D] | rq,rp [S,Kp] | Z [S,Kp,Kp] = logits | m0,l0,m1,l1 [S,Kp] | coef [S,Kp,Kp] | dQn,dPn [S,Kp,D]
 // (m, l) = (max, log sum exp(z - max)) per row (0) / column (1), kept SEPARATE like torch's log_softmax: at
 // T = 0.001 the logits are O(100) and lse - z_ii is O(1e-6), below fp32 resolution at 100.
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace mdl {
 
 struct NceWs {
-    float *Qn, *Pn, *rq, *rp, *Z, *m0, *l0, *m1, *l1, *coef, *dQn, *dPn;
+    float *Qn, *Pn, *rq, *rp, *Z, *m0, *l0, *m1, *l1, *coef, *dQn, *dPn, *rl;
+    int* done;
     int Kp;
 };
 static inline int nce_kp(int Kmax) { return ((Kmax + 31) / 32) * 32; }
@@ -37,6 +42,8 @@ static inline NceWs nce_ws(void* ws, int S, int Kmax, int D) {
     w.coef = p; p += rows * w.Kp;
     w.dQn = p; p += rows * D;
     w.dPn = p; p += rows * D;
+    w.rl = p; p += 2 * rows;          // fused forward: per-row loss of each direction
+    w.done = (int*)p;                 // [S] workgroups of the stain that have finished
     return w;
 }
 
@@ -209,14 +216,244 @@ __global__ __launch_bounds__(64) void nce_norm_bwd_kernel(const float* __restric
     for (int k = lane; k < D; k += 64) o[k] = rn * (g[k] - xn[k] * dot);
 }
 
+
+// ================================================================================================
+// Fused path (Kp <= 256, D <= 512 -- every configuration of the training loop: k <= 256 cases per global batch): ONE launch forward,
+// ONE launch backward.  No normalised copies: the similarity product runs on the raw rows and is scaled by the two reciprocal norms,
+// which fall out of the same streaming pass (each lane owns a row of its operand).
+//   forward  workgroup = 32 rows of Z (dir 0) or of Z^T (dir 1: the column log-sum-exp of the symmetric loss is the row one of the
+//            transposed problem; its strip is recomputed, 67 MFLOP at k = 256), 4 waves x 2 column blocks of 32; the strip goes through
+//            LDS for the row reductions and the coalesced store of Z; the last workgroup of a stain to finish reduces the row losses
+//            (fixed order: deterministic).
+//   backward workgroup = 32 rows of dQ (dir 0) or dP (dir 1): coefficient strip (softmax - delta) in LDS -> MFMA against the
+//            normalised rows of the other side -> normalize() backward on the strip in LDS.
+// ================================================================================================
+constexpr int NCE_FK = 256, NCE_FD = 512;
+
+__device__ __forceinline__ int nce_acc_row(int r, int kh) { return (r & 3) + 8 * (r >> 2) + 4 * kh; }
+
+__global__ __launch_bounds__(256) void nce_fused_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ P,
+                                                            const int32_t* __restrict__ cnt, float* __restrict__ rq,
+                                                            float* __restrict__ rp, float* __restrict__ Z, float* __restrict__ m0,
+                                                            float* __restrict__ l0, float* __restrict__ m1, float* __restrict__ l1,
+                                                            float* __restrict__ rl, int* __restrict__ done, float* __restrict__ loss,
+                                                            float* __restrict__ row_loss, int S, int Kmax, int Kp, int D, float inv_T,
+                                                            int symmetric) {
+    __shared__ float strip[32][NCE_FK + 1];
+    __shared__ float red[4];
+    __shared__ int last;
+    const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, kh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i0 = blockIdx.x * 32, dir = blockIdx.y, s = blockIdx.z;
+    const int k = cnt[s] < Kmax ? cnt[s] : Kmax;
+    const float* __restrict__ X = (dir ? P : Q) + (int64_t)s * Kmax * D;
+    const float* __restrict__ Y = (dir ? Q : P) + (int64_t)s * Kmax * D;
+    // reciprocal clamped norms (x / max(|x|, 1e-12), loss.py:132), one wave per row, the staged path's summation order
+    __shared__ float rnA[32], rnB[NCE_FK];
+    auto rnorm = [&](const float* __restrict__ base, int r) {
+        const bool live = r < k;
+        float ss = 0.f;
+        if (live)
+            for (int c = lane; c < D; c += 64) ss += base[(int64_t)r * D + c] * base[(int64_t)r * D + c];
+        ss = wave_sum(ss);
+        return live ? 1.f / fmaxf(sqrtf(ss), 1e-12f) : 0.f;
+    };
+#pragma unroll 1
+    for (int rr = 0; rr < 8; ++rr) {
+        const float v = rnorm(X, i0 + wave * 8 + rr);
+        if (lane == 0) rnA[wave * 8 + rr] = v;
+    }
+#pragma unroll 1
+    for (int jb = wave; jb * 32 < Kp; jb += 4)
+#pragma unroll 1
+        for (int rr = 0; rr < 32; ++rr) {
+            const float v = rnorm(Y, jb * 32 + rr);
+            if (lane == 0) rnB[jb * 32 + rr] = v;
+        }
+    __syncthreads();
+    if (tid < 32) (dir ? rp : rq)[(int64_t)s * Kp + i0 + tid] = rnA[tid];
+    if (blockIdx.x == 0)
+        for (int j = tid; j < Kp; j += 256) (dir ? rq : rp)[(int64_t)s * Kp + j] = rnB[j];
+    // strip of logits: the normalised rows are formed on the fly (x * 1/|x|, the products the staged path stores)
+    const int ra = i0 + l32;
+    const bool live_a = ra < k;
+    const float* __restrict__ a = X + (int64_t)(ra < Kmax ? ra : Kmax - 1) * D + kh * 4;
+    const float rna = rnA[l32];
+#pragma unroll 1
+    for (int jb = wave; jb * 32 < Kp; jb += 4) {
+        const int rb = jb * 32 + l32;
+        const bool live_b = rb < k;
+        const float* __restrict__ b = Y + (int64_t)(rb < Kmax ? rb : Kmax - 1) * D + kh * 4;
+        const float rnb = rnB[rb];
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int k0 = 0; k0 < D; k0 += 8) {
+            f32x4 av = *reinterpret_cast<const f32x4*>(a + k0) * rna;
+            f32x4 bv = *reinterpret_cast<const f32x4*>(b + k0) * rnb;
+            if (!live_a) av = f32x4{0.f, 0.f, 0.f, 0.f};   // padding rows may hold anything
+            if (!live_b) bv = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[i], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) strip[nce_acc_row(r, kh)][jb * 32 + l32] = acc[r] * inv_T;
+    }
+    __syncthreads();
+    // row reductions (max-subtracted, (m, l) kept separate), diagonal, coalesced store of the strip
+    float* __restrict__ om = (dir ? m1 : m0) + (int64_t)s * Kp;
+    float* __restrict__ ol = (dir ? l1 : l0) + (int64_t)s * Kp;
+#pragma unroll 1
+    for (int rr = 0; rr < 8; ++rr) {
+        const int row = wave * 8 + rr, i = i0 + row;
+        float m = 0.f, l = 0.f, r0 = 0.f;
+        if (i < k) {   // wave-uniform
+            float mx = -INFINITY;
+            for (int j = lane; j < k; j += 64) mx = fmaxf(mx, strip[row][j]);
+            mx = wave_max(mx);
+            float sm = 0.f;
+            for (int j = lane; j < k; j += 64) sm += expf(strip[row][j] - mx);
+            sm = wave_sum(sm);
+            m = mx;
+            l = logf(sm);
+            r0 = l - (strip[row][i] - m);   // -log_softmax(z)[i]
+        }
+        if (lane == 0) {
+            om[i] = m;
+            ol[i] = l;
+            rl[((int64_t)dir * S + s) * Kp + i] = r0;
+        }
+        if (dir == 0)
+            for (int j = lane; j < Kp; j += 64) Z[((int64_t)s * Kp + i) * Kp + j] = strip[row][j];
+    }
+    // the last workgroup of this stain reduces the row losses
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) last = atomicAdd(&done[s], 1) == (int)(gridDim.x * gridDim.y) - 1;
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    const volatile float* r0p = rl + (int64_t)s * Kp;
+    const volatile float* r1p = rl + ((int64_t)S + s) * Kp;
+    float v = 0.f;
+    for (int i = tid; i < k; i += 256) {
+        const float r = symmetric ? 0.5f * r0p[i] + 0.5f * r1p[i] : r0p[i];
+        if (row_loss) row_loss[(int64_t)s * Kmax + i] = r;   // reduction='none' (loss.py:58)
+        v += r;
+    }
+    if (row_loss)
+        for (int i = k + tid; i < Kmax; i += 256) row_loss[(int64_t)s * Kmax + i] = 0.f;
+    v = wave_sum(v);
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    if (tid == 0) {
+        loss[s] = (k > 0) ? (red[0] + red[1] + red[2] + red[3]) / (float)k : 0.f;
+        done[s] = 0;   // ready for the next call on this workspace
+    }
+}
+
+__global__ __launch_bounds__(256) void nce_fused_bwd_kernel(const float* __restrict__ Q, const float* __restrict__ P,
+                                                            const float* __restrict__ rq, const float* __restrict__ rp,
+                                                            const float* __restrict__ Z, const float* __restrict__ m0,
+                                                            const float* __restrict__ l0, const float* __restrict__ m1,
+                                                            const float* __restrict__ l1, const int32_t* __restrict__ cnt,
+                                                            const float* __restrict__ d_loss, const float* __restrict__ d_row,
+                                                            float* __restrict__ dQ, float* __restrict__ dP, int Kmax, int Kp, int D,
+                                                            float inv_T, int symmetric) {
+    __shared__ float cs[32][NCE_FK + 1];
+    __shared__ float og[32][NCE_FD + 4];
+    const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, kh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i0 = blockIdx.x * 32, dir = blockIdx.y, s = blockIdx.z;
+    const int k = cnt[s] < Kmax ? cnt[s] : Kmax;
+    if (i0 >= Kmax) return;   // no such rows in dQ / dP
+    const float* __restrict__ X = (dir ? P : Q) + (int64_t)s * Kmax * D;
+    const float* __restrict__ Y = (dir ? Q : P) + (int64_t)s * Kmax * D;
+    const float* __restrict__ ry = (dir ? rq : rp) + (int64_t)s * Kp;
+    const float* __restrict__ rx = (dir ? rp : rq) + (int64_t)s * Kp;
+    float* __restrict__ dX = (dir ? dP : dQ) + (int64_t)s * Kmax * D;
+    const int64_t zb = (int64_t)s * Kp * Kp, vb = (int64_t)s * Kp;
+    // coefficient strip: cs[rr][kk] = dL/d(cosine) between strip row i0 + rr and row kk of the other side
+    const float w0 = symmetric ? 0.5f : 1.f, w1 = symmetric ? 0.5f : 0.f;
+    for (int e = tid; e < 32 * Kp; e += 256) {
+        const int rr = dir ? (e & 31) : e / Kp, kk = dir ? (e >> 5) : e % Kp;
+        const int i = dir ? kk : i0 + rr, j = dir ? i0 + rr : kk;   // (row, column) of Z
+        float c = 0.f;
+        if (i < k && j < k) {
+            const float z = Z[zb + (int64_t)i * Kp + j];
+            const float dlt = (i == j) ? 1.f : 0.f;   // (softmax - delta) first: exact for a saturated softmax (see nce_coef_kernel)
+            const float a = expf((z - m0[vb + i]) - l0[vb + i]) - dlt;
+            const float b = symmetric ? expf((z - m1[vb + j]) - l1[vb + j]) - dlt : 0.f;
+            if (d_row) c = (w0 * d_row[(int64_t)s * Kmax + i] * a + w1 * d_row[(int64_t)s * Kmax + j] * b) * inv_T;
+            else c = (w0 * a + w1 * b) * d_loss[s] * inv_T / (float)k;
+        }
+        cs[rr][kk] = c;
+    }
+    __syncthreads();
+    // og[32][D] = cs[32][Kp] . Y[Kp][D]: wave w owns the 32-column blocks w, w + 4, ... (<= 4 at D = 512)
+    const int nblk = D / 32;
+    f32x16 acc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
+    const int kend = (k + 7) & ~7;   // coefficients are zero from k on
+    for (int k0 = 0; k0 < kend; k0 += 8) {
+        float av[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) av[i] = cs[l32][k0 + kh * 4 + i];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int nb = wave + 4 * u;
+            if (nb < nblk) {   // wave-uniform
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int kk = k0 + kh * 4 + i;
+                    const float bv = kk < k ? Y[(int64_t)kk * D + nb * 32 + l32] * ry[kk] : 0.f;   // = the staged path's normalised row
+                    acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv, acc[u], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int nb = wave + 4 * u;
+        if (nb < nblk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) og[nce_acc_row(r, kh)][nb * 32 + l32] = acc[u][r];
+    }
+    __syncthreads();
+    // backward of F.normalize on the strip: dX = rn (dXn - Xn <Xn, dXn>)  (clamped rows: dX = rn dXn); padding rows -> 0
+#pragma unroll 1
+    for (int rr = 0; rr < 8; ++rr) {
+        const int row = wave * 8 + rr, i = i0 + row;
+        if (i >= Kmax) break;   // wave-uniform
+        float* __restrict__ o = dX + (int64_t)i * D;
+        if (i >= k) {
+            for (int c = lane; c < D; c += 64) o[c] = 0.f;
+            continue;
+        }
+        const float* __restrict__ x = X + (int64_t)i * D;
+        const float rn = rx[i];
+        float dot = 0.f;
+        for (int c = lane; c < D; c += 64) dot += (x[c] * rn) * og[row][c];
+        dot = wave_sum(dot);
+        if (rn >= 0.99e12f) dot = 0.f;
+        for (int c = lane; c < D; c += 64) o[c] = rn * (og[row][c] - (x[c] * rn) * dot);
+    }
+}
+
 }  // namespace mdl
 
 using namespace mdl;
 
+// MADELEINE_INFONCE_STAGED (tests): run the staged kernels at every size (the two paths produce the same bits)
+static bool nce_fused(int Kp, int D) { return Kp <= NCE_FK && D <= NCE_FD && !getenv("MADELEINE_INFONCE_STAGED"); }
+
 extern "C" int64_t mdl_infonce_ws_bytes(int S, int Kmax, int D) {
     if (S < 0 || Kmax < 0 || D < 8 || (D % 32)) return MDL_E_ARG;
     const int64_t Kp = nce_kp(Kmax), rows = (int64_t)S * Kp;
-    return (4 * rows * D + 6 * rows + 2 * rows * Kp) * 4 + 64;
+    return (4 * rows * D + 8 * rows + 2 * rows * Kp + S) * 4 + 64;
 }
 
 extern "C" int mdl_infonce_fwd(const float* Q, const float* P, const int32_t* cnt, float* loss, float* row_loss, int S, int Kmax,
@@ -228,6 +465,14 @@ extern "C" int mdl_infonce_fwd(const float* Q, const float* P, const int32_t* cn
     hipStream_t st = (hipStream_t)stream;
     const NceWs w = nce_ws(ws, S, Kmax, D);
     const int Kp = w.Kp;
+    if (Kp > 0 && nce_fused(Kp, D)) {   // fused: one launch (the workgroup counters start at zero and reset themselves)
+        const hipError_t e = hipMemsetAsync(w.done, 0, (size_t)S * sizeof(int), st);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(nce_fused_fwd_kernel, dim3(Kp / 32, symmetric ? 2 : 1, S), dim3(256), 0, st, Q, P, cnt, w.rq, w.rp, w.Z,
+                           w.m0, w.l0, w.m1, w.l1, w.rl, w.done, loss, row_loss, S, Kmax, Kp, D, 1.f / temperature, symmetric);
+        MDL_LAUNCH_CHECK();
+        return MDL_OK;
+    }
     if (Kp > 0) {
         hipLaunchKernelGGL(nce_normalize_kernel, dim3(S * Kp, 2), dim3(64), 0, st, Q, P, cnt, w.Qn, w.Pn, w.rq, w.rp, Kmax,
                            Kp, D);
@@ -243,15 +488,21 @@ extern "C" int mdl_infonce_fwd(const float* Q, const float* P, const int32_t* cn
     return MDL_OK;
 }
 
-extern "C" int mdl_infonce_bwd(const float* d_loss, const float* d_row_loss, const int32_t* cnt, float* dQ, float* dP, int S, int Kmax,
-                               int D, float temperature, int symmetric, void* ws, void* stream) {
-    if ((!d_loss && !d_row_loss) || !cnt || !dQ || !dP || !ws) return MDL_E_ARG;
+extern "C" int mdl_infonce_bwd(const float* Q, const float* P, const float* d_loss, const float* d_row_loss, const int32_t* cnt,
+                               float* dQ, float* dP, int S, int Kmax, int D, float temperature, int symmetric, void* ws, void* stream) {
+    if (!Q || !P || (!d_loss && !d_row_loss) || !cnt || !dQ || !dP || !ws) return MDL_E_ARG;
     if (S < 0 || Kmax < 0 || D < 8 || (D % 32) || !(temperature > 0.f)) return MDL_E_ARG;
     if (!host_aligned16(ws)) return MDL_E_ALIGN;
     if (S == 0 || Kmax == 0) return MDL_OK;
     hipStream_t st = (hipStream_t)stream;
     const NceWs w = nce_ws(ws, S, Kmax, D);
     const int Kp = w.Kp;
+    if (nce_fused(Kp, D)) {   // the forward ran fused: no normalised copies in ws
+        hipLaunchKernelGGL(nce_fused_bwd_kernel, dim3(Kp / 32, 2, S), dim3(256), 0, st, Q, P, w.rq, w.rp, w.Z, w.m0, w.l0, w.m1, w.l1,
+                           cnt, d_loss, d_row_loss, dQ, dP, Kmax, Kp, D, 1.f / temperature, symmetric);
+        MDL_LAUNCH_CHECK();
+        return MDL_OK;
+    }
     hipLaunchKernelGGL(nce_coef_kernel, dim3((Kp * Kp + 255) / 256, S), dim3(256), 0, st, w.Z, w.m0, w.l0, w.m1, w.l1, cnt,
                        d_loss, d_row_loss, Kmax, w.coef, Kp, 1.f / temperature, symmetric);
     MDL_LAUNCH_CHECK();

@@ -946,7 +946,7 @@ class InfoNCEFn(torch.autograd.Function):
             rc = lib.mdl_infonce_fwd(_ptr(Q), _ptr(P), _ptr(cnt), _ptr(loss), _ptr(rows), S, Kmax, D, float(temperature),
                                      int(symmetric), _ptr(ws), _stream())
         _native.check(rc, "mdl_infonce_fwd")
-        ctx.save_for_backward(cnt, ws)
+        ctx.save_for_backward(cnt, ws, Q, P)
         ctx.cfg = (S, Kmax, D, float(temperature), int(symmetric), bool(per_row))
         if not per_row:
             rows = loss.new_empty(0)
@@ -955,7 +955,7 @@ class InfoNCEFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_loss, d_rows):
-        cnt, ws = ctx.saved_tensors
+        cnt, ws, Q, P = ctx.saved_tensors
         S, Kmax, D, temperature, symmetric, per_row = ctx.cfg
         lib = _native.lib()
         dev = cnt.device
@@ -968,12 +968,12 @@ class InfoNCEFn(torch.autograd.Function):
                 g = g + d_loss.float().unsqueeze(1) / cnt.clamp_min(1).unsqueeze(1).float()
             g = g.contiguous()
             with _timed("infonce_bwd"):
-                rc = lib.mdl_infonce_bwd(None, _ptr(g), _ptr(cnt), _ptr(dQ), _ptr(dP), S, Kmax, D, temperature, symmetric,
-                                         _ptr(ws), _stream())
+                rc = lib.mdl_infonce_bwd(_ptr(Q), _ptr(P), None, _ptr(g), _ptr(cnt), _ptr(dQ), _ptr(dP), S, Kmax, D, temperature,
+                                         symmetric, _ptr(ws), _stream())
         else:
             d_loss = d_loss.float().contiguous()
             with _timed("infonce_bwd"):
-                rc = lib.mdl_infonce_bwd(_ptr(d_loss), None, _ptr(cnt), _ptr(dQ), _ptr(dP), S, Kmax, D, temperature,
+                rc = lib.mdl_infonce_bwd(_ptr(Q), _ptr(P), _ptr(d_loss), None, _ptr(cnt), _ptr(dQ), _ptr(dP), S, Kmax, D, temperature,
                                          symmetric, _ptr(ws), _stream())
         _native.check(rc, "mdl_infonce_bwd")
         return dQ, dP, None, None, None, None

@@ -263,6 +263,48 @@ def test_infonce_vs_oracle(dev, k, T, sym):
     _grad_ok(pd.grad, p.grad, p64.grad)
 
 
+@pytest.mark.parametrize("k,d", [(300, 64), (40, 1024)])
+@pytest.mark.parametrize("sym", [False, True])
+def test_infonce_staged_path(dev, k, d, sym):
+    """More than 256 cases or an embedding wider than 512 leave the fused one-launch kernels for the staged ones."""
+    from madeleine_amd import InfoNCE
+    T = 0.05
+    q0, p0 = t((k, d), f"nces:q{k}"), t((k, d), f"nces:p{k}")
+    p0 = p0 + 0.3 * q0
+    q64, p64 = q0.double().requires_grad_(), p0.double().requires_grad_()
+    ref = R.info_nce(q64, p64, T, sym)
+    ref.backward()
+    qd, pd = q0.to(dev).requires_grad_(), p0.to(dev).requires_grad_()
+    out = InfoNCE(temperature=T)(qd, pd, symmetric=sym)
+    out.backward()
+    assert abs(float(out) - float(ref)) <= 1e-5 * abs(float(ref))
+    assert rel_err(qd.grad, q64.grad) < 1e-4 and rel_err(pd.grad, p64.grad) < 1e-4
+
+
+@pytest.mark.parametrize("sym", [False, True])
+def test_infonce_fused_equals_staged_bitwise(dev, sym, monkeypatch):
+    """The one-launch kernels (k <= 256, d <= 512) normalise on the fly with the staged path's products and summation orders: same
+    bits for the losses and both gradients, ragged problem sizes and padding rows included."""
+    from madeleine_amd import functional as MF
+    S, Kmax, D = 3, 200, 512
+    Q, P = t((S, Kmax, D), "ncef:q").to(dev), t((S, Kmax, D), "ncef:p").to(dev)
+    P = P + 0.2 * Q
+    cnt = torch.tensor([200, 77, 1], dtype=torch.int32, device=dev)
+    Q[1, 77:] = float("nan")     # padding rows may hold anything
+    res = []
+    for staged in (False, True):
+        if staged:
+            monkeypatch.setenv("MADELEINE_INFONCE_STAGED", "1")
+        q, p = Q.clone().requires_grad_(), P.clone().requires_grad_()
+        loss = MF.info_nce_batched(q, p, cnt, 0.001, sym)
+        (loss * torch.tensor([1.0, 2.0, 3.0], device=dev)).sum().backward()
+        rows = MF.info_nce_rows(Q, P, cnt, 0.001, sym)
+        res.append((loss.detach(), q.grad, p.grad, rows))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    assert torch.isfinite(res[0][0]).all() and torch.isfinite(res[0][1]).all() and torch.isfinite(res[0][2]).all()
+
+
 def test_infonce_golden_and_batched(dev):
     from madeleine_amd import InfoNCE
     from tests._util import golden
