@@ -223,9 +223,9 @@ int mdl_infonce_fwd(const float* Q, const float* P, const int32_t* cnt, float* l
 /* Q,P: the forward's inputs (the fused path keeps no normalised copies).  d_loss [S] incoming gradient of the mean losses -- or, when
  * d_row_loss [S,Kmax] != NULL, the gradients of the per-sample losses (d_loss is then ignored and may be NULL); dQ,dP [S,Kmax,D] (rows
  * >= cnt[s] are zeroed).  ws must be the forward's.
- * Kmax <= 256 and D <= 512 (every configuration of the training loop): ONE launch forward (similarity on the raw rows scaled by the
- * reciprocal norms of the same streaming pass, row / column log-sum-exp, losses; "batched InfoNCE similarity + logsumexp" of the
- * north star) and ONE launch backward (coefficients, both gradient products, normalize() backward). */
+ * Default: staged launches (normalise | similarity | log-sum-exp | loss ; coefficients | products | normalize backward), all stains per
+ * launch.  MADELEINE_INFONCE_FUSED=1 with Kmax <= 256 and D <= 512: ONE launch forward and ONE backward producing the same bits
+ * (measured slower on MI355X: the problem is latency-bound and fusing gives up wave-level parallelism; csrc/infonce.hip). */
 int mdl_infonce_bwd(const float* Q, const float* P, const float* d_loss, const float* d_row_loss, const int32_t* cnt, float* dQ,
                     float* dP, int S, int Kmax, int D, float temperature, int symmetric, void* ws, void* stream);
 

@@ -494,8 +494,8 @@ static int gate_bwd_impl(const float* E, int64_t ldE, const float* Wa, const flo
             if (e != hipSuccess) return (int)e;
         }
         if (T > 0) {
-            if (nblk > 0x7fffffff) return MDL_E_UNSUPPORTED;
-            hipLaunchKernelGGL((gate_dz_kernel<float, float>), dim3((unsigned)nblk, H), dim3(256), 0, s, wc, act_a, act_b, d_scores, dz, slabV,
+            if (nblk * H > 0x7fffffff) return MDL_E_UNSUPPORTED;
+            hipLaunchKernelGGL((gate_dz_kernel<float, float>), dim3((unsigned)(nblk * H)), dim3(256), 0, s, wc, act_a, act_b, d_scores, dz, slabV,
                                T, H, d);
             MDL_LAUNCH_CHECK();
         }

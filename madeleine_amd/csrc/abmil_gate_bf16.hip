@@ -601,14 +601,14 @@ static int gate_bwd_bf16_impl(const uint16_t* E, int64_t ldE, const float* Wa, c
     bf16_t* dz = (bf16_t*)(base + L.odz);
     float* slabW = (float*)(base + L.oslabW);
     float* slabV = (float*)(base + L.oslabV);
-    if (L.nblk > 0x7fffffff) return MDL_E_UNSUPPORTED;
+    if (L.nblk * H > 0x7fffffff) return MDL_E_UNSUPPORTED;
     if (phases & 1) {
         {   // zero pad rows of dz (K-tail of the dW contraction)
             const hipError_t e = hipMemsetAsync(dz + T * H * 1024, 0, (size_t)TNK * H * 1024 * 2, s);
             if (e != hipSuccess) return (int)e;
         }
         if (T > 0) {
-            hipLaunchKernelGGL((gate_dz_kernel<bf16_t, bf16_t>), dim3((unsigned)L.nblk, H), dim3(256), 0, s, wc, (const bf16_t*)act_a,
+            hipLaunchKernelGGL((gate_dz_kernel<bf16_t, bf16_t>), dim3((unsigned)(L.nblk * H)), dim3(256), 0, s, wc, (const bf16_t*)act_a,
                                (const bf16_t*)act_b, d_scores, dz, slabV, T, H, d);
             MDL_LAUNCH_CHECK();
         }

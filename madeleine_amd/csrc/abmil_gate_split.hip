@@ -191,8 +191,11 @@ __global__ __launch_bounds__(256) void sp_gate_dz_kernel(const float* __restrict
                                                          float* __restrict__ slabV, int64_t T, int H, DropCfg drop) {
     constexpr int VEC = 8, NQ = HID / VEC, PH = 256 / NQ;   // 64 groups of 8 columns (16-B image stores) x 4 row phases
     __shared__ float red[PH - 1][NQ][3 * VEC + 1];
-    const int tid = threadIdx.x, q = tid % NQ, ph = tid / NQ, c = blockIdx.y;
-    const int64_t r0 = (int64_t)blockIdx.x * DZ_ROWS;
+    // 1-D grid, head fastest: the H workgroups that cover the same rows run together (head-major [T][H][512] rows: one head alone
+    // touches 2 KB of every 8 KB; measured 1.96 -> 1.85 ms at config 2)
+    const int tid = threadIdx.x, q = tid % NQ, ph = tid / NQ, c = blockIdx.x % H;
+    const int64_t bx = blockIdx.x / H;
+    const int64_t r0 = bx * DZ_ROWS;
     int64_t r1 = r0 + DZ_ROWS;
     if (r1 > T) r1 = T;
     const float s = dz_sc[0];
@@ -262,7 +265,7 @@ __global__ __launch_bounds__(256) void sp_gate_dz_kernel(const float* __restrict
     }
     __syncthreads();
     if (ph == 0) {
-        float* __restrict__ o = slabV + ((int64_t)blockIdx.x * H + c) * 4 * HID + q * VEC;
+        float* __restrict__ o = slabV + (bx * H + c) * 4 * HID + q * VEC;
 #pragma unroll
         for (int p = 0; p < PH - 1; ++p) {
 #pragma unroll
@@ -519,7 +522,7 @@ extern "C" int mdl_abmil_attnpool_bwd_split(const void* E_img, int64_t e_rsb, co
     float* slabW = (float*)(base + L.oslabW);
     float* slabV = (float*)(base + L.oslabV);
     float* sc = (float*)(base + L.osc);
-    if (L.nblk > 0x7fffffff) return MDL_E_UNSUPPORTED;
+    if (L.nblk * H > 0x7fffffff) return MDL_E_UNSUPPORTED;
     const PoolTerm pt{scores, stat_m, stat_l, d_pooled, row_bag, N};
     if (phases & 1) {
         hipError_t e = hipMemsetAsync(sc, 0, 8 * sizeof(float), s);
@@ -540,7 +543,7 @@ extern "C" int mdl_abmil_attnpool_bwd_split(const void* E_img, int64_t e_rsb, co
         hipLaunchKernelGGL(sp_bound_scale_kernel, dim3(1), dim3(1), 0, s, (const float*)(sc + 2), d.inv * d.inv, sc + 4);
         MDL_LAUNCH_CHECK();
         if (T > 0) {
-            hipLaunchKernelGGL(sp_gate_dz_kernel, dim3((unsigned)L.nblk, H), dim3(256), 0, s, wc, act_a, act_b, d_scores, dzi,
+            hipLaunchKernelGGL(sp_gate_dz_kernel, dim3((unsigned)(L.nblk * H)), dim3(256), 0, s, wc, act_a, act_b, d_scores, dzi,
                                (const float*)(sc + 4), slabV, T, H, d);
             MDL_LAUNCH_CHECK();
         }

@@ -158,8 +158,10 @@ __global__ __launch_bounds__(256) void gate_dz_kernel(const float* __restrict__ 
                                                       DropCfg drop) {
     constexpr int VEC = 16 / sizeof(TI), NQ = HID / VEC, PH = 256 / NQ;
     __shared__ float red[PH - 1][NQ][3 * VEC + 1];
-    const int tid = threadIdx.x, q = tid % NQ, ph = tid / NQ, c = blockIdx.y;
-    const int64_t r0 = (int64_t)blockIdx.x * DZ_ROWS;
+    // 1-D grid, head fastest: the H workgroups covering the same rows run together (see sp_gate_dz_kernel)
+    const int tid = threadIdx.x, q = tid % NQ, ph = tid / NQ, c = blockIdx.x % H;
+    const int64_t bx = blockIdx.x / H;
+    const int64_t r0 = bx * DZ_ROWS;
     int64_t r1 = r0 + DZ_ROWS;
     if (r1 > T) r1 = T;
     float vw[VEC], sa[VEC], sb[VEC], sw[VEC];
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(256) void gate_dz_kernel(const float* __restrict__ 
     }
     __syncthreads();
     if (ph == 0) {
-        float* __restrict__ o = slabV + ((int64_t)blockIdx.x * H + c) * 4 * HID + q * VEC;
+        float* __restrict__ o = slabV + (bx * H + c) * 4 * HID + q * VEC;
 #pragma unroll
         for (int p = 0; p < PH - 1; ++p) {
 #pragma unroll

@@ -7,8 +7,8 @@
 // of launches.  At temperature 0.001 the logits are cosines x 1000, so the similarity contraction runs on
 // the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) and every logsumexp is max-subtracted.
 //
-// Two paths: Kp <= 256 and D <= 512 (every configuration of the training loop) -> the fused kernels at the end of this file, one
-// launch forward and one backward; anything larger -> the staged kernels (normalise | logits | lse | loss ; coef | grad | norm-bwd).
+// Two paths: the staged kernels (normalise | logits | lse | loss ; coef | grad | norm-bwd: the default, and the faster one) and, for
+// Kp <= 256 and D <= 512, the opt-in fused kernels at the end of this file (one launch forward, one backward; same bits).
 // Workspace (floats; Kp = Kmax rounded up to 32):
 //   Qn,Pn [S,Kp,D] | rq,rp [S,Kp] | Z [S,Kp,Kp] = logits | m0,l0,m1,l1 [S,Kp] | coef [S,Kp,Kp] | dQn,dPn [S,Kp,D]
 // (m, l) = (max, log sum exp(z - max)) per row (0) / column (1), kept SEPARATE like torch's log_softmax: at
@@ -47,23 +47,37 @@ static inline NceWs nce_ws(void* ws, int S, int Kmax, int D) {
     return w;
 }
 
-// one wave per (row, which): normalised row + reciprocal clamped norm; padded rows -> 0
+// Sum of squares of one row in the order BOTH paths use: lane (l32, kh) of a wave owns row l32 and the k's kh*4 .. kh*4+3 of every
+// group of 8 (the streaming pattern of the similarity product); one fmaf chain per half, the two halves added.  p = row + kh * 4.
+__device__ __forceinline__ float nce_row_ss(const float* __restrict__ p, int D, bool live) {
+    float ss = 0.f;
+    if (live)
+        for (int k0 = 0; k0 < D; k0 += 8) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(p + k0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ss = fmaf(v[i], v[i], ss);
+        }
+    return ss + __shfl_xor(ss, 32, 64);
+}
+__device__ __forceinline__ float nce_inv_norm(float ss, bool live) { return live ? 1.f / fmaxf(sqrtf(ss), 1e-12f) : 0.f; }
+
+// one wave per 32 rows of Q (which = 0) or P (1): normalised rows + reciprocal clamped norms; padded rows -> 0
 __global__ __launch_bounds__(64) void nce_normalize_kernel(const float* __restrict__ Q, const float* __restrict__ P,
                                                            const int32_t* __restrict__ cnt, float* __restrict__ Qn,
                                                            float* __restrict__ Pn, float* __restrict__ rq,
                                                            float* __restrict__ rp, int Kmax, int Kp, int D) {
-    const int r = blockIdx.x % Kp, s = blockIdx.x / Kp, which = blockIdx.y, lane = threadIdx.x;
-    const float* __restrict__ src = (which ? P : Q) + ((int64_t)s * Kmax + r) * D;
-    float* __restrict__ dst = (which ? Pn : Qn) + ((int64_t)s * Kp + r) * D;
-    float* __restrict__ rn = (which ? rp : rq) + (int64_t)s * Kp + r;
+    const int nrb = Kp / 32, rb = blockIdx.x % nrb, s = blockIdx.x / nrb, which = blockIdx.y;
+    const int lane = threadIdx.x, l32 = lane & 31, kh = lane >> 5, r = rb * 32 + l32;
     const bool live = r < cnt[s] && r < Kmax;
-    float ss = 0.f;
-    if (live)
-        for (int k = lane; k < D; k += 64) ss += src[k] * src[k];
-    ss = wave_sum(ss);
-    const float inv = live ? 1.f / fmaxf(sqrtf(ss), 1e-12f) : 0.f;
-    for (int k = lane; k < D; k += 64) dst[k] = live ? src[k] * inv : 0.f;
-    if (lane == 0) *rn = inv;
+    const float* __restrict__ src = (which ? P : Q) + ((int64_t)s * Kmax + (r < Kmax ? r : Kmax - 1)) * D + kh * 4;
+    float* __restrict__ dst = (which ? Pn : Qn) + ((int64_t)s * Kp + r) * D + kh * 4;
+    const float inv = nce_inv_norm(nce_row_ss(src, D, live), live);
+    for (int k0 = 0; k0 < D; k0 += 8) {
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (live) v = *reinterpret_cast<const f32x4*>(src + k0) * inv;
+        *reinterpret_cast<f32x4*>(dst + k0) = v;
+    }
+    if (kh == 0) ((which ? rp : rq) + (int64_t)s * Kp)[r] = inv;
 }
 
 // one wave per 32x32 block of Z = Qn Pn^T * inv_T.  Each lane streams its own row 16 B at a time; the 8
@@ -248,51 +262,27 @@ __global__ __launch_bounds__(256) void nce_fused_fwd_kernel(const float* __restr
     const int k = cnt[s] < Kmax ? cnt[s] : Kmax;
     const float* __restrict__ X = (dir ? P : Q) + (int64_t)s * Kmax * D;
     const float* __restrict__ Y = (dir ? Q : P) + (int64_t)s * Kmax * D;
-    // reciprocal clamped norms (x / max(|x|, 1e-12), loss.py:132), one wave per row, the staged path's summation order
-    __shared__ float rnA[32], rnB[NCE_FK];
-    auto rnorm = [&](const float* __restrict__ base, int r) {
-        const bool live = r < k;
-        float ss = 0.f;
-        if (live)
-            for (int c = lane; c < D; c += 64) ss += base[(int64_t)r * D + c] * base[(int64_t)r * D + c];
-        ss = wave_sum(ss);
-        return live ? 1.f / fmaxf(sqrtf(ss), 1e-12f) : 0.f;
-    };
-#pragma unroll 1
-    for (int rr = 0; rr < 8; ++rr) {
-        const float v = rnorm(X, i0 + wave * 8 + rr);
-        if (lane == 0) rnA[wave * 8 + rr] = v;
-    }
-#pragma unroll 1
-    for (int jb = wave; jb * 32 < Kp; jb += 4)
-#pragma unroll 1
-        for (int rr = 0; rr < 32; ++rr) {
-            const float v = rnorm(Y, jb * 32 + rr);
-            if (lane == 0) rnB[jb * 32 + rr] = v;
-        }
-    __syncthreads();
-    if (tid < 32) (dir ? rp : rq)[(int64_t)s * Kp + i0 + tid] = rnA[tid];
-    if (blockIdx.x == 0)
-        for (int j = tid; j < Kp; j += 256) (dir ? rq : rp)[(int64_t)s * Kp + j] = rnB[j];
-    // strip of logits: the normalised rows are formed on the fly (x * 1/|x|, the products the staged path stores)
+    // each lane streams its own row twice: sum of squares (nce_row_ss, the staged path's order), then the similarity product on the
+    // rows normalised on the fly (x * 1/|x|: the products the staged path stores); the second pass hits the cache
     const int ra = i0 + l32;
     const bool live_a = ra < k;
     const float* __restrict__ a = X + (int64_t)(ra < Kmax ? ra : Kmax - 1) * D + kh * 4;
-    const float rna = rnA[l32];
+    const float rna = nce_inv_norm(nce_row_ss(a, D, live_a), live_a);   // x / max(|x|, 1e-12), loss.py:132
+    if (wave == 0 && kh == 0) (dir ? rp : rq)[(int64_t)s * Kp + ra] = rna;
 #pragma unroll 1
     for (int jb = wave; jb * 32 < Kp; jb += 4) {
         const int rb = jb * 32 + l32;
         const bool live_b = rb < k;
         const float* __restrict__ b = Y + (int64_t)(rb < Kmax ? rb : Kmax - 1) * D + kh * 4;
-        const float rnb = rnB[rb];
+        const float rnb = nce_inv_norm(nce_row_ss(b, D, live_b), live_b);
+        if (blockIdx.x == 0 && kh == 0) (dir ? rq : rp)[(int64_t)s * Kp + rb] = rnb;
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         for (int k0 = 0; k0 < D; k0 += 8) {
-            f32x4 av = *reinterpret_cast<const f32x4*>(a + k0) * rna;
-            f32x4 bv = *reinterpret_cast<const f32x4*>(b + k0) * rnb;
-            if (!live_a) av = f32x4{0.f, 0.f, 0.f, 0.f};   // padding rows may hold anything
-            if (!live_b) bv = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 av = f32x4{0.f, 0.f, 0.f, 0.f}, bv = av;   // padding rows may hold anything
+            if (live_a) av = *reinterpret_cast<const f32x4*>(a + k0) * rna;
+            if (live_b) bv = *reinterpret_cast<const f32x4*>(b + k0) * rnb;
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[i], acc, 0, 0, 0);
         }
@@ -423,23 +413,47 @@ __global__ __launch_bounds__(256) void nce_fused_bwd_kernel(const float* __restr
             for (int r = 0; r < 16; ++r) og[nce_acc_row(r, kh)][nb * 32 + l32] = acc[u][r];
     }
     __syncthreads();
-    // backward of F.normalize on the strip: dX = rn (dXn - Xn <Xn, dXn>)  (clamped rows: dX = rn dXn); padding rows -> 0
+    // backward of F.normalize on the strip: dX = rn (dXn - Xn <Xn, dXn>)  (clamped rows: dX = rn dXn); padding rows -> 0.
+    // 4 rows per trip: their loads are independent (one row at a time is a chain of L2 latencies)
+    constexpr int NC = NCE_FD / 64;
 #pragma unroll 1
-    for (int rr = 0; rr < 8; ++rr) {
-        const int row = wave * 8 + rr, i = i0 + row;
-        if (i >= Kmax) break;   // wave-uniform
-        float* __restrict__ o = dX + (int64_t)i * D;
-        if (i >= k) {
-            for (int c = lane; c < D; c += 64) o[c] = 0.f;
-            continue;
+    for (int g = 0; g < 2; ++g) {
+        float xn[4][NC], rn[4], dot[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int row = wave * 8 + g * 4 + u, i = i0 + row;
+            const bool live = i < k;
+            rn[u] = live ? rx[i] : 0.f;
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+                const int c = lane + 64 * j;
+                xn[u][j] = (live && c < D) ? X[(int64_t)i * D + c] * rn[u] : 0.f;
+            }
         }
-        const float* __restrict__ x = X + (int64_t)i * D;
-        const float rn = rx[i];
-        float dot = 0.f;
-        for (int c = lane; c < D; c += 64) dot += (x[c] * rn) * og[row][c];
-        dot = wave_sum(dot);
-        if (rn >= 0.99e12f) dot = 0.f;
-        for (int c = lane; c < D; c += 64) o[c] = rn * (og[row][c] - (x[c] * rn) * dot);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int row = wave * 8 + g * 4 + u;
+            float d = 0.f;
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+                const int c = lane + 64 * j;
+                if (c < D) d += xn[u][j] * og[row][c];
+            }
+            d = wave_sum(d);
+            dot[u] = rn[u] >= 0.99e12f ? 0.f : d;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int row = wave * 8 + g * 4 + u, i = i0 + row;
+            if (i < Kmax) {   // wave-uniform
+                float* __restrict__ o = dX + (int64_t)i * D;
+#pragma unroll
+                for (int j = 0; j < NC; ++j) {
+                    const int c = lane + 64 * j;
+                    if (c < D) o[c] = i < k ? rn[u] * (og[row][c] - xn[u][j] * dot[u]) : 0.f;
+                }
+            }
+        }
     }
 }
 
@@ -447,8 +461,11 @@ __global__ __launch_bounds__(256) void nce_fused_bwd_kernel(const float* __restr
 
 using namespace mdl;
 
-// MADELEINE_INFONCE_STAGED (tests): run the staged kernels at every size (the two paths produce the same bits)
-static bool nce_fused(int Kp, int D) { return Kp <= NCE_FK && D <= NCE_FD && !getenv("MADELEINE_INFONCE_STAGED"); }
+// The fused kernels are opt-in (MADELEINE_INFONCE_FUSED=1): same bits as the staged ones, but SLOWER at every size measured on MI355X
+// (tools/exp_infonce.py, forward / backward in us: S=3 k=32 58 / 39 against 54 / 24; S=4 k=256 97 / 199 against 63 / 61) -- the
+// problem is latency-bound, launches on one stream pipeline (~5 us each), and fusing trades 4-16x of the wave-level parallelism for
+// them (64 workgroups at k = 256 where the staged gradient product runs 1024 waves).
+static bool nce_fused(int Kp, int D) { return Kp <= NCE_FK && D <= NCE_FD && getenv("MADELEINE_INFONCE_FUSED"); }
 
 extern "C" int64_t mdl_infonce_ws_bytes(int S, int Kmax, int D) {
     if (S < 0 || Kmax < 0 || D < 8 || (D % 32)) return MDL_E_ARG;
@@ -474,7 +491,7 @@ extern "C" int mdl_infonce_fwd(const float* Q, const float* P, const int32_t* cn
         return MDL_OK;
     }
     if (Kp > 0) {
-        hipLaunchKernelGGL(nce_normalize_kernel, dim3(S * Kp, 2), dim3(64), 0, st, Q, P, cnt, w.Qn, w.Pn, w.rq, w.rp, Kmax,
+        hipLaunchKernelGGL(nce_normalize_kernel, dim3(S * (Kp / 32), 2), dim3(64), 0, st, Q, P, cnt, w.Qn, w.Pn, w.rq, w.rp, Kmax,
                            Kp, D);
         MDL_LAUNCH_CHECK();
         hipLaunchKernelGGL(nce_logits_kernel, dim3(Kp / 32, Kp / 32, S), dim3(64), 0, st, w.Qn, w.Pn, w.Z, Kp, D,

@@ -266,7 +266,7 @@ def test_infonce_vs_oracle(dev, k, T, sym):
 @pytest.mark.parametrize("k,d", [(300, 64), (40, 1024)])
 @pytest.mark.parametrize("sym", [False, True])
 def test_infonce_staged_path(dev, k, d, sym):
-    """More than 256 cases or an embedding wider than 512 leave the fused one-launch kernels for the staged ones."""
+    """More than 256 cases / an embedding wider than 512 (sizes the training loop never produces) against the fp64 oracle."""
     from madeleine_amd import InfoNCE
     T = 0.05
     q0, p0 = t((k, d), f"nces:q{k}"), t((k, d), f"nces:p{k}")
@@ -283,8 +283,8 @@ def test_infonce_staged_path(dev, k, d, sym):
 
 @pytest.mark.parametrize("sym", [False, True])
 def test_infonce_fused_equals_staged_bitwise(dev, sym, monkeypatch):
-    """The one-launch kernels (k <= 256, d <= 512) normalise on the fly with the staged path's products and summation orders: same
-    bits for the losses and both gradients, ragged problem sizes and padding rows included."""
+    """The opt-in one-launch kernels (MADELEINE_INFONCE_FUSED=1; k <= 256, d <= 512) normalise on the fly with the staged path's
+    products and summation orders: same bits for the losses and both gradients, ragged problem sizes and padding rows included."""
     from madeleine_amd import functional as MF
     S, Kmax, D = 3, 200, 512
     Q, P = t((S, Kmax, D), "ncef:q").to(dev), t((S, Kmax, D), "ncef:p").to(dev)
@@ -292,9 +292,9 @@ def test_infonce_fused_equals_staged_bitwise(dev, sym, monkeypatch):
     cnt = torch.tensor([200, 77, 1], dtype=torch.int32, device=dev)
     Q[1, 77:] = float("nan")     # padding rows may hold anything
     res = []
-    for staged in (False, True):
-        if staged:
-            monkeypatch.setenv("MADELEINE_INFONCE_STAGED", "1")
+    for fused in (False, True):
+        if fused:
+            monkeypatch.setenv("MADELEINE_INFONCE_FUSED", "1")
         q, p = Q.clone().requires_grad_(), P.clone().requires_grad_()
         loss = MF.info_nce_batched(q, p, cnt, 0.001, sym)
         (loss * torch.tensor([1.0, 2.0, 3.0], device=dev)).sum().backward()
