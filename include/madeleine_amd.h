@@ -54,7 +54,7 @@ const char* mdl_version(void);
 /* ABI revision of this header: bumped whenever an entry point's argument list changes.  A binding compares
  * mdl_abi_version() with the MDL_ABI_VERSION it was written against BEFORE calling anything else, so that a stale
  * shared object fails loudly instead of being called with shifted arguments. */
-#define MDL_ABI_VERSION 12
+#define MDL_ABI_VERSION 13
 int mdl_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -361,16 +361,17 @@ int mdl_abmil_attnpool_bwd_bf16(const uint16_t* E, int64_t ldE, const float* Wa,
 int mdl_split_image(const float* X, int64_t ldx, int64_t rows, int K, void* img, int64_t rsb, int64_t pad_rows, float* scale,
                     void* stream);
 /* row_gate (device float[ceil(M / 256)], may be NULL; only with accumulate != 0 and bias == NULL): output tiles whose entry is 0 are
- * skipped -- mdl_split_tile_absmax(X, ...) fills it with the per-256-row maxima of |X| for A = image(X). */
-int mdl_split_tile_absmax(const float* X, int64_t ldx, int64_t rows, int K, float* gate, void* stream);
+ * skipped -- mdl_split_tile_absmax(X, ...) fills it with the per-256-row maxima of |X| for A = image(X), and chunk_max (float
+ * [ceil(rows / 32)], may be NULL) with the per-32-row maxima that mdl_split_gemm_tn's b_chunk_max takes. */
+int mdl_split_tile_absmax(const float* X, int64_t ldx, int64_t rows, int K, float* gate, float* chunk_max, void* stream);
 int mdl_split_gemm_nt(const void* A, int64_t a_rsb, const float* a_scale, const void* B, int64_t b_rsb, const float* b_scale, float* C,
                       int64_t ldc, int64_t M, int N, int K, const float* bias, int accumulate, float* absmax_out, const float* row_gate,
                       void* stream);
 int64_t mdl_split_gemm_tn_ws_bytes(int64_t T, int Mi, int N);
-/* b_src (fp32 [T, N], row stride b_src_ld; may be NULL): the tensor B is the image of -- 32-row chunks in which it is identically zero
- * are skipped (the token_projector's dW: the local loss reads the first <= 256 tokens of a bag, the rest of d_tok is zero). */
+/* b_chunk_max (float [ceil(T / 32)], may be NULL): per-32-row maxima of |X| for B = image(X) (mdl_split_tile_absmax) -- chunks whose
+ * entry is 0 are skipped (the token_projector's dW: the local loss reads the first <= 256 tokens of a bag, the rest of d_tok is zero). */
 int mdl_split_gemm_tn(const void* A, int64_t a_rsb, const float* a_scale, int Mi, const void* B, int64_t b_rsb, const float* b_scale,
-                      int N, float* out, int64_t T, const float* b_src, int64_t b_src_ld, void* ws, void* stream);
+                      int N, float* out, int64_t T, const float* b_chunk_max, void* ws, void* stream);
 
 /* N1 producers that write split images directly (csrc/preattn_act.hip): mdl_ln_gelu_drop_fwd / _bwd with the output tensor as an
  * image -- the pre-attention activations and their gradients are consumed by contractions only, so no fp32 copy is written (the

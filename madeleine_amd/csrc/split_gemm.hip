@@ -75,21 +75,30 @@ __global__ __launch_bounds__(256) void sp_convert_kernel(const float* __restrict
 }
 
 // gate[i] = max |X[256 i .. 256 i + 255][:]|: lets mdl_split_gemm_nt skip the output tiles whose A rows are all zero (the
-// token_projector's dX in the fused A2 + A3 backward: the local loss reads the first <= 256 tokens of a bag, the rest of d_tok is 0)
+// token_projector's dX in the fused A2 + A3 backward: the local loss reads the first <= 256 tokens of a bag, the rest of d_tok is 0);
+// chunk_max[j] (optional) = the same over the 32 rows of chunk j: the TN product skips all-zero chunks (mdl_split_gemm_tn).
 __global__ __launch_bounds__(256) void sp_tile_absmax_kernel(const float* __restrict__ X, int64_t ldx, int64_t rows, int K,
-                                                             float* __restrict__ gate) {
+                                                             float* __restrict__ gate, float* __restrict__ chunk_max) {
     __shared__ float red[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t r0 = (int64_t)blockIdx.x * SPM;
-    int64_t r1 = r0 + SPM;
-    if (r1 > rows) r1 = rows;
     const int g = K / 4;
-    float m = 0.f;
-    for (int64_t i = threadIdx.x; i < (r1 - r0) * g; i += 256) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(X + (r0 + i / g) * ldx + (i % g) * 4);
-        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    float mt = 0.f;
+    for (int c = wave; c < SPM / SPK; c += 4) {   // one wave per 32-row chunk
+        const int64_t c0 = r0 + (int64_t)c * SPK;
+        if (c0 >= rows) break;
+        int64_t c1 = c0 + SPK;
+        if (c1 > rows) c1 = rows;
+        float m = 0.f;
+        for (int64_t i = lane; i < (c1 - c0) * g; i += 64) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(X + (c0 + i / g) * ldx + (i % g) * 4);
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        }
+        m = wave_max(m);
+        if (chunk_max && lane == 0) chunk_max[c0 / SPK] = m;
+        mt = fmaxf(mt, m);
     }
-    m = wave_max(m);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    if (lane == 0) red[wave] = mt;
     __syncthreads();
     if (threadIdx.x == 0) gate[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
@@ -151,30 +160,18 @@ __global__ __launch_bounds__(SP_THREADS) void sp_nt_kernel(const char* __restric
     if (absmax_out) sp_atomic_absmax(absmax_out, amax);
 }
 
-// Chunk lists for the TN loop: list[sp][0 .. count[sp]) = the 32-row chunks of split sp in which X (the fp32 tensor the B image was built
-// from) is not identically zero, in ascending order.  One workgroup per split; flags in LDS, serial compaction by thread 0.
+// Chunk lists for the TN loop: list[sp][0 .. count[sp]) = the 32-row chunks of split sp whose chunk_max (sp_tile_absmax_kernel over the
+// fp32 tensor the B image was built from) is not zero, in ascending order.  One workgroup per split; flags in LDS, serial compaction.
 constexpr int SP_MAX_LIST = 2048;
-__global__ __launch_bounds__(256) void sp_chunk_list_kernel(const float* __restrict__ X, int64_t ldx, int64_t T, int K, int64_t tok_per_split,
+__global__ __launch_bounds__(256) void sp_chunk_list_kernel(const float* __restrict__ chunk_max, int64_t T, int64_t tok_per_split,
                                                             int32_t* __restrict__ list, int32_t* __restrict__ count, int stride) {
     __shared__ uint8_t flag[SP_MAX_LIST];
-    const int sp = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t ts = (int64_t)sp * tok_per_split;
+    const int sp = blockIdx.x;
+    const int64_t ts = (int64_t)sp * tok_per_split;   // a multiple of 32
     int64_t te = ts + tok_per_split;
     if (te > T) te = T;
     const int nc = te > ts ? (int)((te - ts + SPK - 1) / SPK) : 0;
-    const int g = K / 4;
-    for (int c = wave; c < nc; c += 4) {   // one wave per chunk
-        const int64_t r0 = ts + (int64_t)c * SPK;
-        int64_t r1 = r0 + SPK;
-        if (r1 > T) r1 = T;
-        float m = 0.f;
-        for (int64_t i = lane; i < (r1 - r0) * g; i += 64) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(X + (r0 + i / g) * ldx + (i % g) * 4);
-            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
-        }
-        m = wave_max(m);
-        if (lane == 0) flag[c] = m != 0.f;   // (NaN counts as non-zero)
-    }
+    for (int c = threadIdx.x; c < nc; c += 256) flag[c] = !(chunk_max[ts / SPK + c] == 0.f);   // (NaN counts as non-zero)
     __syncthreads();
     if (threadIdx.x == 0) {
         int n = 0;
@@ -287,11 +284,12 @@ extern "C" int mdl_split_image(const float* X, int64_t ldx, int64_t rows, int K,
 /* C [M, N] (row stride ldc floats) (+)= sum_k A[m][k] B[n][k] (+ bias[n]) on the split images A (M rows) and B (N rows) of K columns;
  * a_scale / b_scale: device floats, the images' scales.  absmax_out (device float, may be NULL): atomically raised to max |C|
  * (the caller zeroes it).  N % 4 == 0, K % 32 == 0. */
-extern "C" int mdl_split_tile_absmax(const float* X, int64_t ldx, int64_t rows, int K, float* gate, void* stream) {
+extern "C" int mdl_split_tile_absmax(const float* X, int64_t ldx, int64_t rows, int K, float* gate, float* chunk_max, void* stream) {
     if (!X || !gate || rows < 0 || K < 4 || (K & 3) || ldx < K || (ldx & 3)) return MDL_E_ARG;
     if (!host_aligned16(X)) return MDL_E_ALIGN;
     if (rows == 0) return MDL_OK;
-    hipLaunchKernelGGL(sp_tile_absmax_kernel, dim3((unsigned)((rows + SPM - 1) / SPM)), dim3(256), 0, (hipStream_t)stream, X, ldx, rows, K, gate);
+    hipLaunchKernelGGL(sp_tile_absmax_kernel, dim3((unsigned)((rows + SPM - 1) / SPM)), dim3(256), 0, (hipStream_t)stream, X, ldx, rows, K, gate,
+                       chunk_max);
     MDL_LAUNCH_CHECK();
     return MDL_OK;
 }
@@ -322,8 +320,7 @@ extern "C" int64_t mdl_split_gemm_tn_ws_bytes(int64_t T, int Mi, int N) {
 /* out [N][Mi] (contiguous: a Linear's dW with A = image(X), B = image(dY)) = sum_t B[t][n] A[t][m] over the T rows of the two
  * token-major images (Mi / N columns).  The B image must be followed by >= 32 all-zero rows.  Mi % 32 == 0, N % 32 == 0. */
 extern "C" int mdl_split_gemm_tn(const void* A, int64_t a_rsb, const float* a_scale, int Mi, const void* B, int64_t b_rsb,
-                                 const float* b_scale, int N, float* out, int64_t T, const float* b_src, int64_t b_src_ld, void* ws,
-                                 void* stream) {
+                                 const float* b_scale, int N, float* out, int64_t T, const float* b_chunk_max, void* ws, void* stream) {
     if (!A || !B || !out || !ws || !a_scale || !b_scale || T < 0 || Mi < 32 || (Mi % 32) || N < 32 || (N % 32)) return MDL_E_ARG;
     if (a_rsb < (int64_t)Mi * 4 || b_rsb < (int64_t)N * 4 || (a_rsb & 15) || (b_rsb & 15) || a_rsb * 32 > 0x7fffffff || b_rsb * 32 > 0x7fffffff)
         return MDL_E_ARG;
@@ -335,11 +332,10 @@ extern "C" int mdl_split_gemm_tn(const void* A, int64_t a_rsb, const float* a_sc
     const int stride = (int)(tps / SPK);
     int32_t* list = nullptr;
     int32_t* count = nullptr;
-    if (b_src && stride <= SP_MAX_LIST && T > 0) {   // skip the 32-row chunks in which b_src (the tensor B is the image of) is all zero
-        if (b_src_ld < N || (b_src_ld & 3) || !host_aligned16(b_src)) return MDL_E_ARG;
+    if (b_chunk_max && stride <= SP_MAX_LIST && T > 0) {   // skip the 32-row chunks in which the tensor B is the image of is all zero
         list = (int32_t*)((char*)ws + (((int64_t)S * Mi * N * 4 + 15) & ~(int64_t)15));
         count = list + (int64_t)S * stride;
-        hipLaunchKernelGGL(sp_chunk_list_kernel, dim3(S), dim3(256), 0, s, b_src, b_src_ld, T, N, tps, list, count, stride);
+        hipLaunchKernelGGL(sp_chunk_list_kernel, dim3(S), dim3(256), 0, s, b_chunk_max, T, tps, list, count, stride);
         MDL_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(sp_tn_kernel, dim3(tiles), dim3(SP_THREADS), 0, s, (const char*)A, a_rsb, a_scale, Mi, (const char*)B, b_rsb, b_scale, N,

@@ -320,13 +320,15 @@ def split_image(x2d, pad_rows=0) -> SplitImage:
     return SplitImage(data, scale, rows, K)
 
 
-def split_tile_absmax(x2d):
-    """max |x| of every block of 256 rows (the row gate of split_gemm_nt)."""
+def split_tile_absmax(x2d, chunks=False):
+    """max |x| of every block of 256 rows (the row gate of split_gemm_nt); chunks=True: also of every 32 rows (split_gemm_tn's
+    b_chunk_max) -> (gate, chunk_max)."""
     lib = _native.lib()
     rows, K = x2d.shape
     gate = torch.empty((rows + 255) // 256, device=x2d.device, dtype=torch.float32)
-    _native.check(lib.mdl_split_tile_absmax(_ptr(x2d), x2d.stride(0), rows, K, _ptr(gate), _stream()), "mdl_split_tile_absmax")
-    return gate
+    cm = torch.empty((rows + 31) // 32, device=x2d.device, dtype=torch.float32) if chunks else None
+    _native.check(lib.mdl_split_tile_absmax(_ptr(x2d), x2d.stride(0), rows, K, _ptr(gate), _ptr(cm), _stream()), "mdl_split_tile_absmax")
+    return (gate, cm) if chunks else gate
 
 
 def split_gemm_nt(A: SplitImage, B: SplitImage, bias=None, out=None, accumulate=False, absmax_out=None, name="split_nt", row_gate=None):
@@ -344,9 +346,9 @@ def split_gemm_nt(A: SplitImage, B: SplitImage, bias=None, out=None, accumulate=
     return C
 
 
-def split_gemm_tn(A: SplitImage, B: SplitImage, name="split_tn", b_src=None):
-    """out [B.K, A.K] = B^T A summed over the rows (tokens) of the two images; B must carry >= 32 zero pad rows.  b_src: the fp32
-    tensor B is the image of -- its all-zero 32-row chunks are skipped."""
+def split_gemm_tn(A: SplitImage, B: SplitImage, name="split_tn", b_chunk_max=None):
+    """out [B.K, A.K] = B^T A summed over the rows (tokens) of the two images; B must carry >= 32 zero pad rows.  b_chunk_max: the
+    per-32-row maxima (split_tile_absmax(x, chunks=True)) of the tensor B is the image of -- its all-zero chunks are skipped."""
     lib = _native.lib()
     T, Mi, N = A.rows, A.K, B.K
     if B.rows != T or B.data.shape[0] < T + 32:
@@ -354,8 +356,8 @@ def split_gemm_tn(A: SplitImage, B: SplitImage, name="split_tn", b_src=None):
     out = torch.empty(N, Mi, device=A.data.device, dtype=torch.float32)
     ws = _ws(lib.mdl_split_gemm_tn_ws_bytes(T, Mi, N), A.data.device)
     with _timed(name, ("flop", 2.0 * T * Mi * N)):
-        rc = lib.mdl_split_gemm_tn(_ptr(A.data), Mi * 4, _ptr(A.scale), Mi, _ptr(B.data), N * 4, _ptr(B.scale), N, _ptr(out), T, _ptr(b_src),
-                                   0 if b_src is None else b_src.stride(0), _ptr(ws), _stream())
+        rc = lib.mdl_split_gemm_tn(_ptr(A.data), Mi * 4, _ptr(A.scale), Mi, _ptr(B.data), N * 4, _ptr(B.scale), N, _ptr(out), T, _ptr(b_chunk_max),
+                                   _ptr(ws), _stream())
     _native.check(rc, "mdl_split_gemm_tn")
     return out
 
@@ -761,9 +763,10 @@ class AttnPoolFn(torch.autograd.Function):
             if tok_after:
                 d_tok = d_tok.float().contiguous()
                 dti = split_image(d_tok, pad_rows=32)
+                gate, chunk_max = split_tile_absmax(d_tok, chunks=True)   # one pass: 256-row tiles (dX) and 32-row chunks (dW)
                 split_gemm_nt(dti, split_image(Wtok.t().contiguous()), out=dE, accumulate=True, absmax_out=am, name="linear_bwd",
-                              row_gate=split_tile_absmax(d_tok))
-                dWtok = split_gemm_tn(ctx.Ei, dti, name="linear_bwd", b_src=d_tok)
+                              row_gate=gate)
+                dWtok = split_gemm_tn(ctx.Ei, dti, name="linear_bwd", b_chunk_max=chunk_max)
                 dbtok = d_tok.sum(0) if has_btok else None
             if am is not None:
                 _put_absmax(dE, am)

@@ -419,8 +419,9 @@ class MADELEINE(nn.Module):
         head = (cu[:-1].unsqueeze(1) + torch.arange(n_loss_tokens).unsqueeze(0)).reshape(-1).to(device)
         tok = self._project_tokens(E.index_select(0, head)).view(bs, n_mod, n_loss_tokens, -1)   # [B,M,n,128]
         all_embeddings, all_token_embeddings = {}, {}
+        slides, toks = slide.unbind(1), tok.unbind(1)   # (see forward: one stacked gradient instead of per-stain fills and adds)
         for idx, modality in enumerate(self.modalities):
-            s, t = slide[:, idx], tok[:, idx]
+            s, t = slides[idx], toks[idx]
             if modality == "HE":
                 s = s.unsqueeze(3).expand(-1, -1, -1, n_mod - 1)
                 t = t.unsqueeze(3).expand(-1, -1, -1, n_mod - 1)
@@ -459,8 +460,11 @@ class MADELEINE(nn.Module):
                 tok, slide = tok.index_select(0, expand), slide.index_select(0, expand)
             tok = tok.view(bs, n_mod, n_tokens, -1)                                   # [B,M,N,128]
             slide = slide.view(bs, n_mod, -1, slide.shape[-1])
+            # unbind, not M selects: its backward stacks the per-stain gradients in ONE pass; M selects make autograd fill a dense
+            # [B,M,N,128] zero tensor per stain and add them pairwise (5 fills + 4 adds of 335 MB each at config 3: 1.1 ms per step)
+            slides, toks = slide.unbind(1), tok.unbind(1)
             for idx, modality in enumerate(self.modalities):
-                s, t = slide[:, idx], tok[:, idx]
+                s, t = slides[idx], toks[idx]
                 if modality == "HE":
                     # reference: .unsqueeze(3).repeat(1,1,1,M-1); expand gives the same values without copies
                     s = s.unsqueeze(3).expand(-1, -1, -1, n_mod - 1)

@@ -262,8 +262,12 @@ def test_split_gemm_tn_chunk_gate(dev):
     dy[5100:8990] = 0
     ref = dy.double().t() @ x.double()
     A, B = MF.split_image(x.to(dev)), MF.split_image(dy.to(dev), pad_rows=32)
-    out_g = MF.split_gemm_tn(A, B, b_src=dy.to(dev))
+    gate, cm = MF.split_tile_absmax(dy.to(dev), chunks=True)
+    assert torch.equal(cm.cpu(), torch.cat([dy, torch.zeros(-T % 32, N)]).view(-1, 32 * N).abs().amax(1))
+    assert torch.equal(gate.cpu(), torch.cat([dy, torch.zeros(-T % 256, N)]).view(-1, 256 * N).abs().amax(1))
+    out_g = MF.split_gemm_tn(A, B, b_chunk_max=cm)
     out_u = MF.split_gemm_tn(A, B)
     assert rel_err(out_g, ref) < 1e-6 and rel_err(out_u, ref) < 1e-6
-    z = MF.split_gemm_tn(A, MF.split_image(torch.zeros(T, N, device=dev), pad_rows=32), b_src=torch.zeros(T, N, device=dev))
+    z = MF.split_gemm_tn(A, MF.split_image(torch.zeros(T, N, device=dev), pad_rows=32),
+                         b_chunk_max=MF.split_tile_absmax(torch.zeros(T, N, device=dev), chunks=True)[1])
     assert float(z.abs().max()) == 0.0
