@@ -185,16 +185,15 @@ __global__ __launch_bounds__(SP_THREADS) void sp_gate_fwd_kernel(const char* __r
 // ================================================================================================
 // backward, stage 1: d(za) | d(zb) as a split image [T + 32][H][1024] (+ the column sums), scale dz_sc[0] from the bound
 // ================================================================================================
-__global__ __launch_bounds__(256) void sp_gate_dz_kernel(const float* __restrict__ wc, const float* __restrict__ act_a,
+// Workgroup = DZ_ROWS token rows x ALL heads (64 H threads: thread = (head, 8 columns)): every row is one contiguous 2 KB H read of
+// each activation and one contiguous 4 KB H write of the image (a workgroup per head touched 2 KB of every 8 KB).
+__global__ __launch_bounds__(64 * MDL_MAX_HEADS) void sp_gate_dz_kernel(const float* __restrict__ wc, const float* __restrict__ act_a,
                                                          const float* __restrict__ act_b, const float* __restrict__ d_scores,
                                                          char* __restrict__ dzi, const float* __restrict__ dz_sc,
                                                          float* __restrict__ slabV, int64_t T, int H, DropCfg drop) {
-    constexpr int VEC = 8, NQ = HID / VEC, PH = 256 / NQ;   // 64 groups of 8 columns (16-B image stores) x 4 row phases
-    __shared__ float red[PH - 1][NQ][3 * VEC + 1];
-    // 1-D grid, head fastest: the H workgroups that cover the same rows run together (head-major [T][H][512] rows: one head alone
-    // touches 2 KB of every 8 KB; measured 1.96 -> 1.85 ms at config 2)
-    const int tid = threadIdx.x, q = tid % NQ, ph = tid / NQ, c = blockIdx.x % H;
-    const int64_t bx = blockIdx.x / H;
+    constexpr int VEC = 8;   // 64 groups of 8 columns per head (16-B image stores)
+    const int tid = threadIdx.x, q = tid & 63, c = tid >> 6;
+    const int64_t bx = blockIdx.x;
     const int64_t r0 = bx * DZ_ROWS;
     int64_t r1 = r0 + DZ_ROWS;
     if (r1 > T) r1 = T;
@@ -208,11 +207,11 @@ __global__ __launch_bounds__(256) void sp_gate_dz_kernel(const float* __restrict
     float sds = 0.f;
     const int64_t offa = sp_img_off(q * VEC, 0), offb = sp_img_off(HID + q * VEC, 0);
     constexpr int UNR = 2;   // 2 rows x (a, b) x 2 x 16 B = 8 loads in flight per thread
-    for (int64_t rb = r0 + ph; rb < r1; rb += PH * UNR) {
+    for (int64_t rb = r0; rb < r1; rb += UNR) {
         float va[UNR][VEC], vb[UNR][VEC], ds[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
-            const int64_t r = rb + PH * u;
+            const int64_t r = rb + u;
             const bool ok = r < r1;
             const int64_t o = ((ok ? r : rb) * H + c) * HID + q * VEC;
             const f32x4 a0 = ld4_nt(act_a + o), a1 = ld4_nt(act_a + o + 4), b0 = ld4_nt(act_b + o), b1 = ld4_nt(act_b + o + 4);
@@ -227,7 +226,7 @@ __global__ __launch_bounds__(256) void sp_gate_dz_kernel(const float* __restrict
         }
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
-            const int64_t r = rb + PH * u;
+            const int64_t r = rb + u;
             if (r < r1) {
                 const int64_t o = (r * H + c) * HID + q * VEC;
                 const uint32_t rkey = drop_row_key(drop, o);   // the 8 elements share the high word (o % 512 + i < 512)
@@ -254,36 +253,14 @@ __global__ __launch_bounds__(256) void sp_gate_dz_kernel(const float* __restrict
             }
         }
     }
-    if (ph > 0) {
+    float* __restrict__ o = slabV + (bx * H + c) * 4 * HID + q * VEC;
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) {
-            red[ph - 1][q][i] = sa[i];
-            red[ph - 1][q][VEC + i] = sb[i];
-            red[ph - 1][q][2 * VEC + i] = sw[i];
-        }
-        red[ph - 1][q][3 * VEC] = sds;
+    for (int i = 0; i < VEC; ++i) {
+        o[i] = sa[i];
+        o[HID + i] = sb[i];
+        o[2 * HID + i] = sw[i];
     }
-    __syncthreads();
-    if (ph == 0) {
-        float* __restrict__ o = slabV + (bx * H + c) * 4 * HID + q * VEC;
-#pragma unroll
-        for (int p = 0; p < PH - 1; ++p) {
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) {
-                sa[i] += red[p][q][i];
-                sb[i] += red[p][q][VEC + i];
-                sw[i] += red[p][q][2 * VEC + i];
-            }
-            sds += red[p][0][3 * VEC];
-        }
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) {
-            o[i] = sa[i];
-            o[HID + i] = sb[i];
-            o[2 * HID + i] = sw[i];
-        }
-        if (q == 0) o[3 * HID] = sds;
-    }
+    if (q == 0) o[3 * HID] = sds;
 }
 
 // ================================================================================================
@@ -543,7 +520,7 @@ extern "C" int mdl_abmil_attnpool_bwd_split(const void* E_img, int64_t e_rsb, co
         hipLaunchKernelGGL(sp_bound_scale_kernel, dim3(1), dim3(1), 0, s, (const float*)(sc + 2), d.inv * d.inv, sc + 4);
         MDL_LAUNCH_CHECK();
         if (T > 0) {
-            hipLaunchKernelGGL(sp_gate_dz_kernel, dim3((unsigned)(L.nblk * H)), dim3(256), 0, s, wc, act_a, act_b, d_scores, dzi,
+            hipLaunchKernelGGL(sp_gate_dz_kernel, dim3((unsigned)L.nblk), dim3(64 * H), 0, s, wc, act_a, act_b, d_scores, dzi,
                                (const float*)(sc + 4), slabV, T, H, d);
             MDL_LAUNCH_CHECK();
         }
