@@ -83,7 +83,7 @@ def pool_traffic_from_profiles(tokens_c2=64 * 4096):
     return int((2.0 * f + w) * 1024)
 
 
-def measure_pool_traffic(timeout_s=150):
+def measure_pool_traffic(timeout_s=150, image=False):
     """HBM bytes per launch of the A3 forward MEASURED IN THIS RUN: two short rocprofv3 passes (`--pmc FETCH_SIZE`, `--pmc
     WRITE_SIZE`; separate passes, kernel-trace only -- MI355X_MICROARCH.md, HBM section) over tools/prof_kernels.py --only pool
     (config-2 geometry), read back from the rocpd database.  FETCH_SIZE is in KiB and on gfx950 counts half of a wide coalesced
@@ -102,7 +102,7 @@ def measure_pool_traffic(timeout_s=150):
         try:
             env = dict(os.environ, TMPDIR="/tmp")
             r = subprocess.run([exe, "--pmc", counter, "--kernel-trace", "-d", d, "--", sys.executable,
-                                os.path.join(ROOT, "tools", "prof_kernels.py"), "--iters", "2", "--only", "pool"],
+                                os.path.join(ROOT, "tools", "prof_kernels.py"), "--iters", "2", "--only", "pool"] + (["--image"] if image else []),
                                cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
             dbs = glob.glob(os.path.join(d, "*", "*.db"))
             if r.returncode != 0 or not dbs:
@@ -121,7 +121,8 @@ def measure_pool_traffic(timeout_s=150):
         finally:
             shutil.rmtree(d, ignore_errors=True)
     return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), \
-        "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (2 passes) over tools/prof_kernels.py --only pool; 2 x FETCH + WRITE"
+        "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (2 passes) over tools/prof_kernels.py --only pool%s; 2 x FETCH + WRITE" % (
+            " --image" if image else "")
 
 
 def cpu_baseline(B_sample, M, N, D, use_got, steps=2):
@@ -568,7 +569,8 @@ def main():
             traffic, traffic_src = None, "not collected (only for c2 at N=1)"
             if a.config == "c2" and world == 1 and a.precision == "float32":
                 if not a.no_pmc:
-                    traffic, traffic_src = measure_pool_traffic()
+                    # the step pools from the split image of E in the split GEMM mode (same bytes): measure that instantiation
+                    traffic, traffic_src = measure_pool_traffic(image=MF.gemm_mode() == "split")
                 if traffic is None:
                     why = traffic_src
                     traffic = pool_traffic_from_profiles()

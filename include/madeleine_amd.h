@@ -54,7 +54,7 @@ const char* mdl_version(void);
 /* ABI revision of this header: bumped whenever an entry point's argument list changes.  A binding compares
  * mdl_abi_version() with the MDL_ABI_VERSION it was written against BEFORE calling anything else, so that a stale
  * shared object fails loudly instead of being called with shifted arguments. */
-#define MDL_ABI_VERSION 13
+#define MDL_ABI_VERSION 14
 int mdl_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -358,6 +358,15 @@ int mdl_abmil_attnpool_bwd_bf16(const uint16_t* E, int64_t ldE, const float* Wa,
  *   mdl_split_gemm_tn : out [N][Mi] = sum_t B[t][n] A[t][m]              A, B images with T rows (contraction = rows); B must be
  *                       followed by >= 32 all-zero rows; ws = mdl_split_gemm_tn_ws_bytes (token-split slabs, reduced in fixed order)
  */
+/* A3 on the image of E (the split GEMM mode keeps E as the image its LayerNorm kernel wrote, nothing else): mdl_abmil_pool_fwd with
+ * E_img = split image [T][H*512] (row stride e_rsb bytes, scale e_scale[0]); mdl_abmil_pool_dscores_img = the score gradients of
+ * mdl_abmil_pool_bwd (d_scores (+)= ...; the dE term is part of mdl_abmil_attnpool_bwd_split's dX epilogue). */
+int mdl_abmil_pool_fwd_img(const void* E_img, int64_t e_rsb, const float* e_scale, const float* scores, float* pooled, float* stat_m,
+                           float* stat_l, int64_t n_bags, int64_t N, const int64_t* cu_seqlens, int64_t max_len, int H, void* ws,
+                           void* stream);
+int mdl_abmil_pool_dscores_img(const void* E_img, int64_t e_rsb, const float* e_scale, const float* scores, const float* pooled,
+                               const float* stat_m, const float* stat_l, const float* d_pooled, float* d_scores, int accumulate_scores,
+                               int64_t n_bags, int64_t N, const int64_t* cu_seqlens, int64_t max_len, int H, void* stream);
 int mdl_split_image(const float* X, int64_t ldx, int64_t rows, int K, void* img, int64_t rsb, int64_t pad_rows, float* scale,
                     void* stream);
 /* row_gate (device float[ceil(M / 256)], may be NULL; only with accumulate != 0 and bias == NULL): output tiles whose entry is 0 are

@@ -12,9 +12,36 @@
 //            order -> deterministic, no atomics).
 // Backward = pool_bwd (one wave per token row; lane-local dot with d_pooled, one 64-lane reduction
 //            per head, dE and d_scores written in the same pass).
-#include "common.hpp"
+#include <type_traits>
+
+#include "split_engine.hpp"
 
 namespace mdl {
+
+// Element types of E: float, bf16_t, or img_t = a split-fp16 image row (csrc/split_engine.hpp) addressed in channel units (4 bytes per
+// channel: 64 B of hi plane | 64 B of lo plane per 32 channels).  In the split GEMM mode the last pre_attn LayerNorm kernel writes E as
+// an image only; the pooling kernels rebuild the fp32 values ((hi + lo) / scale: exact sum, power-of-two scale) -- E is never stored
+// twice.
+struct img_t {
+    uint32_t u;
+};
+template <class TE>
+struct PoolLd {
+    static __device__ __forceinline__ f32x4 ld(const TE* __restrict__ rowp, int col, float) { return ld4_nt(rowp + col); }
+};
+template <>
+struct PoolLd<img_t> {
+    static __device__ __forceinline__ f32x4 ld(const img_t* __restrict__ rowp, int col, float inv) {   // col % 4 == 0
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        const char* p = reinterpret_cast<const char*>(rowp) + (col >> 5) * 128 + (col & 31) * 2;
+        const h4 h = __builtin_bit_cast(h4, __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p)));
+        const h4 l = __builtin_bit_cast(h4, __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p + 64)));
+        f32x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = ((float)h[i] + (float)l[i]) * inv;
+        return v;
+    }
+};
 
 constexpr int POOL_CHUNK = 128;  // tokens per forward workgroup
 constexpr int POOL_BWD_TOKENS = 128;  // tokens per backward workgroup (4 waves)
@@ -50,7 +77,8 @@ __global__ __launch_bounds__(H * 128) void pool_partial_kernel(const TE* __restr
                                                                float* __restrict__ part_m,
                                                                float* __restrict__ part_l, int64_t N,
                                                                const int64_t* __restrict__ cu, int max_chunks,
-                                                               const int32_t* __restrict__ idx = nullptr, int64_t n_idx = -1) {
+                                                               const int32_t* __restrict__ idx = nullptr, int64_t n_idx = -1,
+                                                               const float* __restrict__ e_scale = nullptr) {
     constexpr int NT = H * 128;
     constexpr int NW = NT / 64;
     __shared__ float p_s[POOL_CHUNK * H];  // exp(s - m_chunk), [t][c]
@@ -108,14 +136,15 @@ __global__ __launch_bounds__(H * 128) void pool_partial_kernel(const TE* __restr
 
     // ---- weighted accumulation: thread owns one float4 column, loops over the chunk's tokens -----
     const int ca = tid / 128;
-    const TE* __restrict__ Ep = E + (sp.start + (IDX ? 0 : t0)) * ldE + (int64_t)tid * 4;
+    const float inv = e_scale ? 1.f / e_scale[0] : 1.f;
+    const TE* __restrict__ Er = E + (sp.start + (IDX ? 0 : t0)) * ldE;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     constexpr int U = 8;
     int t = 0;
     for (; t + U <= nt; t += U) {
         f32x4 x[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) x[u] = ld4_nt(Ep + (int64_t)(IDX ? tok_s[t + u] : t + u) * ldE);
+        for (int u = 0; u < U; ++u) x[u] = PoolLd<TE>::ld(Er + (int64_t)(IDX ? tok_s[t + u] : t + u) * ldE, tid * 4, inv);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const float w = p_s[(t + u) * H + ca];
@@ -123,7 +152,7 @@ __global__ __launch_bounds__(H * 128) void pool_partial_kernel(const TE* __restr
         }
     }
     for (; t < nt; ++t) {
-        const f32x4 x = ld4(Ep + (int64_t)(IDX ? tok_s[t] : t) * ldE);
+        const f32x4 x = PoolLd<TE>::ld(Er + (int64_t)(IDX ? tok_s[t] : t) * ldE, tid * 4, inv);
         acc += p_s[t * H + ca] * x;
     }
     *reinterpret_cast<f32x4*>(part_acc + ((int64_t)b * max_chunks + chunk) * (H * HID) + (int64_t)tid * 4) = acc;
@@ -177,8 +206,10 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const TE* __restrict__ E,
                                                        int accumulate, float* __restrict__ d_scores,
                                                        int accumulate_scores, int64_t N,
                                                        const int64_t* __restrict__ cu,
-                                                       const int32_t* __restrict__ idx = nullptr, int64_t n_idx = -1) {
+                                                       const int32_t* __restrict__ idx = nullptr, int64_t n_idx = -1,
+                                                       const float* __restrict__ e_scale = nullptr) {
     const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float inv = e_scale ? 1.f / e_scale[0] : 1.f;
     const BagSpan sp = bag_span(b, N, cu, IDX ? n_idx : -1);
     const int64_t t0 = (int64_t)chunk * POOL_BWD_TOKENS;
     if (t0 >= sp.len) return;
@@ -215,16 +246,17 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const TE* __restrict__ E,
 #pragma unroll
         for (int c = 0; c < H; ++c) w[c] = LIN ? scores[row * H + c] : expf(scores[row * H + c] - m[c]) * rl[c];
         if (!IDX || d_scores) {
-            const TE* __restrict__ er = E + row * ldE + lane * 4;
+            const TE* __restrict__ er = E + row * ldE;
             f32x4 x[2 * H];
 #pragma unroll
-            for (int i = 0; i < 2 * H; ++i) x[i] = ld4_nt(er + i * 256);
+            for (int i = 0; i < 2 * H; ++i) x[i] = PoolLd<TE>::ld(er, lane * 4 + i * 256, inv);
 #pragma unroll
             for (int c = 0; c < H; ++c) {
                 const f32x4 a = x[2 * c] * dp[2 * c] + x[2 * c + 1] * dp[2 * c + 1];
                 dw[c] = wave_sum(a.x + a.y + a.z + a.w);
             }
         }
+        if constexpr (!std::is_same<TE, img_t>::value) {   // (an image E: scores-only pass, dE is never written here)
         if (dE) {  // dE == nullptr: scores-only pass (the dE term is folded into the gate's dX epilogue, mdl_abmil_attnpool_bwd)
             TE* __restrict__ gr = dE + row * ldE + lane * 4;
 #pragma unroll
@@ -233,6 +265,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const TE* __restrict__ E,
                 if (accumulate) g += ld4(gr + i * 256);
                 st4(gr + i * 256, g);
             }
+        }
         }
         if (IDX && !d_scores) continue;
         float ds = 0.f;
@@ -272,7 +305,8 @@ extern "C" int64_t mdl_abmil_pool_ws_bytes(int64_t n_bags, int64_t max_len, int 
 
 template <class TE, bool LIN = false>
 static int pool_fwd_launch(const TE* E, int64_t ldE, const float* scores, float* pooled, float* stat_m, float* stat_l,
-                           int64_t n_bags, int64_t N, const int64_t* cu_seqlens, int64_t max_len, int H, void* ws, void* stream) {
+                           int64_t n_bags, int64_t N, const int64_t* cu_seqlens, int64_t max_len, int H, void* ws, void* stream,
+                           const float* e_scale = nullptr) {
     if (!E || !scores || !pooled || !stat_m || !stat_l || !ws) return MDL_E_ARG;
     if (n_bags < 0 || max_len < 0 || ldE < (int64_t)H * HID || (ldE & 3)) return MDL_E_ARG;
     if (!cu_seqlens && N != max_len) return MDL_E_ARG;
@@ -288,7 +322,7 @@ static int pool_fwd_launch(const TE* E, int64_t ldE, const float* scores, float*
     MDL_DISPATCH_H(H, {
         if (mc > 0) {
             hipLaunchKernelGGL((pool_partial_kernel<HH, TE, false, LIN>), dim3(mc, (unsigned)n_bags), dim3(HH * 128), 0, s, E, ldE, scores,
-                               part_acc, part_m, part_l, N, cu_seqlens, mc);
+                               part_acc, part_m, part_l, N, cu_seqlens, mc, (const int32_t*)nullptr, (int64_t)-1, e_scale);
             MDL_LAUNCH_CHECK();
         }
         hipLaunchKernelGGL((pool_combine_kernel<HH>), dim3((unsigned)n_bags), dim3(HH * 128), 0, s, part_acc, part_m, part_l,
@@ -302,7 +336,7 @@ template <class TE, bool LIN = false>
 static int pool_bwd_launch(const TE* E, int64_t ldE, const float* scores, const float* pooled, const float* stat_m,
                            const float* stat_l, const float* d_pooled, TE* dE, int accumulate, float* d_scores,
                            int accumulate_scores, int64_t n_bags, int64_t N, const int64_t* cu_seqlens, int64_t max_len, int H,
-                           void* stream) {
+                           void* stream, const float* e_scale = nullptr) {
     if (!E || !scores || !d_pooled || !d_scores) return MDL_E_ARG;   // dE may be NULL
     if (!LIN && (!pooled || !stat_m || !stat_l)) return MDL_E_ARG;
     if (n_bags < 0 || max_len < 0 || ldE < (int64_t)H * HID || (ldE & 3)) return MDL_E_ARG;
@@ -314,7 +348,8 @@ static int pool_bwd_launch(const TE* E, int64_t ldE, const float* scores, const 
     const int nc = (int)((max_len + POOL_BWD_TOKENS - 1) / POOL_BWD_TOKENS);
     MDL_DISPATCH_H(H, {
         hipLaunchKernelGGL((pool_bwd_kernel<HH, TE, false, LIN>), dim3(nc, (unsigned)n_bags), dim3(256), 0, s, E, ldE, scores, pooled, stat_m,
-                           stat_l, d_pooled, dE, accumulate, d_scores, accumulate_scores, N, cu_seqlens);
+                           stat_l, d_pooled, dE, accumulate, d_scores, accumulate_scores, N, cu_seqlens, (const int32_t*)nullptr, (int64_t)-1,
+                           e_scale);
         MDL_LAUNCH_CHECK();
     });
     return MDL_OK;
@@ -417,6 +452,24 @@ extern "C" int mdl_abmil_pool_bwd_bf16(const uint16_t* E, int64_t ldE, const flo
                                        const int64_t* cu_seqlens, int64_t max_len, int H, void* stream) {
     return pool_bwd_launch<bf16_t>((const bf16_t*)E, ldE, scores, pooled, stat_m, stat_l, d_pooled, (bf16_t*)dE, accumulate,
                                    d_scores, accumulate_scores, n_bags, N, cu_seqlens, max_len, H, stream);
+}
+
+// ---- E as a split image (the split GEMM mode: E exists as the image its LayerNorm kernel wrote, nothing else) ----
+extern "C" int mdl_abmil_pool_fwd_img(const void* E_img, int64_t e_rsb, const float* e_scale, const float* scores, float* pooled,
+                                      float* stat_m, float* stat_l, int64_t n_bags, int64_t N, const int64_t* cu_seqlens, int64_t max_len,
+                                      int H, void* ws, void* stream) {
+    if (!e_scale || (e_rsb & 15)) return MDL_E_ARG;
+    return pool_fwd_launch<img_t>((const img_t*)E_img, e_rsb / 4, scores, pooled, stat_m, stat_l, n_bags, N, cu_seqlens, max_len, H, ws,
+                                  stream, e_scale);
+}
+// the score gradients of the pooling (d_scores (+)= ...); the dE term belongs to the gate dX epilogue (mdl_abmil_attnpool_bwd_split)
+extern "C" int mdl_abmil_pool_dscores_img(const void* E_img, int64_t e_rsb, const float* e_scale, const float* scores, const float* pooled,
+                                          const float* stat_m, const float* stat_l, const float* d_pooled, float* d_scores,
+                                          int accumulate_scores, int64_t n_bags, int64_t N, const int64_t* cu_seqlens, int64_t max_len,
+                                          int H, void* stream) {
+    if (!e_scale || (e_rsb & 15)) return MDL_E_ARG;
+    return pool_bwd_launch<img_t>((const img_t*)E_img, e_rsb / 4, scores, pooled, stat_m, stat_l, d_pooled, (img_t*)nullptr, 0, d_scores,
+                                  accumulate_scores, n_bags, N, cu_seqlens, max_len, H, stream, e_scale);
 }
 
 // ---- weighted (non-softmax) pooling: pooled[b,c,:] = sum_t weights[t,c] E[t,c,:] (abmil.py:56-61 activations + Model.py:416-417) ----

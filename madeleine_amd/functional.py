@@ -253,6 +253,33 @@ def pool_bwd_raw(E2d, scores, pooled, stat_m, stat_l, d_pooled, dE, accumulate, 
     _native.check(rc, "mdl_abmil_pool_bwd")
 
 
+def pool_fwd_img_raw(Ei, scores, n_bags, N, cu_seqlens, max_len):
+    """pool_fwd_raw on the split image of E (the split GEMM mode stores E as an image only)."""
+    lib = _native.lib()
+    H = scores.shape[-1]
+    dev = scores.device
+    pooled = torch.empty(n_bags, H * HID, device=dev, dtype=torch.float32)
+    stat_m = torch.empty(n_bags, H, device=dev, dtype=torch.float32)
+    stat_l = torch.empty(n_bags, H, device=dev, dtype=torch.float32)
+    ws = _ws(lib.mdl_abmil_pool_ws_bytes(n_bags, max_len, H), dev)
+    with _timed("pool_fwd", ("byte", float(Ei.rows) * H * (HID * 4 + 4) + n_bags * H * HID * 4.0)):
+        rc = lib.mdl_abmil_pool_fwd_img(_ptr(Ei.data), Ei.K * 4, _ptr(Ei.scale), _ptr(scores), _ptr(pooled), _ptr(stat_m), _ptr(stat_l),
+                                        n_bags, N, _ptr(cu_seqlens), max_len, H, _ptr(ws), _stream())
+    _native.check(rc, "mdl_abmil_pool_fwd_img")
+    return pooled, stat_m, stat_l
+
+
+def pool_dscores_img_raw(Ei, scores, pooled, stat_m, stat_l, d_pooled, d_scores, accumulate_scores, n_bags, N, cu_seqlens, max_len):
+    """The score gradients of the pooling from the split image of E (pool_bwd_raw with dE = None)."""
+    lib = _native.lib()
+    H = scores.shape[-1]
+    with _timed("pool_bwd", ("byte", float(Ei.rows) * H * (HID * 4 + 8) + n_bags * H * HID * 4.0)):
+        rc = lib.mdl_abmil_pool_dscores_img(_ptr(Ei.data), Ei.K * 4, _ptr(Ei.scale), _ptr(scores), _ptr(pooled), _ptr(stat_m), _ptr(stat_l),
+                                            _ptr(d_pooled), _ptr(d_scores), int(accumulate_scores), n_bags, N, _ptr(cu_seqlens), max_len,
+                                            H, _stream())
+    _native.check(rc, "mdl_abmil_pool_dscores_img")
+
+
 def pool_view_fwd_raw(E2d, scores, n_bags, N, token_idx):
     lib = _native.lib()
     H = scores.shape[-1]
@@ -674,7 +701,10 @@ class AttnPoolFn(torch.autograd.Function):
     3 x |E| elementwise pass (3.8 ms per config-3 step); without it the third output is an empty tensor."""
 
     @staticmethod
-    def forward(ctx, E, Wa, ba, Wb, bb, wc, bc, p_drop, seed, keep_a, keep_b, cu_seqlens, max_len, Wtok, btok, Eimg, Escale, *views):
+    def forward(ctx, E, Wa, ba, Wb, bb, wc, bc, p_drop, seed, keep_a, keep_b, cu_seqlens, max_len, Wtok, btok, Eimg, Escale, e_only_image,
+                *views):
+        # e_only_image: E IS the image tensor (Eimg is E, an opaque float32 [.., H*512] tensor written by the last pre_attn block's
+        # LayerNorm kernel) -- no fp32 copy of E exists; the pooling kernels read the image, dE is the gradient of that tensor
         _require_act(E, "E")
         for t, n in ((Wa, "Wa"), (ba, "ba"), (Wb, "Wb"), (bb, "bb"), (wc, "wc"), (bc, "bc")):
             _require(t, n)
@@ -687,6 +717,10 @@ class AttnPoolFn(torch.autograd.Function):
         need = any(ctx.needs_input_grad[:7]) or any(ctx.needs_input_grad[13:15])   # (inputs 15, 16 = the image of E: no gradient)
         ctx.Ei = None
         Ei = None
+        if e_only_image and (Eimg is None or views or not _split_gate(E2d)
+                             or (Wtok is not None and not split_linear_supported(E2d.shape[0], Wtok.shape[0], Wtok.shape[1]))):
+            raise RuntimeError("attn_pool: an image-only E needs the split GEMM mode, no token views and a token projection the split "
+                               "engine serves")
         if _split_gate(E2d):
             # the image of E: written by the producing LayerNorm kernel (Eimg / Escale), else built here (3 passes over E)
             Ei = SplitImage(Eimg, Escale, E2d.shape[0], E2d.shape[1]) if Eimg is not None else split_image(E2d)
@@ -694,7 +728,8 @@ class AttnPoolFn(torch.autograd.Function):
             ctx.Ei = Ei if need else None
         else:
             scores, act_a, act_b = gate_fwd_raw(E2d, Wa, ba, Wb, bb, wc, bc, p_drop, seed, keep_a, keep_b, need)
-        pooled, m, l = pool_fwd_raw(E2d, scores, n_bags, N, cu_seqlens, max_len)
+        pooled, m, l = (pool_fwd_img_raw(Ei, scores, n_bags, N, cu_seqlens, max_len) if e_only_image
+                        else pool_fwd_raw(E2d, scores, n_bags, N, cu_seqlens, max_len))
         vstate = [pool_view_fwd_raw(E2d, scores, n_bags, N, v) for v in views]
         if Wtok is not None:
             _require(Wtok, "token_projector weight")
@@ -716,6 +751,7 @@ class AttnPoolFn(torch.autograd.Function):
                                   cu_seqlens if cu_seqlens is not None else none, Wtok if Wtok is not None else none, *views, *flat)
             ctx.cfg = (p_drop, seed, keep_a, keep_b, n_bags, N, max_len, cu_seqlens is not None, E.shape, len(views),
                        Wtok is not None, btok is not None)
+            ctx.e_only_image = bool(e_only_image)
         if views:
             pooled = torch.stack([pooled] + [st[0] for st in vstate], dim=1)
         return pooled, scores, tok
@@ -749,7 +785,10 @@ class AttnPoolFn(torch.autograd.Function):
             dWtok, dbtok = linear_bwd_raw(E2d, Wtok, d_tok.to(E2d.dtype).contiguous(), dE, has_btok)
             acc_e = 1
         # scores-only pooling backward (one read of E), then the gate backward whose dX epilogue adds the pooling term
-        pool_bwd_raw(E2d, scores, pooled, m, l, d_main, None, 0, ds, acc_s, n_bags, N, cu, max_len)
+        if ctx.e_only_image:
+            pool_dscores_img_raw(ctx.Ei, scores, pooled, m, l, d_main, ds, acc_s, n_bags, N, cu, max_len)
+        else:
+            pool_bwd_raw(E2d, scores, pooled, m, l, d_main, None, 0, ds, acc_s, n_bags, N, cu, max_len)
         for i in range(V):   # the views' score gradients must be in ds before the gate backward consumes it
             vp, vm, vl = vflat[3 * i:3 * i + 3]
             pool_view_bwd_raw(E2d, scores, vp, vm, vl, d_pooled[:, 1 + i].contiguous(), None, ds, n_bags, N, views[i])
@@ -777,18 +816,19 @@ class AttnPoolFn(torch.autograd.Function):
         for i in range(V):   # ... and their dE terms are added once dE has been written (no read of E)
             vp, vm, vl = vflat[3 * i:3 * i + 3]
             pool_view_bwd_raw(E2d, scores, vp, vm, vl, d_pooled[:, 1 + i].contiguous(), dE, None, n_bags, N, views[i])
-        return (dE.view(e_shape), dWa, dba, dWb, dbb, dwc, dbc, None, None, None, None, None, None, dWtok, dbtok, None, None) + (None,) * V
+        return (dE.view(e_shape), dWa, dba, dWb, dbb, dwc, dbc, None, None, None, None, None, None, dWtok, dbtok, None, None, None) + (None,) * V
 
 
 def attn_pool(E, Wa, ba, Wb, bb, wc, bc, p_drop=0.0, seed=0, keep_a=None, keep_b=None, cu_seqlens=None, max_len=None, views=(),
-              tok_proj=None, e_img=None):
+              tok_proj=None, e_img=None, e_only_image=False):
     """-> (pooled, raw scores), or (pooled, raw scores, token projections [T,P]) with tok_proj = (Wtok [P,H*512], btok or None).
-    e_img = (image data, scale) of E when the producing kernel wrote one (split GEMM mode)."""
+    e_img = (image data, scale) of E when the producing kernel wrote one (split GEMM mode); e_only_image: E is that image tensor itself
+    (no fp32 E was written) and the node's E-gradient is the image tensor's."""
     Wtok, btok = tok_proj if tok_proj is not None else (None, None)
     Eimg, Escale = e_img if e_img is not None else (None, None)
     pooled, scores, tok = AttnPoolFn.apply(E, Wa, ba, Wb, bb, wc, bc, float(p_drop), int(seed), keep_a, keep_b, cu_seqlens, max_len,
                                            None if Wtok is None else Wtok.contiguous(), None if btok is None else btok.contiguous(),
-                                           Eimg, Escale, *views)
+                                           Eimg, Escale, bool(e_only_image), *views)
     return (pooled, scores) if tok_proj is None else (pooled, scores, tok)
 
 

@@ -156,9 +156,11 @@ class ABMILEmbedder(nn.Module):
         p, seed, keep = self._drop_cfg(blk, perm)
         return MF.ln_gelu_drop(x if x.dtype == torch.bfloat16 else x.float(), g, b, ln.eps, p, seed, keep, lin_bias)
 
-    def embed_tokens_headmajor(self, bags: torch.Tensor, return_image: bool = False):
+    def embed_tokens_headmajor(self, bags: torch.Tensor, return_image: bool = False, want_fp32: bool = True):
         """pre_attn(bags) with the 2048 output channels in head-major order: [BM, N, H*512]  (with return_image: (E, image of E or
-        None) -- in the split GEMM mode the last block's kernel writes the split image the gate contractions read).
+        None) -- in the split GEMM mode the last block's kernel writes the split image the gate contractions read).  want_fp32 = False
+        (with return_image, split GEMM mode only): no fp32 copy of E is written -- the returned "E" IS the image tensor (an opaque
+        float32 [BM, N, H*512] tensor that only functional.attn_pool(..., e_only_image=True) can read; `image_only(E, e_img)` tells).
 
         Under torch.autocast(bfloat16) -- the reference's `precision: bfloat16` runs (trainer.py:101-103) -- the
         activations are kept in bf16 end to end (Linear outputs, the fused LayerNorm-GELU-Dropout input/output and E):
@@ -177,13 +179,19 @@ class ABMILEmbedder(nn.Module):
             # split GEMM mode: three fused blocks; the activations between them exist as split images only
             img, sc, _ = self._block_split(x2d.float().contiguous(), None, 0)
             img, sc, _ = self._block_split(img, sc, 1)
-            img, sc, E = self._block_split(img, sc, 2, perm, want_fp32=True)
-            E = E.view(*bags.shape[:-1], E.shape[-1])
+            keep_fp32 = want_fp32 or not return_image
+            img, sc, E = self._block_split(img, sc, 2, perm, want_fp32=keep_fp32)
+            E = (E if keep_fp32 else img).view(*bags.shape[:-1], img.shape[-1])
             return (E, (img, sc)) if return_image else E
         x = self._act(MF.linear(bags.float(), pa[0].weight), pa[1], 0, None, pa[0].bias)
         x = self._act(MF.linear(x, pa[4].weight), pa[5], 1, None, pa[4].bias)
         E = self._act(MF.linear(x, self.permuted(pa[8].weight, 0)), pa[9], 2, perm, pa[8].bias)
         return (E, None) if return_image else E
+
+    @staticmethod
+    def image_only(E, e_img) -> bool:
+        """True when `E` of embed_tokens_headmajor(..., want_fp32=False) is the image tensor itself."""
+        return e_img is not None and E.data_ptr() == e_img[0].data_ptr()
 
     def gate_params_stacked(self):
         ps = [h.gate_params() for h in self.attn]
@@ -212,7 +220,8 @@ class ABMILEmbedder(nn.Module):
         BM, N, _ = E_hm.shape
         wa, ba, wb, bb, wc, bc = self.gate_params_stacked()
         p, seed, ka, kb = self._gate_dropout((BM, N))
-        out = MF.attn_pool(E_hm, wa, ba, wb, bb, wc, bc, p, seed, ka, kb, views=views, tok_proj=tok_proj, e_img=e_img)
+        out = MF.attn_pool(E_hm, wa, ba, wb, bb, wc, bc, p, seed, ka, kb, views=views, tok_proj=tok_proj, e_img=e_img,
+                           e_only_image=self.image_only(E_hm, e_img))
         if tok_proj is None:
             return out[0], out[1].view(BM, N, self.n_heads)
         return out[0], out[1].view(BM, N, self.n_heads), out[2].view(BM, N, -1)
@@ -241,15 +250,23 @@ class ABMILEmbedder(nn.Module):
         lead = pooled_hm.shape[:-1]
         return pooled_hm.view(*lead, self.n_heads, -1).transpose(-1, -2).contiguous()  # [...,512,H]
 
-    def forward_headmajor(self, bags, n_views=1, tok_proj=None):
+    def forward_headmajor(self, bags, n_views=1, tok_proj=None, need_tokens=True):
         """Fast path used by MADELEINE: returns (pooled_hm [BM,(V,)H*512], E_hm, raw scores [BM,N,H]) and, with tok_proj = (W, bias)
-        of a Linear over the head-major token embeddings (MADELEINE's token_projector), its output [BM,N,P] as a fourth result."""
+        of a Linear over the head-major token embeddings (MADELEINE's token_projector), its output [BM,N,P] as a fourth result.
+        need_tokens = False: the caller does not read E_hm (it is returned as None when the split GEMM mode then keeps E as an image
+        only: its LayerNorm kernel writes 4 instead of 8 bytes per element and the pooling kernels read the image)."""
         if self.agg_type != 'regular':
             raise NotImplementedError('Agg type not supported. Options are "regular".')
-        E, e_img = self.embed_tokens_headmajor(bags, return_image=True)
         act = self.attn[0].activation
+        fused = act == 'softmax' and n_views == 1
+        tok_on_image = tok_proj is None or MF.split_linear_supported(bags.numel() // bags.shape[-1], tok_proj[0].shape[0],
+                                                                     tok_proj[0].shape[1])
+        E, e_img = self.embed_tokens_headmajor(bags, return_image=True, want_fp32=need_tokens or not fused or not tok_on_image)
+        if self.image_only(E, e_img):
+            out = self.pool_headmajor(E, tok_proj=tok_proj, e_img=e_img)
+            return (out[0], None, out[1]) + tuple(out[2:])
         if tok_proj is not None:
-            if act == 'softmax' and n_views == 1:
+            if fused:
                 pooled, scores, tok = self.pool_headmajor(E, tok_proj=tok_proj, e_img=e_img)   # one autograd node for both consumers of E
                 return pooled, E, scores, tok
             with torch.autocast(device_type="cuda", enabled=False):
@@ -292,7 +309,7 @@ class ABMILEmbedder(nn.Module):
     # ------------------------------------------------------------------ reference-shaped API
     def forward(self, bags: torch.Tensor, return_attention: bool = False, return_preattn_feats: bool = False, n_views=1):
         """Model.py:375-451.  slide embeddings [BM,(V,)512,H]; raw attention [BM,N,1,H]; tokens [BM,N,512,H]."""
-        pooled, E, scores = self.forward_headmajor(bags, n_views)
+        pooled, E, scores = self.forward_headmajor(bags, n_views, need_tokens=return_preattn_feats)
         slide = self._to_reference_slide(pooled)
         if return_attention:
             return slide, scores.unsqueeze(2)
@@ -384,7 +401,7 @@ class MADELEINE(nn.Module):
     def encode_he(self, feats, device):
         """Model.py:97-107: [B,N,D] -> [B,512]."""
         feats = feats.to(device)
-        pooled, _, _ = self.wsi_embedders.forward_headmajor(feats)
+        pooled, _, _ = self.wsi_embedders.forward_headmajor(feats, need_tokens=False)
         return self._project_slide(pooled)
 
     def forward_ragged(self, bags, device, n_loss_tokens=None):
@@ -452,7 +469,7 @@ class MADELEINE(nn.Module):
             if self.stain_encoding:
                 x = self._cat_stain(x, stain_of_row)
             # token_projector (Model.py:140) inside the pooling node: the two gradients of E are accumulated in the gate dX epilogue
-            pooled, E, _, tok = emb.forward_headmajor(x, n_views=n_views, tok_proj=(
+            pooled, _, _, tok = emb.forward_headmajor(x, n_views=n_views, need_tokens=False, tok_proj=(
                 emb.permuted(self.token_projector.weight, 1), self.token_projector.bias))   # tok [rows,N,128]
             slide = self._project_slide(pooled.view(x.shape[0], -1, pooled.shape[-1]))  # [rows,V,512]
             if expand is not None:       # absent rows take the outputs of their all-zero representative
@@ -482,7 +499,7 @@ class MADELEINE(nn.Module):
                 if self.stain_encoding:
                     key = custom_stain_idx if custom_stain_idx else stain_idx
                     cur = self._cat_stain(cur, torch.full((bs,), key, dtype=torch.long))
-                pooled, _, _ = emb.forward_headmajor(cur)
+                pooled, _, _ = emb.forward_headmajor(cur, need_tokens=False)
                 # the reference's .view(bs*n_mod, ...) / .view(bs, n_mod, d) only type-checks for n_mod == 1
                 all_embeddings[stain_name] = self._project_slide(pooled).view(bs, n_mod, -1)
             return all_embeddings
@@ -490,6 +507,6 @@ class MADELEINE(nn.Module):
         else:  # Model.py:206-216
             bs, n_mod, n_tokens, d_in = all_wsi_feats.shape
             self._require_single_modality(n_mod)
-            pooled, _, scores = emb.forward_headmajor(all_wsi_feats[:, HE_POSITION])
+            pooled, _, scores = emb.forward_headmajor(all_wsi_feats[:, HE_POSITION], need_tokens=False)
             he = self._project_slide(pooled).view(bs, n_mod, -1)
             return he, scores.unsqueeze(2)

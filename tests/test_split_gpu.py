@@ -271,3 +271,52 @@ def test_split_gemm_tn_chunk_gate(dev):
     z = MF.split_gemm_tn(A, MF.split_image(torch.zeros(T, N, device=dev), pad_rows=32),
                          b_chunk_max=MF.split_tile_absmax(torch.zeros(T, N, device=dev), chunks=True)[1])
     assert float(z.abs().max()) == 0.0
+
+
+def test_pool_from_image_vs_fp32(dev):
+    """The pooling kernels on the split image of E (the split GEMM mode never stores an fp32 E): pooled embeddings, statistics and the
+    score gradients against the fp32-E kernels, dense and ragged."""
+    from madeleine_amd import functional as MF
+    H, N, BM = 4, 700, 5
+    E = (t((BM * N, H * 512), "pimg:E") * 2.0).to(dev)
+    E[17] = 0.0
+    scores = (t((BM * N, H), "pimg:s") * 3.0).to(dev)
+    dp = t((BM, H * 512), "pimg:dp").to(dev)
+    Ei = MF.split_image(E)
+    for cu, nb, mx in ((None, BM, N), (torch.tensor([0, 1, 900, 900, 2100, 3500], device=dev), 5, 1400)):
+        p0, m0, l0 = MF.pool_fwd_raw(E, scores, nb, N if cu is None else 0, cu, mx)
+        p1, m1, l1 = MF.pool_fwd_img_raw(Ei, scores, nb, N if cu is None else 0, cu, mx)
+        assert torch.equal(m0, m1) and torch.equal(l0, l1)
+        assert rel_err(p1, p0) < 2e-7
+        ds0, ds1 = torch.empty_like(scores), torch.empty_like(scores)
+        MF.pool_bwd_raw(E, scores, p0, m0, l0, dp[:nb], None, 0, ds0, 0, nb, N if cu is None else 0, cu, mx)
+        MF.pool_dscores_img_raw(Ei, scores, p0, m0, l0, dp[:nb], ds1, 0, nb, N if cu is None else 0, cu, mx)
+        assert rel_err(ds1, ds0) < 2e-6
+
+
+def test_embedder_image_only_matches_fp32_tokens(dev):
+    """ABMILEmbedder.forward_headmajor(need_tokens=False) keeps E as an image only (LayerNorm kernel writes 4 B per element, pooling reads
+    the image): same pooled embeddings, token projections and parameter gradients as the path that also writes the fp32 E."""
+    from madeleine_amd.model import ABMILEmbedder
+    torch.manual_seed(3)
+    emb = ABMILEmbedder(pre_attention_params={"input_dim": 512, "hidden_dim": 512}, attention_params={
+        "model": "ABMIL", "params": {"input_dim": 512, "hidden_dim": 512, "dropout": False, "activation": "softmax", "n_heads": 4,
+                                     "n_classes": 1}}).to(dev).eval()
+    bags = t((3, 600, 512), "pimg:bags").to(dev)
+    Wt = (t((128, 2048), "pimg:wt") * 0.02).to(dev).requires_grad_()
+    res = []
+    for need in (True, False):
+        emb.zero_grad()
+        Wt.grad = None
+        pooled, E, scores, tok = emb.forward_headmajor(bags, tok_proj=(Wt, None), need_tokens=need)
+        assert (E is None) == (not need)
+        (pooled.square().sum() + tok[:, :40].square().sum()).backward()
+        res.append((pooled.detach(), tok.detach(), Wt.grad.clone(), [p.grad.clone() for p in emb.parameters() if p.grad is not None]))
+    assert rel_err(res[1][0], res[0][0]) < 1e-6 and rel_err(res[1][1], res[0][1]) < 1e-6
+    assert rel_err(res[1][2], res[0][2]) < 1e-5
+    top = max(float(b.norm()) for b in res[0][3])
+    for a, b in zip(res[1][3], res[0][3]):   # (measured <= 2.7e-5: the two paths pool values that differ in the last bit)
+        if b.numel() == 1:   # attention_c.bias: shift invariance of the softmax makes its gradient rounding noise
+            assert float((a - b).abs().max()) < 1e-6 * top
+        else:
+            assert rel_err(a, b) < 1e-4

@@ -17,6 +17,7 @@ ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--only", default="all")
 ap.add_argument("--bags", type=int, default=64)
 ap.add_argument("--tokens", type=int, default=4096)
+ap.add_argument("--image", action="store_true", help="--only pool: E as a split image (what the split GEMM mode's step pools from)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 BM, N, H = a.bags, a.tokens, 4
@@ -34,7 +35,12 @@ for it in range(a.iters):
         scores, aa, ab = MF.gate_fwd_raw(E2, Wa, ba, Wb, bb, wc, bc, 0.25, 123 + it, None, None, True)
     else:
         scores = torch.randn(BM * N, H, device=dev, generator=g)
-    if a.only in ("all", "pool"):
+    if a.only == "pool" and a.image:
+        Ei = MF.split_image(E2)
+        pooled, m, l = MF.pool_fwd_img_raw(Ei, scores, BM, N, None, N)
+        ds = torch.empty_like(scores)
+        MF.pool_dscores_img_raw(Ei, scores, pooled, m, l, dpool, ds, 0, BM, N, None, N)
+    elif a.only in ("all", "pool"):
         pooled, m, l = MF.pool_fwd_raw(E2, scores, BM, N, None, N)
         dE = torch.empty_like(E2)
         ds = torch.empty_like(scores)
