@@ -31,11 +31,20 @@ struct PoolLd {
 };
 template <>
 struct PoolLd<img_t> {
+    // col = 4 x (lane index of a full wave): lanes 2k, 2k+1 own channels [8k, 8k+4), [8k+4, 8k+8) of one 32-channel block.  ONE 16-B load
+    // per lane -- the even lane fetches the hi plane of the 8 channels, the odd lane their lo plane -- and the halves each lane is
+    // missing come from its neighbour by DPP (two 8-B loads per lane cost the pooling kernels 12 %).  Every lane of the wave must call.
     static __device__ __forceinline__ f32x4 ld(const img_t* __restrict__ rowp, int col, float inv) {   // col % 4 == 0
         typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-        const char* p = reinterpret_cast<const char*>(rowp) + (col >> 5) * 128 + (col & 31) * 2;
-        const h4 h = __builtin_bit_cast(h4, __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p)));
-        const h4 l = __builtin_bit_cast(h4, __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p + 64)));
+        const bool odd = (col >> 2) & 1;
+        const char* p = reinterpret_cast<const char*>(rowp) + (col >> 5) * 128 + ((col & 31) & ~7) * 2 + (odd ? 64 : 0);
+        const u32x4 w = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+        // even: w = hi[0..7]: keeps hi[0..3] = w.xy, sends hi[4..7] = w.zw;  odd: w = lo[0..7]: keeps lo[4..7] = w.zw, sends lo[0..3] = w.xy
+        const uint32_t s0 = odd ? w.x : w.z, s1 = odd ? w.y : w.w;
+        const uint32_t r0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s0, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]: lane ^ 1
+        const uint32_t r1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s1, 0xB1, 0xF, 0xF, false);
+        const h4 h = __builtin_bit_cast(h4, odd ? u32x2{r0, r1} : u32x2{w.x, w.y});
+        const h4 l = __builtin_bit_cast(h4, odd ? u32x2{w.z, w.w} : u32x2{r0, r1});
         f32x4 v;
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = ((float)h[i] + (float)l[i]) * inv;
