@@ -226,15 +226,17 @@ class ABMILEmbedder(nn.Module):
             return out[0], out[1].view(BM, N, self.n_heads)
         return out[0], out[1].view(BM, N, self.n_heads), out[2].view(BM, N, -1)
 
-    def pool_headmajor_ragged(self, E_hm: torch.Tensor, cu_seqlens: torch.Tensor, max_len: int, e_img=None):
-        """Packed E_hm [T,H*512] + cu_seqlens int64 [n_bags+1] -> (pooled_hm [n_bags,H*512], raw scores [T,H])."""
+    def pool_headmajor_ragged(self, E_hm: torch.Tensor, cu_seqlens: torch.Tensor, max_len: int, e_img=None, tok_proj=None):
+        """Packed E_hm [T,H*512] + cu_seqlens int64 [n_bags+1] -> (pooled_hm [n_bags,H*512], raw scores [T,H]) (+ the token projections
+        [T,P] with tok_proj = (W, bias), see pool_headmajor)."""
         for h in self.attn:
             h._check_geometry()
         if self.attn[0].activation != 'softmax':
             raise NotImplementedError("ragged bags are supported for activation='softmax' (the reference's scripts)")
         wa, ba, wb, bb, wc, bc = self.gate_params_stacked()
         p, seed, ka, kb = self._gate_dropout((E_hm.shape[0], 1))
-        return MF.attn_pool(E_hm, wa, ba, wb, bb, wc, bc, p, seed, ka, kb, cu_seqlens, max_len, e_img=e_img)
+        return MF.attn_pool(E_hm, wa, ba, wb, bb, wc, bc, p, seed, ka, kb, cu_seqlens, max_len, e_img=e_img, tok_proj=tok_proj,
+                            e_only_image=self.image_only(E_hm, e_img))
 
     def _scores_only(self, E_hm):
         BM, N, _ = E_hm.shape
@@ -429,12 +431,21 @@ class MADELEINE(nn.Module):
             tok_stain = torch.repeat_interleave(row_stain, torch.tensor(lens)).to(device)
             x = torch.cat([x, self.embedding(tok_stain).to(x.dtype)], dim=-1)
         emb = self.wsi_embedders
-        E, e_img = emb.embed_tokens_headmajor(x, return_image=True)             # [T, H*512]
         cu_d = cu.to(device)
-        pooled, _ = emb.pool_headmajor_ragged(E, cu_d, max(lens), e_img=e_img)
-        slide = self._project_slide(pooled).view(bs, n_mod, 1, -1)              # [B,M,1,512]
         head = (cu[:-1].unsqueeze(1) + torch.arange(n_loss_tokens).unsqueeze(0)).reshape(-1).to(device)
-        tok = self._project_tokens(E.index_select(0, head)).view(bs, n_mod, n_loss_tokens, -1)   # [B,M,n,128]
+        tp = (emb.permuted(self.token_projector.weight, 1), self.token_projector.bias)
+        # Split GEMM mode: the token projection is part of the pooling node (every token, on the image of E) and the head tokens are
+        # gathered from ITS output -- gathering rows of E instead makes autograd fill a zero [T, 2048] tensor and add it to the node's dE
+        # (3 x 11 GB of traffic per config-5 step), and E need not exist in fp32 at all.
+        fuse_tok = (not bf16_mode()) and MF.split_linear_supported(x.shape[0], tp[0].shape[0], tp[0].shape[1])
+        E, e_img = emb.embed_tokens_headmajor(x, return_image=True, want_fp32=not fuse_tok)   # [T, H*512]
+        if fuse_tok and e_img is not None:
+            pooled, _, tok_all = emb.pool_headmajor_ragged(E, cu_d, max(lens), e_img=e_img, tok_proj=tp)
+            tok = tok_all.index_select(0, head).view(bs, n_mod, n_loss_tokens, -1)          # [B,M,n,128]
+        else:
+            pooled, _ = emb.pool_headmajor_ragged(E, cu_d, max(lens), e_img=e_img)
+            tok = self._project_tokens(E.index_select(0, head)).view(bs, n_mod, n_loss_tokens, -1)
+        slide = self._project_slide(pooled).view(bs, n_mod, 1, -1)              # [B,M,1,512]
         all_embeddings, all_token_embeddings = {}, {}
         slides, toks = slide.unbind(1), tok.unbind(1)   # (see forward: one stacked gradient instead of per-stain fills and adds)
         for idx, modality in enumerate(self.modalities):
