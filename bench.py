@@ -23,7 +23,9 @@ import sys
 import time
 from types import SimpleNamespace
 
-import torch
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before the HIP runtime starts: one hardware queue per GOT stream (madeleine_amd/__init__.py)
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
