@@ -462,11 +462,13 @@ def main():
         step()
     fence()
     MF.TIMER = None if os.environ.get("BENCH_NO_TIMER") else MF.KernelTimer()
+    dev_allocs0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = step()
     fence()
     elapsed = time.perf_counter() - t0
+    dev_allocs = torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - dev_allocs0   # hipMalloc calls inside the timed region (0 = steady state)
     prof = MF.TIMER.report() if MF.TIMER is not None else {}
     work = MF.TIMER.work() if MF.TIMER is not None else {}
     MF.TIMER = None
@@ -559,6 +561,7 @@ def main():
                                    f"{', absent-stain zero bags encoded once (N4)' if a.skip_absent else ''}",
                        "global_batch": B * world, "bags_per_sec": round(value * M, 2), "parallelism": f"dp{world}",
                        "final_loss": final_loss,
+                       "device_allocs_in_timed_region": int(dev_allocs),
                        "collective_backend": (torch.distributed.get_backend() if world > 1 else "none"),
                        "ranks_seen": (torch.distributed.get_world_size() if world > 1 else 1),
                        "host_label_exchange": ("gloo" if hgroup is not None else ("device" if world > 1 else "none"))},
