@@ -372,3 +372,41 @@ def test_train_step_issues_no_library_gemm(dev, config, precision):
     for k, p in model.named_parameters():
         if p.grad is not None:
             assert torch.isfinite(p.grad).all(), k
+
+
+@pytest.mark.parametrize("config", ["c2", "c3"])
+def test_train_step_is_reproducible(dev, config):
+    """Same seeds -> the same bits: the dropout masks come from a counter hash seeded by torch's CPU generator, every reduction of the
+    dense step (split-K slabs, column sums, InfoNCE, GOT) is merged in a fixed order, the only atomics are order-independent maxima.
+    Two fresh runs of two train steps give identical losses and identical parameters."""
+    from madeleine_amd import InfoNCE, MADELEINE
+    from madeleine_amd import distributed as D
+    from madeleine_amd import functional as MF
+    B, M, N, Dm, use_got = {"c2": (8, 2, 512, 512, False), "c3": (8, 5, 512, 512, True)}[config]
+    mods = MODS5[:M]
+
+    def run():
+        torch.manual_seed(42)
+        model = MADELEINE(SimpleNamespace(MODALITIES=mods, wsi_encoder="abmil", patch_embedding_dim=Dm, wsi_encoder_hidden_dim=512,
+                                          activation="softmax", n_heads=4)).to(dev).train()
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+        gen = torch.Generator(device=dev).manual_seed(1)
+        labels = torch.ones(B, M)
+        data = {"feats": torch.randn(B, M, N, Dm, device=dev, generator=gen), "modality_labels": labels}
+        crit = InfoNCE(temperature=0.001)
+        largs = SimpleNamespace(global_loss="info-nce", symmetric_cl=True, local_loss_weight=1.0)
+        losses = []
+        for _ in range(2):
+            opt.zero_grad(set_to_none=True)
+            embs, toks = model(data, device=dev)
+            loss, _ = D.calculate_losses_dp(mods[1:], crit, MF.HipGotImpl if use_got else None, embs, toks, labels[:, 1:], largs,
+                                            use_local_loss=use_got)
+            loss.backward()
+            opt.step()
+            losses.append(loss.detach().clone())
+        return losses, [p.detach().clone() for p in model.parameters()]
+
+    l0, p0 = run()
+    l1, p1 = run()
+    assert all(torch.equal(a, b) for a, b in zip(l0, l1))
+    assert all(torch.equal(a, b) for a, b in zip(p0, p1))
