@@ -1,10 +1,12 @@
-"""Loss trajectory of a short pretrain run (fixed synthetic batch set, AdamW) in fp32 and under bf16 autocast:
-python tools/train_curve.py [--steps 40].  Both modes start from the same weights and see the same batches."""
+"""Loss trajectory of a short pretrain run (fixed synthetic batch set, AdamW) in fp32 -- split GEMM mode (default) and exact-fp32
+matrix-core mode -- and under bf16 autocast: python tools/train_curve.py [--steps 40].  All modes start from the same weights, see the
+same batches and draw the same dropout masks."""
 import argparse, os, sys
 from types import SimpleNamespace
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from madeleine_amd import GOT, InfoNCE, MADELEINE, calculate_losses
+from madeleine_amd import functional as MF
 
 ap = argparse.ArgumentParser(); ap.add_argument("--steps", type=int, default=40); a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -18,7 +20,8 @@ base = torch.randn(4, B, 1, N, D, generator=g)                       # 4 batches
 batches = [(base[i] + 0.5 * torch.randn(B, M, N, D, generator=g)).to(dev) for i in range(4)]
 labels = torch.ones(B, M)
 curves = {}
-for mode in ("float32", "bfloat16"):
+for mode in ("float32", "float32-mfma", "bfloat16"):
+    MF.set_gemm_mode("fp32" if mode == "float32-mfma" else "split")
     torch.manual_seed(42)
     model = MADELEINE(cfg).to(dev).train()
     opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
@@ -34,6 +37,9 @@ for mode in ("float32", "bfloat16"):
         opt.step()
         out.append(float(loss.detach()))
     curves[mode] = out
+MF.set_gemm_mode("split")
 for s in range(0, a.steps, max(1, a.steps // 10)):
-    print(f"step {s:3d}  fp32 {curves['float32'][s]:9.4f}   bf16 {curves['bfloat16'][s]:9.4f}")
-print(f"last    fp32 {curves['float32'][-1]:9.4f}   bf16 {curves['bfloat16'][-1]:9.4f}")
+    print(f"step {s:3d}  fp32(split) {curves['float32'][s]:10.5f}   fp32(mfma) {curves['float32-mfma'][s]:10.5f}   bf16 {curves['bfloat16'][s]:10.5f}")
+print(f"last      fp32(split) {curves['float32'][-1]:10.5f}   fp32(mfma) {curves['float32-mfma'][-1]:10.5f}   bf16 {curves['bfloat16'][-1]:10.5f}")
+d = [abs(x - y) / max(abs(y), 1e-12) for x, y in zip(curves["float32"], curves["float32-mfma"])]
+print("split vs exact-fp32 kernels: max relative loss difference over %d steps %.2e (first 10 steps: %.2e)" % (a.steps, max(d), max(d[:10])))
