@@ -389,14 +389,10 @@ def main():
     model.eval() if a.eval_mode else model.train()
     model.skip_absent_stains = bool(a.skip_absent)
     net = model
-    if world > 1:
-        # without the local loss the token_projector takes no part in the graph (as in the reference's global-only
-        # configuration): DDP must be told, or it raises on the second step.
-        # 20 MB of fp32 gradients: 8-MB buckets start their all-reduce while the pre_attn backward is still running
-        # (the default single 25-MB bucket would only fire after the last gradient), bucket views avoid the copy-back.
-        # (kept as find_unused_parameters: freezing the projector instead would change which tensors the optimizer owns)
-        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], find_unused_parameters=not use_got,
-                                                        bucket_cap_mb=8, gradient_as_bucket_view=True)
+    dist_on = D.collectives_on()   # world > 1, or world == 1 launched by torch.distributed.run: the whole N-rank path (RCCL, DDP, gloo side group)
+    if dist_on:
+        # 8-MB gradient buckets, bucket views; token_projector excluded from the bucket set when the local loss is off
+        net = D.wrap_ddp(model, dev, use_local_loss=use_got)
     opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
     torch.manual_seed(1000 + rank)   # dropout seeds are drawn from torch's CPU generator: decorrelate the ranks
     crit = InfoNCE(temperature=0.001)
@@ -454,7 +450,7 @@ def main():
         return loss
 
     def fence():
-        if world > 1:
+        if dist_on:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -535,7 +531,7 @@ def main():
         torch.cuda.empty_cache()
 
     tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    if world > 1:
+    if dist_on:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     elapsed = float(tmax)
     ms_per_step = 1e3 * elapsed / a.steps
@@ -562,9 +558,10 @@ def main():
                        "global_batch": B * world, "bags_per_sec": round(value * M, 2), "parallelism": f"dp{world}",
                        "final_loss": final_loss,
                        "device_allocs_in_timed_region": int(dev_allocs),
-                       "collective_backend": (torch.distributed.get_backend() if world > 1 else "none"),
-                       "ranks_seen": (torch.distributed.get_world_size() if world > 1 else 1),
-                       "host_label_exchange": ("gloo" if hgroup is not None else ("device" if world > 1 else "none"))},
+                       "collective_backend": (torch.distributed.get_backend() if dist_on else "none"),
+                       "ranks_seen": (torch.distributed.get_world_size() if dist_on else 1),
+                       "host_label_exchange": ("gloo" if hgroup is not None else ("device" if dist_on else "none")),
+                       "ddp": bool(dist_on)},
         }
         if "pool_fwd" in prof:
             ms, n = prof["pool_fwd"]
@@ -647,7 +644,7 @@ def main():
                                            "sample": f"failed: {type(e2).__name__}: {e2}"}
         print(json.dumps(out), flush=True)
 
-    if world > 1:
+    if dist_on:
         torch.distributed.destroy_process_group()
 
 

@@ -37,7 +37,10 @@ def init_from_env(backend: Optional[str] = None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    # launched by torch.distributed.run (RANK and WORLD_SIZE exported): join the group even at world size 1 -- the collectives,
+    # the gloo side group and DDP then run through RCCL exactly as on N GPUs (a 1-GPU box can execute that path)
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ and "MASTER_ADDR" in os.environ
+    if (world > 1 or launched) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
@@ -46,8 +49,31 @@ def init_from_env(backend: Optional[str] = None):
     return rank, world, local_rank
 
 
+def wrap_ddp(model, device, use_local_loss: bool = True, bucket_cap_mb: int = 8):
+    """The model under DistributedDataParallel as the data-parallel step uses it: 20 MB of fp32 gradients in 8-MB buckets (their
+    all-reduce starts while the pre_attn backward is still running; the default single 25-MB bucket would only fire after the last
+    gradient), bucket views instead of a copy-back.  Without the local (GOT) loss the token_projector takes no part in the graph
+    (as in the reference's global-only configuration, trainer.py:36-46): it is excluded from DDP's bucket set instead of paying
+    find_unused_parameters' per-step graph walk; its .grad stays None and the optimizer skips it."""
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    if not use_local_loss:
+        ignore = [n for n, _ in model.named_parameters() if n.startswith("token_projector.")]
+        DDP._set_params_and_buffers_to_ignore_for_model(model, ignore)
+    else:
+        DDP._set_params_and_buffers_to_ignore_for_model(model, [])
+    dev = torch.device(device)
+    return DDP(model, device_ids=[dev.index] if dev.type == "cuda" else None, find_unused_parameters=False,
+               bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True)
+
+
 def world_size(group=None) -> int:
     return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
+def collectives_on() -> bool:
+    """True when a process group exists: every collective of the step is then issued, also at world size 1 (where each is an
+    identity) -- one code path for 1 and N ranks, and a single GPU exercises the RCCL transport."""
+    return dist.is_available() and dist.is_initialized()
 
 
 def _host_staged(x: torch.Tensor, group) -> bool:
@@ -97,14 +123,14 @@ class _AllGatherReplicatedLoss(torch.autograd.Function):
 
 
 def all_gather_replicated(x: torch.Tensor, group=None) -> torch.Tensor:
-    if world_size(group) == 1:
+    if not collectives_on():
         return x
     return _AllGatherReplicatedLoss.apply(x, group)
 
 
 def all_gather_labels(labels: torch.Tensor, device, group=None) -> torch.Tensor:
     """[B_l, M] presence labels of every rank -> [W*B_l, M] on the host (tiny; issued at step start)."""
-    if world_size(group) == 1:
+    if not collectives_on():
         return labels.cpu()
     x = labels.to(dtype=torch.float32).contiguous()
     if dist.get_backend(group) != "gloo":
@@ -135,7 +161,7 @@ _HOST_GROUP = {}
 def host_group():
     """A gloo (CPU) process group next to the default one, for host-resident control data (presence labels).  Returns
     None when it cannot be created (the callers then fall back to the device path)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not collectives_on():
         return None
     if dist.get_backend() == "gloo":
         return dist.group.WORLD
@@ -156,7 +182,7 @@ def host_group():
 def all_gather_labels_async(labels: torch.Tensor, hgroup=None):
     """Starts the host-side exchange of the [B_l, M] presence labels; .wait() returns the [W*B_l, M] CPU tensor.  No
     device work, no device synchronisation (issue at step begin, wait after the encoder forward has been queued)."""
-    if world_size() == 1:
+    if not collectives_on():
         return _Ready(labels.detach().cpu().float())
     if hgroup is None:
         hgroup = host_group()
@@ -192,7 +218,7 @@ def gather_packed(wsi_embs: Dict[str, torch.Tensor], modalities: Sequence[str], 
     Returns (global embedding dict, presence mask [W*B_l, M] on the device, extrema of every rank [W, S, 6] or None).
     Gradients flow to the embedding part only (own slice x W, no collective in backward)."""
     W = world_size(group)
-    if W == 1:
+    if not collectives_on():
         return wsi_embs, labels_local.to(wsi_embs["HE"].device), None if extrema_local is None else extrema_local.unsqueeze(0)
     emb, geom = _pack_embeddings(wsi_embs, modalities)
     dev, dt = emb.device, emb.dtype
@@ -213,7 +239,7 @@ def gather_packed(wsi_embs: Dict[str, torch.Tensor], modalities: Sequence[str], 
 
 def gather_slide_embeddings(wsi_embs: Dict[str, torch.Tensor], modalities: Sequence[str], group=None):
     """Slide embeddings only (one all-gather of the packed [B_l, M*V*512] payload); see gather_packed."""
-    if world_size(group) == 1:
+    if not collectives_on():
         return wsi_embs
     emb, geom = _pack_embeddings(wsi_embs, modalities)
     return _unpack_embeddings(all_gather_replicated(emb.unsqueeze(0), group), modalities, geom)
@@ -323,7 +349,7 @@ class _GOTMulti(torch.autograd.Function):
                     with lanes(s):
                         parts.append(impl.backward_begin(st, d_outs[s]))
         dmm = torch.stack(parts)
-        if world_size(ctx.group) > 1:
+        if collectives_on():
             dmm = _all_reduce_sum(dmm, ctx.group)
         grads = []
         with _fan_out(dev, len(states)) as lanes:
@@ -343,7 +369,7 @@ def got_multi(problems, impl=None, group=None, extrema=None) -> torch.Tensor:
         from .functional import HipGotImpl as impl  # noqa: N813
     if extrema is None:
         extrema = got_local_extrema(problems, impl)
-        if world_size(group) > 1:
+        if collectives_on():
             extrema = _reduce_extrema(_all_gather_cat(extrema, group).view(world_size(group), -1, 6))
     flat = []
     for V, Q in problems:
@@ -381,7 +407,7 @@ def calculate_losses_dp(STAINS, loss_fn_interMod, got_impl, wsi_embs, token_embs
     labels_l = modality_labels_withoutHE.detach().cpu()
     if labels_global_withoutHE is not None:
         labels_g = labels_global_withoutHE
-    elif W == 1:
+    elif not collectives_on():
         labels_g = labels_l
     else:
         if group is not None and group is not dist.group.WORLD:

@@ -8,6 +8,7 @@ points; anything else raises (there is no CPU or eager fallback).
 Layouts (see include/madeleine_amd.h): token embeddings are head-major [T, H*512]; scores [T, H].
 """
 import os
+import threading
 from typing import Optional
 
 import torch
@@ -411,16 +412,15 @@ class SplitLinearFn(torch.autograd.Function):
             _require(bias, "bias")
         xi = split_image(x)
         y = split_gemm_nt(xi, split_image(W), bias, name="linear_fwd")
-        ctx.xi = xi
-        ctx.save_for_backward(W)
+        ctx.save_for_backward(W, xi.data, xi.scale)     # (the image is an ordinary saved tensor: hooks, retain_graph, version checks)
+        ctx.geom = (xi.rows, xi.K)
         ctx.has_bias = bias is not None
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        (W,) = ctx.saved_tensors
-        xi = ctx.xi
-        ctx.xi = None
+        W, xdata, xscale = ctx.saved_tensors
+        xi = SplitImage(xdata, xscale, *ctx.geom)
         dy = dy.float().contiguous()
         dyi = split_image(dy, pad_rows=32)
         dx = None
@@ -431,18 +431,37 @@ class SplitLinearFn(torch.autograd.Function):
         return dx, dW, db
 
 
-# max |t| of a gradient tensor, published by the kernel that produced it (epilogue atomics) for the consumer that needs a bound on it
+# max |t| of a gradient tensor, published by the kernel that produced it (epilogue atomics) for the consumer that needs a bound on it.
+# An entry binds to the CONTENTS of the buffer, not just its address: it keeps the producer's tensor alive (the address cannot be
+# recycled for another tensor, and the autograd engine cannot steal the buffer to sum a second gradient into it in place -- it
+# allocates the sum elsewhere, which misses here) and records the version counter the tensor had when the kernel wrote it (views share
+# the counter: an in-place update by a hook or another consumer shows as a newer version).  A miss or a stale entry returns None and the
+# consumer takes its own one-pass absmax (the dy_absmax = NULL path of mdl_ln_gelu_drop_bwd_split).
 _ABSMAX = {}
+_ABSMAX_LOCK = threading.Lock()
 
 
 def _put_absmax(t, amax):
-    if len(_ABSMAX) > 64:
-        _ABSMAX.clear()
-    _ABSMAX[(t.data_ptr(), t.numel())] = amax
+    with _ABSMAX_LOCK:
+        if len(_ABSMAX) > 8:
+            _ABSMAX.clear()
+        _ABSMAX[(t.data_ptr(), t.numel())] = (t, t._version, amax)
 
 
 def _take_absmax(t):
-    return _ABSMAX.pop((t.data_ptr(), t.numel()), None)
+    with _ABSMAX_LOCK:
+        e = _ABSMAX.pop((t.data_ptr(), t.numel()), None)
+    if e is None:
+        return None
+    src, version, amax = e
+    fresh = (src._version == version and t._version == version
+             and src.untyped_storage().data_ptr() == t.untyped_storage().data_ptr())
+    return amax if fresh else None
+
+
+def _clear_absmax():
+    with _ABSMAX_LOCK:
+        _ABSMAX.clear()
 
 
 class PreAttnBlockFn(torch.autograd.Function):
@@ -465,7 +484,7 @@ class PreAttnBlockFn(torch.autograd.Function):
         N = W.shape[0]
         dev = x.device
         if x_scale is None:
-            _ABSMAX.clear()      # first block of an encoder forward: no published maximum outlives a step
+            _clear_absmax()      # first block of an encoder forward: no published maximum outlives a step
         xi = SplitImage(x, x_scale, T, K) if x_scale is not None else split_image(x)
         y = split_gemm_nt(xi, split_image(W), name="linear_fwd")          # pre-LN values (the Linear's bias is added by the LN kernel)
         img = torch.empty(T, N, device=dev, dtype=torch.float32)
@@ -529,7 +548,9 @@ def preattn_block(x, x_scale, W, lin_bias, gamma, beta, eps=1e-5, p_drop=0.0, se
 
 
 def preattn_split_supported(x2d, K) -> bool:
-    return GEMM_MODE == "split" and x2d.is_cuda and x2d.dtype == torch.float32 and x2d.shape[0] > 256 and K % 32 == 0
+    """x2d: the [T, K] bags as the caller holds them (any floating dtype: they are widened to fp32 for the first block, no copy is made
+    to answer this)."""
+    return GEMM_MODE == "split" and x2d.is_cuda and x2d.is_floating_point() and x2d.shape[0] > 256 and K % 32 == 0
 
 
 def linear_fwd_raw(x2d, W, bias):
@@ -589,28 +610,29 @@ class GateScoresFn(torch.autograd.Function):
         for t, n in ((Wa, "Wa"), (ba, "ba"), (Wb, "Wb"), (bb, "bb"), (wc, "wc"), (bc, "bc")):
             _require(t, n)
         need = any(ctx.needs_input_grad[:7])
-        ctx.Ei = None
+        Ei = None
         if _split_gate(E2d):
             Ei = split_image(E2d)
             scores, act_a, act_b = gate_fwd_split_raw(Ei, Wa, ba, Wb, bb, wc, bc, p_drop, seed, keep_a, keep_b, need)
-            ctx.Ei = Ei if need else None
         else:
             scores, act_a, act_b = gate_fwd_raw(E2d, Wa, ba, Wb, bb, wc, bc, p_drop, seed, keep_a, keep_b, need)
         if need:
-            ctx.save_for_backward(E2d, Wa, Wb, wc, act_a, act_b)
+            none = torch.empty(0)
+            ctx.save_for_backward(E2d, Wa, Wb, wc, act_a, act_b, Ei.data if Ei is not None else none, Ei.scale if Ei is not None else none)
             ctx.drop = (p_drop, seed, keep_a, keep_b)
+            ctx.has_image = Ei is not None
         return scores
 
     @staticmethod
     def backward(ctx, d_scores):
-        E2d, Wa, Wb, wc, act_a, act_b = ctx.saved_tensors
+        E2d, Wa, Wb, wc, act_a, act_b, Eidata, Eiscale = ctx.saved_tensors
         p_drop, seed, keep_a, keep_b = ctx.drop
         d_scores = d_scores.float().contiguous()
         dE = torch.empty_like(E2d)
-        if ctx.Ei is not None:
-            dWa, dWb, dba, dbb, dwc, dbc = attnpool_bwd_split_raw(ctx.Ei, Wa, Wb, wc, act_a, act_b, d_scores, dE, p_drop, seed, keep_a,
+        if ctx.has_image:
+            Ei = SplitImage(Eidata, Eiscale, E2d.shape[0], E2d.shape[1])
+            dWa, dWb, dba, dbb, dwc, dbc = attnpool_bwd_split_raw(Ei, Wa, Wb, wc, act_a, act_b, d_scores, dE, p_drop, seed, keep_a,
                                                                   keep_b, None, None, None, None, None, 0)
-            ctx.Ei = None
         else:
             dWa, dWb, dba, dbb, dwc, dbc = gate_bwd_raw(E2d, Wa, Wb, wc, act_a, act_b, d_scores, dE, 0, p_drop, seed, keep_a,
                                                         keep_b)
@@ -715,7 +737,6 @@ class AttnPoolFn(torch.autograd.Function):
             _require(v, "view token indices", torch.int32)
         ctx.set_materialize_grads(False)
         need = any(ctx.needs_input_grad[:7]) or any(ctx.needs_input_grad[13:15])   # (inputs 15, 16 = the image of E: no gradient)
-        ctx.Ei = None
         Ei = None
         if e_only_image and (Eimg is None or views or not _split_gate(E2d)
                              or (Wtok is not None and not split_linear_supported(E2d.shape[0], Wtok.shape[0], Wtok.shape[1]))):
@@ -725,7 +746,6 @@ class AttnPoolFn(torch.autograd.Function):
             # the image of E: written by the producing LayerNorm kernel (Eimg / Escale), else built here (3 passes over E)
             Ei = SplitImage(Eimg, Escale, E2d.shape[0], E2d.shape[1]) if Eimg is not None else split_image(E2d)
             scores, act_a, act_b = gate_fwd_split_raw(Ei, Wa, ba, Wb, bb, wc, bc, p_drop, seed, keep_a, keep_b, need)
-            ctx.Ei = Ei if need else None
         else:
             scores, act_a, act_b = gate_fwd_raw(E2d, Wa, ba, Wb, bb, wc, bc, p_drop, seed, keep_a, keep_b, need)
         pooled, m, l = (pool_fwd_img_raw(Ei, scores, n_bags, N, cu_seqlens, max_len) if e_only_image
@@ -747,11 +767,14 @@ class AttnPoolFn(torch.autograd.Function):
         if need:
             flat = [t for st in vstate for t in st]
             none = torch.empty(0)
+            # (the image of E travels as saved tensors like everything else: saved-tensor hooks, retain_graph and version checks apply)
             ctx.save_for_backward(E2d, Wa, Wb, wc, act_a, act_b, scores, pooled, m, l,
-                                  cu_seqlens if cu_seqlens is not None else none, Wtok if Wtok is not None else none, *views, *flat)
+                                  cu_seqlens if cu_seqlens is not None else none, Wtok if Wtok is not None else none,
+                                  Ei.data if Ei is not None else none, Ei.scale if Ei is not None else none, *views, *flat)
             ctx.cfg = (p_drop, seed, keep_a, keep_b, n_bags, N, max_len, cu_seqlens is not None, E.shape, len(views),
                        Wtok is not None, btok is not None)
             ctx.e_only_image = bool(e_only_image)
+            ctx.has_image = Ei is not None
         if views:
             pooled = torch.stack([pooled] + [st[0] for st in vstate], dim=1)
         return pooled, scores, tok
@@ -760,8 +783,9 @@ class AttnPoolFn(torch.autograd.Function):
     def backward(ctx, d_pooled, d_scores_in, d_tok):
         p_drop, seed, keep_a, keep_b, n_bags, N, max_len, ragged, e_shape, V, has_tok, has_btok = ctx.cfg
         saved = ctx.saved_tensors
-        E2d, Wa, Wb, wc, act_a, act_b, scores, pooled, m, l, cu, Wtok = saved[:12]
-        views, vflat = saved[12:12 + V], saved[12 + V:]
+        E2d, Wa, Wb, wc, act_a, act_b, scores, pooled, m, l, cu, Wtok, Eidata, Eiscale = saved[:14]
+        views, vflat = saved[14:14 + V], saved[14 + V:]
+        Ei = SplitImage(Eidata, Eiscale, E2d.shape[0], E2d.shape[1]) if ctx.has_image else None
         cu = cu if ragged else None
         dE = torch.empty_like(E2d)
         if d_scores_in is not None:
@@ -780,13 +804,13 @@ class AttnPoolFn(torch.autograd.Function):
         # before it (the gate dX epilogue then accumulates).
         dWtok = dbtok = None
         acc_e = 0
-        tok_after = has_tok and d_tok is not None and ctx.Ei is not None and split_linear_supported(E2d.shape[0], Wtok.shape[0], Wtok.shape[1])
+        tok_after = has_tok and d_tok is not None and Ei is not None and split_linear_supported(E2d.shape[0], Wtok.shape[0], Wtok.shape[1])
         if has_tok and d_tok is not None and not tok_after:
             dWtok, dbtok = linear_bwd_raw(E2d, Wtok, d_tok.to(E2d.dtype).contiguous(), dE, has_btok)
             acc_e = 1
         # scores-only pooling backward (one read of E), then the gate backward whose dX epilogue adds the pooling term
         if ctx.e_only_image:
-            pool_dscores_img_raw(ctx.Ei, scores, pooled, m, l, d_main, ds, acc_s, n_bags, N, cu, max_len)
+            pool_dscores_img_raw(Ei, scores, pooled, m, l, d_main, ds, acc_s, n_bags, N, cu, max_len)
         else:
             pool_bwd_raw(E2d, scores, pooled, m, l, d_main, None, 0, ds, acc_s, n_bags, N, cu, max_len)
         for i in range(V):   # the views' score gradients must be in ds before the gate backward consumes it
@@ -795,9 +819,9 @@ class AttnPoolFn(torch.autograd.Function):
         row_bag = None
         if ragged:   # bag index of every packed token row, on the device (no sync)
             row_bag = torch.searchsorted(cu[1:].contiguous(), torch.arange(E2d.shape[0], device=E2d.device), right=True).to(torch.int32)
-        if ctx.Ei is not None:
+        if Ei is not None:
             am = torch.zeros(1, device=dE.device, dtype=torch.float32) if V == 0 else None   # (views add to dE afterwards)
-            dWa, dWb, dba, dbb, dwc, dbc = attnpool_bwd_split_raw(ctx.Ei, Wa, Wb, wc, act_a, act_b, ds, dE, p_drop, seed, keep_a, keep_b,
+            dWa, dWb, dba, dbb, dwc, dbc = attnpool_bwd_split_raw(Ei, Wa, Wb, wc, act_a, act_b, ds, dE, p_drop, seed, keep_a, keep_b,
                                                                   scores, m, l, d_main, row_bag, N if not ragged else 0, acc_e, am)
             if tok_after:
                 d_tok = d_tok.float().contiguous()
@@ -805,11 +829,10 @@ class AttnPoolFn(torch.autograd.Function):
                 gate, chunk_max = split_tile_absmax(d_tok, chunks=True)   # one pass: 256-row tiles (dX) and 32-row chunks (dW)
                 split_gemm_nt(dti, split_image(Wtok.t().contiguous()), out=dE, accumulate=True, absmax_out=am, name="linear_bwd",
                               row_gate=gate)
-                dWtok = split_gemm_tn(ctx.Ei, dti, name="linear_bwd", b_chunk_max=chunk_max)
+                dWtok = split_gemm_tn(Ei, dti, name="linear_bwd", b_chunk_max=chunk_max)
                 dbtok = d_tok.sum(0) if has_btok else None
             if am is not None:
                 _put_absmax(dE, am)
-            ctx.Ei = None
         else:
             dWa, dWb, dba, dbb, dwc, dbc = attnpool_bwd_raw(E2d, Wa, Wb, wc, act_a, act_b, ds, dE, p_drop, seed, keep_a, keep_b,
                                                             scores, m, l, d_main, row_bag, N if not ragged else 0, acc_e)

@@ -175,7 +175,7 @@ class ABMILEmbedder(nn.Module):
                 E = self._act(MF.linear(x, self.permuted(pa[8].weight, 0)), pa[9], 2, perm, pa[8].bias)
                 return (E, None) if return_image else E
         x2d = bags.reshape(-1, bags.shape[-1])
-        if MF.preattn_split_supported(x2d.float(), x2d.shape[-1]) and pa[0].weight.shape[0] % 32 == 0:
+        if MF.preattn_split_supported(x2d, x2d.shape[-1]) and pa[0].weight.shape[0] % 32 == 0:
             # split GEMM mode: three fused blocks; the activations between them exist as split images only
             img, sc, _ = self._block_split(x2d.float().contiguous(), None, 0)
             img, sc, _ = self._block_split(img, sc, 1)

@@ -410,3 +410,50 @@ def test_train_step_is_reproducible(dev, config):
     l1, p1 = run()
     assert all(torch.equal(a, b) for a, b in zip(l0, l1))
     assert all(torch.equal(a, b) for a, b in zip(p0, p1))
+
+
+# ------------------------------------------------------------------------------------------ config-4 rank shape of GOT
+C4_SHAPE = [(23, 112), (27, 180), (25, 185), (24, 188)]   # (cases this rank owns, n = min(k_global, 256)) per stain
+
+
+def test_got_multi_c4_rank_shape_vs_fp64_oracle(dev):
+    """what a rank of the 8-GPU config runs -- FOUR GOT problems (one per stain) of k = 23..27 local cases
+    at n = min(k_global, 256) = 112 / 180 / 185 / 188 tokens, concurrently on four side streams (got_multi's fan-out: per-phase
+    launches and workspace-resident plan gradients for n > 128), with supplied threshold extrema -- against the fp64 oracle
+    (loss.py:278-302) problem by problem: both distances and the token gradients; and twice, for bit-reproducibility (a workspace
+    overlap or a missing stream dependency between the concurrent chains would show as run-to-run differences)."""
+    from madeleine_amd import distributed as DP
+    from madeleine_amd import functional as MF
+    probs64, refs = [], []
+    for s, (k, n) in enumerate(C4_SHAPE):
+        v = t((k, n, 128), f"got:c4:v{s}")
+        q = t((k, n, 128), f"got:c4:q{s}") + 0.7 * v
+        v64, q64 = v.double().requires_grad_(), q.double().requires_grad_()
+        ref = R.got(v64, q64, subsample=None)
+        ref.backward()
+        probs64.append((v, q))
+        refs.append((float(ref), v64.grad, q64.grad))
+
+    def run():
+        probs = [(v.to(dev).requires_grad_(), q.to(dev).requires_grad_()) for v, q in probs64]
+        ext = DP.got_local_extrema([(a.detach(), b.detach()) for a, b in probs], MF.HipGotImpl)
+        outs = DP.got_multi(probs, MF.HipGotImpl, None, extrema=ext)            # [S, 2] on four streams
+        (outs[:, 0] + outs[:, 1]).sum().backward()
+        torch.cuda.synchronize()
+        return outs.detach().clone(), [(a.grad.clone(), b.grad.clone()) for a, b in probs]
+
+    o1, g1 = run()
+    o2, g2 = run()
+    assert torch.equal(o1, o2)
+    for (a1, b1), (a2, b2) in zip(g1, g2):
+        assert torch.equal(a1, a2) and torch.equal(b1, b2)
+    for s, (ref, dv, dq) in enumerate(refs):
+        got = float(o1[s].sum())
+        assert abs(got - ref) < TOL * abs(ref), (s, got, ref)
+        assert rel_err(g1[s][0], dv) < TOL and rel_err(g1[s][1], dq) < TOL, (s, rel_err(g1[s][0], dv), rel_err(g1[s][1], dq))
+    # the same four problems one after the other on the caller's stream: the concurrent result is the sequential one, bit for bit
+    for s, (v, q) in enumerate(probs64):
+        vd, qd = v.to(dev).requires_grad_(), q.to(dev).requires_grad_()
+        o = MF.got(vd, qd)
+        (o[0] + o[1]).backward()
+        assert torch.equal(o, o1[s]) and torch.equal(vd.grad, g1[s][0]) and torch.equal(qd.grad, g1[s][1]), s

@@ -73,8 +73,7 @@ def _worker(rank, world, port, backend, use_got, ret, ddp=False):
         from madeleine_amd import distributed as DP
         model = _build_model(dev)
         if ddp:   # the wrapper bench.py uses for N > 1: bucketed gradient all-reduce (mean), unused-parameter detection
-            model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], find_unused_parameters=not use_got,
-                                                              bucket_cap_mb=8, gradient_as_bucket_view=True)
+            model = DP.wrap_ddp(model, dev, use_local_loss=use_got)
         Bl = B // world
         sl = slice(rank * Bl, (rank + 1) * Bl)
         pending = DP.all_gather_labels_async(LABELS[sl, 1:])          # host-side label exchange (gloo group)
@@ -88,8 +87,6 @@ def _worker(rank, world, port, backend, use_got, ret, ddp=False):
             g = p.grad.detach().clone()
             if not ddp:
                 g = DP._all_reduce_sum(g) / world
-            elif not use_got and "token_projector" in k:
-                continue                                               # zero-filled by DDP: the loss does not depend on it
             grads[k[7:] if k.startswith("module.") else k] = g.cpu()
         # loss value of the global batch: replicated global part + sum over ranks of the local parts (undo the W scaling)
         loss_nogot, _ = _step(model, t((B, M, N, D), "dpg:feats")[sl], LABELS[sl], dev, False, labels_global=lab_g, sync=False)
@@ -144,3 +141,62 @@ def test_two_ranks_under_ddp_equal_global_batch(use_got):
         err = float((torch.from_numpy(got) - g).norm())
         assert err <= 1e-4 * float(g.norm()) + 1e-6 * top, (k, err, float(g.norm()))
     assert len(ret["grads"]) >= len(ref_grads) - 2
+
+
+def _worker_rccl_w1(rank, port, use_got, ret):
+    """World size 1 on the RCCL backend, entered the way torch.distributed.run enters bench.py (init_from_env reading RANK /
+    WORLD_SIZE / MASTER_*): every collective of the step runs as a real RCCL call on device tensors."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    os.environ.pop("MADELEINE_DIST_BACKEND", None)
+    from madeleine_amd import distributed as DP
+    r, w, lr = DP.init_from_env()
+    try:
+        assert (r, w, lr) == (0, 1, 0) and dist.is_initialized() and dist.get_backend() == "nccl" and DP.collectives_on()
+        dev = torch.device("cuda", 0)
+        hg = DP.host_group()                                            # nccl default group + gloo side group
+        assert hg is not None and dist.get_backend(hg) == "gloo"
+        # the raw collectives on device tensors
+        x = torch.arange(12, device=dev, dtype=torch.float32).view(3, 4)
+        assert torch.equal(DP._all_gather_cat(x), x) and not DP._host_staged(x, None)
+        assert torch.equal(DP._all_reduce_sum(x.clone()), x)
+        y = x.clone().requires_grad_()
+        g = DP.all_gather_replicated(y)
+        assert g.grad_fn is not None and type(g.grad_fn).__name__.startswith("_AllGatherReplicatedLoss")
+        g.sum().backward()
+        assert torch.equal(y.grad, torch.ones_like(y))
+        model = DP.wrap_ddp(_build_model(dev), dev, use_local_loss=use_got)
+        pending = DP.all_gather_labels_async(LABELS[:, 1:], hg)
+        assert isinstance(pending, DP._PendingLabels)
+        loss, flag = _step(model, t((B, M, N, D), "dpg:feats"), LABELS, dev, use_got, labels_global=pending.wait())
+        # ... and with the labels gathered inside calculate_losses_dp (its own host exchange)
+        loss2, _ = _step(model, t((B, M, N, D), "dpg:feats"), LABELS, dev, use_got, labels_global=None)
+        dist.barrier()
+        torch.cuda.synchronize()
+        ret["loss"], ret["loss2"], ret["flag"] = float(loss), float(loss2), bool(flag)
+        ret["grads"] = {k[7:]: p.grad.detach().cpu().numpy() for k, p in model.named_parameters() if p.grad is not None}
+        ret["backend"] = dist.get_backend()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("use_got", [False, True])
+def test_rccl_world_size_one_equals_no_process_group(use_got):
+    """the RCCL transport at world size 1 -- init_from_env (nccl), host_group() (gloo side group), the
+    async label exchange, the packed all_gather_into_tensor on device tensors, the [S,6] all-reduce inside the GOT backward and
+    DDP's bucketed gradient all-reduce (8-MB buckets, bucket views, token_projector excluded when the local loss is off) -- must
+    reproduce the run without a process group: same kernels, same order, every collective an identity."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    ref_loss, ref_grads = _single(torch.device("cuda:0"), use_got)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_rccl_w1, args=(_free_port(), use_got, ret), nprocs=1, join=True)
+    assert ret["flag"] and ret["backend"] == "nccl"
+    assert abs(ret["loss"] - ref_loss) <= 1e-6 * abs(ref_loss), (ret["loss"], ref_loss)
+    assert ret["loss2"] == ret["loss"]
+    assert set(ret["grads"]) == set(ref_grads)
+    for k, g in ref_grads.items():
+        got = torch.from_numpy(ret["grads"][k])
+        err = float((got - g).norm())
+        assert err <= 1e-6 * float(g.norm()) + 1e-30, (k, err, float(g.norm()))
