@@ -390,9 +390,15 @@ def main():
     model.skip_absent_stains = bool(a.skip_absent)
     net = model
     dist_on = D.collectives_on()   # world > 1, or world == 1 launched by torch.distributed.run: the whole N-rank path (RCCL, DDP, gloo side group)
+    gsync = None
     if dist_on:
-        # 8-MB gradient buckets, bucket views; token_projector excluded from the bucket set when the local loss is off
-        net = D.wrap_ddp(model, dev, use_local_loss=use_got)
+        # gradient mean over the ranks: ONE flat 20-MB all-reduce after backward (distributed.FlatGradSync) -- the DDP wrapper's per-step
+        # host bookkeeping measured +4.5 ms on this 24-ms step against +1.0 (tools/exp_ddp.py, profiles/r04_exp_ddp_*.txt);
+        # BENCH_DDP=1 selects the wrapper (distributed.wrap_ddp: 8-MB buckets overlapped with backward)
+        if os.environ.get("BENCH_DDP"):
+            net = D.wrap_ddp(model, dev, use_local_loss=use_got)
+        else:
+            gsync = D.FlatGradSync(model, use_local_loss=use_got)
     opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
     torch.manual_seed(1000 + rank)   # dropout seeds are drawn from torch's CPU generator: decorrelate the ranks
     crit = InfoNCE(temperature=0.001)
@@ -446,6 +452,8 @@ def main():
             loss, flag = D.calculate_losses_dp(mods[1:], crit, got_impl, embs, toks, labels[:, 1:], largs,
                                                labels_global_withoutHE=pending.wait(), use_local_loss=use_got)
         loss.backward()
+        if gsync is not None:
+            gsync.all_reduce_mean()
         opt.step()
         return loss
 
@@ -561,7 +569,7 @@ def main():
                        "collective_backend": (torch.distributed.get_backend() if dist_on else "none"),
                        "ranks_seen": (torch.distributed.get_world_size() if dist_on else 1),
                        "host_label_exchange": ("gloo" if hgroup is not None else ("device" if dist_on else "none")),
-                       "ddp": bool(dist_on)},
+                       "grad_sync": ("none" if not dist_on else ("ddp" if gsync is None else "flat_all_reduce"))},
         }
         if "pool_fwd" in prof:
             ms, n = prof["pool_fwd"]

@@ -54,7 +54,7 @@ const char* mdl_version(void);
 /* ABI revision of this header: bumped whenever an entry point's argument list changes.  A binding compares
  * mdl_abi_version() with the MDL_ABI_VERSION it was written against BEFORE calling anything else, so that a stale
  * shared object fails loudly instead of being called with shifted arguments. */
-#define MDL_ABI_VERSION 14
+#define MDL_ABI_VERSION 15
 int mdl_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -369,13 +369,23 @@ int mdl_abmil_pool_dscores_img(const void* E_img, int64_t e_rsb, const float* e_
                                int64_t n_bags, int64_t N, const int64_t* cu_seqlens, int64_t max_len, int H, void* stream);
 int mdl_split_image(const float* X, int64_t ldx, int64_t rows, int K, void* img, int64_t rsb, int64_t pad_rows, float* scale,
                     void* stream);
+/* ROW-SCALED image (round 4): row r of X is scaled by its own power of two s_r (max_k |s_r X[r][k]| in [2^13, 2^14); 1 for an all-zero
+ * row) -- for the tensor whose rows a CALLER controls, the patch features (Model.py:113, :351): with one common scale a patch 2^20 times
+ * larger than the others would cost them their low bits (fp32 nn.Linear has no such coupling between rows).  row_inv (device
+ * float[rows]) receives 1 / s_r (0 for an all-zero row: it contributes nothing to any product), scale = {1, max |X|}.  Consumers: mdl_split_gemm_nt(A = this image, a_row_mul = row_inv) -- the row
+ * factor is undone in the epilogue, exactly; mdl_split_gemm_tn pairs it with a gradient image written with row_mul = row_inv
+ * (mdl_ln_gelu_drop_bwd_split), so that the row factors cancel inside the contraction over rows. */
+int mdl_split_image_rows(const float* X, int64_t ldx, int64_t rows, int K, void* img, int64_t rsb, int64_t pad_rows, float* row_inv,
+                         float* scale, void* stream);
 /* row_gate (device float[ceil(M / 256)], may be NULL; only with accumulate != 0 and bias == NULL): output tiles whose entry is 0 are
  * skipped -- mdl_split_tile_absmax(X, ...) fills it with the per-256-row maxima of |X| for A = image(X), and chunk_max (float
  * [ceil(rows / 32)], may be NULL) with the per-32-row maxima that mdl_split_gemm_tn's b_chunk_max takes. */
 int mdl_split_tile_absmax(const float* X, int64_t ldx, int64_t rows, int K, float* gate, float* chunk_max, void* stream);
+/* a_row_mul (device float[M], may be NULL): row m of the product is multiplied by a_row_mul[m] before bias / accumulation (the
+ * 1 / s_r of a row-scaled A image, or the s_r that undoes a row_mul folded into a gradient image). */
 int mdl_split_gemm_nt(const void* A, int64_t a_rsb, const float* a_scale, const void* B, int64_t b_rsb, const float* b_scale, float* C,
                       int64_t ldc, int64_t M, int N, int K, const float* bias, int accumulate, float* absmax_out, const float* row_gate,
-                      void* stream);
+                      const float* a_row_mul, void* stream);
 int64_t mdl_split_gemm_tn_ws_bytes(int64_t T, int Mi, int N);
 /* b_chunk_max (float [ceil(T / 32)], may be NULL): per-32-row maxima of |X| for B = image(X) (mdl_split_tile_absmax) -- chunks whose
  * entry is 0 are skipped (the token_projector's dW: the local loss reads the first <= 256 tokens of a bag, the rest of d_tok is zero). */
@@ -391,10 +401,12 @@ int mdl_split_gemm_tn(const void* A, int64_t a_rsb, const float* a_scale, int Mi
 int mdl_ln_gelu_drop_fwd_split(const float* x, const float* bias, const float* gamma, const float* beta, float* y, void* img, float* scale,
                                float* mean, float* rstd, int64_t rows, int W, float eps, float p_drop, uint64_t seed, const uint8_t* keep,
                                void* stream);
+/* row_mul (device float[rows], may be NULL): the dx image holds row_mul[r] dx[r][:] (bound through max_r rstd[r] row_mul[r]); dgamma,
+ * dbeta, dbias are unaffected.  For the first pre_attn block, whose input image is row-scaled (mdl_split_image_rows): row_mul = row_inv. */
 int mdl_ln_gelu_drop_bwd_split(const float* x, const float* bias, const float* gamma, const float* beta, const float* mean,
                                const float* rstd, const float* dy, const float* dy_absmax, void* dx_img, float* dx_scale, float* dgamma,
-                               float* dbeta, float* dbias, int64_t rows, int W, float p_drop, uint64_t seed, const uint8_t* keep, void* ws,
-                               void* stream);
+                               float* dbeta, float* dbias, int64_t rows, int W, float p_drop, uint64_t seed, const uint8_t* keep,
+                               const float* row_mul, void* ws, void* stream);
 
 /* A2 on the split engine (csrc/abmil_gate_split.hip): mdl_abmil_gate_fwd / mdl_abmil_attnpool_bwd(_phases) with E given as a split
  * image (rows of e_rsb bytes holding the H*512 head-major channels, scale e_scale) -- everything else (parameters, scores, saved

@@ -287,7 +287,8 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_bwd_kernel(const IO* _
                                                                      const IO* __restrict__ dy, IO* __restrict__ dx,
                                                                      float* __restrict__ part, int64_t rows, ActDrop drop,
                                                                      char* __restrict__ img = nullptr,
-                                                                     const float* __restrict__ img_sc = nullptr) {
+                                                                     const float* __restrict__ img_sc = nullptr,
+                                                                     const float* __restrict__ row_mul = nullptr) {
     constexpr int W = NV * 256 * WPR, RPB = 4 / WPR;
     __shared__ float red[1][4][2];
     __shared__ float csum[WPR < 4 ? 3 * W : 1];  // WPR < 4: several waves own the same columns -> merged through LDS
@@ -364,13 +365,16 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_bwd_kernel(const IO* _
         if (live) {
             IO* __restrict__ o = dx + r * W + cb;
             f32x4 prev = {0.f, 0.f, 0.f, 0.f};
+            // image row factor: the common scale, times row_mul[r] when the image pairs (in the dW contraction over rows) with a
+            // row-scaled image of this layer's input -- row_mul[r] = that image's 1 / s_r, so that the row factors cancel in the sum
+            const float isc = IMG ? (row_mul ? img_sc[0] * row_mul[r] : img_sc[0]) : 0.f;
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = rstd * (dxh[i][e] - m1 - xh[i][e] * m2);
                 sx[i] += v;
-                if (IMG) img_store4(img + r * (int64_t)(W * 4), cb + CM::off(i, lane), v, img_sc[0]);
+                if (IMG) img_store4(img + r * (int64_t)(W * 4), cb + CM::off(i, lane), v, isc);
                 else group_store<IO, NV>(o, lane, i, prev, v);
                 prev = v;
             }
@@ -469,6 +473,14 @@ __global__ __launch_bounds__(256) void ln_bound_scale_kernel(const float* __rest
         sc[1] = bound;
         sc[0] = sp_scale_for(bound);
     }
+}
+
+// *out is raised to max_r |a[r] b[r]| (the caller zeroes it)
+__global__ __launch_bounds__(256) void absmax_prod_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n,
+                                                          float* __restrict__ out) {
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(a[i] * b[i]));
+    sp_atomic_absmax(out, m);
 }
 
 int sp_launch_absmax(const float* X, int64_t ldx, int64_t rows, int K, float* out, hipStream_t s);   // split_gemm.hip
@@ -642,7 +654,7 @@ extern "C" int mdl_ln_gelu_drop_fwd_split(const float* x, const float* bias, con
 extern "C" int mdl_ln_gelu_drop_bwd_split(const float* x, const float* bias, const float* gamma, const float* beta, const float* mean,
                                           const float* rstd, const float* dy, const float* dy_absmax, void* dx_img, float* dx_scale,
                                           float* dgamma, float* dbeta, float* dbias, int64_t rows, int W, float p_drop, uint64_t seed,
-                                          const uint8_t* keep, void* ws, void* stream) {
+                                          const uint8_t* keep, const float* row_mul, void* ws, void* stream) {
     if (!x || !gamma || !beta || !mean || !rstd || !dy || !dx_img || !dx_scale || !dgamma || !dbeta || !ws || rows < 0) return MDL_E_ARG;
     if (!(p_drop >= 0.f && p_drop < 1.f)) return MDL_E_ARG;
     if (!act_width_ok(W) || W > 4096) return MDL_E_UNSUPPORTED;
@@ -663,7 +675,15 @@ extern "C" int mdl_ln_gelu_drop_bwd_split(const float* x, const float* bias, con
     if (e != hipSuccess) return (int)e;
     e = hipMemsetAsync((char*)dx_img + rows * (int64_t)W * 4, 0, (size_t)32 * W * 4, s);
     if (e != hipSuccess) return (int)e;
-    int rc = sp_launch_absmax_flat(rstd, rows, aux, s);
+    int rc = MDL_OK;
+    if (row_mul && rows > 0) {   // the image holds row_mul[r] dx[r][:]: bound through max_r rstd[r] row_mul[r]
+        int nbm = (int)((rows + 2047) / 2048);
+        if (nbm > 2048) nbm = 2048;
+        hipLaunchKernelGGL(absmax_prod_kernel, dim3(nbm), dim3(256), 0, s, rstd, row_mul, rows, aux);
+        MDL_LAUNCH_CHECK();
+    } else {
+        rc = sp_launch_absmax_flat(rstd, rows, aux, s);
+    }
     if (rc) return rc;
     if (dy_absmax) {
         e = hipMemcpyAsync(aux + 1, dy_absmax, sizeof(float), hipMemcpyDeviceToDevice, s);
@@ -676,13 +696,13 @@ extern "C" int mdl_ln_gelu_drop_bwd_split(const float* x, const float* bias, con
     MDL_LAUNCH_CHECK();
     if (W == 2048 && nb > 0) {
         hipLaunchKernelGGL((ln_gelu_drop_bwd_kernel<4, 2, float, true>), dim3(nb), dim3(ACT_BLOCK), 0, s, x, bias, gamma, beta, mean, rstd, dy,
-                           (float*)nullptr, part, rows, d, (char*)dx_img, (const float*)dx_scale);
+                           (float*)nullptr, part, rows, d, (char*)dx_img, (const float*)dx_scale, row_mul);
         MDL_LAUNCH_CHECK();
     } else
     MDL_DISPATCH_W(W, {
         if (nb > 0) {
             hipLaunchKernelGGL((ln_gelu_drop_bwd_kernel<NV, WPR, float, true>), dim3(nb), dim3(ACT_BLOCK), 0, s, x, bias, gamma, beta, mean,
-                               rstd, dy, (float*)nullptr, part, rows, d, (char*)dx_img, (const float*)dx_scale);
+                               rstd, dy, (float*)nullptr, part, rows, d, (char*)dx_img, (const float*)dx_scale, row_mul);
             MDL_LAUNCH_CHECK();
         }
     });

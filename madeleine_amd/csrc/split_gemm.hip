@@ -74,6 +74,45 @@ __global__ __launch_bounds__(256) void sp_convert_kernel(const float* __restrict
     *reinterpret_cast<u32x4*>(row + sp_img_off(k, 1)) = lo;
 }
 
+// Row-scaled image (mdl_split_image_rows): every row r carries its own power-of-two scale s_r with max_k |s_r X[r][k]| in [2^13, 2^14)
+// (an all-zero row: row_inv = 0) -- the image of a tensor whose ROWS differ in magnitude by more than the ~2^16 a common scale represents
+// at full precision (the patch features a caller hands in: one outlier patch must not cost the other patches their low bits).
+// row_inv[r] = 1 / s_r.  One wave per row: pass 1 the row maximum, pass 2 (the row is in L1 / L2) the planes; *absmax is raised to max |X|.
+__global__ __launch_bounds__(256) void sp_image_rows_kernel(const float* __restrict__ X, int64_t ldx, int64_t rows, int K,
+                                                            char* __restrict__ img, int64_t rsb, float* __restrict__ row_inv,
+                                                            float* __restrict__ absmax) {
+    const int lane = threadIdx.x & 63;
+    float tot = 0.f;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (int64_t)gridDim.x * 4) {
+        const float* __restrict__ xr = X + r * ldx;
+        float m = 0.f;
+        for (int k = lane * 8; k < K; k += 512) {
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(xr + k), x1 = *reinterpret_cast<const f32x4*>(xr + k + 4);
+            m = fmaxf(m, fmaxf(fmaxf(fmaxf(fabsf(x0.x), fabsf(x0.y)), fmaxf(fabsf(x0.z), fabsf(x0.w))),
+                               fmaxf(fmaxf(fabsf(x1.x), fabsf(x1.y)), fmaxf(fabsf(x1.z), fabsf(x1.w)))));
+        }
+        m = wave_max(m);
+        tot = fmaxf(tot, m);
+        const float s = sp_scale_for(m);
+        // exact: s is a power of two.  An all-zero row (absent-stain bag, wsi_dataset.py:66) gets factor 0: its products vanish anyway, and
+        // as row_mul of the paired gradient image (mdl_ln_gelu_drop_bwd_split) 0 keeps that row -- which contributes x = 0 to dW -- from
+        // setting the gradient image's scale
+        if (lane == 0) row_inv[r] = m > 0.f ? 1.f / s : 0.f;
+        char* row = img + r * rsb;
+        for (int k = lane * 8; k < K; k += 512) {
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(xr + k), x1 = *reinterpret_cast<const f32x4*>(xr + k + 4);
+            const float v[8] = {x0.x * s, x0.y * s, x0.z * s, x0.w * s, x1.x * s, x1.y * s, x1.z * s, x1.w * s};
+            u32x4 hi, lo;
+            sp_split8(v, hi, lo);
+            *reinterpret_cast<u32x4*>(row + sp_img_off(k, 0)) = hi;
+            *reinterpret_cast<u32x4*>(row + sp_img_off(k, 1)) = lo;
+        }
+    }
+    if (lane == 0) atomicMax(reinterpret_cast<unsigned int*>(absmax), __float_as_uint(tot));
+}
+// sc = {1, absmax already in sc[1]}: the common factor of a row-scaled image is 1 (the row factors travel in row_inv)
+__global__ void sp_unit_scale_kernel(float* __restrict__ sc) { sc[0] = 1.f; }
+
 // gate[i] = max |X[256 i .. 256 i + 255][:]|: lets mdl_split_gemm_nt skip the output tiles whose A rows are all zero (the
 // token_projector's dX in the fused A2 + A3 backward: the local loss reads the first <= 256 tokens of a bag, the rest of d_tok is 0);
 // chunk_max[j] (optional) = the same over the 32 rows of chunk j: the TN product skips all-zero chunks (mdl_split_gemm_tn).
@@ -109,7 +148,7 @@ __global__ __launch_bounds__(SP_THREADS) void sp_nt_kernel(const char* __restric
                                                     const char* __restrict__ B, int64_t b_rsb, const float* __restrict__ b_sc,
                                                     float* __restrict__ C, int64_t ldc, int64_t M, int N, int nblk, int n_tiles,
                                                     const float* __restrict__ bias, int accumulate, float* __restrict__ absmax_out,
-                                                    const float* __restrict__ row_gate) {
+                                                    const float* __restrict__ row_gate, const float* __restrict__ a_row_mul) {
     __shared__ SmemSP sm;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -148,7 +187,7 @@ __global__ __launch_bounds__(SP_THREADS) void sp_nt_kernel(const char* __restric
     const int cols_valid = N - n0;
     auto emit = [&](int row, int col, const f32x4& v) {
         if (col >= cols_valid) return;
-        f32x4 r = v * inv;
+        f32x4 r = v * (a_row_mul ? inv * a_row_mul[m0 + row] : inv);   // row-scaled A image: its row factor (a power of two) comes back here
         if (bias) r += *reinterpret_cast<const f32x4*>(bias + n0 + col);
         f32x4* o = reinterpret_cast<f32x4*>(cb + (int64_t)row * ldc4 + (uint32_t)col * 4u);
         if (accumulate) r += *o;
@@ -281,6 +320,32 @@ extern "C" int mdl_split_image(const float* X, int64_t ldx, int64_t rows, int K,
     return MDL_OK;
 }
 
+/* Row-scaled split image of X [rows, K]: row r scaled by its own power of two s_r (max |s_r X[r][:]| in [2^13, 2^14); 1 for a zero row);
+ * row_inv (device float[rows]) receives 1 / s_r, scale = {1, max |X|}.  As the A operand of mdl_split_gemm_nt pass a_row_mul = row_inv. */
+extern "C" int mdl_split_image_rows(const float* X, int64_t ldx, int64_t rows, int K, void* img, int64_t rsb, int64_t pad_rows,
+                                    float* row_inv, float* scale, void* stream) {
+    if (!X || !img || !scale || !row_inv || rows < 0 || K < 32 || (K % 32) || ldx < K || (ldx & 3) || rsb < (int64_t)K * 4 || (rsb & 15) ||
+        pad_rows < 0)
+        return MDL_E_ARG;
+    if (!host_aligned16(X) || !host_aligned16(img)) return MDL_E_ALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(scale, 0, 2 * sizeof(float), s);
+    if (e != hipSuccess) return (int)e;
+    if (pad_rows > 0) {
+        e = hipMemsetAsync((char*)img + rows * rsb, 0, (size_t)(pad_rows * rsb), s);
+        if (e != hipSuccess) return (int)e;
+    }
+    if (rows > 0) {
+        int64_t nb = (rows + 3) / 4;
+        if (nb > 8192) nb = 8192;
+        hipLaunchKernelGGL(sp_image_rows_kernel, dim3((unsigned)nb), dim3(256), 0, s, X, ldx, rows, K, (char*)img, rsb, row_inv, scale + 1);
+        MDL_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(sp_unit_scale_kernel, dim3(1), dim3(1), 0, s, scale);
+    MDL_LAUNCH_CHECK();
+    return MDL_OK;
+}
+
 /* C [M, N] (row stride ldc floats) (+)= sum_k A[m][k] B[n][k] (+ bias[n]) on the split images A (M rows) and B (N rows) of K columns;
  * a_scale / b_scale: device floats, the images' scales.  absmax_out (device float, may be NULL): atomically raised to max |C|
  * (the caller zeroes it).  N % 4 == 0, K % 32 == 0. */
@@ -296,7 +361,7 @@ extern "C" int mdl_split_tile_absmax(const float* X, int64_t ldx, int64_t rows, 
 
 extern "C" int mdl_split_gemm_nt(const void* A, int64_t a_rsb, const float* a_scale, const void* B, int64_t b_rsb, const float* b_scale,
                                  float* C, int64_t ldc, int64_t M, int N, int K, const float* bias, int accumulate, float* absmax_out,
-                                 const float* row_gate, void* stream) {
+                                 const float* row_gate, const float* a_row_mul, void* stream) {
     if (row_gate && (!accumulate || bias)) return MDL_E_ARG;   // skipping a tile is only the identity when it would add zeros
     if (!A || !B || !C || !a_scale || !b_scale || M < 0 || N < 4 || (N & 3) || K < 32 || (K % 32) || ldc < N || (ldc & 3)) return MDL_E_ARG;
     if (a_rsb < (int64_t)K * 4 || b_rsb < (int64_t)K * 4 || (a_rsb & 15) || (b_rsb & 15)) return MDL_E_ARG;
@@ -305,7 +370,7 @@ extern "C" int mdl_split_gemm_nt(const void* A, int64_t a_rsb, const float* a_sc
     const int64_t tiles = ((M + SPM - 1) / SPM) * ((N + SPN - 1) / SPN);
     if (tiles > 0x7fffffff || a_rsb * SPM > 0x7fffffff || b_rsb * SPN > 0x7fffffff) return MDL_E_UNSUPPORTED;
     hipLaunchKernelGGL(sp_nt_kernel, dim3((unsigned)tiles), dim3(SP_THREADS), 0, (hipStream_t)stream, (const char*)A, a_rsb, a_scale,
-                       (const char*)B, b_rsb, b_scale, C, ldc, M, N, K / 32, (int)tiles, bias, accumulate, absmax_out, row_gate);
+                       (const char*)B, b_rsb, b_scale, C, ldc, M, N, K / 32, (int)tiles, bias, accumulate, absmax_out, row_gate, a_row_mul);
     MDL_LAUNCH_CHECK();
     return MDL_OK;
 }

@@ -348,6 +348,21 @@ def split_image(x2d, pad_rows=0) -> SplitImage:
     return SplitImage(data, scale, rows, K)
 
 
+def split_image_rows(x2d, pad_rows=0):
+    """Row-scaled image of x2d (mdl_split_image_rows): -> (SplitImage with common scale 1, row_inv [rows] = 1 / the row scales).  For the
+    tensor whose rows the caller controls (the patch features): one outlier patch does not cost the other patches their low bits."""
+    _require(x2d, "x")
+    lib = _native.lib()
+    rows, K = x2d.shape
+    data = torch.empty(rows + pad_rows, K, device=x2d.device, dtype=torch.float32)
+    scale = torch.empty(2, device=x2d.device, dtype=torch.float32)
+    row_inv = torch.empty(rows, device=x2d.device, dtype=torch.float32)
+    with _timed("split_image", ("byte", 8.0 * rows * K)):   # one HBM read (the second pass hits the cache) + write
+        rc = lib.mdl_split_image_rows(_ptr(x2d), x2d.stride(0), rows, K, _ptr(data), K * 4, pad_rows, _ptr(row_inv), _ptr(scale), _stream())
+    _native.check(rc, "mdl_split_image_rows")
+    return SplitImage(data, scale, rows, K), row_inv
+
+
 def split_tile_absmax(x2d, chunks=False):
     """max |x| of every block of 256 rows (the row gate of split_gemm_nt); chunks=True: also of every 32 rows (split_gemm_tn's
     b_chunk_max) -> (gate, chunk_max)."""
@@ -359,9 +374,11 @@ def split_tile_absmax(x2d, chunks=False):
     return (gate, cm) if chunks else gate
 
 
-def split_gemm_nt(A: SplitImage, B: SplitImage, bias=None, out=None, accumulate=False, absmax_out=None, name="split_nt", row_gate=None):
+def split_gemm_nt(A: SplitImage, B: SplitImage, bias=None, out=None, accumulate=False, absmax_out=None, name="split_nt", row_gate=None,
+                  a_row_mul=None):
     """C [A.rows, B.rows] (+)= A B^T (+ bias) on two images with the same K.  row_gate (accumulate mode only): per-256-row maxima of
-    the tensor A is the image of; output tiles of all-zero A rows are skipped."""
+    the tensor A is the image of; output tiles of all-zero A rows are skipped.  a_row_mul [A.rows]: per-row factor applied to the
+    product (row_inv of a row-scaled A image)."""
     lib = _native.lib()
     M, N, K = A.rows, B.rows, A.K
     if B.K != K:
@@ -369,7 +386,7 @@ def split_gemm_nt(A: SplitImage, B: SplitImage, bias=None, out=None, accumulate=
     C = out if out is not None else torch.empty(M, N, device=A.data.device, dtype=torch.float32)
     with _timed(name, ("flop", 2.0 * M * N * K)):
         rc = lib.mdl_split_gemm_nt(_ptr(A.data), K * 4, _ptr(A.scale), _ptr(B.data), K * 4, _ptr(B.scale), _ptr(C), C.stride(0), M, N, K,
-                                   _ptr(bias), int(accumulate), _ptr(absmax_out), _ptr(row_gate), _stream())
+                                   _ptr(bias), int(accumulate), _ptr(absmax_out), _ptr(row_gate), _ptr(a_row_mul), _stream())
     _native.check(rc, "mdl_split_gemm_nt")
     return C
 
@@ -485,8 +502,14 @@ class PreAttnBlockFn(torch.autograd.Function):
         dev = x.device
         if x_scale is None:
             _clear_absmax()      # first block of an encoder forward: no published maximum outlives a step
-        xi = SplitImage(x, x_scale, T, K) if x_scale is not None else split_image(x)
-        y = split_gemm_nt(xi, split_image(W), name="linear_fwd")          # pre-LN values (the Linear's bias is added by the LN kernel)
+        # first block: x = the caller's patch features -> ROW-scaled image (an outlier patch must not cost the others their low bits;
+        # nn.Linear in fp32 has no coupling between rows); later blocks: the previous block's LayerNorm output, rows of one magnitude
+        row_inv = None
+        if x_scale is not None:
+            xi = SplitImage(x, x_scale, T, K)
+        else:
+            xi, row_inv = split_image_rows(x)
+        y = split_gemm_nt(xi, split_image(W), name="linear_fwd", a_row_mul=row_inv)   # pre-LN values (the Linear's bias is added by the LN kernel)
         img = torch.empty(T, N, device=dev, dtype=torch.float32)
         scale = torch.empty(2, device=dev, dtype=torch.float32)
         out = torch.empty(T, N, device=dev, dtype=torch.float32) if want_fp32 else None
@@ -498,7 +521,8 @@ class PreAttnBlockFn(torch.autograd.Function):
         if rc == -3:
             raise NotImplementedError("fused LayerNorm-GELU-Dropout supports widths 256/512/1024/2048/4096 (got %d)" % N)
         _native.check(rc, "mdl_ln_gelu_drop_fwd_split")
-        ctx.save_for_backward(xi.data, xi.scale, W, y, gamma, beta, mean, rstd, lin_bias if lin_bias is not None else torch.empty(0))
+        ctx.save_for_backward(xi.data, xi.scale, W, y, gamma, beta, mean, rstd, lin_bias if lin_bias is not None else torch.empty(0),
+                              row_inv if row_inv is not None else torch.empty(0))
         ctx.cfg = (float(p_drop), int(seed), keep, lin_bias is not None, bool(want_fp32), T, K, N, x_scale is not None)
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(scale)
@@ -511,9 +535,12 @@ class PreAttnBlockFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_img, _d_scale, d_out):
-        xdata, xscale, W, y, gamma, beta, mean, rstd, lin_bias = ctx.saved_tensors
+        xdata, xscale, W, y, gamma, beta, mean, rstd, lin_bias, row_inv = ctx.saved_tensors
         p_drop, seed, keep, has_bias, want_fp32, T, K, N, x_is_image = ctx.cfg
         lin_bias = lin_bias if has_bias else None
+        # first block (row-scaled input image): the gradient image carries row_inv[r] dx[r][:], so that the row factors of the two images
+        # cancel inside the dW contraction over rows
+        row_inv = None if x_is_image else row_inv
         dy = d_out if want_fp32 else d_img
         if dy is None:
             dy = torch.zeros(T, N, device=y.device, dtype=torch.float32)
@@ -529,13 +556,27 @@ class PreAttnBlockFn(torch.autograd.Function):
         with _timed("ln_gelu_drop_bwd", ("byte", (3.0 if amax is not None else 4.0) * T * N * 4)):
             rc = lib.mdl_ln_gelu_drop_bwd_split(_ptr(y), _ptr(lin_bias), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(dy), _ptr(amax),
                                                 _ptr(dximg), _ptr(dxscale), _ptr(dg), _ptr(db), _ptr(dbias), T, N, p_drop, seed, _ptr(keep),
-                                                _ptr(ws), _stream())
+                                                _ptr(row_inv), _ptr(ws), _stream())
         _native.check(rc, "mdl_ln_gelu_drop_bwd_split")
         dyi = SplitImage(dximg, dxscale, T, N)
         dx = None
         if ctx.needs_input_grad[0]:
             am = torch.zeros(1, device=dev, dtype=torch.float32)
-            dx = split_gemm_nt(dyi, split_image(W.t().contiguous()), absmax_out=am, name="linear_bwd")
+            dxi = dyi
+            if row_inv is not None:
+                # d(patch features) is wanted (stain-encoding tokens concatenated to the bags, Model.py:132; a caller differentiating
+                # w.r.t. its features): the image above carries the dW pairing's row factors, under which a row's own gradient can sit
+                # far below the image's scale.  A second pass writes d(pre-LN) under the common scale for this product alone.
+                dximg2 = torch.empty(T + 32, N, device=dev, dtype=torch.float32)
+                dxscale2 = torch.empty(2, device=dev, dtype=torch.float32)
+                dg2, db2 = torch.empty_like(gamma), torch.empty_like(beta)
+                with _timed("ln_gelu_drop_bwd", ("byte", 3.0 * T * N * 4)):
+                    rc = lib.mdl_ln_gelu_drop_bwd_split(_ptr(y), _ptr(lin_bias), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(dy), _ptr(amax),
+                                                        _ptr(dximg2), _ptr(dxscale2), _ptr(dg2), _ptr(db2), None, T, N, p_drop, seed, _ptr(keep),
+                                                        None, _ptr(ws), _stream())
+                _native.check(rc, "mdl_ln_gelu_drop_bwd_split")
+                dxi = SplitImage(dximg2, dxscale2, T, N)
+            dx = split_gemm_nt(dxi, split_image(W.t().contiguous()), absmax_out=am, name="linear_bwd")
             if x_is_image:       # the consumer is the previous block's LayerNorm backward (this node's input was its image)
                 _put_absmax(dx, am)
         dW = split_gemm_tn(SplitImage(xdata, xscale, T, K), dyi, name="linear_bwd")

@@ -93,12 +93,13 @@ def _worker(rank, world, port, use_got, ret):
         loss, flag = DP.calculate_losses_dp(mods[1:], nce, OracleGotImpl if use_got else None, embs, toks,
                                             LABELS[sl, 1:], args, use_local_loss=use_got)
         loss.backward()
-        # what DDP does: mean of the parameter gradients over ranks
-        grads = {}
-        for k, v in sd.items():
-            g = v.grad.clone() if v.grad is not None else torch.zeros_like(v)
-            dist.all_reduce(g)
-            grads[k] = g / world
+        # the gradient mean over ranks bench.py performs for N > 1: distributed.FlatGradSync (one packed all-reduce); the parameters
+        # outside the step's graph (token_projector without the local loss) are excluded on every rank alike
+        sync = DP.FlatGradSync(sd.items(), use_local_loss=use_got)
+        assert all(v.grad is not None for v in sync.params)
+        sync.all_reduce_mean()
+        assert all(v.grad.data_ptr() == w.data_ptr() for v, w in zip(sync.params, sync.views))
+        grads = {k: (v.grad.clone() if v.grad is not None else torch.zeros_like(v)) for k, v in sd.items()}
         # true loss value = replicated global part + sum over ranks of the local part (undo the W scaling)
         with torch.no_grad():
             embs_g = DP.gather_slide_embeddings({k: v.detach() for k, v in embs.items()}, mods)

@@ -72,7 +72,10 @@ def _worker(rank, world, port, backend, use_got, ret, ddp=False):
     try:
         from madeleine_amd import distributed as DP
         model = _build_model(dev)
-        if ddp:   # the wrapper bench.py uses for N > 1: bucketed gradient all-reduce (mean), unused-parameter detection
+        sync = None
+        if ddp == "flat":   # what bench.py uses for N > 1: one flat all-reduce (mean) of the packed gradients after backward
+            sync = DP.FlatGradSync(model, use_local_loss=use_got)
+        elif ddp:   # the DistributedDataParallel wrapper (bench.py BENCH_DDP=1): bucketed gradient all-reduce (mean) inside backward
             model = DP.wrap_ddp(model, dev, use_local_loss=use_got)
         Bl = B // world
         sl = slice(rank * Bl, (rank + 1) * Bl)
@@ -80,6 +83,8 @@ def _worker(rank, world, port, backend, use_got, ret, ddp=False):
         loss, flag = _step(model, t((B, M, N, D), "dpg:feats")[sl], LABELS[sl], dev, use_got, labels_global=None)
         lab_g = pending.wait()
         assert torch.equal(lab_g, LABELS[:, 1:])
+        if sync is not None:
+            sync.all_reduce_mean()
         grads = {}
         for k, p in model.named_parameters():                          # what DDP does: mean over ranks
             if p.grad is None:
@@ -122,8 +127,9 @@ def test_two_ranks_equal_global_batch(backend, use_got):
         assert err <= 1e-4 * float(g.norm()) + 1e-6 * top, (k, err, float(g.norm()))
 
 
+@pytest.mark.parametrize("ddp", [True, "flat"])
 @pytest.mark.parametrize("use_got", [False, True])
-def test_two_ranks_under_ddp_equal_global_batch(use_got):
+def test_two_ranks_under_ddp_equal_global_batch(use_got, ddp):
     """The same decomposition with the model wrapped in DistributedDataParallel exactly as bench.py wraps it for N > 1 (8-MB
     buckets, bucket views, unused-parameter detection when the local loss is off): DDP's own bucketed mean of the gradients,
     the packed all-gather in forward and the [S,6] all-reduce inside the backward of the GOT node while DDP's hooks are live."""
@@ -132,7 +138,7 @@ def test_two_ranks_under_ddp_equal_global_batch(use_got):
     ref_loss, ref_grads = _single(torch.device("cuda:0"), use_got)
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(2, _free_port(), "gloo", use_got, ret, True), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), "gloo", use_got, ret, ddp), nprocs=2, join=True)
     assert ret["flag"]
     assert abs(ret["loss"] - ref_loss) < 1e-4 * abs(ref_loss), (ret["loss"], ref_loss)
     top = max(float(g.norm()) for g in ref_grads.values())
@@ -143,7 +149,7 @@ def test_two_ranks_under_ddp_equal_global_batch(use_got):
     assert len(ret["grads"]) >= len(ref_grads) - 2
 
 
-def _worker_rccl_w1(rank, port, use_got, ret):
+def _worker_rccl_w1(rank, port, use_got, ret, flat=False):
     """World size 1 on the RCCL backend, entered the way torch.distributed.run enters bench.py (init_from_env reading RANK /
     WORLD_SIZE / MASTER_*): every collective of the step runs as a real RCCL call on device tensors."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
@@ -165,33 +171,44 @@ def _worker_rccl_w1(rank, port, use_got, ret):
         assert g.grad_fn is not None and type(g.grad_fn).__name__.startswith("_AllGatherReplicatedLoss")
         g.sum().backward()
         assert torch.equal(y.grad, torch.ones_like(y))
-        model = DP.wrap_ddp(_build_model(dev), dev, use_local_loss=use_got)
+        sync = None
+        if flat:
+            model = _build_model(dev)
+            sync = DP.FlatGradSync(model, use_local_loss=use_got)
+        else:
+            model = DP.wrap_ddp(_build_model(dev), dev, use_local_loss=use_got)
         pending = DP.all_gather_labels_async(LABELS[:, 1:], hg)
         assert isinstance(pending, DP._PendingLabels)
         loss, flag = _step(model, t((B, M, N, D), "dpg:feats"), LABELS, dev, use_got, labels_global=pending.wait())
         # ... and with the labels gathered inside calculate_losses_dp (its own host exchange)
         loss2, _ = _step(model, t((B, M, N, D), "dpg:feats"), LABELS, dev, use_got, labels_global=None)
+        if sync is not None:
+            sync.all_reduce_mean()      # ReduceOp.AVG on the flat 20-MB buffer, RCCL
+            assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(sync.params, sync.views))
         dist.barrier()
         torch.cuda.synchronize()
         ret["loss"], ret["loss2"], ret["flag"] = float(loss), float(loss2), bool(flag)
-        ret["grads"] = {k[7:]: p.grad.detach().cpu().numpy() for k, p in model.named_parameters() if p.grad is not None}
+        ret["grads"] = {(k[7:] if k.startswith("module.") else k): p.grad.detach().cpu().numpy()
+                        for k, p in model.named_parameters() if p.grad is not None}
         ret["backend"] = dist.get_backend()
     finally:
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("flat", [False, True])
 @pytest.mark.parametrize("use_got", [False, True])
-def test_rccl_world_size_one_equals_no_process_group(use_got):
+def test_rccl_world_size_one_equals_no_process_group(use_got, flat):
     """the RCCL transport at world size 1 -- init_from_env (nccl), host_group() (gloo side group), the
     async label exchange, the packed all_gather_into_tensor on device tensors, the [S,6] all-reduce inside the GOT backward and
-    DDP's bucketed gradient all-reduce (8-MB buckets, bucket views, token_projector excluded when the local loss is off) -- must
-    reproduce the run without a process group: same kernels, same order, every collective an identity."""
+    DDP's bucketed gradient all-reduce (8-MB buckets, bucket views, token_projector excluded when the local loss is off) or, with
+    `flat`, FlatGradSync's single all-reduce of the packed gradients (what bench.py runs for N > 1) -- must reproduce the run
+    without a process group: same kernels, same order, every collective an identity."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     ref_loss, ref_grads = _single(torch.device("cuda:0"), use_got)
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker_rccl_w1, args=(_free_port(), use_got, ret), nprocs=1, join=True)
+    mp.spawn(_worker_rccl_w1, args=(_free_port(), use_got, ret, flat), nprocs=1, join=True)
     assert ret["flag"] and ret["backend"] == "nccl"
     assert abs(ret["loss"] - ref_loss) <= 1e-6 * abs(ref_loss), (ret["loss"], ref_loss)
     assert ret["loss2"] == ret["loss"]
