@@ -127,8 +127,74 @@ def measure_pool_traffic(timeout_s=150, image=False):
             " --image" if image else "")
 
 
-def cpu_baseline(B_sample, M, N, D, use_got, steps=2):
-    """Times the CPU oracle's full step (fwd + losses + bwd + AdamW, train-mode dropout) on B_sample slides."""
+class PowerSampler:
+    """Socket power (W) and shader clock (MHz) from the amdgpu hwmon files (power1_input / power1_average, freq1_input), sampled by a
+    background thread -- cheap file reads, no rocm-smi process.  Used over a step loop OUTSIDE the timed region."""
+
+    def __init__(self, period_s=0.05):
+        import glob
+        self.period = period_s
+        self.power = self.freq = self.cap = None
+        for d in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+            for name in ("power1_input", "power1_average"):
+                if os.path.exists(os.path.join(d, name)) and os.path.exists(os.path.join(d, "freq1_input")):
+                    self.power, self.freq = os.path.join(d, name), os.path.join(d, "freq1_input")
+                    cap = os.path.join(d, "power1_cap")
+                    self.cap = cap if os.path.exists(cap) else None
+                    break
+            if self.power:
+                break
+        self.samples = []
+        self._stop = None
+
+    @staticmethod
+    def _read(path):
+        with open(path) as f:
+            return float(f.read().strip())
+
+    def __enter__(self):
+        import threading
+        if self.power is None:
+            return self
+        self._stop = threading.Event()
+
+        def run():
+            while not self._stop.is_set():
+                try:
+                    self.samples.append((time.perf_counter(), self._read(self.power) / 1e6, self._read(self.freq) / 1e6))
+                except (OSError, ValueError):
+                    pass
+                self._stop.wait(self.period)
+        self._th = threading.Thread(target=run, daemon=True)
+        self._th.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self._stop is not None:
+            self._stop.set()
+            self._th.join()
+        return False
+
+    def summary(self, skip_s=0.3):
+        if not self.samples:
+            return {"source": "amdgpu hwmon not readable on this box"}
+        t0 = self.samples[0][0]
+        xs = [x for x in self.samples if x[0] - t0 >= skip_s] or self.samples
+        pw, fq = sorted(x[1] for x in xs), sorted(x[2] for x in xs)
+        med = lambda v: v[len(v) // 2]   # noqa: E731
+        out = {"source": "amdgpu hwmon (%s, freq1_input), %d samples at %.0f ms over the step loop" % (os.path.basename(self.power), len(xs), 1e3 * self.period),
+               "socket_power_W": {"median": round(med(pw), 1), "min": round(pw[0], 1), "max": round(pw[-1], 1)},
+               "sclk_MHz": {"median": round(med(fq)), "min": round(fq[0]), "max": round(fq[-1])}}
+        if self.cap:
+            try:
+                out["power_cap_W"] = round(self._read(self.cap) / 1e6, 1)
+            except (OSError, ValueError):
+                pass
+        return out
+
+
+def cpu_baseline(B_sample, M, N, D, use_got, steps=2, train=True):
+    """Times the CPU oracle's full step (fwd + losses + bwd + AdamW; train: dropout on, as the reference trains) on B_sample slides."""
     from oracle import restatement as R
     threads = usable_cores()
     torch.set_num_threads(threads)
@@ -143,7 +209,7 @@ def cpu_baseline(B_sample, M, N, D, use_got, steps=2):
     for it in range(steps + 1):
         t0 = time.perf_counter()
         opt.zero_grad()
-        pre, gate = R.random_keep_masks(B_sample * M, N, 4, g)
+        pre, gate = R.random_keep_masks(B_sample * M, N, 4, g) if train else (None, None)
         loss, flag, _ = R.pretrain_step_loss(feats, labels, sd, mods, 0.001, True, use_got=use_got, pre_keep=pre,
                                              gate_keep=gate)
         loss.backward()
@@ -155,7 +221,29 @@ def cpu_baseline(B_sample, M, N, D, use_got, steps=2):
     med = times[len(times) // 2]
     return {"value": round(B_sample / med, 4), "unit": "slides/s", "cores": threads, "kind": "port",
             "sample": f"{B_sample} of the step's slides x {M} stains x {N} x {D}, full step (fwd+loss+bwd+AdamW), "
-                      f"train-mode dropout, median of {steps} after 1 warm-up; {med:.2f} s/step"}
+                      f"{'train-mode dropout' if train else 'dropout off'}, median of {steps} after 1 warm-up; {med:.2f} s/step"}
+
+
+def measure_leg(MF, stepf, steps, warmup=2, prof_steps=3):
+    """A secondary leg: `steps` timed steps with NO per-launch events (cuda synchronize on both sides), then a short profiled pass for
+    the per-kernel figures.  -> (seconds for the timed steps, last loss, {kernel: (avg ms, calls)}, declared work)."""
+    for _ in range(warmup):
+        stepf()
+    torch.cuda.synchronize()
+    MF.TIMER = None
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = stepf()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    MF.TIMER = MF.KernelTimer()
+    try:
+        for _ in range(prof_steps):
+            stepf()
+        prof, work = MF.TIMER.report(), MF.TIMER.work()
+    finally:
+        MF.TIMER = None
+    return el, loss, prof, work, prof_steps
 
 
 def secondary_c3_leg(dev, D, MF, InfoNCE, MADELEINE, steps=5, warmup=2):
@@ -185,23 +273,12 @@ def secondary_c3_leg(dev, D, MF, InfoNCE, MADELEINE, steps=5, warmup=2):
         opt.step()
         return loss
 
-    for _ in range(warmup):
-        step()
-    torch.cuda.synchronize()
-    MF.TIMER = MF.KernelTimer()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = step()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    prof = MF.TIMER.report()
-    work = MF.TIMER.work()
-    MF.TIMER = None
+    el, loss, prof, work, psteps = measure_leg(MF, step, steps, warmup)
     k = [int(labels[:, s].sum()) for s in range(1, M)]
     return {"value": round(B * steps / el, 3), "unit": "slides/s", "ms_per_step": round(1e3 * el / steps, 3), "steps": steps,
             "workload": f"c3: {B} slides x {M} stains (cases per stain {k}) x {N} x {Dm}, InfoNCE + GOT, train mode, AdamW",
             "final_loss": float(loss.detach()),
-            "kernel_ms": {n: round(v[0], 4) for n, v in prof.items()}, "kernel_calls_per_step": {n: v[1] // steps for n, v in prof.items()},
+            "kernel_ms": {n: round(v[0], 4) for n, v in prof.items()}, "kernel_calls_per_step": {n: v[1] // psteps for n, v in prof.items()},
             "kernel_roofline": kernel_rooflines(prof, work, "float32", MF.gemm_mode())}
 
 
@@ -285,25 +362,15 @@ def secondary_c4_rank_leg(dev, D, MF, InfoNCE, MADELEINE, world=8, steps=4, warm
         opt.step()
         return loss
 
-    for _ in range(warmup):
-        step()
-    torch.cuda.synchronize()
-    MF.TIMER = MF.KernelTimer()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = step()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    prof = MF.TIMER.report()
-    MF.TIMER = None
-    got_ms = sum(prof[k][0] * prof[k][1] / steps for k in ("got_fwd", "got_bwd", "got_bwd_finish") if k in prof)
+    el, loss, prof, _work, psteps = measure_leg(MF, step, steps, warmup)
+    got_ms = sum(prof[k][0] * prof[k][1] / psteps for k in ("got_fwd", "got_bwd", "got_bwd_finish") if k in prof)
     return {"ms_per_step": round(1e3 * el / steps, 3), "steps": steps, "emulated_world": world,
             "workload": f"one rank of c4: {B} local slides x {M} stains x {N} x {Dm}; global batch {world * B} emulated: cases per stain "
                         f"{k_g} -> GOT token count n = min(k_global, 256) = {[min(k, 256) for k in k_g]}, replicated InfoNCE over "
                         f"k_global rows; no collective",
             "final_loss": float(loss.detach()), "got_ms_per_step_sum_over_stains": round(got_ms, 3),
             "kernel_ms": {n: round(v[0], 4) for n, v in prof.items()},
-            "kernel_calls_per_step": {n: v[1] // steps for n, v in prof.items()}}
+            "kernel_calls_per_step": {n: v[1] // psteps for n, v in prof.items()}}
 
 
 def secondary_inference_leg(dev, MF, MADELEINE, n_patches=30000, bags=20):
@@ -317,14 +384,16 @@ def secondary_inference_leg(dev, MF, MADELEINE, n_patches=30000, bags=20):
         for _ in range(3):
             model.encode_he(bag, dev)
         torch.cuda.synchronize()
-        MF.TIMER = MF.KernelTimer()
         t0 = time.perf_counter()
         for _ in range(bags):
             model.encode_he(bag, dev)
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
-    prof = MF.TIMER.report()
-    MF.TIMER = None
+        MF.TIMER = MF.KernelTimer()
+        for _ in range(5):
+            model.encode_he(bag, dev)
+        prof = MF.TIMER.report()
+        MF.TIMER = None
     out = {"value": round(bags / el, 2), "unit": "bags/s", "ms_per_bag": round(1e3 * el / bags, 3), "patches_per_bag": n_patches,
            "patches_per_sec": round(bags * n_patches / el), "workload": "encode_he, batch 1, fp32, no_grad",
            "kernel_ms": {n: round(v[0], 4) for n, v in prof.items()}}
@@ -465,7 +534,10 @@ def main():
     for _ in range(a.warmup):
         step()
     fence()
-    MF.TIMER = None if os.environ.get("BENCH_NO_TIMER") else MF.KernelTimer()
+    # THE timed region: K steps, barrier + synchronize on both sides.  Only the A3 forward (the roofline kernel) carries HIP events here
+    # -- one pair per step on the launch stream; the fused backward runs as its single call.  Every other per-kernel figure comes from
+    # the short profiled pass below, outside the timed region.
+    MF.TIMER = None if os.environ.get("BENCH_NO_TIMER") else MF.KernelTimer(only=("pool_fwd",))
     dev_allocs0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -473,26 +545,35 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     dev_allocs = torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - dev_allocs0   # hipMalloc calls inside the timed region (0 = steady state)
-    prof = MF.TIMER.report() if MF.TIMER is not None else {}
-    work = MF.TIMER.work() if MF.TIMER is not None else {}
+    prof_pool = MF.TIMER.report() if MF.TIMER is not None else {}
     MF.TIMER = None
+    # profiled pass (not part of `value`): every C-ABI launch between HIP events, the fused backward in its two phases
+    prof, work, prof_steps, profiled_ms = {}, {}, max(3, min(5, a.steps)), None
+    if not os.environ.get("BENCH_NO_TIMER"):
+        MF.TIMER = MF.KernelTimer()
+        tp = time.perf_counter()
+        for _ in range(prof_steps):
+            step()
+        fence()
+        profiled_ms = 1e3 * (time.perf_counter() - tp) / prof_steps
+        prof, work = MF.TIMER.report(), MF.TIMER.work()
+        MF.TIMER = None
+        if "pool_fwd" in prof_pool:
+            prof["pool_fwd"] = prof_pool["pool_fwd"]      # the roofline kernel: events of the timed region itself
+    # socket power / shader clock over the same step loop (hwmon reads from a sampling thread; outside the timed region)
+    power = None
+    if world == 1 and not dist_on and host_iter is None and not a.no_extra_legs:
+        with PowerSampler() as ps:
+            for _ in range(max(40, a.steps)):
+                step()
+            fence()
+        power = ps.summary()
     final_loss = float(loss.detach())
     bf16_leg = None
     if a.precision == "float32" and world == 1 and not a.no_bf16_leg and host_iter is None:
         # short secondary measurement of the bf16 mode (same model, same batch); reported beside, never as, `value`
-        for _ in range(2):
-            step(True)
-        fence()
-        MF.TIMER = MF.KernelTimer()
         nb = max(3, min(10, a.steps))
-        tb = time.perf_counter()
-        for _ in range(nb):
-            lb = step(True)
-        fence()
-        eb = time.perf_counter() - tb
-        pb = MF.TIMER.report()
-        wb = MF.TIMER.work()
-        MF.TIMER = None
+        eb, lb, pb, wb, _ = measure_leg(MF, lambda: step(True), nb)
         bf16_leg = {"value": round(B * nb / eb, 3), "unit": "slides/s", "ms_per_step": round(1e3 * eb / nb, 3), "steps": nb,
                     "dtype": "bf16 activation storage + v_mfma_f32_32x32x16_bf16, fp32 accumulate/epilogues/params "
                              "(torch.autocast(bfloat16), the reference's `precision: bfloat16`)",
@@ -503,18 +584,8 @@ def main():
         # the same step with every contraction on the exact-fp32 matrix-core kernels (v_mfma_f32_32x32x2_f32): the 'fp32' GEMM mode
         MF.set_gemm_mode("fp32")
         try:
-            for _ in range(2):
-                step()
-            fence()
-            MF.TIMER = MF.KernelTimer()
             nf = max(3, min(10, a.steps))
-            tf0 = time.perf_counter()
-            for _ in range(nf):
-                lf = step()
-            fence()
-            ef = time.perf_counter() - tf0
-            pf, wf = MF.TIMER.report(), MF.TIMER.work()
-            MF.TIMER = None
+            ef, lf, pf, wf, _ = measure_leg(MF, step, nf)
             f32_leg = {"value": round(B * nf / ef, 3), "unit": "slides/s", "ms_per_step": round(1e3 * ef / nf, 3), "steps": nf,
                        "dtype": "f32 on v_mfma_f32_32x32x2_f32 (MADELEINE_GEMM=fp32): the round-1/2 engine, 157.3 TFLOP/s peak",
                        "final_loss": float(lf.detach()), "kernel_ms": {k: round(v[0], 4) for k, v in pf.items()},
@@ -522,6 +593,38 @@ def main():
         finally:
             MF.TIMER = None
             MF.set_gemm_mode("split")
+    # PCIe-inclusive leg ("a second number including pinned-host H2D"): the same step fed from HOST memory -- pinned
+    # batches, as DataLoader(pin_memory=True) delivers them -- through data.DevicePrefetcher (side-stream H2D two batches ahead,
+    # the step waits on the upload event only).  Never `value`.
+    host_leg = None
+    if a.precision == "float32" and world == 1 and not dist_on and not a.no_extra_legs and host_iter is None and not ragged:
+        from madeleine_amd.data import DevicePrefetcher
+        pool = [torch.randn(B, M, N, Dm).pin_memory() for _ in range(3)]
+
+        def pinned_batches():
+            i = 0
+            while True:
+                yield {"feats": pool[i % 3], "modality_labels": labels}
+                i += 1
+        it = iter(DevicePrefetcher(pinned_batches(), dev, depth=2))
+        keep = data
+
+        def host_step():
+            nonlocal data
+            data = next(it)
+            return step()
+        try:
+            nh = max(5, min(10, a.steps))
+            eh, lh, _ph, _wh, _ = measure_leg(MF, host_step, nh, warmup=3, prof_steps=0)
+            mb = B * M * N * Dm * 4 / 2 ** 20
+            host_leg = {"value": round(B * nh / eh, 3), "unit": "slides/s", "ms_per_step": round(1e3 * eh / nh, 3), "steps": nh,
+                        "source": "pinned host batches (%.0f MiB of fp32 features per step) -> DevicePrefetcher: H2D on a side stream, depth 2; "
+                                  "PCIe-inclusive, never `value`" % mb,
+                        "h2d_GBs_needed_at_this_rate": round(mb * 2 ** 20 * nh / eh / 1e9, 1)}
+        finally:
+            it.close()
+            data = keep
+            del pool
     if host_iter is not None:
         host_iter.close()   # stops and joins the stager thread
 
@@ -625,9 +728,16 @@ def main():
                                                    "achieved_GBs": round(dz_bytes / (msz * 1e-3) / 1e9, 1),
                                                    "frac": round(dz_bytes / (msz * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         out["kernel_ms"] = {k: round(v[0], 4) for k, v in prof.items()}
-        out["kernel_calls_per_step"] = {k: v[1] // a.steps for k, v in prof.items()}
+        out["kernel_calls_per_step"] = {k: v[1] // (a.steps if k == "pool_fwd" and prof_pool else prof_steps) for k, v in prof.items()}
+        out["kernel_ms_source"] = ("pool_fwd: HIP events inside the timed region (one pair per step); all other kernels: a separate profiled "
+                                   "pass of %d steps after it (%s ms/step with per-launch events and the backward in two phases)"
+                                   % (prof_steps, "n/a" if profiled_ms is None else "%.3f" % profiled_ms))
+        if power is not None:
+            out["power_clock"] = power
         out["kernel_roofline"] = kernel_rooflines(prof, work, a.precision, MF.gemm_mode())
         out["config"]["gemm_mode"] = MF.gemm_mode() if a.precision == "float32" else "bf16"
+        if host_leg is not None:
+            out["host_input_mode"] = host_leg
         if bf16_leg is not None:
             out["bf16_mode"] = bf16_leg
         if f32_leg is not None:
@@ -643,6 +753,17 @@ def main():
                 nb = min(a.cpu_sample, B)
                 out["cpu_baseline"] = cpu_baseline(nb, M, N, Dm, use_got, steps=1 if nb >= 16 else 2)
                 out["cpu_baseline"]["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+                if a.config == "c2" and not a.no_extra_legs:
+                    # SURVEY 8(d) context entries beside the train-mode C2 step (never the baseline `value` is compared with):
+                    # the same step with dropout off (bounded sample) and the reference's own CPU-runnable config 1
+                    extra = {}
+                    try:
+                        extra["c2_dropout_off"] = cpu_baseline(min(8, B), M, N, Dm, use_got, steps=1, train=False)
+                        c1 = CONFIGS["c1"]
+                        extra["c1_train"] = cpu_baseline(c1[0], c1[1], c1[2], c1[3], c1[4], steps=3, train=True)
+                    except Exception as e:  # context only
+                        extra["error"] = "%s: %s" % (type(e).__name__, e)
+                    out["cpu_baseline"]["variants"] = extra
             except Exception as e:  # never lose the GPU line because the host box is short on RAM: fall back to a 4-slide sample
                 try:
                     out["cpu_baseline"] = cpu_baseline(min(4, B), M, N, Dm, use_got)

@@ -150,16 +150,18 @@ class DevicePrefetcher:
             present = batch['modality_labels'].reshape(-1) != 0
             if not bool(present.all()):
                 rows = present.nonzero(as_tuple=True)[0]
-        if len(self._pinned) <= slot or self._pinned[slot].shape != feats.shape:
+        direct = rows is None and feats.is_pinned()        # a DataLoader(pin_memory=True) batch: uploaded from where it lies
+        if not direct and (len(self._pinned) <= slot or self._pinned[slot] is None or self._pinned[slot].shape != feats.shape):
             buf = torch.empty(feats.shape, dtype=feats.dtype, pin_memory=True)   # sized for a full batch; compact uploads use a prefix
-            if len(self._pinned) <= slot:
-                self._pinned.append(buf)
-            else:
-                self._pinned[slot] = buf
-        pin = self._pinned[slot]
+            while len(self._pinned) <= slot:
+                self._pinned.append(None)
+            self._pinned[slot] = buf
+        pin = feats if direct else self._pinned[slot]
         if slot in self._busy:
             self._busy.pop(slot).synchronize()             # the ring slot's previous upload must have finished
-        if rows is None:
+        if direct:
+            pass
+        elif rows is None:
             pin.copy_(feats)                               # host memcpy into the pinned ring slot
         else:
             flat = feats.reshape(-1, feats.shape[2], feats.shape[3])

@@ -57,9 +57,15 @@ class KernelTimer:
     A call may declare its algorithmic work -- ("flop", n) for the matrix-core contractions, ("byte", n) for the HBM-bound
     passes -- so that bench.py can print achieved TFLOP/s / GB/s per kernel family (work())."""
 
-    def __init__(self):
+    def __init__(self, only=None):
+        """only: names to time (None = every call).  bench.py's headline region times the A3 forward alone -- one event pair per
+        step -- so that the fused backward runs as ONE call and no per-launch events sit in the measured step."""
         self.pairs = {}
         self.works = {}
+        self.only = None if only is None else frozenset(only)
+
+    def wants(self, name) -> bool:
+        return self.only is None or name in self.only
 
     def start(self, name, work=None):
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -89,7 +95,7 @@ class _timed:
         self.name, self.work = name, work
 
     def __enter__(self):
-        self.ev = TIMER.start(self.name, self.work) if TIMER is not None else None
+        self.ev = TIMER.start(self.name, self.work) if TIMER is not None and TIMER.wants(self.name) else None
 
     def __exit__(self, *exc):
         if self.ev is not None:
@@ -164,7 +170,7 @@ def attnpool_bwd_split_raw(Ei, Wa, Wb, wc, act_a, act_b, d_scores, dE, p_drop, s
                                               _ptr(stat_m), _ptr(stat_l), _ptr(d_pooled), _ptr(row_bag), int(N), _ptr(dE_absmax), _ptr(ws),
                                               _stream(), phases)
         _native.check(rc, "mdl_abmil_attnpool_bwd_split")
-    if TIMER is not None:
+    if TIMER is not None and TIMER.wants("gate_bwd_dz"):
         with _timed("gate_bwd_dz", ("byte", float(T) * H * 4 * HID * 4)):
             call(1)
         with _timed("gate_bwd_gemm", ("flop", 4.0 * T * H * HID * 2 * HID)):
@@ -209,7 +215,7 @@ def attnpool_bwd_raw(E2d, Wa, Wb, wc, act_a, act_b, d_scores, dE, p_drop, seed, 
     args = (_ptr(E2d), E2d.stride(0), _ptr(Wa), _ptr(Wb), _ptr(wc), _ptr(act_a), _ptr(act_b), _ptr(d_scores), _ptr(dE), int(accumulate), _ptr(dWa),
             _ptr(dWb), _ptr(dba), _ptr(dbb), _ptr(dwc), _ptr(dbc), T, H, float(p_drop), int(seed), _ptr(keep_a), _ptr(keep_b),
             _ptr(scores), _ptr(stat_m), _ptr(stat_l), _ptr(d_pooled), _ptr(row_bag), int(N), _ptr(ws), _stream())
-    if TIMER is not None:
+    if TIMER is not None and TIMER.wants("gate_bwd_dz"):
         # profiling: the HBM-bound dz pass and the MFMA-bound contractions as two calls on the same workspace, timed separately
         # ("gate_bwd" stays their sum in KernelTimer.report)
         fn = getattr(lib, "mdl_abmil_attnpool_bwd_phases" + sfx)

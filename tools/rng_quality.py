@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Statistical check of the dropout counter hash (csrc/common.hpp:mix32) and of cheaper candidates, on the CPU: the 16-bit halves of
+h(idx ^ key) drive two Bernoulli draws per gate element.  Reports keep rate, lag correlations of the keep masks, a-vs-b correlation,
+bucket chi-square, and mask independence across keys."""
+import numpy as np
+
+M32 = np.uint64(0xFFFFFFFF)
+
+
+def lowbias32(x):
+    x = x.astype(np.uint64)
+    x ^= x >> np.uint64(16); x = (x * np.uint64(0x7feb352d)) & M32
+    x ^= x >> np.uint64(15); x = (x * np.uint64(0x846ca68b)) & M32
+    x ^= x >> np.uint64(16)
+    return x.astype(np.uint32)
+
+
+def mul24(x, k):
+    return ((x & np.uint64(0xFFFFFF)) * np.uint64(k & 0xFFFFFF)) & M32
+
+
+def mix24(x, k1=0x7feb35, k2=0x6ca68b, s=15):
+    x = x.astype(np.uint64)
+    x ^= x >> np.uint64(16); x = mul24(x, k1)
+    x ^= x >> np.uint64(s); x = mul24(x, k2)
+    x ^= x >> np.uint64(16)
+    return x.astype(np.uint32)
+
+
+def mix24c(x, k1=0xD35A2D, k2=0x9E3779, k3=0):
+    """three folds, two 24-bit multiplies, final fold with a 24-bit-safe shift"""
+    x = x.astype(np.uint64)
+    x ^= x >> np.uint64(16); x = mul24(x, k1)
+    x ^= x >> np.uint64(13); x = mul24(x, k2)
+    x ^= x >> np.uint64(16)
+    return x.astype(np.uint32)
+
+
+def report(name, f, n=1 << 22):
+    idx = np.arange(n, dtype=np.uint64)
+    out = {}
+    for key in (0x12345678, 0x9abcdef1, 0):
+        h = f((idx ^ np.uint64(key)) & M32)
+        a, b = (h & 0xFFFF).astype(np.int64), (h >> 16).astype(np.int64)
+        for p in (0.25, 0.1):
+            thr = int(p * 65536 + 0.5)
+            ka, kb = (a >= thr).astype(np.float64), (b >= thr).astype(np.float64)
+            out.setdefault("rate", []).append((ka.mean() - (1 - p), kb.mean() - (1 - p)))
+            za, zb = ka - ka.mean(), kb - kb.mean()
+            cors = [abs(float((za[:-l] * za[l:]).mean() / za.var())) for l in (1, 2, 3, 4, 7, 8, 16, 512, 2048, 4096)]
+            corsb = [abs(float((zb[:-l] * zb[l:]).mean() / zb.var())) for l in (1, 2, 3, 4, 7, 8, 16, 512, 2048, 4096)]
+            out.setdefault("lagmax", []).append(max(cors + corsb))
+            out.setdefault("ab", []).append(abs(float((za * zb).mean() / np.sqrt(za.var() * zb.var()))))
+        cnt = np.bincount((a >> 8).astype(np.int64), minlength=256) + np.bincount((b >> 8).astype(np.int64), minlength=256)
+        e = 2 * n / 256
+        out.setdefault("chi2", []).append(float(((cnt - e) ** 2 / e).sum()))
+        # 2-D pattern: (token row, column) grid 2048 wide: row/column means of the keep mask
+        k2 = (a >= 16384).reshape(-1, 2048).astype(np.float64)
+        out.setdefault("rowdev", []).append(float(np.abs(k2.mean(1) - 0.75).max()))
+        out.setdefault("coldev", []).append(float(np.abs(k2.mean(0) - 0.75).max()))
+    h1, h2 = f((idx ^ np.uint64(0x1111)) & M32), f((idx ^ np.uint64(0x1112)) & M32)
+    m1, m2 = ((h1 & 0xFFFF) >= 16384).astype(np.float64), ((h2 & 0xFFFF) >= 16384).astype(np.float64)
+    key_cor = abs(float(((m1 - m1.mean()) * (m2 - m2.mean())).mean() / np.sqrt(m1.var() * m2.var())))
+    sig = 1 / np.sqrt(n)
+    print(f"{name:10s} max|rate err| {max(abs(v) for t in out['rate'] for v in t):.2e} (sigma {0.43 * sig:.1e})  max lag corr {max(out['lagmax']):.2e} "
+          f"(sigma {sig:.1e})  a-b corr {max(out['ab']):.2e}  chi2/255 {max(out['chi2']) / 255:.2f}  row dev {max(out['rowdev']):.3f} col dev "
+          f"{max(out['coldev']):.3f}  adjacent-key corr {key_cor:.2e}")
+
+
+if __name__ == "__main__":
+    report("lowbias32", lowbias32)
+    report("mix24", mix24)
+    report("mix24c", mix24c)
+    report("mix24_s13", lambda x: mix24(x, s=13))
