@@ -23,7 +23,6 @@ import sys
 import time
 from types import SimpleNamespace
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before the HIP runtime starts: one hardware queue per GOT stream (madeleine_amd/__init__.py)
 
 import torch  # noqa: E402
 
@@ -135,15 +134,34 @@ class PowerSampler:
         import glob
         self.period = period_s
         self.power = self.freq = self.cap = None
+        # the hwmon directory of the device HIP runs on (a host can hold many amdgpu cards): match its PCI address
+        want = None
+        try:
+            pr = torch.cuda.get_device_properties(torch.cuda.current_device())
+            want = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        except Exception:  # noqa: BLE001
+            pass
+        cands = []
         for d in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
             for name in ("power1_input", "power1_average"):
                 if os.path.exists(os.path.join(d, name)) and os.path.exists(os.path.join(d, "freq1_input")):
-                    self.power, self.freq = os.path.join(d, name), os.path.join(d, "freq1_input")
-                    cap = os.path.join(d, "power1_cap")
-                    self.cap = cap if os.path.exists(cap) else None
+                    addr = os.path.basename(os.path.realpath(os.path.join(d, "..", "..")))
+                    cands.append((addr, d, name))
                     break
-            if self.power:
-                break
+        pick = [c for c in cands if want and c[0].startswith(want)]
+        self.matched_by = "pci address %s" % want if pick else ("highest power reading" if cands else None)
+        if not pick and cands:   # fall back to the card that draws the most power right now (the caller is running a step loop)
+            def rd(c):
+                try:
+                    return self._read(os.path.join(c[1], c[2]))
+                except (OSError, ValueError):
+                    return -1.0
+            pick = [max(cands, key=rd)]
+        if pick:
+            _, d, name = pick[0]
+            self.power, self.freq = os.path.join(d, name), os.path.join(d, "freq1_input")
+            cap = os.path.join(d, "power1_cap")
+            self.cap = cap if os.path.exists(cap) else None
         self.samples = []
         self._stop = None
 
@@ -182,7 +200,8 @@ class PowerSampler:
         xs = [x for x in self.samples if x[0] - t0 >= skip_s] or self.samples
         pw, fq = sorted(x[1] for x in xs), sorted(x[2] for x in xs)
         med = lambda v: v[len(v) // 2]   # noqa: E731
-        out = {"source": "amdgpu hwmon (%s, freq1_input), %d samples at %.0f ms over the step loop" % (os.path.basename(self.power), len(xs), 1e3 * self.period),
+        out = {"source": "amdgpu hwmon (%s, freq1_input; card matched by %s), %d samples at %.0f ms over the step loop" % (
+                   os.path.basename(self.power), self.matched_by, len(xs), 1e3 * self.period),
                "socket_power_W": {"median": round(med(pw), 1), "min": round(pw[0], 1), "max": round(pw[-1], 1)},
                "sclk_MHz": {"median": round(med(fq)), "min": round(fq[0]), "max": round(fq[-1])}}
         if self.cap:
@@ -345,7 +364,7 @@ def secondary_c4_rank_leg(dev, D, MF, InfoNCE, MADELEINE, world=8, steps=4, warm
         problems = []
         for s_idx, stain in enumerate(mods[1:]):
             n = min(k_g[s_idx], 256)
-            rows = labels[:, 1 + s_idx].bool().nonzero(as_tuple=True)[0].to(dev)
+            rows = MF.h2d(labels[:, 1 + s_idx].bool().nonzero(as_tuple=True)[0], dev)
             problems.append((toks["HE"][:, :n, :, s_idx].index_select(0, rows).float().contiguous(),
                              toks[stain][:, :n].index_select(0, rows).float().contiguous()))
         ext = D.got_local_extrema(problems, MF.HipGotImpl)      # "gathered" extrema: this rank's own stand in for the global ones
@@ -564,10 +583,10 @@ def main():
     power = None
     if world == 1 and not dist_on and host_iter is None and not a.no_extra_legs:
         with PowerSampler() as ps:
-            for _ in range(max(40, a.steps)):
+            for _ in range(max(120, a.steps)):   # ~3 s: the hwmon averages update a few times per second
                 step()
             fence()
-        power = ps.summary()
+        power = ps.summary(skip_s=1.0)
     final_loss = float(loss.detach())
     bf16_leg = None
     if a.precision == "float32" and world == 1 and not a.no_bf16_leg and host_iter is None:

@@ -10,15 +10,7 @@ The numeric work runs in csrc/libmadeleine_amd.so through the C ABI of include/m
 Importing this package does not load the library (so model construction / state_dict handling works on
 any box); the first forward does, and raises if it is unavailable -- there is no fallback path.
 """
-import os as _os
-
-# The per-stain GOT chains run on one HIP stream each (distributed._fan_out).  ROCm maps streams onto GPU_MAX_HW_QUEUES hardware queues
-# (default 4, one of them the main stream's): with 5 stains the side streams share queues and serialise -- 14.2 ms for the four GOT
-# problems of a config-4 rank against 10.2 ms with 8 queues (tools/exp_got_overlap.py).  Read by the HIP runtime when it initialises, so
-# this only takes effect if the package is imported before the first device call; an explicit setting of the user wins.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
-from .abmil import BatchedABMIL  # noqa: E402
+from .abmil import BatchedABMIL
 from .loss import GOT, InfoNCE, info_nce, init_intra_wsi_loss_function
 from .model import ABMILEmbedder, MADELEINE, create_model
 from .trainer import calculate_losses, train_loop

@@ -270,14 +270,16 @@ def gather_packed(wsi_embs: Dict[str, torch.Tensor], modalities: Sequence[str], 
     Gradients flow to the embedding part only (own slice x W, no collective in backward)."""
     W = world_size(group)
     if not collectives_on():
-        return wsi_embs, labels_local.to(wsi_embs["HE"].device), None if extrema_local is None else extrema_local.unsqueeze(0)
+        from .functional import h2d
+        return wsi_embs, h2d(labels_local, wsi_embs["HE"].device), None if extrema_local is None else extrema_local.unsqueeze(0)
     emb, geom = _pack_embeddings(wsi_embs, modalities)
     dev, dt = emb.device, emb.dtype
     if extrema_local is not None and dt not in (torch.float32, torch.float64):
         # the thresholds travel in the embedding payload: a narrower dtype would round them away from the local cost extrema
         # the GOT backward routes their gradient by
         raise TypeError("gather_packed: slide embeddings must be float32 / float64 when GOT extrema are packed (got %s)" % dt)
-    lab = labels_local.to(device=dev, dtype=dt).reshape(-1)
+    from .functional import h2d
+    lab = h2d(labels_local, dev, dt).reshape(-1)
     ext = extrema_local.to(dt).reshape(-1) if extrema_local is not None else emb.new_zeros(0)
     payload = torch.cat([emb, lab, ext]).unsqueeze(0)                               # [1, P]
     full = all_gather_replicated(payload, group)                                    # [W, P]
@@ -303,12 +305,16 @@ _SIDE_STREAMS = {}
 
 
 class _fan_out:
-    """Run independent launches on side HIP streams and join them back into the current stream:
+    """Run independent launches concurrently and join them back into the current stream:
         with _fan_out(device, n) as lanes:
             with lanes(i): launch_i()
-    Each lane first waits for the work already queued on the current stream; on exit the current stream waits for
-    every lane.  Tensors allocated inside a lane are only consumed after the join (same allocator stream semantics
-    as torch.cuda.stream + wait_stream).  On CPU tensors (gloo tests) it is a no-op."""
+    Lane 0 IS the current stream; lanes 1 .. n-1 are side HIP streams that first wait for the work already queued on the current
+    stream; on exit the current stream waits for every side lane.  n lanes = n streams in total: with the four stains of the reference's
+    datasets that is 4 streams on ROCm's default 4 hardware queues (GPU_MAX_HW_QUEUES) -- one queue per chain.  (Round 3 used n side
+    streams + the main one and raised GPU_MAX_HW_QUEUES to 8; with 8 queues a host that runs ahead of the device pays for it: every
+    small kernel behind pending queues takes 3-4x as long -- +8 ms per config-3 step, +4 ms under DDP; profiles/r04_hw_queues_*.txt.)
+    Tensors allocated inside a lane are only consumed after the join (same allocator stream semantics as torch.cuda.stream +
+    wait_stream).  On CPU tensors (gloo tests) it is a no-op."""
 
     def __init__(self, device, n):
         self.on = torch.device(device).type == "cuda" and n > 1
@@ -318,19 +324,22 @@ class _fan_out:
         if self.on:
             key = (str(self.device), self.n)
             if key not in _SIDE_STREAMS:
-                _SIDE_STREAMS[key] = [torch.cuda.Stream(device=self.device) for _ in range(self.n)]
+                _SIDE_STREAMS[key] = [torch.cuda.Stream(device=self.device) for _ in range(self.n - 1)]
             self.streams = _SIDE_STREAMS[key]
             self.main = torch.cuda.current_stream(self.device)
             self.used = set()
+            # the side lanes depend on what the current stream held BEFORE the fan-out, not on lane 0's own launches
+            self.start = torch.cuda.Event()
+            self.start.record(self.main)
         return self._lane
 
     def _lane(self, i):
         import contextlib
-        if not self.on:
+        if not self.on or i == 0:
             return contextlib.nullcontext()
-        st = self.streams[i]
-        st.wait_stream(self.main)
-        self.used.add(i)
+        st = self.streams[i - 1]
+        st.wait_event(self.start)
+        self.used.add(i - 1)
         return torch.cuda.stream(st)
 
     def __exit__(self, *exc):
@@ -354,8 +363,16 @@ def got_local_extrema(problems, impl=None) -> torch.Tensor:
     dev, dt = problems[0][0].device, problems[0][0].dtype
     # (on the caller's stream: fanning these small cost-matrix passes out over the per-stain streams saved 0.2 ms in the four-stain lab
     # and cost 6.5 ms per config-3 step -- their workspaces then come from the side streams' allocator pools)
-    return torch.stack([impl.extrema(V.contiguous(), Q.contiguous()) if V.shape[0] > 0 else
-                        torch.tensor([inf, -inf] * 3, device=dev, dtype=dt) for V, Q in problems])
+    empty = None
+    out = []
+    for V, Q in problems:
+        if V.shape[0] > 0:
+            out.append(impl.extrema(V.contiguous(), Q.contiguous()))
+        else:
+            if empty is None:   # (min, max) x 3 = (+inf, -inf) x 3, built on the device: a host constant would be a blocking copy
+                empty = torch.stack([torch.full((3,), inf, device=dev, dtype=dt), torch.full((3,), -inf, device=dev, dtype=dt)], dim=1).reshape(6)
+            out.append(empty)
+    return torch.stack(out)
 
 
 class _GOTMulti(torch.autograd.Function):
@@ -452,6 +469,7 @@ def calculate_losses_dp(STAINS, loss_fn_interMod, got_impl, wsi_embs, token_embs
     replicated global InfoNCE (+ intra-modality terms) plus W x (this rank's GOT sum); averaged over ranks its gradient
     equals the single-process global-batch gradient of  sum_stains [InfoNCE + w * GOT]  (SURVEY.md section 8(e)).
     One data-path collective in forward (gather_packed) and one [S,6] all-reduce in backward."""
+    from .functional import h2d
     from .trainer import calculate_losses
     W = world_size(group)
     dev = wsi_embs["HE"].device
@@ -486,7 +504,7 @@ def calculate_losses_dp(STAINS, loss_fn_interMod, got_impl, wsi_embs, token_embs
             if int(tok_idx.max()) >= token_embs["HE"].shape[1]:
                 raise ValueError("GOT sub-samples token indices randperm(k)[:%d] with k = %d participating cases, but the bags "
                                  "carry only %d tokens (reference quirk, loss.py:282)" % (subsample, k_g, token_embs["HE"].shape[1]))
-            rows = labels_l[:, s_idx].bool().nonzero(as_tuple=True)[0].to(dev, non_blocking=True)
+            rows = h2d(labels_l[:, s_idx].bool().nonzero(as_tuple=True)[0], dev)
             if first_local < 0:
                 first_local, he_shared = s_idx, _shared_he_tokens(token_embs["HE"])
             he = he_shared if he_shared is not None else token_embs["HE"][:, :, :, s_idx]
@@ -496,7 +514,7 @@ def calculate_losses_dp(STAINS, loss_fn_interMod, got_impl, wsi_embs, token_embs
             if k_g <= subsample:
                 he, st = he[:, :k_g], st[:, :k_g]
             else:
-                tok_idx = tok_idx.to(dev, non_blocking=True)
+                tok_idx = h2d(tok_idx, dev)
                 he, st = he.index_select(1, tok_idx), st.index_select(1, tok_idx)
             he, st = he.index_select(0, rows), st.index_select(0, rows)
             problems.append((he if he.dtype == torch.float64 else he.float(), st if st.dtype == torch.float64 else st.float()))

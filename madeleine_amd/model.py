@@ -284,7 +284,7 @@ class ABMILEmbedder(nn.Module):
             all_indices = np.arange(E.shape[1])
             np.random.shuffle(all_indices)
             mid = len(all_indices) // 2
-            views = tuple(torch.as_tensor(idx, dtype=torch.int32).to(E.device) for idx in (all_indices[:mid], all_indices[mid:]))
+            views = tuple(MF.h2d(torch.as_tensor(idx, dtype=torch.int32), E.device) for idx in (all_indices[:mid], all_indices[mid:]))
             pooled, scores = self.pool_headmajor(E, views, e_img=e_img)
             return pooled, E, scores
         if act == 'softmax':
@@ -304,7 +304,7 @@ class ABMILEmbedder(nn.Module):
         mid = len(all_indices) // 2
         views = [pooled.unsqueeze(1)]
         for idx in (all_indices[:mid], all_indices[mid:]):
-            ti = torch.as_tensor(idx, device=E.device, dtype=torch.long)
+            ti = MF.h2d(torch.as_tensor(idx, dtype=torch.long), E.device)
             views.append(MF.softmax_pool(E.index_select(1, ti), scores.index_select(1, ti).contiguous()).unsqueeze(1))
         return torch.cat(views, dim=1), E, scores
 
@@ -430,11 +430,11 @@ class MADELEINE(nn.Module):
             row_stain = torch.arange(bs * n_mod) // bs                          # the train-branch quirk
             # one embedding row per BAG, broadcast to its tokens by a gather: an embedding lookup per token makes the backward sort
             # 1.4 M indices per config-5 step (9 ms); the gather's backward is one index_add over [T, 32]
-            bag_of_tok = torch.repeat_interleave(torch.arange(bs * n_mod), torch.tensor(lens)).to(device)
-            x = torch.cat([x, self.embedding(row_stain.to(device)).index_select(0, bag_of_tok).to(x.dtype)], dim=-1)
+            bag_of_tok = MF.h2d(torch.repeat_interleave(torch.arange(bs * n_mod), torch.tensor(lens)), device)
+            x = torch.cat([x, self.embedding(MF.h2d(row_stain, device)).index_select(0, bag_of_tok).to(x.dtype)], dim=-1)
         emb = self.wsi_embedders
-        cu_d = cu.to(device)
-        head = (cu[:-1].unsqueeze(1) + torch.arange(n_loss_tokens).unsqueeze(0)).reshape(-1).to(device)
+        cu_d = MF.h2d(cu, device)
+        head = MF.h2d((cu[:-1].unsqueeze(1) + torch.arange(n_loss_tokens).unsqueeze(0)).reshape(-1), device)
         tp = (emb.permuted(self.token_projector.weight, 1), self.token_projector.bias)
         # Split GEMM mode: the token projection is part of the pooling node (every token, on the image of E) and the head tokens are
         # gathered from ITS output -- gathering rows of E instead makes autograd fill a zero [T, 2048] tensor and add it to the node's dE
@@ -477,7 +477,7 @@ class MADELEINE(nn.Module):
                 compact, expand = self._absent_stain_plan(data['modality_labels'],
                                                           stain_of_row if self.stain_encoding else torch.zeros_like(stain_of_row))
                 if expand is not None:   # encode every present bag + ONE all-zero bag per distinct input among the absent ones
-                    x = x.index_select(0, compact.to(device))
+                    x = x.index_select(0, MF.h2d(compact, device))
                     stain_of_row = stain_of_row[compact]
             if self.stain_encoding:
                 x = self._cat_stain(x, stain_of_row)
@@ -486,7 +486,7 @@ class MADELEINE(nn.Module):
                 emb.permuted(self.token_projector.weight, 1), self.token_projector.bias))   # tok [rows,N,128]
             slide = self._project_slide(pooled.view(x.shape[0], -1, pooled.shape[-1]))  # [rows,V,512]
             if expand is not None:       # absent rows take the outputs of their all-zero representative
-                expand = expand.to(device)
+                expand = MF.h2d(expand, device)
                 tok, slide = tok.index_select(0, expand), slide.index_select(0, expand)
             tok = tok.view(bs, n_mod, n_tokens, -1)                                   # [B,M,N,128]
             slide = slide.view(bs, n_mod, -1, slide.shape[-1])

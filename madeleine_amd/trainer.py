@@ -17,6 +17,7 @@ import torch
 
 from .loss import GOT as _GOT
 
+from .functional import h2d
 from .loss import InfoNCE as _HipInfoNCE
 from .utils import set_model_precision, smooth_rank_measure
 
@@ -56,11 +57,11 @@ def _global_terms_batched(criterion, parts: List[_Participant], wsi_embs, symmet
     Q = he_all.new_zeros(len(parts), k_max, d)
     P = he_all.new_zeros(len(parts), k_max, d)
     for s, part in enumerate(parts):
-        rows = part.rows_cpu.to(dev, non_blocking=True)
+        rows = h2d(part.rows_cpu, dev)
         q, p = _pair(wsi_embs, part, rows, WHOLE_VIEW_POSITION)
         Q[s, :rows.numel()] = q
         P[s, :rows.numel()] = p
-    counts = torch.tensor([p.rows_cpu.numel() for p in parts], dtype=torch.int32).to(dev, non_blocking=True)
+    counts = h2d(torch.tensor([p.rows_cpu.numel() for p in parts], dtype=torch.int32), dev)
     per_problem = criterion.batched(Q, P, counts, symmetric=symmetric)
     return {part.column: per_problem[s] for s, part in enumerate(parts)}
 
@@ -81,7 +82,7 @@ def calculate_losses(STAINS, loss_fn_interMod, loss_fn_interMod_local, loss_fn_i
     dev = wsi_embs["HE"].device
     terms = []
     for part in parts:
-        rows = part.rows_cpu.to(dev, non_blocking=True)
+        rows = h2d(part.rows_cpu, dev)
         if loss_fn_interMod:                                     # global: slide-level InfoNCE, whole-bag view
             if precomputed is not None:
                 terms.append(precomputed[part.column])

@@ -12,7 +12,6 @@ import sys
 import time
 from types import SimpleNamespace
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import torch  # noqa: E402
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
