@@ -579,14 +579,6 @@ def main():
         MF.TIMER = None
         if "pool_fwd" in prof_pool:
             prof["pool_fwd"] = prof_pool["pool_fwd"]      # the roofline kernel: events of the timed region itself
-    # socket power / shader clock over the same step loop (hwmon reads from a sampling thread; outside the timed region)
-    power = None
-    if world == 1 and not dist_on and host_iter is None and not a.no_extra_legs:
-        with PowerSampler() as ps:
-            for _ in range(max(120, a.steps)):   # ~3 s: the hwmon averages update a few times per second
-                step()
-            fence()
-        power = ps.summary(skip_s=1.0)
     final_loss = float(loss.detach())
     bf16_leg = None
     if a.precision == "float32" and world == 1 and not a.no_bf16_leg and host_iter is None:
@@ -647,6 +639,15 @@ def main():
     if host_iter is not None:
         host_iter.close()   # stops and joins the stager thread
 
+    # socket power / shader clock over the same step loop (hwmon reads from a sampling thread; outside the timed region, after the
+    # secondary legs of this model so that ~3 s at the power cap do not precede any of them)
+    power = None
+    if world == 1 and not dist_on and host_iter is None and not a.no_extra_legs:
+        with PowerSampler() as ps:
+            for _ in range(max(120, a.steps)):   # ~3 s: the hwmon averages update a few times per second
+                step()
+            fence()
+        power = ps.summary(skip_s=1.0)
     c3_leg = infer_leg = c4_leg = None
     if a.config == "c2" and a.precision == "float32" and world == 1 and not a.no_extra_legs and host_iter is None:
         # free the c2 working set first (the c3 step keeps ~60 GiB live)

@@ -338,6 +338,18 @@ def gemm_mode() -> str:
     return GEMM_MODE
 
 
+# Activation recomputation for the fused A2 + A3 node (opt-in; MADELEINE_GATE_RECOMPUTE=1 or set_gate_recompute(True)): the gate forward
+# then saves NO tanh / sigmoid activations (2 x 8 KiB per token at H = 4: 4.3 GB per config-2 step, 10.7 GB at config 3) and the
+# backward runs the gate forward once more (same seed -> same dropout masks, same bits) to rebuild them -- memory for time
+# (+1 gate forward per step).  The default keeps the activations: with 288 GB of HBM the step's 60 GiB at config 3 fit many times over.
+GATE_RECOMPUTE = os.environ.get("MADELEINE_GATE_RECOMPUTE", "0") == "1"
+
+
+def set_gate_recompute(on: bool):
+    global GATE_RECOMPUTE
+    GATE_RECOMPUTE = bool(on)
+
+
 def set_gemm_mode(mode: str):
     """'split' (default): the fp32 contractions run as ah bh + ah bl + al bh on the fp16 matrix cores (fp32-level accuracy, ~2x the
     rate); 'fp32': the exact-fp32 matrix-core kernels (v_mfma_f32_32x32x2_f32)."""
@@ -803,12 +815,13 @@ class AttnPoolFn(torch.autograd.Function):
                              or (Wtok is not None and not split_linear_supported(E2d.shape[0], Wtok.shape[0], Wtok.shape[1]))):
             raise RuntimeError("attn_pool: an image-only E needs the split GEMM mode, no token views and a token projection the split "
                                "engine serves")
+        recompute = need and GATE_RECOMPUTE
         if _split_gate(E2d):
             # the image of E: written by the producing LayerNorm kernel (Eimg / Escale), else built here (3 passes over E)
             Ei = SplitImage(Eimg, Escale, E2d.shape[0], E2d.shape[1]) if Eimg is not None else split_image(E2d)
-            scores, act_a, act_b = gate_fwd_split_raw(Ei, Wa, ba, Wb, bb, wc, bc, p_drop, seed, keep_a, keep_b, need)
+            scores, act_a, act_b = gate_fwd_split_raw(Ei, Wa, ba, Wb, bb, wc, bc, p_drop, seed, keep_a, keep_b, need and not recompute)
         else:
-            scores, act_a, act_b = gate_fwd_raw(E2d, Wa, ba, Wb, bb, wc, bc, p_drop, seed, keep_a, keep_b, need)
+            scores, act_a, act_b = gate_fwd_raw(E2d, Wa, ba, Wb, bb, wc, bc, p_drop, seed, keep_a, keep_b, need and not recompute)
         pooled, m, l = (pool_fwd_img_raw(Ei, scores, n_bags, N, cu_seqlens, max_len) if e_only_image
                         else pool_fwd_raw(E2d, scores, n_bags, N, cu_seqlens, max_len))
         vstate = [pool_view_fwd_raw(E2d, scores, n_bags, N, v) for v in views]
@@ -829,9 +842,11 @@ class AttnPoolFn(torch.autograd.Function):
             flat = [t for st in vstate for t in st]
             none = torch.empty(0)
             # (the image of E travels as saved tensors like everything else: saved-tensor hooks, retain_graph and version checks apply)
-            ctx.save_for_backward(E2d, Wa, Wb, wc, act_a, act_b, scores, pooled, m, l,
+            ctx.save_for_backward(E2d, Wa, Wb, wc, act_a if not recompute else none, act_b if not recompute else none, scores, pooled, m, l,
                                   cu_seqlens if cu_seqlens is not None else none, Wtok if Wtok is not None else none,
-                                  Ei.data if Ei is not None else none, Ei.scale if Ei is not None else none, *views, *flat)
+                                  Ei.data if Ei is not None else none, Ei.scale if Ei is not None else none,
+                                  ba if recompute else none, bb if recompute else none, bc if recompute else none, *views, *flat)
+            ctx.recompute = recompute
             ctx.cfg = (p_drop, seed, keep_a, keep_b, n_bags, N, max_len, cu_seqlens is not None, E.shape, len(views),
                        Wtok is not None, btok is not None)
             ctx.e_only_image = bool(e_only_image)
@@ -844,9 +859,14 @@ class AttnPoolFn(torch.autograd.Function):
     def backward(ctx, d_pooled, d_scores_in, d_tok):
         p_drop, seed, keep_a, keep_b, n_bags, N, max_len, ragged, e_shape, V, has_tok, has_btok = ctx.cfg
         saved = ctx.saved_tensors
-        E2d, Wa, Wb, wc, act_a, act_b, scores, pooled, m, l, cu, Wtok, Eidata, Eiscale = saved[:14]
-        views, vflat = saved[14:14 + V], saved[14 + V:]
+        E2d, Wa, Wb, wc, act_a, act_b, scores, pooled, m, l, cu, Wtok, Eidata, Eiscale, ba, bb, bc = saved[:17]
+        views, vflat = saved[17:17 + V], saved[17 + V:]
         Ei = SplitImage(Eidata, Eiscale, E2d.shape[0], E2d.shape[1]) if ctx.has_image else None
+        if ctx.recompute:   # rebuild the activations: the same kernel, seed and masks as the forward -> the same bits
+            if Ei is not None:
+                _s, act_a, act_b = gate_fwd_split_raw(Ei, Wa, ba, Wb, bb, wc, bc, p_drop, seed, keep_a, keep_b, True)
+            else:
+                _s, act_a, act_b = gate_fwd_raw(E2d, Wa, ba, Wb, bb, wc, bc, p_drop, seed, keep_a, keep_b, True)
         cu = cu if ragged else None
         dE = torch.empty_like(E2d)
         if d_scores_in is not None:

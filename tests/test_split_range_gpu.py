@@ -355,3 +355,35 @@ def test_engine_precision_by_binades_below_the_scale(dev):
     C2 = MF.split_gemm_nt(Ai, MF.split_image(b.to(dev)), a_row_mul=row_inv).double().cpu()
     for k in range(M):
         assert float((C2[k] - ref[k]).abs().max() / ref[k].abs().max()) <= 2.0 ** -20, k
+
+
+def test_gate_activation_recompute_is_bit_identical(dev):
+    """Opt-in recomputation of the saved gate activations (functional.set_gate_recompute): nothing but E, the parameters and the
+    softmax statistics is kept by the fused A2 + A3 node; the backward re-runs the gate forward with the forward's seed.  Same bits
+    as the default path, dropout on, both GEMM modes."""
+    from madeleine_amd import functional as MF
+    E0 = (t((3, 500, 2048), "rng:rc:E") * 1.5)
+    w0 = _gate_weights(4, "rng:rc:gw")
+    dp = t((3, 2048), "rng:rc:dp").to(dev)
+    old = MF.gemm_mode()
+    try:
+        for mode in ("split", "fp32"):
+            MF.set_gemm_mode(mode)
+            res = []
+            for rc in (False, True):
+                MF.set_gate_recompute(rc)
+                E = E0.to(dev).requires_grad_()
+                w = [v.to(dev).requires_grad_() for v in w0]
+                torch.cuda.reset_peak_memory_stats()
+                base = torch.cuda.memory_allocated()
+                pooled, scores = MF.attn_pool(E, *w, p_drop=0.25, seed=1234)
+                held = torch.cuda.memory_allocated() - base
+                pooled.backward(dp)
+                res.append((pooled.detach().clone(), E.grad.clone(), [v.grad.clone() for v in w], held))
+            assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), mode
+            for a, b in zip(res[0][2], res[1][2]):
+                assert torch.equal(a, b), mode
+            assert res[1][3] < res[0][3] - 2 * 1500 * 4 * 512 * 4 * 0.9, (mode, res[0][3], res[1][3])   # the two activation tensors are gone
+    finally:
+        MF.set_gate_recompute(False)
+        MF.set_gemm_mode(old)

@@ -4,7 +4,9 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from madeleine_amd import functional as MF
 dev = torch.device("cuda:0")
-for (k, n) in ((32, 32), (32, 64), (32, 128), (32, 192), (32, 256)):
+import json
+GEOMS = json.loads(os.environ.get('GOT_GEOMS', '[[32,32],[32,64],[32,128],[32,192],[32,256]]'))
+for (k, n) in GEOMS:
     g = torch.Generator(device=dev).manual_seed(0)
     v = torch.randn(k, n, 128, device=dev, generator=g).requires_grad_()
     q = (torch.randn(k, n, 128, device=dev, generator=g) + 0.7 * v.detach()).requires_grad_()
