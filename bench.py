@@ -30,6 +30,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MODS5 = ["HE", "HER2", "PGR", "KI67", "ER"]
+# torch.optim.AdamW(params, lr) as the reference builds it (setup_components.py:196: betas, eps, weight_decay 0.01 = torch defaults), in
+# torch's single-kernel `fused` implementation: same update, one launch instead of ~8 multi-tensor launches (23.7 -> 23.1 ms per
+# config-2 step in a same-box A/B).  BENCH_FOREACH_ADAMW=1 selects torch's default (foreach) implementation.
+FUSED_ADAMW = not os.environ.get("BENCH_FOREACH_ADAMW")
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 F32_MFMA_PEAK_TF = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 
@@ -273,7 +277,7 @@ def secondary_c3_leg(dev, D, MF, InfoNCE, MADELEINE, steps=5, warmup=2):
     mods = MODS5[:M]
     torch.manual_seed(42)
     model = MADELEINE(make_cfg(M, Dm)).to(dev).train()
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, fused=FUSED_ADAMW)
     gen = torch.Generator(device=dev).manual_seed(1234)
     feats = torch.randn(B, M, N, Dm, device=dev, generator=gen)
     rates = torch.tensor([1.0, 0.46, 0.73, 0.73, 0.73])
@@ -344,7 +348,7 @@ def secondary_c4_rank_leg(dev, D, MF, InfoNCE, MADELEINE, world=8, steps=4, warm
     mods = MODS5[:M]
     torch.manual_seed(42)
     model = MADELEINE(make_cfg(M, Dm)).to(dev).train()
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, fused=FUSED_ADAMW)
     gen = torch.Generator(device=dev).manual_seed(1234)
     feats = torch.randn(B, M, N, Dm, device=dev, generator=gen)
     rates = torch.tensor([1.0, 0.46, 0.73, 0.73, 0.73])
@@ -487,7 +491,7 @@ def main():
             net = D.wrap_ddp(model, dev, use_local_loss=use_got)
         else:
             gsync = D.FlatGradSync(model, use_local_loss=use_got)
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, fused=FUSED_ADAMW)
     torch.manual_seed(1000 + rank)   # dropout seeds are drawn from torch's CPU generator: decorrelate the ranks
     crit = InfoNCE(temperature=0.001)
     got_impl = MF.HipGotImpl if use_got else None
@@ -687,7 +691,7 @@ def main():
                                    f"{'eval (dropout off)' if a.eval_mode else 'train mode (dropout on)'}, AdamW"
                                    f"{', absent-stain zero bags encoded once (N4)' if a.skip_absent else ''}",
                        "global_batch": B * world, "bags_per_sec": round(value * M, 2), "parallelism": f"dp{world}",
-                       "final_loss": final_loss,
+                       "final_loss": final_loss, "optimizer": "torch.optim.AdamW(lr=1e-4%s)" % (", fused=True" if FUSED_ADAMW else ""),
                        "device_allocs_in_timed_region": int(dev_allocs),
                        "collective_backend": (torch.distributed.get_backend() if dist_on else "none"),
                        "ranks_seen": (torch.distributed.get_world_size() if dist_on else 1),
