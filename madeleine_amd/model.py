@@ -334,6 +334,12 @@ class MADELEINE(nn.Module):
         else:
             self.stain_encoding_dim = 0
         if self.config.wsi_encoder == "abmil":
+            in_dim = self.config.patch_embedding_dim + self.stain_encoding_dim
+            if in_dim % 32:
+                # fail at construction with the reason, not at the first big bag with a kernel return code
+                raise ValueError("madeleine_amd: patch_embedding_dim%s must be a multiple of 32 (got %d): the encoder's Linears run on "
+                                 "hand-written HIP kernels (32-column blocks) and there is no library-GEMM fallback"
+                                 % (" + 32 stain-encoding channels" if self.stain_encoding else "", in_dim))
             pre_params = {'input_dim': self.config.patch_embedding_dim + self.stain_encoding_dim,
                           'hidden_dim': self.config.wsi_encoder_hidden_dim}
             attention_params = {'model': 'ABMIL',
@@ -360,7 +366,7 @@ class MADELEINE(nn.Module):
 
     def _cat_stain(self, feats, idx):
         """feats [R,N,D], idx LongTensor [R] -> cat([feats, embedding[idx] broadcast over N])."""
-        enc = self.embedding(idx.to(feats.device)).unsqueeze(1).expand(-1, feats.shape[1], -1)
+        enc = self.embedding(MF.h2d(idx, feats.device)).unsqueeze(1).expand(-1, feats.shape[1], -1)
         return torch.cat([feats, enc.to(feats.dtype)], dim=-1)
 
     @staticmethod
