@@ -70,11 +70,10 @@ __global__ __launch_bounds__(256, 2) void gate_fwd_bf16_kernel(const bf16_t* __r
                                                                const float* __restrict__ bb, const float* __restrict__ wc,
                                                                float* __restrict__ part, bf16_t* __restrict__ act_a,
                                                                bf16_t* __restrict__ act_b, int64_t T, int H, int n_ttiles,
-                                                               DropCfg drop, int stagger, int first_wave) {
+                                                               DropCfg drop) {
     __shared__ SmemNT sm;
     const int tid = threadIdx.x, lane = tid & 63, wm = (tid >> 6) >> 1, wn = (tid >> 6) & 1;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    gate_stagger(stagger, first_wave);
     const XcdHead xh = xcd_head(blockIdx.x, H);
     const int jt = xh.li % GATE_JT, c = xh.c, tt = (xh.li / GATE_JT) * xh.nshare + xh.share;
     if (tt >= n_ttiles) return;  // block-uniform
@@ -542,9 +541,7 @@ extern "C" int mdl_abmil_gate_fwd_bf16(const uint16_t* E, int64_t ldE, const flo
     const int dm = !d.on ? 0 : (d.ka ? 2 : 1);
 #define MDL_GATE_FWD16(DM, SAVE)                                                                                                   \
     hipLaunchKernelGGL((gate_fwd_bf16_kernel<DM, SAVE>), dim3((unsigned)grid), dim3(256), 0, s, (const bf16_t*)E, ldE, (const bf16_t*)WK, \
-                       ba, bb, wc, part, (bf16_t*)act_a, (bf16_t*)act_b, T, H, (int)n_tt, d, stagger, first_wave)
-    const char* sg = getenv("MADELEINE_GATE_STAGGER");
-    const int stagger = sg ? atoi(sg) : 0, first_wave = 2 * 256;
+                       ba, bb, wc, part, (bf16_t*)act_a, (bf16_t*)act_b, T, H, (int)n_tt, d)
     const int64_t n_tt256 = (T + QM - 1) / QM;
     const int64_t grid256 = xcd_head_grid(n_tt256, GATE_JT, H);
 #define MDL_GATE_FWD256(DM, SAVE)                                                                                                  \

@@ -27,25 +27,6 @@ static inline int64_t xcd_head_grid(int64_t units, int per_unit, int H) {  // un
     return 8 * ((units + nshare - 1) / nshare) * per_unit;
 }
 
-// Phase stagger of the workgroups that share a CU (two resident per CU): tiles take the same time, so co-resident workgroups that start
-// together stay in lockstep -- both in the MFMA-bound main loop, then both in the VALU-bound epilogue, each phase with the other pipe
-// idle.  The workgroups of the FIRST wave of the grid that sit in an odd workgroup slot of their CU (HW_ID.TG_ID) start `units` x 64 clocks
-// late; every slot then runs its tiles back to back, so the offset persists for the whole launch and one workgroup's epilogue overlaps the
-// other's main loop.
-__device__ __forceinline__ void gate_stagger(int units, int first_wave) {
-    if (units == 0 || (int)blockIdx.x >= first_wave) return;
-    bool odd;
-    if (units > 0) {
-        const uint32_t hw = __builtin_amdgcn_s_getreg((4 /* HW_REG_HW_ID */) | (0 << 6) | (31 << 11));
-        odd = ((hw >> 16) & 1u) != 0;   // TG_ID bit 0
-    } else {   // index-based guess: block b -> XCD b % 8, workgroup b / 8 of that XCD; the first 32 fill slot 0 of its 32 CUs
-        odd = (((int)blockIdx.x >> 3) >> 5) & 1;
-        units = -units;
-    }
-    if (!odd) return;
-    for (int i = 0; i < units; i += 127) __builtin_amdgcn_s_sleep(127);
-}
-
 struct DropCfg {
     float p, inv;
     uint32_t thr;   // 16-bit threshold

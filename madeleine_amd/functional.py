@@ -834,6 +834,9 @@ class AttnPoolFn(torch.autograd.Function):
                 # the fp32 tall tile)
                 tok = split_gemm_nt(Ei, split_image(Wtok), btok, name="linear_fwd")
             else:
+                if not linear_supported(E2d, Wtok):   # a clear message instead of a kernel return code
+                    raise NotImplementedError("attn_pool: token projection %s on %s %s rows is outside the HIP Linear kernels' geometries "
+                                              "(functional.linear_supported)" % (tuple(Wtok.shape), E2d.shape[0], E2d.dtype))
                 tok = linear_fwd_raw(E2d, Wtok, btok)
         else:
             tok = E2d.new_empty(0)

@@ -10,11 +10,12 @@ from madeleine_amd import distributed as D
 from madeleine_amd import functional as MF
 dev = torch.device("cuda:0")
 cfgname = sys.argv[1] if len(sys.argv) > 1 else "c2"
+BF16 = len(sys.argv) > 2 and sys.argv[2] == "bf16"
 B, M, N, Dm, use_got, stain_enc = BN.CONFIGS[cfgname]
 mods = BN.MODS5[:M]
 torch.manual_seed(42)
 model = MADELEINE(BN.make_cfg(M, Dm)).to(dev).train()
-opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
+opt = torch.optim.AdamW(model.parameters(), lr=1e-4, fused=True)
 feats = torch.randn(B, M, N, Dm, device=dev)
 labels = torch.ones(B, M)
 if M > 2:
@@ -32,8 +33,9 @@ for it in range(12):
     torch.cuda.synchronize()
     t = time.perf_counter(); t_start = t
     opt.zero_grad(set_to_none=True); t = tick("zero_grad", t)
-    embs, toks = model(data, device=dev); t = tick("forward", t)
-    loss, flag = D.calculate_losses_dp(mods[1:], crit, got_impl, embs, toks, labels[:, 1:], largs, use_local_loss=use_got); t = tick("loss", t)
+    with torch.autocast(device_type="cuda", dtype=torch.bfloat16, enabled=BF16):
+        embs, toks = model(data, device=dev); t = tick("forward", t)
+        loss, flag = D.calculate_losses_dp(mods[1:], crit, got_impl, embs, toks, labels[:, 1:], largs, use_local_loss=use_got); t = tick("loss", t)
     loss.backward(); t = tick("backward", t)
     opt.step(); t = tick("optimizer", t)
     acc.setdefault("host_total", []).append(1e3 * (t - t_start))
