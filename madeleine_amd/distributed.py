@@ -41,6 +41,10 @@ def init_from_env(backend: Optional[str] = None):
     # the gloo side group and DDP then run through RCCL exactly as on N GPUs (a 1-GPU box can execute that path)
     launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ and "MASTER_ADDR" in os.environ
     if (world > 1 or launched) and not dist.is_initialized():
+        # single-node rendezvous on the loopback address: pin gloo (the host-side label exchange) to the loopback interface as well --
+        # it otherwise resolves the container's hostname, which may not resolve (an explicit GLOO_SOCKET_IFNAME of the user wins)
+        if os.environ.get("MASTER_ADDR") in ("127.0.0.1", "localhost", "::1"):
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
