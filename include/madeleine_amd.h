@@ -54,7 +54,7 @@ const char* mdl_version(void);
 /* ABI revision of this header: bumped whenever an entry point's argument list changes.  A binding compares
  * mdl_abi_version() with the MDL_ABI_VERSION it was written against BEFORE calling anything else, so that a stale
  * shared object fails loudly instead of being called with shifted arguments. */
-#define MDL_ABI_VERSION 15
+#define MDL_ABI_VERSION 16
 int mdl_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -372,7 +372,8 @@ int mdl_split_image(const float* X, int64_t ldx, int64_t rows, int K, void* img,
 /* ROW-SCALED image (round 4): row r of X is scaled by its own power of two s_r (max_k |s_r X[r][k]| in [2^13, 2^14); 1 for an all-zero
  * row) -- for the tensor whose rows a CALLER controls, the patch features (Model.py:113, :351): with one common scale a patch 2^20 times
  * larger than the others would cost them their low bits (fp32 nn.Linear has no such coupling between rows).  row_inv (device
- * float[rows]) receives 1 / s_r (0 for an all-zero row: it contributes nothing to any product), scale = {1, max |X|}.  Consumers: mdl_split_gemm_nt(A = this image, a_row_mul = row_inv) -- the row
+ * float[rows]) receives 1 / s_r (0 for an all-zero row: it contributes nothing to any product), scale = {1, max |X|}; scale may be NULL
+ * (no bookkeeping launches: the image is ONE kernel -- the weights' images, built every forward; pass a constant {1, .} as its scale).  Consumers: mdl_split_gemm_nt(A = this image, a_row_mul = row_inv) -- the row
  * factor is undone in the epilogue, exactly; mdl_split_gemm_tn pairs it with a gradient image written with row_mul = row_inv
  * (mdl_ln_gelu_drop_bwd_split), so that the row factors cancel inside the contraction over rows. */
 int mdl_split_image_rows(const float* X, int64_t ldx, int64_t rows, int K, void* img, int64_t rsb, int64_t pad_rows, float* row_inv,
@@ -382,10 +383,11 @@ int mdl_split_image_rows(const float* X, int64_t ldx, int64_t rows, int K, void*
  * [ceil(rows / 32)], may be NULL) with the per-32-row maxima that mdl_split_gemm_tn's b_chunk_max takes. */
 int mdl_split_tile_absmax(const float* X, int64_t ldx, int64_t rows, int K, float* gate, float* chunk_max, void* stream);
 /* a_row_mul (device float[M], may be NULL): row m of the product is multiplied by a_row_mul[m] before bias / accumulation (the
- * 1 / s_r of a row-scaled A image, or the s_r that undoes a row_mul folded into a gradient image). */
+ * 1 / s_r of a row-scaled A image, or the s_r that undoes a row_mul folded into a gradient image).  b_col_mul (device float[N], N % 4
+ * == 0, may be NULL): the same per output column = per row of a row-scaled B image (a weight matrix W [N, K]: nn.Linear's rows). */
 int mdl_split_gemm_nt(const void* A, int64_t a_rsb, const float* a_scale, const void* B, int64_t b_rsb, const float* b_scale, float* C,
                       int64_t ldc, int64_t M, int N, int K, const float* bias, int accumulate, float* absmax_out, const float* row_gate,
-                      const float* a_row_mul, void* stream);
+                      const float* a_row_mul, const float* b_col_mul, void* stream);
 int64_t mdl_split_gemm_tn_ws_bytes(int64_t T, int Mi, int N);
 /* b_chunk_max (float [ceil(T / 32)], may be NULL): per-32-row maxima of |X| for B = image(X) (mdl_split_tile_absmax) -- chunks whose
  * entry is 0 are skipped (the token_projector's dW: the local loss reads the first <= 256 tokens of a bag, the rest of d_tok is zero). */

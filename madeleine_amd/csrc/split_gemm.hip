@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void sp_image_rows_kernel(const float* __restr
             *reinterpret_cast<u32x4*>(row + sp_img_off(k, 1)) = lo;
         }
     }
-    if (lane == 0) atomicMax(reinterpret_cast<unsigned int*>(absmax), __float_as_uint(tot));
+    if (lane == 0 && absmax) atomicMax(reinterpret_cast<unsigned int*>(absmax), __float_as_uint(tot));
 }
 // K <= 512 SEG: SEG x 8 values per lane and row stay in registers, ROWS rows per wave in flight (2 ROWS SEG 16-B loads per lane before the
 // first reduction): one HBM read of X, no second pass.  (The two-pass kernel above moved 1.07 GB in 415 us at config 2 = 2.6 TB/s.)
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void sp_image_rows_reg_kernel(const float* __r
             }
         }
     }
-    if (lane == 0) atomicMax(reinterpret_cast<unsigned int*>(absmax), __float_as_uint(tot));
+    if (lane == 0 && absmax) atomicMax(reinterpret_cast<unsigned int*>(absmax), __float_as_uint(tot));
 }
 // sc = {1, absmax already in sc[1]}: the common factor of a row-scaled image is 1 (the row factors travel in row_inv)
 __global__ void sp_unit_scale_kernel(float* __restrict__ sc) { sc[0] = 1.f; }
@@ -205,7 +205,8 @@ __global__ __launch_bounds__(SP_THREADS) void sp_nt_kernel(const char* __restric
                                                     const char* __restrict__ B, int64_t b_rsb, const float* __restrict__ b_sc,
                                                     float* __restrict__ C, int64_t ldc, int64_t M, int N, int nblk, int n_tiles,
                                                     const float* __restrict__ bias, int accumulate, float* __restrict__ absmax_out,
-                                                    const float* __restrict__ row_gate, const float* __restrict__ a_row_mul) {
+                                                    const float* __restrict__ row_gate, const float* __restrict__ a_row_mul,
+                                                    const float* __restrict__ b_col_mul) {
     __shared__ SmemSP sm;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -245,6 +246,7 @@ __global__ __launch_bounds__(SP_THREADS) void sp_nt_kernel(const char* __restric
     auto emit = [&](int row, int col, const f32x4& v) {
         if (col >= cols_valid) return;
         f32x4 r = v * (a_row_mul ? inv * a_row_mul[m0 + row] : inv);   // row-scaled A image: its row factor (a power of two) comes back here
+        if (b_col_mul) r *= *reinterpret_cast<const f32x4*>(b_col_mul + n0 + col);   // row-scaled B image (a weight: one factor per output column)
         if (bias) r += *reinterpret_cast<const f32x4*>(bias + n0 + col);
         f32x4* o = reinterpret_cast<f32x4*>(cb + (int64_t)row * ldc4 + (uint32_t)col * 4u);
         if (accumulate) r += *o;
@@ -381,13 +383,16 @@ extern "C" int mdl_split_image(const float* X, int64_t ldx, int64_t rows, int K,
  * row_inv (device float[rows]) receives 1 / s_r, scale = {1, max |X|}.  As the A operand of mdl_split_gemm_nt pass a_row_mul = row_inv. */
 extern "C" int mdl_split_image_rows(const float* X, int64_t ldx, int64_t rows, int K, void* img, int64_t rsb, int64_t pad_rows,
                                     float* row_inv, float* scale, void* stream) {
-    if (!X || !img || !scale || !row_inv || rows < 0 || K < 32 || (K % 32) || ldx < K || (ldx & 3) || rsb < (int64_t)K * 4 || (rsb & 15) ||
+    if (!X || !img || !row_inv || rows < 0 || K < 32 || (K % 32) || ldx < K || (ldx & 3) || rsb < (int64_t)K * 4 || (rsb & 15) ||
         pad_rows < 0)
         return MDL_E_ARG;
     if (!host_aligned16(X) || !host_aligned16(img)) return MDL_E_ALIGN;
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(scale, 0, 2 * sizeof(float), s);
-    if (e != hipSuccess) return (int)e;
+    hipError_t e = hipSuccess;
+    if (scale) {   // scale == NULL: the caller supplies the constant {1, .} itself -- the whole image is ONE launch (weights: every forward)
+        e = hipMemsetAsync(scale, 0, 2 * sizeof(float), s);
+        if (e != hipSuccess) return (int)e;
+    }
     if (pad_rows > 0) {
         e = hipMemsetAsync((char*)img + rows * rsb, 0, (size_t)(pad_rows * rsb), s);
         if (e != hipSuccess) return (int)e;
@@ -399,19 +404,22 @@ extern "C" int mdl_split_image_rows(const float* X, int64_t ldx, int64_t rows, i
             int64_t n4 = (rows + 15) / 16;   // 4 waves x 4 rows per block iteration
             if (n4 > 4096) n4 = 4096;
             hipLaunchKernelGGL((sp_image_rows_reg_kernel<1, 4>), dim3((unsigned)n4), dim3(256), 0, s, X, ldx, rows, K, (char*)img, rsb, row_inv,
-                               scale + 1);
+                               scale ? scale + 1 : nullptr);
         } else if (K <= 1024) {
             int64_t n2 = (rows + 7) / 8;
             if (n2 > 4096) n2 = 4096;
             hipLaunchKernelGGL((sp_image_rows_reg_kernel<2, 2>), dim3((unsigned)n2), dim3(256), 0, s, X, ldx, rows, K, (char*)img, rsb, row_inv,
-                               scale + 1);
+                               scale ? scale + 1 : nullptr);
         } else {
-            hipLaunchKernelGGL(sp_image_rows_kernel, dim3((unsigned)nb), dim3(256), 0, s, X, ldx, rows, K, (char*)img, rsb, row_inv, scale + 1);
+            hipLaunchKernelGGL(sp_image_rows_kernel, dim3((unsigned)nb), dim3(256), 0, s, X, ldx, rows, K, (char*)img, rsb, row_inv,
+                               scale ? scale + 1 : nullptr);
         }
         MDL_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(sp_unit_scale_kernel, dim3(1), dim3(1), 0, s, scale);
-    MDL_LAUNCH_CHECK();
+    if (scale) {
+        hipLaunchKernelGGL(sp_unit_scale_kernel, dim3(1), dim3(1), 0, s, scale);
+        MDL_LAUNCH_CHECK();
+    }
     return MDL_OK;
 }
 
@@ -430,7 +438,7 @@ extern "C" int mdl_split_tile_absmax(const float* X, int64_t ldx, int64_t rows, 
 
 extern "C" int mdl_split_gemm_nt(const void* A, int64_t a_rsb, const float* a_scale, const void* B, int64_t b_rsb, const float* b_scale,
                                  float* C, int64_t ldc, int64_t M, int N, int K, const float* bias, int accumulate, float* absmax_out,
-                                 const float* row_gate, const float* a_row_mul, void* stream) {
+                                 const float* row_gate, const float* a_row_mul, const float* b_col_mul, void* stream) {
     if (row_gate && (!accumulate || bias)) return MDL_E_ARG;   // skipping a tile is only the identity when it would add zeros
     if (!A || !B || !C || !a_scale || !b_scale || M < 0 || N < 4 || (N & 3) || K < 32 || (K % 32) || ldc < N || (ldc & 3)) return MDL_E_ARG;
     if (a_rsb < (int64_t)K * 4 || b_rsb < (int64_t)K * 4 || (a_rsb & 15) || (b_rsb & 15)) return MDL_E_ARG;
@@ -439,7 +447,8 @@ extern "C" int mdl_split_gemm_nt(const void* A, int64_t a_rsb, const float* a_sc
     const int64_t tiles = ((M + SPM - 1) / SPM) * ((N + SPN - 1) / SPN);
     if (tiles > 0x7fffffff || a_rsb * SPM > 0x7fffffff || b_rsb * SPN > 0x7fffffff) return MDL_E_UNSUPPORTED;
     hipLaunchKernelGGL(sp_nt_kernel, dim3((unsigned)tiles), dim3(SP_THREADS), 0, (hipStream_t)stream, (const char*)A, a_rsb, a_scale,
-                       (const char*)B, b_rsb, b_scale, C, ldc, M, N, K / 32, (int)tiles, bias, accumulate, absmax_out, row_gate, a_row_mul);
+                       (const char*)B, b_rsb, b_scale, C, ldc, M, N, K / 32, (int)tiles, bias, accumulate, absmax_out, row_gate, a_row_mul,
+                       b_col_mul);
     MDL_LAUNCH_CHECK();
     return MDL_OK;
 }

@@ -362,10 +362,11 @@ def set_gemm_mode(mode: str):
 class SplitImage:
     """Split image of a [rows, K] fp32 tensor: `data` float32 [rows + pad, K] (opaque bytes: per 32-column block the fp16 hi plane
     | lo plane), `scale` float32 [2] = {scale, absmax} on the device."""
-    __slots__ = ("data", "scale", "rows", "K")
+    __slots__ = ("data", "scale", "rows", "K", "row_inv")
 
-    def __init__(self, data, scale, rows, K):
-        self.data, self.scale, self.rows, self.K = data, scale, rows, K
+    def __init__(self, data, scale, rows, K, row_inv=None):
+        # row_inv [rows] (row-scaled images only): 1 / the power-of-two scale of every row; the common `scale` of such an image is 1
+        self.data, self.scale, self.rows, self.K, self.row_inv = data, scale, rows, K, row_inv
 
 
 def split_image(x2d, pad_rows=0) -> SplitImage:
@@ -395,6 +396,31 @@ def split_image_rows(x2d, pad_rows=0):
     return SplitImage(data, scale, rows, K), row_inv
 
 
+_UNIT_SCALE = {}
+
+
+def _unit_scale(device):
+    """The constant {1, 0} on `device`: the common scale of a row-scaled image (one tensor per device, never written)."""
+    key = str(device)
+    if key not in _UNIT_SCALE:
+        _UNIT_SCALE[key] = torch.tensor([1.0, 0.0], device=device, dtype=torch.float32)
+    return _UNIT_SCALE[key]
+
+
+def weight_image(W) -> SplitImage:
+    """Row-scaled image of a weight matrix W [N, K] (one power of two per output channel) in ONE launch -- instead of the memset, absmax,
+    scale and convert launches of split_image, every forward and backward of every Linear.  As the B operand of split_gemm_nt its row
+    factors become per-output-column factors of the product (b_col_mul)."""
+    _require(W, "weight")
+    lib = _native.lib()
+    rows, K = W.shape
+    data = torch.empty(rows, K, device=W.device, dtype=torch.float32)
+    row_inv = torch.empty(rows, device=W.device, dtype=torch.float32)
+    rc = lib.mdl_split_image_rows(_ptr(W), W.stride(0), rows, K, _ptr(data), K * 4, 0, _ptr(row_inv), None, _stream())
+    _native.check(rc, "mdl_split_image_rows")
+    return SplitImage(data, _unit_scale(W.device), rows, K, row_inv)
+
+
 def split_tile_absmax(x2d, chunks=False):
     """max |x| of every block of 256 rows (the row gate of split_gemm_nt); chunks=True: also of every 32 rows (split_gemm_tn's
     b_chunk_max) -> (gate, chunk_max)."""
@@ -415,10 +441,12 @@ def split_gemm_nt(A: SplitImage, B: SplitImage, bias=None, out=None, accumulate=
     M, N, K = A.rows, B.rows, A.K
     if B.K != K:
         raise ValueError("split_gemm_nt: contraction lengths differ")
+    if a_row_mul is None:
+        a_row_mul = A.row_inv
     C = out if out is not None else torch.empty(M, N, device=A.data.device, dtype=torch.float32)
     with _timed(name, ("flop", 2.0 * M * N * K)):
         rc = lib.mdl_split_gemm_nt(_ptr(A.data), K * 4, _ptr(A.scale), _ptr(B.data), K * 4, _ptr(B.scale), _ptr(C), C.stride(0), M, N, K,
-                                   _ptr(bias), int(accumulate), _ptr(absmax_out), _ptr(row_gate), _ptr(a_row_mul), _stream())
+                                   _ptr(bias), int(accumulate), _ptr(absmax_out), _ptr(row_gate), _ptr(a_row_mul), _ptr(B.row_inv), _stream())
     _native.check(rc, "mdl_split_gemm_nt")
     return C
 
@@ -428,6 +456,8 @@ def split_gemm_tn(A: SplitImage, B: SplitImage, name="split_tn", b_chunk_max=Non
     per-32-row maxima (split_tile_absmax(x, chunks=True)) of the tensor B is the image of -- its all-zero chunks are skipped."""
     lib = _native.lib()
     T, Mi, N = A.rows, A.K, B.K
+    if B.row_inv is not None:
+        raise ValueError("split_gemm_tn: a row-scaled image cannot be the B operand of a contraction over its rows")
     if B.rows != T or B.data.shape[0] < T + 32:
         raise ValueError("split_gemm_tn: images need the same number of rows and B 32 zero pad rows")
     out = torch.empty(N, Mi, device=A.data.device, dtype=torch.float32)
@@ -460,7 +490,7 @@ class SplitLinearFn(torch.autograd.Function):
         if bias is not None:
             _require(bias, "bias")
         xi = split_image(x)
-        y = split_gemm_nt(xi, split_image(W), bias, name="linear_fwd")
+        y = split_gemm_nt(xi, weight_image(W), bias, name="linear_fwd")
         ctx.save_for_backward(W, xi.data, xi.scale)     # (the image is an ordinary saved tensor: hooks, retain_graph, version checks)
         ctx.geom = (xi.rows, xi.K)
         ctx.has_bias = bias is not None
@@ -474,7 +504,7 @@ class SplitLinearFn(torch.autograd.Function):
         dyi = split_image(dy, pad_rows=32)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = split_gemm_nt(dyi, split_image(W.t().contiguous()), name="linear_bwd")
+            dx = split_gemm_nt(dyi, weight_image(W.t().contiguous()), name="linear_bwd")
         dW = split_gemm_tn(xi, dyi, name="linear_bwd")
         db = dy.sum(0) if ctx.has_bias else None
         return dx, dW, db
@@ -541,7 +571,7 @@ class PreAttnBlockFn(torch.autograd.Function):
             xi = SplitImage(x, x_scale, T, K)
         else:
             xi, row_inv = split_image_rows(x)
-        y = split_gemm_nt(xi, split_image(W), name="linear_fwd", a_row_mul=row_inv)   # pre-LN values (the Linear's bias is added by the LN kernel)
+        y = split_gemm_nt(xi, weight_image(W), name="linear_fwd", a_row_mul=row_inv)   # pre-LN values (the Linear's bias is added by the LN kernel)
         img = torch.empty(T, N, device=dev, dtype=torch.float32)
         scale = torch.empty(2, device=dev, dtype=torch.float32)
         out = torch.empty(T, N, device=dev, dtype=torch.float32) if want_fp32 else None
@@ -608,7 +638,7 @@ class PreAttnBlockFn(torch.autograd.Function):
                                                         None, _ptr(ws), _stream())
                 _native.check(rc, "mdl_ln_gelu_drop_bwd_split")
                 dxi = SplitImage(dximg2, dxscale2, T, N)
-            dx = split_gemm_nt(dxi, split_image(W.t().contiguous()), absmax_out=am, name="linear_bwd")
+            dx = split_gemm_nt(dxi, weight_image(W.t().contiguous()), absmax_out=am, name="linear_bwd")
             if x_is_image:       # the consumer is the previous block's LayerNorm backward (this node's input was its image)
                 _put_absmax(dx, am)
         dW = split_gemm_tn(SplitImage(xdata, xscale, T, K), dyi, name="linear_bwd")
@@ -832,7 +862,7 @@ class AttnPoolFn(torch.autograd.Function):
             if Ei is not None and split_linear_supported(E2d.shape[0], Wtok.shape[0], Wtok.shape[1]):
                 # split engine on the image of E the gate forward used (N = 128: half of the 256-wide tile idles, still faster than
                 # the fp32 tall tile)
-                tok = split_gemm_nt(Ei, split_image(Wtok), btok, name="linear_fwd")
+                tok = split_gemm_nt(Ei, weight_image(Wtok), btok, name="linear_fwd")
             else:
                 if not linear_supported(E2d, Wtok):   # a clear message instead of a kernel return code
                     raise NotImplementedError("attn_pool: token projection %s on %s %s rows is outside the HIP Linear kernels' geometries "
@@ -911,7 +941,7 @@ class AttnPoolFn(torch.autograd.Function):
                 d_tok = d_tok.float().contiguous()
                 dti = split_image(d_tok, pad_rows=32)
                 gate, chunk_max = split_tile_absmax(d_tok, chunks=True)   # one pass: 256-row tiles (dX) and 32-row chunks (dW)
-                split_gemm_nt(dti, split_image(Wtok.t().contiguous()), out=dE, accumulate=True, absmax_out=am, name="linear_bwd",
+                split_gemm_nt(dti, weight_image(Wtok.t().contiguous()), out=dE, accumulate=True, absmax_out=am, name="linear_bwd",
                               row_gate=gate)
                 dWtok = split_gemm_tn(Ei, dti, name="linear_bwd", b_chunk_max=chunk_max)
                 dbtok = d_tok.sum(0) if has_btok else None

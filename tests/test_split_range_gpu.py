@@ -387,3 +387,28 @@ def test_gate_activation_recompute_is_bit_identical(dev):
     finally:
         MF.set_gate_recompute(False)
         MF.set_gemm_mode(old)
+
+
+def test_weight_image_keeps_every_output_channel_at_full_precision(dev):
+    """functional.weight_image: one power-of-two scale per ROW of W (= per output channel of nn.Linear, Model.py:351), applied as a
+    per-column factor in the NT epilogue -- output channels whose weights are 2^-30 of the largest row's keep full precision
+    (a per-tensor scale would leave them ~8 bits), an all-zero weight row gives exactly bias, and the product equals the fp64 one."""
+    from madeleine_amd import functional as MF
+    M, N, K = 700, 256, 512
+    x = t((M, K), "wimg:x") * 2
+    W = 0.05 * t((N, K), "wimg:w") * (2.0 ** -torch.linspace(0, 30, N)).unsqueeze(1)
+    W[17] = 0.0
+    bias = 0.3 * t((N,), "wimg:b")
+    Wi = MF.weight_image(W.to(dev))
+    assert Wi.row_inv is not None and float(Wi.row_inv[17]) == 0.0 and float(Wi.scale[0]) == 1.0
+    xi, row_inv = MF.split_image_rows(x.to(dev))
+    Cb = MF.split_gemm_nt(xi, Wi, bias.to(dev), a_row_mul=row_inv).double().cpu()
+    assert float((Cb[:, 17] - bias[17].double()).abs().max()) == 0.0
+    C = MF.split_gemm_nt(xi, Wi, a_row_mul=row_inv).double().cpu()
+    lin = x.double() @ W.double().t()
+    assert float((Cb - (lin + bias.double())).abs().max()) < 1e-6 * float(lin.abs().max())
+    col_err = ((C - lin).abs().amax(0) / lin.abs().amax(0).clamp_min(1e-300))
+    col_err[17] = 0.0
+    assert float(col_err.max()) < 2.0 ** -20, float(col_err.max())
+    with pytest.raises(ValueError):
+        MF.split_gemm_tn(xi, Wi)      # a row-scaled image cannot be contracted over its rows
