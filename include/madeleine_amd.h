@@ -54,7 +54,7 @@ const char* mdl_version(void);
 /* ABI revision of this header: bumped whenever an entry point's argument list changes.  A binding compares
  * mdl_abi_version() with the MDL_ABI_VERSION it was written against BEFORE calling anything else, so that a stale
  * shared object fails loudly instead of being called with shifted arguments. */
-#define MDL_ABI_VERSION 16
+#define MDL_ABI_VERSION 17
 int mdl_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -400,15 +400,19 @@ int mdl_split_gemm_tn(const void* A, int64_t a_rsb, const float* a_scale, int Mi
  *   forward  |y|  <= (max|gamma| sqrt(W-1) + max|beta|) / (1-p)
  *   backward |dx| <= rstd_max 1.13 max|gamma| max|dy| (2 + sqrt(W)) / (1-p);  dy_absmax = device float with max |dy| (from the producing
  *            kernel's epilogue) or NULL (one extra pass over dy).  The dx image is followed by 32 zero rows; ws as mdl_ln_gelu_drop_bwd. */
+/* row_mul / rstd_max (forward, both may be NULL): rstd_max (device float) receives max_r rstd[r] * row_mul[r] (row_mul NULL: max rstd) --
+ * handed to the backward it replaces that call's pass over rstd. */
 int mdl_ln_gelu_drop_fwd_split(const float* x, const float* bias, const float* gamma, const float* beta, float* y, void* img, float* scale,
                                float* mean, float* rstd, int64_t rows, int W, float eps, float p_drop, uint64_t seed, const uint8_t* keep,
-                               void* stream);
+                               const float* row_mul, float* rstd_max, void* stream);
 /* row_mul (device float[rows], may be NULL): the dx image holds row_mul[r] dx[r][:] (bound through max_r rstd[r] row_mul[r]); dgamma,
- * dbeta, dbias are unaffected.  For the first pre_attn block, whose input image is row-scaled (mdl_split_image_rows): row_mul = row_inv. */
+ * dbeta, dbias are unaffected.  For the first pre_attn block, whose input image is row-scaled (mdl_split_image_rows): row_mul = row_inv.
+ * rstd_max (device float, may be NULL): the forward's max_r rstd[r] * row_mul[r] for THE SAME row_mul; with it and dy_absmax the call
+ * issues no bookkeeping launch but the bound kernel. */
 int mdl_ln_gelu_drop_bwd_split(const float* x, const float* bias, const float* gamma, const float* beta, const float* mean,
                                const float* rstd, const float* dy, const float* dy_absmax, void* dx_img, float* dx_scale, float* dgamma,
                                float* dbeta, float* dbias, int64_t rows, int W, float p_drop, uint64_t seed, const uint8_t* keep,
-                               const float* row_mul, void* ws, void* stream);
+                               const float* row_mul, const float* rstd_max, void* ws, void* stream);
 
 /* A2 on the split engine (csrc/abmil_gate_split.hip): mdl_abmil_gate_fwd / mdl_abmil_attnpool_bwd(_phases) with E given as a split
  * image (rows of e_rsb bytes holding the H*512 head-major channels, scale e_scale) -- everything else (parameters, scores, saved

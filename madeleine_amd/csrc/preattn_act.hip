@@ -203,12 +203,17 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_fwd_kernel(const IO* _
                                                                      IO* __restrict__ y, float* __restrict__ mean_o,
                                                                      float* __restrict__ rstd_o, int64_t rows, float eps,
                                                                      ActDrop drop, char* __restrict__ img = nullptr,
-                                                                     const float* __restrict__ img_sc = nullptr) {
+                                                                     const float* __restrict__ img_sc = nullptr,
+                                                                     const float* __restrict__ row_mul = nullptr,
+                                                                     float* __restrict__ rstd_max = nullptr) {
+    // rstd_max (split variant): raised to max_r rstd[r] * row_mul[r] -- the factor of the backward's dx-image bound, taken here where the
+    // statistics are computed instead of by a pass over rstd in every backward (one atomic per wave)
     constexpr int W = NV * 256 * WPR, RPB = 4 / WPR;
     __shared__ float red[1][4][2];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, slot = wv / WPR, seg = wv % WPR;
     typedef ColMap<IO, NV> CM;
     const int cb = seg * NV * 256;   // first column of this wave's segment
+    float rmax = 0.f;
     f32x4 g[NV], b[NV], lb[NV];   // lb: bias of the preceding Linear (added here instead of in the GEMM epilogue)
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -272,8 +277,10 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_fwd_kernel(const IO* _
                 mean_o[r] = mean;
                 rstd_o[r] = rstd;
             }
+            rmax = fmaxf(rmax, row_mul ? rstd * row_mul[r] : rstd);
         }
     }
+    if (rstd_max && lane == 0 && seg == 0) atomicMax(reinterpret_cast<unsigned int*>(rstd_max), __float_as_uint(rmax));
 }
 
 // IMG: dx is written as a split image (rows of 4 W bytes at `img`, scale img_sc[0]) instead of dx
@@ -451,7 +458,11 @@ __global__ __launch_bounds__(256) void ln_reduce_kernel(const float* __restrict_
 //             (|GELU'| <= 1.13, mean|x^| <= 1)
 // sc[0] = scale, sc[1] = the bound.  aux[0] = max rstd, aux[1] = max |dy| (backward only).
 __global__ __launch_bounds__(256) void ln_bound_scale_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, int W,
-                                                             float inv_keep, const float* __restrict__ aux, float* __restrict__ sc) {
+                                                             float inv_keep, const float* __restrict__ aux, float* __restrict__ sc,
+                                                             float* __restrict__ zero_me = nullptr,
+                                                             const float* __restrict__ aux1 = nullptr) {
+    // zero_me: a float this launch clears (the forward's rstd_max accumulator); aux1: max |dy| when it does not lie at aux[1]
+    if (zero_me && threadIdx.x == 0) *zero_me = 0.f;
     __shared__ float red[2][4];
     float g = 0.f, b = 0.f;
     for (int c = threadIdx.x; c < W; c += 256) {
@@ -468,7 +479,7 @@ __global__ __launch_bounds__(256) void ln_bound_scale_kernel(const float* __rest
     if (threadIdx.x == 0) {
         g = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
         b = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
-        const float bound = aux ? aux[0] * (1.13f * g * aux[1] * inv_keep) * (2.f + sqrtf((float)W))
+        const float bound = aux ? aux[0] * (1.13f * g * (aux1 ? aux1[0] : aux[1]) * inv_keep) * (2.f + sqrtf((float)W))
                                 : (g * sqrtf((float)(W - 1)) + b) * inv_keep;
         sc[1] = bound;
         sc[0] = sp_scale_for(bound);
@@ -616,7 +627,7 @@ extern "C" int mdl_ln_gelu_drop_bwd_bf16(const uint16_t* x, const float* bias, c
  * parameters: |y| <= (max|gamma| sqrt(W-1) + max|beta|) / (1-p)) -- and, when y != NULL, as fp32 as well. */
 extern "C" int mdl_ln_gelu_drop_fwd_split(const float* x, const float* bias, const float* gamma, const float* beta, float* y, void* img,
                                           float* scale, float* mean, float* rstd, int64_t rows, int W, float eps, float p_drop,
-                                          uint64_t seed, const uint8_t* keep, void* stream) {
+                                          uint64_t seed, const uint8_t* keep, const float* row_mul, float* rstd_max, void* stream) {
     if (!x || !gamma || !beta || !img || !scale || !mean || !rstd || rows < 0) return MDL_E_ARG;
     if (!(p_drop >= 0.f && p_drop < 1.f) || !(eps > 0.f)) return MDL_E_ARG;
     if (!act_width_ok(W) || W > 4096) return MDL_E_UNSUPPORTED;
@@ -625,15 +636,16 @@ extern "C" int mdl_ln_gelu_drop_fwd_split(const float* x, const float* bias, con
         return MDL_E_ALIGN;
     hipStream_t s = (hipStream_t)stream;
     const ActDrop d = make_act_drop(p_drop, seed, keep);
-    hipLaunchKernelGGL(ln_bound_scale_kernel, dim3(1), dim3(256), 0, s, gamma, beta, W, d.inv, (const float*)nullptr, scale);
+    hipLaunchKernelGGL(ln_bound_scale_kernel, dim3(1), dim3(256), 0, s, gamma, beta, W, d.inv, (const float*)nullptr, scale, rstd_max,
+                       (const float*)nullptr);
     MDL_LAUNCH_CHECK();
     if (rows == 0) return MDL_OK;
 #define MDL_LN_FWD_IMG(NVV, WPRV, NB)                                                                                                    \
     do {                                                                                                                               \
         if (y) hipLaunchKernelGGL((ln_gelu_drop_fwd_kernel<NVV, WPRV, float, 2>), dim3((unsigned)(NB)), dim3(ACT_BLOCK), 0, s, x, bias, \
-                                  gamma, beta, y, mean, rstd, rows, eps, d, (char*)img, (const float*)scale);                           \
+                                  gamma, beta, y, mean, rstd, rows, eps, d, (char*)img, (const float*)scale, row_mul, rstd_max);        \
         else hipLaunchKernelGGL((ln_gelu_drop_fwd_kernel<NVV, WPRV, float, 1>), dim3((unsigned)(NB)), dim3(ACT_BLOCK), 0, s, x, bias,   \
-                                gamma, beta, y, mean, rstd, rows, eps, d, (char*)img, (const float*)scale);                             \
+                                gamma, beta, y, mean, rstd, rows, eps, d, (char*)img, (const float*)scale, row_mul, rstd_max);          \
     } while (0)
     if (W == 2048) {
         int64_t nb = (rows + 3) / 4;
@@ -654,7 +666,7 @@ extern "C" int mdl_ln_gelu_drop_fwd_split(const float* x, const float* bias, con
 extern "C" int mdl_ln_gelu_drop_bwd_split(const float* x, const float* bias, const float* gamma, const float* beta, const float* mean,
                                           const float* rstd, const float* dy, const float* dy_absmax, void* dx_img, float* dx_scale,
                                           float* dgamma, float* dbeta, float* dbias, int64_t rows, int W, float p_drop, uint64_t seed,
-                                          const uint8_t* keep, const float* row_mul, void* ws, void* stream) {
+                                          const uint8_t* keep, const float* row_mul, const float* rstd_max, void* ws, void* stream) {
     if (!x || !gamma || !beta || !mean || !rstd || !dy || !dx_img || !dx_scale || !dgamma || !dbeta || !ws || rows < 0) return MDL_E_ARG;
     if (!(p_drop >= 0.f && p_drop < 1.f)) return MDL_E_ARG;
     if (!act_width_ok(W) || W > 4096) return MDL_E_UNSUPPORTED;
@@ -671,29 +683,41 @@ extern "C" int mdl_ln_gelu_drop_bwd_split(const float* x, const float* bias, con
     }
     float* part = (float*)ws;
     float* aux = (float*)((char*)ws + (((int64_t)act_blocks(rows, W) * 3 * W * 4 + 15) & ~(int64_t)15));   // [0] max rstd, [1] max |dy|
-    hipError_t e = hipMemsetAsync(aux, 0, 2 * sizeof(float), s);
-    if (e != hipSuccess) return (int)e;
-    e = hipMemsetAsync((char*)dx_img + rows * (int64_t)W * 4, 0, (size_t)32 * W * 4, s);
+    hipError_t e = hipMemsetAsync((char*)dx_img + rows * (int64_t)W * 4, 0, (size_t)32 * W * 4, s);
     if (e != hipSuccess) return (int)e;
     int rc = MDL_OK;
-    if (row_mul && rows > 0) {   // the image holds row_mul[r] dx[r][:]: bound through max_r rstd[r] row_mul[r]
-        int nbm = (int)((rows + 2047) / 2048);
-        if (nbm > 2048) nbm = 2048;
-        hipLaunchKernelGGL(absmax_prod_kernel, dim3(nbm), dim3(256), 0, s, rstd, row_mul, rows, aux);
+    if (rstd_max && dy_absmax) {
+        // both factors of the bound were published by the kernels that produced them (the forward: max rstd * row_mul; the producer of
+        // dy: max |dy|): no memset, no pass over rstd, no copy -- the bound kernel reads them where they lie
+        hipLaunchKernelGGL(ln_bound_scale_kernel, dim3(1), dim3(256), 0, s, gamma, beta, W, d.inv, rstd_max, dx_scale, (float*)nullptr,
+                           dy_absmax);
         MDL_LAUNCH_CHECK();
     } else {
-        rc = sp_launch_absmax_flat(rstd, rows, aux, s);
-    }
-    if (rc) return rc;
-    if (dy_absmax) {
-        e = hipMemcpyAsync(aux + 1, dy_absmax, sizeof(float), hipMemcpyDeviceToDevice, s);
+        e = hipMemsetAsync(aux, 0, 2 * sizeof(float), s);
         if (e != hipSuccess) return (int)e;
-    } else {
-        rc = sp_launch_absmax(dy, W, rows, W, aux + 1, s);
+        if (rstd_max) {
+            e = hipMemcpyAsync(aux, rstd_max, sizeof(float), hipMemcpyDeviceToDevice, s);
+            if (e != hipSuccess) return (int)e;
+        } else if (row_mul && rows > 0) {   // the image holds row_mul[r] dx[r][:]: bound through max_r rstd[r] row_mul[r]
+            int nbm = (int)((rows + 2047) / 2048);
+            if (nbm > 2048) nbm = 2048;
+            hipLaunchKernelGGL(absmax_prod_kernel, dim3(nbm), dim3(256), 0, s, rstd, row_mul, rows, aux);
+            MDL_LAUNCH_CHECK();
+        } else {
+            rc = sp_launch_absmax_flat(rstd, rows, aux, s);
+        }
         if (rc) return rc;
+        if (dy_absmax) {
+            e = hipMemcpyAsync(aux + 1, dy_absmax, sizeof(float), hipMemcpyDeviceToDevice, s);
+            if (e != hipSuccess) return (int)e;
+        } else {
+            rc = sp_launch_absmax(dy, W, rows, W, aux + 1, s);
+            if (rc) return rc;
+        }
+        hipLaunchKernelGGL(ln_bound_scale_kernel, dim3(1), dim3(256), 0, s, gamma, beta, W, d.inv, (const float*)aux, dx_scale, (float*)nullptr,
+                           (const float*)nullptr);
+        MDL_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(ln_bound_scale_kernel, dim3(1), dim3(256), 0, s, gamma, beta, W, d.inv, (const float*)aux, dx_scale);
-    MDL_LAUNCH_CHECK();
     if (W == 2048 && nb > 0) {
         hipLaunchKernelGGL((ln_gelu_drop_bwd_kernel<4, 2, float, true>), dim3(nb), dim3(ACT_BLOCK), 0, s, x, bias, gamma, beta, mean, rstd, dy,
                            (float*)nullptr, part, rows, d, (char*)dx_img, (const float*)dx_scale, row_mul);

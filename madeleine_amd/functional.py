@@ -577,14 +577,16 @@ class PreAttnBlockFn(torch.autograd.Function):
         out = torch.empty(T, N, device=dev, dtype=torch.float32) if want_fp32 else None
         mean = torch.empty(T, device=dev, dtype=torch.float32)
         rstd = torch.empty_like(mean)
+        rstd_max = torch.empty(1, device=dev, dtype=torch.float32)   # max_r rstd[r] row_inv[r]: a factor of the backward's image bound
         with _timed("ln_gelu_drop_fwd", ("byte", (3.0 if want_fp32 else 2.0) * T * N * 4)):
             rc = lib.mdl_ln_gelu_drop_fwd_split(_ptr(y), _ptr(lin_bias), _ptr(gamma), _ptr(beta), _ptr(out), _ptr(img), _ptr(scale),
-                                                _ptr(mean), _ptr(rstd), T, N, float(eps), float(p_drop), int(seed), _ptr(keep), _stream())
+                                                _ptr(mean), _ptr(rstd), T, N, float(eps), float(p_drop), int(seed), _ptr(keep),
+                                                _ptr(row_inv), _ptr(rstd_max), _stream())
         if rc == -3:
             raise NotImplementedError("fused LayerNorm-GELU-Dropout supports widths 256/512/1024/2048/4096 (got %d)" % N)
         _native.check(rc, "mdl_ln_gelu_drop_fwd_split")
         ctx.save_for_backward(xi.data, xi.scale, W, y, gamma, beta, mean, rstd, lin_bias if lin_bias is not None else torch.empty(0),
-                              row_inv if row_inv is not None else torch.empty(0))
+                              row_inv if row_inv is not None else torch.empty(0), rstd_max)
         ctx.cfg = (float(p_drop), int(seed), keep, lin_bias is not None, bool(want_fp32), T, K, N, x_scale is not None)
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(scale)
@@ -597,7 +599,7 @@ class PreAttnBlockFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_img, _d_scale, d_out):
-        xdata, xscale, W, y, gamma, beta, mean, rstd, lin_bias, row_inv = ctx.saved_tensors
+        xdata, xscale, W, y, gamma, beta, mean, rstd, lin_bias, row_inv, rstd_max = ctx.saved_tensors
         p_drop, seed, keep, has_bias, want_fp32, T, K, N, x_is_image = ctx.cfg
         lin_bias = lin_bias if has_bias else None
         # first block (row-scaled input image): the gradient image carries row_inv[r] dx[r][:], so that the row factors of the two images
@@ -618,7 +620,7 @@ class PreAttnBlockFn(torch.autograd.Function):
         with _timed("ln_gelu_drop_bwd", ("byte", (3.0 if amax is not None else 4.0) * T * N * 4)):
             rc = lib.mdl_ln_gelu_drop_bwd_split(_ptr(y), _ptr(lin_bias), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(dy), _ptr(amax),
                                                 _ptr(dximg), _ptr(dxscale), _ptr(dg), _ptr(db), _ptr(dbias), T, N, p_drop, seed, _ptr(keep),
-                                                _ptr(row_inv), _ptr(ws), _stream())
+                                                _ptr(row_inv), _ptr(rstd_max), _ptr(ws), _stream())
         _native.check(rc, "mdl_ln_gelu_drop_bwd_split")
         dyi = SplitImage(dximg, dxscale, T, N)
         dx = None
@@ -635,7 +637,7 @@ class PreAttnBlockFn(torch.autograd.Function):
                 with _timed("ln_gelu_drop_bwd", ("byte", 3.0 * T * N * 4)):
                     rc = lib.mdl_ln_gelu_drop_bwd_split(_ptr(y), _ptr(lin_bias), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(dy), _ptr(amax),
                                                         _ptr(dximg2), _ptr(dxscale2), _ptr(dg2), _ptr(db2), None, T, N, p_drop, seed, _ptr(keep),
-                                                        None, _ptr(ws), _stream())
+                                                        None, None, _ptr(ws), _stream())   # (no row factors: its own pass over rstd)
                 _native.check(rc, "mdl_ln_gelu_drop_bwd_split")
                 dxi = SplitImage(dximg2, dxscale2, T, N)
             dx = split_gemm_nt(dxi, weight_image(W.t().contiguous()), absmax_out=am, name="linear_bwd")
