@@ -608,6 +608,21 @@ def main():
         finally:
             MF.TIMER = None
             MF.set_gemm_mode("split")
+    g2_leg = None
+    if a.precision == "float32" and world == 1 and not a.no_bf16_leg and host_iter is None and MF.gemm_mode() == "split":
+        # opt-in variant: backward products with two matrix terms (the non-gradient operand at its hi plane, functional.set_gradient_terms);
+        # same forward bits, gradients at ~2^-12 relative.  Reported beside, never as, `value`.
+        MF.set_gradient_terms(2)
+        try:
+            ng = max(3, min(10, a.steps))
+            eg, lg, pg, wg, _ = measure_leg(MF, step, ng)
+            g2_leg = {"value": round(B * ng / eg, 3), "unit": "slides/s", "ms_per_step": round(1e3 * eg / ng, 3), "steps": ng,
+                      "dtype": "forward as the headline (3-term split-fp16); dX / dW products with 2 terms: weights (dX) and activations (dW) "
+                               "at 11 bits, gradients ~2^-12 relative (tests/test_grad_terms_gpu.py)",
+                      "final_loss": float(lg.detach()), "kernel_ms": {k: round(v[0], 4) for k, v in pg.items()}}
+        finally:
+            MF.TIMER = None
+            MF.set_gradient_terms(3)
     # PCIe-inclusive leg ("a second number including pinned-host H2D"): the same step fed from HOST memory -- pinned
     # batches, as DataLoader(pin_memory=True) delivers them -- through data.DevicePrefetcher (side-stream H2D two batches ahead,
     # the step waits on the upload event only).  Never `value`.
@@ -766,6 +781,8 @@ def main():
             out["bf16_mode"] = bf16_leg
         if f32_leg is not None:
             out["fp32_mfma_mode"] = f32_leg
+        if g2_leg is not None:
+            out["grad_terms2_mode"] = g2_leg
         if c3_leg is not None:
             out["c3_mode"] = c3_leg
         if infer_leg is not None:

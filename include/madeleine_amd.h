@@ -54,7 +54,7 @@ const char* mdl_version(void);
 /* ABI revision of this header: bumped whenever an entry point's argument list changes.  A binding compares
  * mdl_abi_version() with the MDL_ABI_VERSION it was written against BEFORE calling anything else, so that a stale
  * shared object fails loudly instead of being called with shifted arguments. */
-#define MDL_ABI_VERSION 17
+#define MDL_ABI_VERSION 18
 int mdl_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -382,17 +382,22 @@ int mdl_split_image_rows(const float* X, int64_t ldx, int64_t rows, int K, void*
  * skipped -- mdl_split_tile_absmax(X, ...) fills it with the per-256-row maxima of |X| for A = image(X), and chunk_max (float
  * [ceil(rows / 32)], may be NULL) with the per-32-row maxima that mdl_split_gemm_tn's b_chunk_max takes. */
 int mdl_split_tile_absmax(const float* X, int64_t ldx, int64_t rows, int K, float* gate, float* chunk_max, void* stream);
-/* a_row_mul (device float[M], may be NULL): row m of the product is multiplied by a_row_mul[m] before bias / accumulation (the
+/* terms (round 4; 3 everywhere by default, anything but 2 / 3 is MDL_E_ARG): 3 = ah bh + ah bl + al bh, the fp32-class product.  2 = the
+ * operand that is NOT a gradient enters with its hi plane only (11 significant bits): mdl_split_gemm_nt drops ah bl (B = the weight of
+ * dX = dY W), mdl_split_gemm_tn drops al bh (A = the activations of dW = dY^T X), mdl_abmil_attnpool_bwd_split does both for the gate's
+ * dX / dW -- 4 instead of 6 MFMA sets per 32-k block, results at ~2^-12 relative.  Only ever selected for BACKWARD products, by
+ * madeleine_amd.functional.set_gradient_terms(2); the forward (every value the losses see) always runs with 3.
+ * a_row_mul (device float[M], may be NULL): row m of the product is multiplied by a_row_mul[m] before bias / accumulation (the
  * 1 / s_r of a row-scaled A image, or the s_r that undoes a row_mul folded into a gradient image).  b_col_mul (device float[N], N % 4
  * == 0, may be NULL): the same per output column = per row of a row-scaled B image (a weight matrix W [N, K]: nn.Linear's rows). */
 int mdl_split_gemm_nt(const void* A, int64_t a_rsb, const float* a_scale, const void* B, int64_t b_rsb, const float* b_scale, float* C,
                       int64_t ldc, int64_t M, int N, int K, const float* bias, int accumulate, float* absmax_out, const float* row_gate,
-                      const float* a_row_mul, const float* b_col_mul, void* stream);
+                      const float* a_row_mul, const float* b_col_mul, int terms, void* stream);
 int64_t mdl_split_gemm_tn_ws_bytes(int64_t T, int Mi, int N);
 /* b_chunk_max (float [ceil(T / 32)], may be NULL): per-32-row maxima of |X| for B = image(X) (mdl_split_tile_absmax) -- chunks whose
  * entry is 0 are skipped (the token_projector's dW: the local loss reads the first <= 256 tokens of a bag, the rest of d_tok is zero). */
 int mdl_split_gemm_tn(const void* A, int64_t a_rsb, const float* a_scale, int Mi, const void* B, int64_t b_rsb, const float* b_scale,
-                      int N, float* out, int64_t T, const float* b_chunk_max, void* ws, void* stream);
+                      int N, float* out, int64_t T, const float* b_chunk_max, void* ws, int terms, void* stream);
 
 /* N1 producers that write split images directly (csrc/preattn_act.hip): mdl_ln_gelu_drop_fwd / _bwd with the output tensor as an
  * image -- the pre-attention activations and their gradients are consumed by contractions only, so no fp32 copy is written (the
@@ -428,7 +433,7 @@ int mdl_abmil_attnpool_bwd_split(const void* E_img, int64_t e_rsb, const float* 
                                  float* dWa, float* dWb, float* dba, float* dbb, float* dwc, float* dbc, int64_t T, int H, float p_drop,
                                  uint64_t seed, const uint8_t* keep_a, const uint8_t* keep_b, const float* scores, const float* stat_m,
                                  const float* stat_l, const float* d_pooled, const int32_t* row_bag, int64_t N, float* dE_absmax, void* ws,
-                                 void* stream, int phases);
+                                 void* stream, int phases, int terms);
 
 #ifdef __cplusplus
 }

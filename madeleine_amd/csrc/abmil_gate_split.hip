@@ -266,6 +266,7 @@ __global__ __launch_bounds__(64 * MDL_MAX_HEADS) void sp_gate_dz_kernel(const fl
 // ================================================================================================
 // backward, stage 2: dE[t, c, n0 + n] (+)= sum_j dz[t, c, j] WN[c][n0 + n][j]  (+ pooling term), K = 1024
 // ================================================================================================
+template <int TERMS>
 __global__ __launch_bounds__(SP_THREADS) void sp_gate_dx_kernel(const char* __restrict__ dzi, const float* __restrict__ dz_sc,
                                                          const char* __restrict__ WN, const float* __restrict__ w_sc,
                                                          float* __restrict__ dE, int64_t ldE, int accumulate, int64_t T, int H,
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(SP_THREADS) void sp_gate_dx_kernel(const char* __re
     }
     SpAcc acc;
     sp_zero(acc);
-    sp_nt_mainloop(sm, acc, 1024 / 32, wm, wn, lane, [&](int st, int f, int piece) {
+    sp_nt_mainloop<TERMS>(sm, acc, 1024 / 32, wm, wn, lane, [&](int st, int f, int piece) {
         const int i = piece % SP_PW;
         if (piece < SP_PW) glds16_s(voA[i], sp_uniform(baseA + (int64_t)f * 128), lds_addr_of(&sm.A[st][(wave * SP_PW + i) * 1024]));
         else glds16_s(voB[i], sp_uniform(baseB + (int64_t)f * 128), lds_addr_of(&sm.B[st][(wave * SP_PW + i) * 1024]));
@@ -326,6 +327,7 @@ __global__ __launch_bounds__(SP_THREADS) void sp_gate_dx_kernel(const char* __re
 // ================================================================================================
 // backward, stage 3: slabW[sp][c][k' 512][1024: a | b] = sum_{t in split} E[t, c, k'] dz[t, c, n]      (TN over tokens)
 // ================================================================================================
+template <int TERMS>
 __global__ __launch_bounds__(SP_THREADS) void sp_gate_dw_kernel(const char* __restrict__ Ei, int64_t e_rsb, const float* __restrict__ e_sc,
                                                          const char* __restrict__ dzi, const float* __restrict__ dz_sc,
                                                          float* __restrict__ slabW, int64_t T, int H, int64_t tok_per_split,
@@ -356,7 +358,7 @@ __global__ __launch_bounds__(SP_THREADS) void sp_gate_dw_kernel(const char* __re
     const char* baseB = dzi + (ts * H + c) * (int64_t)4096;
     SpAcc acc;
     sp_zero(acc);
-    sp_tn_mainloop(sm, acc, nch, wm, wn, lane, [&](int st, int64_t f, int piece) {
+    sp_tn_mainloop<TERMS>(sm, acc, nch, wm, wn, lane, [&](int st, int64_t f, int piece) {
         const int q = piece % SP_PW;
         if (piece < SP_PW) {   // E rows past T - 1 re-read row T - 1: their dz rows are the zero pad
             uint32_t tk = tokq[q];
@@ -476,7 +478,8 @@ extern "C" int mdl_abmil_attnpool_bwd_split(const void* E_img, int64_t e_rsb, co
                                             float* dbc, int64_t T, int H, float p_drop, uint64_t seed, const uint8_t* keep_a,
                                             const uint8_t* keep_b, const float* scores, const float* stat_m, const float* stat_l,
                                             const float* d_pooled, const int32_t* row_bag, int64_t N, float* dE_absmax, void* ws,
-                                            void* stream, int phases) {
+                                            void* stream, int phases, int terms) {
+    if (terms != 2 && terms != 3) return MDL_E_ARG;
     if (!E_img || !e_scale || !Wa || !Wb || !wc || !act_a || !act_b || !d_scores || !dE || !dWa || !dWb || !dba || !dbb || !dwc || !ws)
         return MDL_E_ARG;
     if (phases < 1 || phases > 3) return MDL_E_ARG;
@@ -534,11 +537,11 @@ extern "C" int mdl_abmil_attnpool_bwd_split(const void* E_img, int64_t e_rsb, co
             const int64_t n_tt = (T + SPM - 1) / SPM;
             const int64_t grid = xcd_head_grid(n_tt, 2, H);
             if (grid > 0x7fffffff) return MDL_E_UNSUPPORTED;
-            hipLaunchKernelGGL(sp_gate_dx_kernel, dim3((unsigned)grid), dim3(SP_THREADS), 0, s, (const char*)dzi, (const float*)(sc + 4),
+            hipLaunchKernelGGL(terms == 2 ? sp_gate_dx_kernel<2> : sp_gate_dx_kernel<3>, dim3((unsigned)grid), dim3(SP_THREADS), 0, s, (const char*)dzi, (const float*)(sc + 4),
                                (const char*)WN, (const float*)sc, dE, ldE, accumulate, T, H, pt, dE_absmax);
             MDL_LAUNCH_CHECK();
         }
-        hipLaunchKernelGGL(sp_gate_dw_kernel, dim3((unsigned)xcd_head_grid(L.S, 8, H)), dim3(SP_THREADS), 0, s, (const char*)E_img, e_rsb, e_scale,
+        hipLaunchKernelGGL(terms == 2 ? sp_gate_dw_kernel<2> : sp_gate_dw_kernel<3>, dim3((unsigned)xcd_head_grid(L.S, 8, H)), dim3(SP_THREADS), 0, s, (const char*)E_img, e_rsb, e_scale,
                            (const char*)dzi, (const float*)(sc + 4), slabW, T, H, L.tps, L.S);
         MDL_LAUNCH_CHECK();
         const int rc = gate_launch_reduce_w(slabW, dWa, dWb, H, L.S, s);

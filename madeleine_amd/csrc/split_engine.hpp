@@ -85,7 +85,9 @@ __device__ __forceinline__ void sp_nt_slot(int wave, int i, int lane, int& row, 
     c = (lane & 7) ^ ((row >> 1) & 7);
 }
 // dma(stage, block, piece): piece < SP_PW = this wave's A row groups, SP_PW .. SP_NP - 1 = its B row groups (glds16_s).
-template <class Dma>
+// TERMS = 3: ah bh + ah bl + al bh.  TERMS = 2 drops ah bl, i.e. the B operand enters rounded to its hi plane (11 bits): four MFMA sets
+// per chunk instead of six.  For gradient products whose B operand is a weight (dX = dY W); never the default.
+template <int TERMS = 3, class Dma>
 __device__ __forceinline__ void sp_nt_mainloop(SmemSP& sm, SpAcc& acc, int nblk, int wm, int wn, int lane, Dma&& dma) {
     const int l32 = lane & 31, kh = lane >> 5;
     uint32_t offA[4], offB[SPNCT];
@@ -134,11 +136,17 @@ __device__ __forceinline__ void sp_nt_mainloop(SmemSP& sm, SpAcc& acc, int nblk,
     for (int ch = 0; ch < nblk; ++ch) {
         const int st = ch & 1;
         // ks: 0 = hi k 0-15, 1 = hi k 16-31, 2 = lo k 0-15, 3 = lo k 16-31;  a0 = A hi s0, b0 = B hi s0 on entry
-        SP_SET(a0, b0, ldB(b1, st, 2))                   // hi hi, s0   | B lo s0
-        SP_SET(a0, b1, ldA(a1, st, 2))                   // hi lo, s0   | A lo s0
-        SP_SET(a1, b0, ldA(a2, st, 1); ldB(b2, st, 1))   // lo hi, s0   | A hi s1, B hi s1
-        SP_SET(a2, b2, ldB(b1, st, 3))                   // hi hi, s1   | B lo s1
-        SP_SET(a2, b1, ldA(a1, st, 3))                   // hi lo, s1   | A lo s1
+        if constexpr (TERMS == 3) {
+            SP_SET(a0, b0, ldB(b1, st, 2))                   // hi hi, s0   | B lo s0
+            SP_SET(a0, b1, ldA(a1, st, 2))                   // hi lo, s0   | A lo s0
+            SP_SET(a1, b0, ldA(a2, st, 1); ldB(b2, st, 1))   // lo hi, s0   | A hi s1, B hi s1
+            SP_SET(a2, b2, ldB(b1, st, 3))                   // hi hi, s1   | B lo s1
+            SP_SET(a2, b1, ldA(a1, st, 3))                   // hi lo, s1   | A lo s1
+        } else {
+            SP_SET(a0, b0, ldA(a1, st, 2))                   // hi hi, s0   | A lo s0
+            SP_SET(a1, b0, ldA(a2, st, 1); ldB(b2, st, 1))   // lo hi, s0   | A hi s1, B hi s1
+            SP_SET(a2, b2, ldA(a1, st, 3))                   // hi hi, s1   | A lo s1
+        }
         // last set of the chunk: every read of stage st has been requested -> barrier, then the next chunk's first fragments and
         // the DMA of block ch + 2 between this set's MFMAs (the last two iterations re-fetch the last block: branch-free body)
         SP_DMA_WAIT();
@@ -202,7 +210,8 @@ __device__ __forceinline__ void sp_tn_mma(SpAcc& acc, const SpFragA& fa, const S
 }
 #define SP_LGKM_WAIT() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 // acc[rt][ct] += sum over nch chunks of 32 tokens of A[t][wm*128 + rt*32 ..] B[t][wn*SP_WCOLS + ct*32 ..];  dma(stage, chunk, piece < SP_NP)
-template <class Dma>
+// TERMS = 2 drops al bh: the A operand (the activations of a dW product; B is the gradient) enters rounded to its hi plane.
+template <int TERMS = 3, class Dma>
 __device__ __forceinline__ void sp_tn_mainloop(SmemSP& sm, SpAcc& acc, int64_t nch, int wm, int wn, int lane, Dma&& dma) {
     const int g = lane >> 4, r = lane & 15;
     const int kb = (g >> 1) * 8 + (r >> 2);
@@ -251,11 +260,17 @@ __device__ __forceinline__ void sp_tn_mainloop(SmemSP& sm, SpAcc& acc, int64_t n
             aB[ct] = b_0[ct] + st * SP_STAGE;
             nB[ct] = b_0[ct] + (st ^ 1) * SP_STAGE;
         }
-        SP_TSET(a0, b0, sp_tn_ldB<2>(b1, aB))                          // hi hi, s0 | B lo s0
-        SP_TSET(a0, b1, sp_tn_ldA<2>(a1, aA))                          // hi lo, s0 | A lo s0
-        SP_TSET(a1, b0, sp_tn_ldA<1>(a2, aA); sp_tn_ldB<1>(b2, aB))    // lo hi, s0 | A hi s1, B hi s1
-        SP_TSET(a2, b2, sp_tn_ldB<3>(b1, aB))                          // hi hi, s1 | B lo s1
-        SP_TSET(a2, b1, sp_tn_ldA<3>(a1, aA))                          // hi lo, s1 | A lo s1
+        if constexpr (TERMS == 3) {
+            SP_TSET(a0, b0, sp_tn_ldB<2>(b1, aB))                          // hi hi, s0 | B lo s0
+            SP_TSET(a0, b1, sp_tn_ldA<2>(a1, aA))                          // hi lo, s0 | A lo s0
+            SP_TSET(a1, b0, sp_tn_ldA<1>(a2, aA); sp_tn_ldB<1>(b2, aB))    // lo hi, s0 | A hi s1, B hi s1
+            SP_TSET(a2, b2, sp_tn_ldB<3>(b1, aB))                          // hi hi, s1 | B lo s1
+            SP_TSET(a2, b1, sp_tn_ldA<3>(a1, aA))                          // hi lo, s1 | A lo s1
+        } else {
+            SP_TSET(a0, b0, sp_tn_ldB<2>(b1, aB))                          // hi hi, s0 | B lo s0
+            SP_TSET(a0, b1, sp_tn_ldA<1>(a2, aA); sp_tn_ldB<1>(b2, aB))    // hi lo, s0 | A hi s1, B hi s1
+            SP_TSET(a2, b2, sp_tn_ldB<3>(b1, aB))                          // hi hi, s1 | B lo s1
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         SP_SB();
         __syncthreads();
@@ -265,7 +280,8 @@ __device__ __forceinline__ void sp_tn_mainloop(SmemSP& sm, SpAcc& acc, int64_t n
         const int64_t f = (ch + 2 < nch) ? ch + 2 : nch - 1;
 #pragma unroll
         for (int m = 0; m < SP_NP; ++m) {
-            sp_tn_mma(acc, a1, b2, m);                                 // lo hi, s1
+            if constexpr (TERMS == 3) sp_tn_mma(acc, a1, b2, m);       // lo hi, s1
+            else sp_tn_mma(acc, a2, b1, m);                            // hi lo, s1
             SP_SB();
             dma(st, f, m);
             SP_SB();

@@ -201,6 +201,7 @@ __global__ __launch_bounds__(256) void sp_tile_absmax_kernel(const float* __rest
 
 // ---- NT -------------------------------------------------------------------------------------------------------------------------------
 // C[m][n] (+)= inv * sum_k A[m][k] B[n][k] (+ bias[n]);  rows m >= M / n >= N re-read the last valid row (discarded).
+template <int TERMS>
 __global__ __launch_bounds__(SP_THREADS) void sp_nt_kernel(const char* __restrict__ A, int64_t a_rsb, const float* __restrict__ a_sc,
                                                     const char* __restrict__ B, int64_t b_rsb, const float* __restrict__ b_sc,
                                                     float* __restrict__ C, int64_t ldc, int64_t M, int N, int nblk, int n_tiles,
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(SP_THREADS) void sp_nt_kernel(const char* __restric
     }
     SpAcc acc;
     sp_zero(acc);
-    sp_nt_mainloop(sm, acc, nblk, wm, wn, lane, [&](int st, int f, int piece) {
+    sp_nt_mainloop<TERMS>(sm, acc, nblk, wm, wn, lane, [&](int st, int f, int piece) {
         const int i = piece % SP_PW;
         if (piece < SP_PW) glds16_s(voA[i], sp_uniform(baseA + (int64_t)f * 128), lds_addr_of(&sm.A[st][(wave * SP_PW + i) * 1024]));
         else glds16_s(voB[i], sp_uniform(baseB + (int64_t)f * 128), lds_addr_of(&sm.B[st][(wave * SP_PW + i) * 1024]));
@@ -282,6 +283,7 @@ __global__ __launch_bounds__(256) void sp_chunk_list_kernel(const float* __restr
 // ---- TN -------------------------------------------------------------------------------------------------------------------------------
 // slab[sp][m][n] = inv * sum_{t in split sp} A[t][m] B[t][n].  A rows t >= T re-read row T - 1; the B image must continue with >= 32
 // all-zero rows after row T - 1 (their products vanish).  Columns >= Mi / >= N fetch column 0 (discarded).
+template <int TERMS>
 __global__ __launch_bounds__(SP_THREADS) void sp_tn_kernel(const char* __restrict__ A, int64_t a_rsb, const float* __restrict__ a_sc, int Mi,
                                                     const char* __restrict__ B, int64_t b_rsb, const float* __restrict__ b_sc, int N,
                                                     float* __restrict__ slab, int64_t T, int64_t tok_per_split, int n_tiles,
@@ -316,7 +318,7 @@ __global__ __launch_bounds__(SP_THREADS) void sp_tn_kernel(const char* __restric
     const char* baseB = B + ts * b_rsb;
     SpAcc acc;
     sp_zero(acc);
-    sp_tn_mainloop(sm, acc, nch, wm, wn, lane, [&](int st, int64_t fl, int piece) {
+    sp_tn_mainloop<TERMS>(sm, acc, nch, wm, wn, lane, [&](int st, int64_t fl, int piece) {
         const int q = piece % SP_PW;
         const int64_t f = clist ? (int64_t)clist[fl] : fl;
         if (piece < SP_PW) {
@@ -438,7 +440,8 @@ extern "C" int mdl_split_tile_absmax(const float* X, int64_t ldx, int64_t rows, 
 
 extern "C" int mdl_split_gemm_nt(const void* A, int64_t a_rsb, const float* a_scale, const void* B, int64_t b_rsb, const float* b_scale,
                                  float* C, int64_t ldc, int64_t M, int N, int K, const float* bias, int accumulate, float* absmax_out,
-                                 const float* row_gate, const float* a_row_mul, const float* b_col_mul, void* stream) {
+                                 const float* row_gate, const float* a_row_mul, const float* b_col_mul, int terms, void* stream) {
+    if (terms != 2 && terms != 3) return MDL_E_ARG;
     if (row_gate && (!accumulate || bias)) return MDL_E_ARG;   // skipping a tile is only the identity when it would add zeros
     if (!A || !B || !C || !a_scale || !b_scale || M < 0 || N < 4 || (N & 3) || K < 32 || (K % 32) || ldc < N || (ldc & 3)) return MDL_E_ARG;
     if (a_rsb < (int64_t)K * 4 || b_rsb < (int64_t)K * 4 || (a_rsb & 15) || (b_rsb & 15)) return MDL_E_ARG;
@@ -446,9 +449,9 @@ extern "C" int mdl_split_gemm_nt(const void* A, int64_t a_rsb, const float* a_sc
     if (M == 0) return MDL_OK;
     const int64_t tiles = ((M + SPM - 1) / SPM) * ((N + SPN - 1) / SPN);
     if (tiles > 0x7fffffff || a_rsb * SPM > 0x7fffffff || b_rsb * SPN > 0x7fffffff) return MDL_E_UNSUPPORTED;
-    hipLaunchKernelGGL(sp_nt_kernel, dim3((unsigned)tiles), dim3(SP_THREADS), 0, (hipStream_t)stream, (const char*)A, a_rsb, a_scale,
-                       (const char*)B, b_rsb, b_scale, C, ldc, M, N, K / 32, (int)tiles, bias, accumulate, absmax_out, row_gate, a_row_mul,
-                       b_col_mul);
+    hipLaunchKernelGGL(terms == 2 ? sp_nt_kernel<2> : sp_nt_kernel<3>, dim3((unsigned)tiles), dim3(SP_THREADS), 0, (hipStream_t)stream,
+                       (const char*)A, a_rsb, a_scale, (const char*)B, b_rsb, b_scale, C, ldc, M, N, K / 32, (int)tiles, bias, accumulate,
+                       absmax_out, row_gate, a_row_mul, b_col_mul);
     MDL_LAUNCH_CHECK();
     return MDL_OK;
 }
@@ -463,7 +466,9 @@ extern "C" int64_t mdl_split_gemm_tn_ws_bytes(int64_t T, int Mi, int N) {
 /* out [N][Mi] (contiguous: a Linear's dW with A = image(X), B = image(dY)) = sum_t B[t][n] A[t][m] over the T rows of the two
  * token-major images (Mi / N columns).  The B image must be followed by >= 32 all-zero rows.  Mi % 32 == 0, N % 32 == 0. */
 extern "C" int mdl_split_gemm_tn(const void* A, int64_t a_rsb, const float* a_scale, int Mi, const void* B, int64_t b_rsb,
-                                 const float* b_scale, int N, float* out, int64_t T, const float* b_chunk_max, void* ws, void* stream) {
+                                 const float* b_scale, int N, float* out, int64_t T, const float* b_chunk_max, void* ws, int terms,
+                                 void* stream) {
+    if (terms != 2 && terms != 3) return MDL_E_ARG;
     if (!A || !B || !out || !ws || !a_scale || !b_scale || T < 0 || Mi < 32 || (Mi % 32) || N < 32 || (N % 32)) return MDL_E_ARG;
     if (a_rsb < (int64_t)Mi * 4 || b_rsb < (int64_t)N * 4 || (a_rsb & 15) || (b_rsb & 15) || a_rsb * 32 > 0x7fffffff || b_rsb * 32 > 0x7fffffff)
         return MDL_E_ARG;
@@ -481,7 +486,7 @@ extern "C" int mdl_split_gemm_tn(const void* A, int64_t a_rsb, const float* a_sc
         hipLaunchKernelGGL(sp_chunk_list_kernel, dim3(S), dim3(256), 0, s, b_chunk_max, T, tps, list, count, stride);
         MDL_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(sp_tn_kernel, dim3(tiles), dim3(SP_THREADS), 0, s, (const char*)A, a_rsb, a_scale, Mi, (const char*)B, b_rsb, b_scale, N,
+    hipLaunchKernelGGL(terms == 2 ? sp_tn_kernel<2> : sp_tn_kernel<3>, dim3(tiles), dim3(SP_THREADS), 0, s, (const char*)A, a_rsb, a_scale, Mi, (const char*)B, b_rsb, b_scale, N,
                        (float*)ws, T, tps, tiles, (const int32_t*)list, (const int32_t*)count, stride);
     MDL_LAUNCH_CHECK();
     return lin_launch_reduce((const float*)ws, out, Mi, N, S, s);

@@ -182,7 +182,7 @@ def attnpool_bwd_split_raw(Ei, Wa, Wb, wc, act_a, act_b, d_scores, dE, p_drop, s
                                               _ptr(d_scores), _ptr(dE), dE.stride(0), int(accumulate), _ptr(dWa), _ptr(dWb), _ptr(dba), _ptr(dbb),
                                               _ptr(dwc), _ptr(dbc), T, H, float(p_drop), int(seed), _ptr(keep_a), _ptr(keep_b), _ptr(scores),
                                               _ptr(stat_m), _ptr(stat_l), _ptr(d_pooled), _ptr(row_bag), int(N), _ptr(dE_absmax), _ptr(ws),
-                                              _stream(), phases)
+                                              _stream(), phases, GRAD_TERMS)
         _native.check(rc, "mdl_abmil_attnpool_bwd_split")
     if TIMER is not None and TIMER.wants("gate_bwd_dz"):
         with _timed("gate_bwd_dz", ("byte", float(T) * H * 4 * HID * 4)):
@@ -345,6 +345,20 @@ def gemm_mode() -> str:
 GATE_RECOMPUTE = os.environ.get("MADELEINE_GATE_RECOMPUTE", "0") == "1"
 
 
+# Matrix terms of the split engine's BACKWARD products (opt-in; MADELEINE_GRAD_TERMS=2 or set_gradient_terms(2)).  3: every product is
+# ah bh + ah bl + al bh.  2: in dX = dY W the weight, and in dW = dY^T X the activations, enter rounded to their hi plane (11 bits) --
+# a third fewer matrix instructions in the backward, gradients at ~2^-12 relative instead of ~2^-22; the forward (every value the
+# losses and the caller see) is untouched.  Measured in DESIGN.md 3.7; never the default.
+GRAD_TERMS = int(os.environ.get("MADELEINE_GRAD_TERMS", "3"))
+
+
+def set_gradient_terms(terms: int):
+    global GRAD_TERMS
+    if terms not in (2, 3):
+        raise ValueError("gradient terms: 2 or 3")
+    GRAD_TERMS = int(terms)
+
+
 def set_gate_recompute(on: bool):
     global GATE_RECOMPUTE
     GATE_RECOMPUTE = bool(on)
@@ -433,10 +447,10 @@ def split_tile_absmax(x2d, chunks=False):
 
 
 def split_gemm_nt(A: SplitImage, B: SplitImage, bias=None, out=None, accumulate=False, absmax_out=None, name="split_nt", row_gate=None,
-                  a_row_mul=None):
+                  a_row_mul=None, terms=3):
     """C [A.rows, B.rows] (+)= A B^T (+ bias) on two images with the same K.  row_gate (accumulate mode only): per-256-row maxima of
     the tensor A is the image of; output tiles of all-zero A rows are skipped.  a_row_mul [A.rows]: per-row factor applied to the
-    product (row_inv of a row-scaled A image)."""
+    product (row_inv of a row-scaled A image).  terms=2: B enters with its hi plane only (GRAD_TERMS)."""
     lib = _native.lib()
     M, N, K = A.rows, B.rows, A.K
     if B.K != K:
@@ -446,12 +460,13 @@ def split_gemm_nt(A: SplitImage, B: SplitImage, bias=None, out=None, accumulate=
     C = out if out is not None else torch.empty(M, N, device=A.data.device, dtype=torch.float32)
     with _timed(name, ("flop", 2.0 * M * N * K)):
         rc = lib.mdl_split_gemm_nt(_ptr(A.data), K * 4, _ptr(A.scale), _ptr(B.data), K * 4, _ptr(B.scale), _ptr(C), C.stride(0), M, N, K,
-                                   _ptr(bias), int(accumulate), _ptr(absmax_out), _ptr(row_gate), _ptr(a_row_mul), _ptr(B.row_inv), _stream())
+                                   _ptr(bias), int(accumulate), _ptr(absmax_out), _ptr(row_gate), _ptr(a_row_mul), _ptr(B.row_inv), int(terms),
+                                   _stream())
     _native.check(rc, "mdl_split_gemm_nt")
     return C
 
 
-def split_gemm_tn(A: SplitImage, B: SplitImage, name="split_tn", b_chunk_max=None):
+def split_gemm_tn(A: SplitImage, B: SplitImage, name="split_tn", b_chunk_max=None, terms=3):
     """out [B.K, A.K] = B^T A summed over the rows (tokens) of the two images; B must carry >= 32 zero pad rows.  b_chunk_max: the
     per-32-row maxima (split_tile_absmax(x, chunks=True)) of the tensor B is the image of -- its all-zero chunks are skipped."""
     lib = _native.lib()
@@ -464,7 +479,7 @@ def split_gemm_tn(A: SplitImage, B: SplitImage, name="split_tn", b_chunk_max=Non
     ws = _ws(lib.mdl_split_gemm_tn_ws_bytes(T, Mi, N), A.data.device)
     with _timed(name, ("flop", 2.0 * T * Mi * N)):
         rc = lib.mdl_split_gemm_tn(_ptr(A.data), Mi * 4, _ptr(A.scale), Mi, _ptr(B.data), N * 4, _ptr(B.scale), N, _ptr(out), T, _ptr(b_chunk_max),
-                                   _ptr(ws), _stream())
+                                   _ptr(ws), int(terms), _stream())
     _native.check(rc, "mdl_split_gemm_tn")
     return out
 
@@ -504,8 +519,8 @@ class SplitLinearFn(torch.autograd.Function):
         dyi = split_image(dy, pad_rows=32)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = split_gemm_nt(dyi, weight_image(W.t().contiguous()), name="linear_bwd")
-        dW = split_gemm_tn(xi, dyi, name="linear_bwd")
+            dx = split_gemm_nt(dyi, weight_image(W.t().contiguous()), name="linear_bwd", terms=GRAD_TERMS)
+        dW = split_gemm_tn(xi, dyi, name="linear_bwd", terms=GRAD_TERMS)
         db = dy.sum(0) if ctx.has_bias else None
         return dx, dW, db
 
@@ -640,10 +655,10 @@ class PreAttnBlockFn(torch.autograd.Function):
                                                         None, None, _ptr(ws), _stream())   # (no row factors: its own pass over rstd)
                 _native.check(rc, "mdl_ln_gelu_drop_bwd_split")
                 dxi = SplitImage(dximg2, dxscale2, T, N)
-            dx = split_gemm_nt(dxi, weight_image(W.t().contiguous()), absmax_out=am, name="linear_bwd")
+            dx = split_gemm_nt(dxi, weight_image(W.t().contiguous()), absmax_out=am, name="linear_bwd", terms=GRAD_TERMS)
             if x_is_image:       # the consumer is the previous block's LayerNorm backward (this node's input was its image)
                 _put_absmax(dx, am)
-        dW = split_gemm_tn(SplitImage(xdata, xscale, T, K), dyi, name="linear_bwd")
+        dW = split_gemm_tn(SplitImage(xdata, xscale, T, K), dyi, name="linear_bwd", terms=GRAD_TERMS)
         return dx, None, dW, dbias, dg, db, None, None, None, None, None
 
 
@@ -944,8 +959,8 @@ class AttnPoolFn(torch.autograd.Function):
                 dti = split_image(d_tok, pad_rows=32)
                 gate, chunk_max = split_tile_absmax(d_tok, chunks=True)   # one pass: 256-row tiles (dX) and 32-row chunks (dW)
                 split_gemm_nt(dti, weight_image(Wtok.t().contiguous()), out=dE, accumulate=True, absmax_out=am, name="linear_bwd",
-                              row_gate=gate)
-                dWtok = split_gemm_tn(Ei, dti, name="linear_bwd", b_chunk_max=chunk_max)
+                              row_gate=gate, terms=GRAD_TERMS)
+                dWtok = split_gemm_tn(Ei, dti, name="linear_bwd", b_chunk_max=chunk_max, terms=GRAD_TERMS)
                 dbtok = d_tok.sum(0) if has_btok else None
             if am is not None:
                 _put_absmax(dE, am)

@@ -23,6 +23,15 @@ def main():
     for kind in ("uniform", "outlier_patch_2^20", "student_t2", "zero_bags"):
         out["full_step_T0.001"][kind] = TR.case_full_step(dev, kind)
     out["full_step_T0.01_got"] = {"outlier_patch_2^20": TR.case_full_step(dev, "outlier_patch_2^20", use_got=True, T_=0.01)}
+    # the opt-in two-term backward (functional.set_gradient_terms(2)): same cases, split mode only
+    from madeleine_amd import functional as MF
+    MF.set_gradient_terms(2)
+    try:
+        out["full_step_T0.001_grad_terms2"] = {k: TR.case_full_step(dev, k)["split"]
+                                               for k in ("uniform", "outlier_patch_2^20", "student_t2", "zero_bags")}
+        out["first_block_grad_terms2"] = {k: TR.case_block1(dev, k) for k in ("uniform", "outlier_patch_2^20")}
+    finally:
+        MF.set_gradient_terms(3)
     with open(sys.argv[1], "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out)[:3000])
