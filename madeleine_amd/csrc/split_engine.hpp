@@ -168,6 +168,140 @@ __device__ __forceinline__ void sp_nt_mainloop(SmemSP& sm, SpAcc& acc, int nblk,
 #undef SP_SET
 }
 
+// ---- NT, tall tile (round 4): 512 x 128 outputs -----------------------------------------------------------------------------------
+// For products with at most 128 output columns (the token_projector, Model.py:140: 2048 -> 128): on the 256 x 256 tile half of every
+// MFMA is spent on columns that do not exist.  Here the workgroup covers 512 rows x 128 columns: 8 waves stacked over the rows, 64 rows x
+// 128 columns = 2 x 4 MFMA tiles each (128 accumulators, 24 fragment reads per 48 MFMAs -- the ratios of the square tile); stage = 64 KiB
+// of A + 16 KiB of B, two stages = the whole 160 KiB of LDS.  Same LDS row format / swizzle / six-set schedule as sp_nt_mainloop.
+constexpr int SPT_M = 512, SPT_N = 128;
+constexpr int SPT_PA = 8, SPT_PB = 2;   // LDS-DMA pieces (8 rows x 128 B) per wave, stage and operand
+typedef f32x16 SpAccT[2][4];
+struct __attribute__((aligned(16))) SmemSPT {
+    char A[2][SPT_M * 128];
+    char B[2][SPT_N * 128];
+};
+__device__ __forceinline__ void sp_zero(SpAccT& acc) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+}
+// row / stored chunk of DMA piece i of this wave: A pieces i < SPT_PA (rows of the 512), B pieces i < SPT_PB (rows of the 128)
+__device__ __forceinline__ void sp_tall_slot(int wave, int i, int per_wave, int lane, int& row, int& c) {
+    row = (wave * per_wave + i) * 8 + (lane >> 3);
+    c = (lane & 7) ^ ((row >> 1) & 7);
+}
+// dmaA(stage, block, i < SPT_PA), dmaB(stage, block, j < SPT_PB)
+template <int TERMS = 3, class DmaA, class DmaB>
+__device__ __forceinline__ void sp_nt_tall_mainloop(SmemSPT& sm, SpAccT& acc, int nblk, int wave, int lane, DmaA&& dmaA, DmaB&& dmaB) {
+    const int l32 = lane & 31, kh = lane >> 5;
+    uint32_t offA[2], offB[4];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const int r = wave * 64 + rt * 32 + l32;
+        offA[rt] = r * 128 + ((kh ^ ((r >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        const int r = ct * 32 + l32;
+        offB[ct] = r * 128 + ((kh ^ ((r >> 1) & 7)) << 4);
+    }
+    auto ldA = [&](u32x4 (&fa)[2], int st, int ks) {
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) fa[rt] = *reinterpret_cast<const u32x4*>(&sm.A[st][offA[rt] ^ (ks << 5)]);
+    };
+    auto ldB = [&](u32x4 (&fb)[4], int st, int ks) {
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) fb[ct] = *reinterpret_cast<const u32x4*>(&sm.B[st][offB[ct] ^ (ks << 5)]);
+    };
+    auto mma1 = [&](const u32x4 (&fa)[2], const u32x4 (&fb)[4], int m) {
+        const int rt = m >> 2, ct = m & 3;
+        acc[rt][ct] = sp_mfma(fa[rt], fb[ct], acc[rt][ct]);
+    };
+#define SPT_SET(FA, FB, LOADS)                                         \
+    mma1(FA, FB, 0);                                                   \
+    SP_SB();                                                           \
+    LOADS;                                                             \
+    SP_SB();                                                           \
+    _Pragma("unroll") for (int m = 1; m < 8; ++m) mma1(FA, FB, m);     \
+    SP_SB();
+    if (nblk <= 0) return;
+    u32x4 a0[2], a1[2], a2[2], b0[4], b1[4], b2[4];
+    auto dma_all = [&](int st, int f) {
+#pragma unroll
+        for (int i = 0; i < SPT_PA; ++i) dmaA(st, f, i);
+#pragma unroll
+        for (int j = 0; j < SPT_PB; ++j) dmaB(st, f, j);
+    };
+    dma_all(0, 0);
+    SP_DMA_WAIT();
+    __syncthreads();
+    dma_all(1, nblk > 1 ? 1 : 0);
+    ldA(a0, 0, 0);
+    ldB(b0, 0, 0);
+    for (int ch = 0; ch < nblk; ++ch) {
+        const int st = ch & 1;
+        if constexpr (TERMS == 3) {
+            SPT_SET(a0, b0, ldB(b1, st, 2))                   // hi hi, s0   | B lo s0
+            SPT_SET(a0, b1, ldA(a1, st, 2))                   // hi lo, s0   | A lo s0
+            SPT_SET(a1, b0, ldA(a2, st, 1); ldB(b2, st, 1))   // lo hi, s0   | A hi s1, B hi s1
+            SPT_SET(a2, b2, ldB(b1, st, 3))                   // hi hi, s1   | B lo s1
+            SPT_SET(a2, b1, ldA(a1, st, 3))                   // hi lo, s1   | A lo s1
+        } else {
+            SPT_SET(a0, b0, ldA(a1, st, 2))
+            SPT_SET(a1, b0, ldA(a2, st, 1); ldB(b2, st, 1))
+            SPT_SET(a2, b2, ldA(a1, st, 3))
+        }
+        SP_DMA_WAIT();
+        __syncthreads();
+        ldA(a0, st ^ 1, 0);
+        ldB(b0, st ^ 1, 0);
+        SP_SB();
+        const int f = (ch + 2 < nblk) ? ch + 2 : nblk - 1;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            mma1(a1, b2, m);                                  // lo hi, s1
+            SP_SB();
+            dmaA(st, f, m);
+            if (m < SPT_PB) dmaB(st, f, m);
+            SP_SB();
+        }
+    }
+    SP_DMA_WAIT();
+    __syncthreads();   // staging memory is free for the epilogue
+#undef SPT_SET
+}
+// the wave's 64 x 128 sub-tile as row-contiguous float4s: emit(row, col, v) in tile coordinates (sp_epilogue_rows for the tall tile)
+template <bool FULL, int INFLIGHT = 4, class Emit>
+__device__ __forceinline__ void sp_epilogue_rows_tall(const SpAccT& acc, SmemSPT& sm, int wave, int lane, int rows_valid, Emit&& emit) {
+    float* tile = reinterpret_cast<float*>(&sm) + wave * (32 * 64);
+    const int l32 = lane & 31, rl = lane >> 4, c4 = lane & 15;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int cp = 0; cp < 2; ++cp) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) tile[acc_row(r, lane) * 64 + c2 * 32 + l32] = acc[rt][cp * 2 + c2][r];
+#pragma unroll
+            for (int h = 0; h < 8 / INFLIGHT; ++h) {
+                f32x4 v[INFLIGHT];
+#pragma unroll
+                for (int j = 0; j < INFLIGHT; ++j)
+                    v[j] = *reinterpret_cast<const f32x4*>(&tile[((h * INFLIGHT + j) * 4 + rl) * 64 + c4 * 4]);
+#pragma unroll
+                for (int j = 0; j < INFLIGHT; ++j) {
+                    const int row = wave * 64 + rt * 32 + (h * INFLIGHT + j) * 4 + rl;
+                    if (FULL || row < rows_valid) emit(row, cp * 64 + c4 * 4, v[j]);
+                }
+                SP_SB();
+            }
+        }
+}
+
 // ---- TN ---------------------------------------------------------------------------------------------------------------------------
 // LDS stage image of one operand: [64 kr][256 columns] fp16, kr = plane * 32 + token of the 32-token chunk, 512 B per kr row, 64-B
 // unit u of row kr stored at unit u ^ (kr & 3).  Fragments (8 consecutive tokens of the lane's output row / column) are gathered by

@@ -259,6 +259,61 @@ __global__ __launch_bounds__(SP_THREADS) void sp_nt_kernel(const char* __restric
     if (absmax_out) sp_atomic_absmax(absmax_out, amax);
 }
 
+// The same product on the tall tile (512 rows x 128 columns per workgroup) for N <= 128: no row gate (callers with a row gate have wide
+// outputs), everything else as sp_nt_kernel.
+template <int TERMS>
+__global__ __launch_bounds__(SP_THREADS) void sp_nt_tall_kernel(const char* __restrict__ A, int64_t a_rsb, const float* __restrict__ a_sc,
+                                                         const char* __restrict__ B, int64_t b_rsb, const float* __restrict__ b_sc,
+                                                         float* __restrict__ C, int64_t ldc, int64_t M, int N, int nblk, int n_tiles,
+                                                         const float* __restrict__ bias, int accumulate, float* __restrict__ absmax_out,
+                                                         const float* __restrict__ a_row_mul, const float* __restrict__ b_col_mul) {
+    __shared__ SmemSPT sm;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lid = xcd_remap(blockIdx.x, n_tiles);
+    const int64_t m0 = (int64_t)lid * SPT_M;
+    const char* baseA = A + m0 * a_rsb;
+    uint32_t voA[SPT_PA], voB[SPT_PB];
+#pragma unroll
+    for (int i = 0; i < SPT_PA; ++i) {
+        int row, c;
+        sp_tall_slot(wave, i, SPT_PA, lane, row, c);
+        int64_t ra = row;
+        if (m0 + ra > M - 1) ra = M - 1 - m0;
+        voA[i] = (uint32_t)(ra * a_rsb + c * 16);
+    }
+#pragma unroll
+    for (int j = 0; j < SPT_PB; ++j) {
+        int row, c;
+        sp_tall_slot(wave, j, SPT_PB, lane, row, c);
+        if (row > N - 1) row = N - 1;
+        voB[j] = (uint32_t)((int64_t)row * b_rsb + c * 16);
+    }
+    SpAccT acc;
+    sp_zero(acc);
+    sp_nt_tall_mainloop<TERMS>(
+        sm, acc, nblk, wave, lane,
+        [&](int st, int f, int i) { glds16_s(voA[i], sp_uniform(baseA + (int64_t)f * 128), lds_addr_of(&sm.A[st][(wave * SPT_PA + i) * 1024])); },
+        [&](int st, int f, int j) { glds16_s(voB[j], sp_uniform(B + (int64_t)f * 128), lds_addr_of(&sm.B[st][(wave * SPT_PB + j) * 1024])); });
+    const float inv = 1.f / (a_sc[0] * b_sc[0]);
+    float amax = 0.f;
+    char* cb = reinterpret_cast<char*>(C + m0 * ldc);
+    const uint32_t ldc4 = (uint32_t)ldc * 4u;
+    auto emit = [&](int row, int col, const f32x4& v) {
+        if (col >= N) return;
+        f32x4 r = v * (a_row_mul ? inv * a_row_mul[m0 + row] : inv);
+        if (b_col_mul) r *= *reinterpret_cast<const f32x4*>(b_col_mul + col);
+        if (bias) r += *reinterpret_cast<const f32x4*>(bias + col);
+        f32x4* o = reinterpret_cast<f32x4*>(cb + (int64_t)row * ldc4 + (uint32_t)col * 4u);
+        if (accumulate) r += *o;
+        *o = r;
+        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));
+    };
+    if (m0 + SPT_M <= M) sp_epilogue_rows_tall<true>(acc, sm, wave, lane, SPT_M, emit);
+    else sp_epilogue_rows_tall<false>(acc, sm, wave, lane, (int)(M - m0), emit);
+    if (absmax_out) sp_atomic_absmax(absmax_out, amax);
+}
+
 // Chunk lists for the TN loop: list[sp][0 .. count[sp]) = the 32-row chunks of split sp whose chunk_max (sp_tile_absmax_kernel over the
 // fp32 tensor the B image was built from) is not zero, in ascending order.  One workgroup per split; flags in LDS, serial compaction.
 constexpr int SP_MAX_LIST = 2048;
@@ -447,6 +502,15 @@ extern "C" int mdl_split_gemm_nt(const void* A, int64_t a_rsb, const float* a_sc
     if (a_rsb < (int64_t)K * 4 || b_rsb < (int64_t)K * 4 || (a_rsb & 15) || (b_rsb & 15)) return MDL_E_ARG;
     if (!host_aligned16(A) || !host_aligned16(B) || !host_aligned16(C) || !host_aligned16(bias)) return MDL_E_ALIGN;
     if (M == 0) return MDL_OK;
+    if (N <= SPT_N && !row_gate && M > SPM) {   // narrow output (the token_projector): the 512 x 128 tile
+        const int64_t tt = (M + SPT_M - 1) / SPT_M;
+        if (tt > 0x7fffffff || a_rsb * SPT_M > 0x7fffffff || b_rsb * SPT_N > 0x7fffffff) return MDL_E_UNSUPPORTED;
+        hipLaunchKernelGGL(terms == 2 ? sp_nt_tall_kernel<2> : sp_nt_tall_kernel<3>, dim3((unsigned)tt), dim3(SP_THREADS), 0, (hipStream_t)stream,
+                           (const char*)A, a_rsb, a_scale, (const char*)B, b_rsb, b_scale, C, ldc, M, N, K / 32, (int)tt, bias, accumulate,
+                           absmax_out, a_row_mul, b_col_mul);
+        MDL_LAUNCH_CHECK();
+        return MDL_OK;
+    }
     const int64_t tiles = ((M + SPM - 1) / SPM) * ((N + SPN - 1) / SPN);
     if (tiles > 0x7fffffff || a_rsb * SPM > 0x7fffffff || b_rsb * SPN > 0x7fffffff) return MDL_E_UNSUPPORTED;
     hipLaunchKernelGGL(terms == 2 ? sp_nt_kernel<2> : sp_nt_kernel<3>, dim3((unsigned)tiles), dim3(SP_THREADS), 0, (hipStream_t)stream,

@@ -30,7 +30,7 @@ def _hi_plane(img, rows, K):
     return v.cpu()
 
 
-@pytest.mark.parametrize("M,N,K", [(700, 512, 512), (513, 800, 2048), (257, 4, 32)])
+@pytest.mark.parametrize("M,N,K", [(700, 512, 512), (513, 800, 2048), (257, 4, 32), (3000, 128, 2048)])
 def test_nt_two_terms_is_the_product_with_the_hi_plane_of_b(dev, M, N, K):
     from madeleine_amd import functional as MF
     a = t((M, K), f"gt:a{M}{K}") * torch.logspace(0, -3, M).unsqueeze(1)           # a gradient-like A: rows 1000x apart

@@ -42,7 +42,9 @@ def test_split_image_represents_fp32(dev, rows, K, spread):
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 512, 512), (1000, 2048, 512), (513, 800, 512), (2500, 512, 1056), (257, 4, 32),
-                                   (256 * 3, 256, 2048)])
+                                   (256 * 3, 256, 2048),
+                                   # N <= 128 with more than 256 rows: the 512 x 128 tile (the token_projector's shape, ragged rows / columns)
+                                   (3000, 128, 2048), (513, 128, 512), (1024, 96, 64), (70000, 128, 512), (511, 4, 32)])
 def test_split_gemm_nt_vs_fp64(dev, M, N, K):
     from madeleine_amd import functional as MF
     a = t((M, K), f"spn:a{M}{K}") * 3
