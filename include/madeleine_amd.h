@@ -54,7 +54,7 @@ const char* mdl_version(void);
 /* ABI revision of this header: bumped whenever an entry point's argument list changes.  A binding compares
  * mdl_abi_version() with the MDL_ABI_VERSION it was written against BEFORE calling anything else, so that a stale
  * shared object fails loudly instead of being called with shifted arguments. */
-#define MDL_ABI_VERSION 18
+#define MDL_ABI_VERSION 19
 int mdl_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -367,6 +367,14 @@ int mdl_abmil_pool_fwd_img(const void* E_img, int64_t e_rsb, const float* e_scal
 int mdl_abmil_pool_dscores_img(const void* E_img, int64_t e_rsb, const float* e_scale, const float* scores, const float* pooled,
                                const float* stat_m, const float* stat_l, const float* d_pooled, float* d_scores, int accumulate_scores,
                                int64_t n_bags, int64_t N, const int64_t* cu_seqlens, int64_t max_len, int H, void* stream);
+/* Dispatch timer of the A3 forward (measurement only; bench.py's roofline.achieved).  mdl_pool_timer_arm(slot), 0 <= slot < 64 (negative:
+ * disarm): the NEXT mdl_abmil_pool_fwd / _bf16 / _img call on this process launches its two kernels through hipExtLaunchKernel with
+ * start / stop events on the caller's stream, i.e. the begin / end timestamps of the dispatches themselves (what rocprofv3
+ * --kernel-trace reports) instead of the distance between two markers in a busy stream.  Nothing waits at launch;
+ * mdl_pool_timer_read(slot, ms[3]) blocks until that slot's launches finished and returns {pool_partial, pool_combine, start of the
+ * first to end of the second} in milliseconds (MDL_E_ARG for a slot that was never used).  Process-wide state, one training thread. */
+int mdl_pool_timer_arm(int slot);
+int mdl_pool_timer_read(int slot, float* ms);
 int mdl_split_image(const float* X, int64_t ldx, int64_t rows, int K, void* img, int64_t rsb, int64_t pad_rows, float* scale,
                     void* stream);
 /* ROW-SCALED image (round 4): row r of X is scaled by its own power of two s_r (max_k |s_r X[r][k]| in [2^13, 2^14); 1 for an all-zero

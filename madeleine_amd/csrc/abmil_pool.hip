@@ -12,6 +12,7 @@
 //            order -> deterministic, no atomics).
 // Backward = pool_bwd (one wave per token row; lane-local dot with d_pooled, one 64-lane reduction
 //            per head, dE and d_scores written in the same pass).
+#include <hip/hip_ext.h>
 #include <type_traits>
 
 #include "split_engine.hpp"
@@ -330,6 +331,42 @@ extern "C" int64_t mdl_abmil_pool_ws_bytes(int64_t n_bags, int64_t max_len, int 
         default: return MDL_E_UNSUPPORTED;           \
     }
 
+// Dispatch timer of the A3 forward (the north_star kernel, bench.py's roofline): when a slot is armed, the NEXT pooling forward launches
+// its two kernels through hipExtLaunchKernel with start / stop events -- the begin / end timestamps of the dispatches themselves (what
+// rocprofv3 --kernel-trace reports), not the distance between two markers in a busy stream.  Nothing waits: the slot is read after the
+// timed region.  Process-wide, not thread-safe (one training thread per process).
+constexpr int POOL_TIMER_SLOTS = 64;
+static hipEvent_t g_pool_ev[POOL_TIMER_SLOTS][4];
+static bool g_pool_ev_made[POOL_TIMER_SLOTS];
+static int g_pool_armed = -1;
+static bool g_pool_used[POOL_TIMER_SLOTS];
+
+extern "C" int mdl_pool_timer_arm(int slot) {
+    if (slot >= POOL_TIMER_SLOTS) return MDL_E_ARG;
+    if (slot >= 0 && !g_pool_ev_made[slot]) {
+        for (int i = 0; i < 4; ++i) {
+            const hipError_t e = hipEventCreate(&g_pool_ev[slot][i]);
+            if (e != hipSuccess) return (int)e;
+        }
+        g_pool_ev_made[slot] = true;
+    }
+    if (slot >= 0) g_pool_used[slot] = false;
+    g_pool_armed = slot;
+    return MDL_OK;
+}
+// ms[0] = pool_partial, ms[1] = pool_combine, ms[2] = start of the first to end of the second.  Blocks until the slot's launches finished.
+extern "C" int mdl_pool_timer_read(int slot, float* ms) {
+    if (slot < 0 || slot >= POOL_TIMER_SLOTS || !ms || !g_pool_ev_made[slot] || !g_pool_used[slot]) return MDL_E_ARG;
+    hipError_t e = hipEventSynchronize(g_pool_ev[slot][3]);
+    if (e != hipSuccess) return (int)e;
+    e = hipEventElapsedTime(&ms[0], g_pool_ev[slot][0], g_pool_ev[slot][1]);
+    if (e != hipSuccess) return (int)e;
+    e = hipEventElapsedTime(&ms[1], g_pool_ev[slot][2], g_pool_ev[slot][3]);
+    if (e != hipSuccess) return (int)e;
+    e = hipEventElapsedTime(&ms[2], g_pool_ev[slot][0], g_pool_ev[slot][3]);
+    return e == hipSuccess ? MDL_OK : (int)e;
+}
+
 template <class TE, bool LIN = false>
 static int pool_fwd_launch(const TE* E, int64_t ldE, const float* scores, float* pooled, float* stat_m, float* stat_l,
                            int64_t n_bags, int64_t N, const int64_t* cu_seqlens, int64_t max_len, int H, void* ws, void* stream,
@@ -346,15 +383,29 @@ static int pool_fwd_launch(const TE* E, int64_t ldE, const float* scores, float*
     const int64_t st = ((n_bags * (int64_t)mc * H * 4 + 15) / 16) * 16;
     float* part_m = (float*)((char*)ws + n_bags * (int64_t)mc * H * HID * 4);
     float* part_l = (float*)((char*)part_m + st);
+    const int slot = mc > 0 ? g_pool_armed : -1;
+    g_pool_armed = -1;
     MDL_DISPATCH_H(H, {
-        if (mc > 0) {
-            hipLaunchKernelGGL((pool_partial_kernel<HH, TE, false, LIN>), dim3(mc, (unsigned)n_bags), dim3(HH * 128), 0, s, E, ldE, scores,
-                               part_acc, part_m, part_l, N, cu_seqlens, mc, (const int32_t*)nullptr, (int64_t)-1, e_scale);
+        if (slot >= 0) {   // the same two launches with the dispatches' own begin / end events
+            hipExtLaunchKernelGGL((pool_partial_kernel<HH, TE, false, LIN>), dim3(mc, (unsigned)n_bags), dim3(HH * 128), 0, s,
+                                  g_pool_ev[slot][0], g_pool_ev[slot][1], 0, E, ldE, scores, part_acc, part_m, part_l, N, cu_seqlens, mc,
+                                  (const int32_t*)nullptr, (int64_t)-1, e_scale);
+            MDL_LAUNCH_CHECK();
+            hipExtLaunchKernelGGL((pool_combine_kernel<HH>), dim3((unsigned)n_bags), dim3(HH * 128), 0, s, g_pool_ev[slot][2],
+                                  g_pool_ev[slot][3], 0, (const float*)part_acc, (const float*)part_m, (const float*)part_l, pooled, stat_m,
+                                  stat_l, N, cu_seqlens, mc, (int64_t)-1);
+            MDL_LAUNCH_CHECK();
+            g_pool_used[slot] = true;
+        } else {
+            if (mc > 0) {
+                hipLaunchKernelGGL((pool_partial_kernel<HH, TE, false, LIN>), dim3(mc, (unsigned)n_bags), dim3(HH * 128), 0, s, E, ldE, scores,
+                                   part_acc, part_m, part_l, N, cu_seqlens, mc, (const int32_t*)nullptr, (int64_t)-1, e_scale);
+                MDL_LAUNCH_CHECK();
+            }
+            hipLaunchKernelGGL((pool_combine_kernel<HH>), dim3((unsigned)n_bags), dim3(HH * 128), 0, s, part_acc, part_m, part_l,
+                               pooled, stat_m, stat_l, N, cu_seqlens, mc);
             MDL_LAUNCH_CHECK();
         }
-        hipLaunchKernelGGL((pool_combine_kernel<HH>), dim3((unsigned)n_bags), dim3(HH * 128), 0, s, part_acc, part_m, part_l,
-                           pooled, stat_m, stat_l, N, cu_seqlens, mc);
-        MDL_LAUNCH_CHECK();
     });
     return MDL_OK;
 }

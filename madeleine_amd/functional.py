@@ -90,12 +90,42 @@ class KernelTimer:
 TIMER: Optional[KernelTimer] = None
 
 
+class PoolDispatchTimer:
+    """Execution time of the A3 forward's two kernels (pool_partial, pool_combine) from the dispatches' own begin / end events
+    (mdl_pool_timer_arm / _read: hipExtLaunchKernel start / stop events on the launch stream) -- what rocprofv3 --kernel-trace
+    reports for them, not the distance between two markers in a busy stream.  Every pooling forward issued while POOL_TIMER is set
+    takes the next of 64 slots; nothing is synchronised until report()."""
+    SLOTS = 64
+
+    def __init__(self):
+        self.n = 0
+
+    def arm(self):
+        _native.check(_native.lib().mdl_pool_timer_arm(self.n % self.SLOTS), "mdl_pool_timer_arm")
+        self.n += 1
+
+    def report(self):
+        """[(pool_partial ms, pool_combine ms, first start -> last end ms)] of the last min(calls, 64) pooling forwards."""
+        import ctypes
+        lib, out = _native.lib(), []
+        for i in range(max(0, self.n - self.SLOTS), self.n):
+            ms = (ctypes.c_float * 3)()
+            _native.check(lib.mdl_pool_timer_read(i % self.SLOTS, ms), "mdl_pool_timer_read")
+            out.append((float(ms[0]), float(ms[1]), float(ms[2])))
+        return out
+
+
+POOL_TIMER: Optional[PoolDispatchTimer] = None
+
+
 class _timed:
     def __init__(self, name, work=None):
         self.name, self.work = name, work
 
     def __enter__(self):
         self.ev = TIMER.start(self.name, self.work) if TIMER is not None and TIMER.wants(self.name) else None
+        if POOL_TIMER is not None and self.name == "pool_fwd":
+            POOL_TIMER.arm()
 
     def __exit__(self, *exc):
         if self.ev is not None:
