@@ -205,6 +205,14 @@ __global__ __launch_bounds__(256) void gate_bwd_dx_kernel(const float* __restric
     const uint32_t voB = lane * 16;
     constexpr int64_t rowB = HID * 4;
     const int colb[4] = {wn * 128, wn * 128 + 32, wn * 128 + 64, wn * 128 + 96};
+    // fused A3 term: softmax weight and d_pooled row of every tile row, once per row (see sp_gate_dx_kernel)
+    float row_w = 0.f;
+    int row_off = 0;
+    if (pt.scores && tid < GBM && t0 + tid < T) {
+        int bag;
+        row_w = pool_term_weight(pt, t0 + tid, c, H, bag);
+        row_off = (bag * H + c) * HID;
+    }
     f32x16 acc[2][4];
     tile_zero(acc);
     tile_loop_nn(acc, sm, 2 * HID / GBK, wm, colb, lane, [&](int st, int f, int piece) {
@@ -218,13 +226,23 @@ __global__ __launch_bounds__(256) void gate_bwd_dx_kernel(const float* __restric
 
     char* ob = reinterpret_cast<char*>(dE + t0 * ldE + (int64_t)c * HID + n0);
     const uint32_t ld4 = (uint32_t)ldE * 4u;
+    float* rw_s = reinterpret_cast<float*>(&sm) + 4 * (32 * 64);   // behind the four waves' transpose areas
+    int* ro_s = reinterpret_cast<int*>(rw_s + GBM);
+    if (pt.scores) {
+        __syncthreads();   // every wave has left the main loop: the staging memory is free
+        if (tid < GBM) {
+            rw_s[tid] = row_w;
+            ro_s[tid] = row_off;
+        }
+        __syncthreads();
+    }
+    const float* dpb = pt.d_pooled + n0;
     auto emit = [&](int row_u, int rl, int lane_col, const f32x4& v, int) {
         f32x4* o = reinterpret_cast<f32x4*>(ob + (int64_t)row_u * ld4 + ((uint32_t)rl * ld4 + (uint32_t)lane_col * 4u));
         f32x4 r = v;
         if (pt.scores) {  // fused A3 term: + w[t,c] * d_pooled[bag(t), c, :]  (cache-resident row, no dE re-read)
-            int bag;
-            const float w = pool_term_weight(pt, t0 + row_u + rl, c, H, bag);
-            const f32x4 dp = *reinterpret_cast<const f32x4*>(pt.d_pooled + ((int64_t)bag * H + c) * HID + n0 + lane_col);
+            const float w = rw_s[row_u + rl];
+            const f32x4 dp = *reinterpret_cast<const f32x4*>(dpb + (ro_s[row_u + rl] + lane_col));
 #pragma unroll
             for (int i = 0; i < 4; ++i) r[i] = fmaf(w, dp[i], v[i]);
         }

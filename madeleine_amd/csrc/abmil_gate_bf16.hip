@@ -315,20 +315,38 @@ __global__ __launch_bounds__(256, 2) void gate_dx_bf16_kernel(const bf16_t* __re
     const int colb[4] = {wn * 128, wn * 128 + 32, wn * 128 + 64, wn * 128 + 96};
     int offA[2], offB[4];
     nt_offsets(wm, colb, lane, offA, offB);
+    // fused A3 term: softmax weight and d_pooled row of every tile row, once per row (see sp_gate_dx_kernel)
+    float row_w = 0.f;
+    int row_off = 0;
+    if (pt.scores && tid < BBM && t0 + tid < T) {
+        int bag;
+        row_w = pool_term_weight(pt, t0 + tid, c, H, bag);
+        row_off = (bag * H + c) * HID;
+    }
     f32x16 acc[2][4];
     zero_acc8(acc);
     nt_mainloop(sm, acc, 1024 / BBK, issue, offA, offB);
 
     // dE (bf16) leaves through the LDS transpose: 8 columns = one 16-B store per lane, 128 contiguous bytes per row
     float* tile = reinterpret_cast<float*>(&sm) + wave * (32 * 64);
+    float* rw_s = reinterpret_cast<float*>(&sm) + 4 * (32 * 64);   // behind the four waves' transpose areas
+    int* ro_s = reinterpret_cast<int*>(rw_s + BBM);
+    if (pt.scores) {
+        __syncthreads();   // every wave has left the main loop: the staging memory is free
+        if (tid < BBM) {
+            rw_s[tid] = row_w;
+            ro_s[tid] = row_off;
+        }
+        __syncthreads();
+    }
+    const float* dpb = pt.d_pooled + n0;
     bf16_t* ob = dE + t0 * ldE + (int64_t)c * HID + n0;
     auto emit = [&](int row_u, int rl, int lane_col, const f32x4& lo, const f32x4& hi, int) {
         bf16_t* o = ob + (int64_t)row_u * ldE + ((uint32_t)rl * (uint32_t)ldE + (uint32_t)lane_col);
         f32x4 a = lo, b = hi;
         if (pt.scores) {  // fused A3 term: + w[t,c] * d_pooled[bag(t), c, :]
-            int bag;
-            const float w = pool_term_weight(pt, t0 + row_u + rl, c, H, bag);
-            const float* __restrict__ dp = pt.d_pooled + ((int64_t)bag * H + c) * HID + n0 + lane_col;
+            const float w = rw_s[row_u + rl];
+            const float* __restrict__ dp = dpb + (ro_s[row_u + rl] + lane_col);
             const f32x4 d0 = *reinterpret_cast<const f32x4*>(dp), d1 = *reinterpret_cast<const f32x4*>(dp + 4);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -385,17 +403,35 @@ __global__ __launch_bounds__(512) void gate_dx256_bf16_kernel(const bf16_t* __re
         if (piece < 4) glds16_s(voA[i], baseA + f * (QK * 2), lds_addr_of(&sm.A[st][(wave * 4 + i) * 1024]));
         else glds16_s(voB[i], baseB + f * (QK * 2), lds_addr_of(&sm.B[st][(wave * 4 + i) * 1024]));
     };
+    // fused A3 term: softmax weight and d_pooled row of every tile row, once per row (see sp_gate_dx_kernel)
+    float row_w = 0.f;
+    int row_off = 0;
+    if (pt.scores && tid < QM && t0 + tid < T) {
+        int bag;
+        row_w = pool_term_weight(pt, t0 + tid, c, H, bag);
+        row_off = (bag * H + c) * HID;
+    }
     f32x16 acc[4][2];
     nt256_mainloop(sm, acc, 1024 / QK, wm, wn, lane, dma);
 
+    float* rw_s = reinterpret_cast<float*>(&sm) + 8 * (32 * 64);   // behind the eight waves' transpose areas
+    int* ro_s = reinterpret_cast<int*>(rw_s + QM);
+    if (pt.scores) {
+        __syncthreads();   // every wave has left the main loop: the staging memory is free
+        if (tid < QM) {
+            rw_s[tid] = row_w;
+            ro_s[tid] = row_off;
+        }
+        __syncthreads();
+    }
+    const float* dpb = pt.d_pooled + n0;
     bf16_t* ob = dE + t0 * ldE + (int64_t)c * HID + n0;
     auto emit = [&](int row_u, int rl, int lane_col, const f32x4& lo, const f32x4& hi, int) {
         bf16_t* o = ob + (int64_t)row_u * ldE + ((uint32_t)rl * (uint32_t)ldE + (uint32_t)lane_col);
         f32x4 a = lo, b = hi;
         if (pt.scores) {  // fused A3 term: + w[t,c] * d_pooled[bag(t), c, :]
-            int bag;
-            const float w = pool_term_weight(pt, t0 + row_u + rl, c, H, bag);
-            const float* __restrict__ dp = pt.d_pooled + ((int64_t)bag * H + c) * HID + n0 + lane_col;
+            const float w = rw_s[row_u + rl];
+            const float* __restrict__ dp = dpb + (ro_s[row_u + rl] + lane_col);
             const f32x4 d0 = *reinterpret_cast<const f32x4*>(dp), d1 = *reinterpret_cast<const f32x4*>(dp + 4);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {

@@ -294,6 +294,16 @@ __global__ __launch_bounds__(SP_THREADS) void sp_gate_dx_kernel(const char* __re
         voA[i] = (uint32_t)ra * rowA + ch * 16;
         voB[i] = (uint32_t)row * 4096u + ch * 16;
     }
+    // fused A3 term: the softmax weight and the d_pooled row of every tile row, ONCE per row (thread r < 256 owns row r; the loads
+    // fly behind the main loop) -- per output vector this was a 64-bit division, three dependent loads and an exp: 8,400 epilogue
+    // instructions per wave against the main loop's 5,000
+    float row_w = 0.f;
+    int row_off = 0;
+    if (pt.scores && tid < SPM && t0 + tid < T) {
+        int bag;
+        row_w = pool_term_weight(pt, t0 + tid, c, H, bag);
+        row_off = (bag * H + c) * HID;
+    }
     SpAcc acc;
     sp_zero(acc);
     sp_nt_mainloop<TERMS>(sm, acc, 1024 / 32, wm, wn, lane, [&](int st, int f, int piece) {
@@ -305,13 +315,23 @@ __global__ __launch_bounds__(SP_THREADS) void sp_gate_dx_kernel(const char* __re
     float amax = 0.f;
     char* ob = reinterpret_cast<char*>(dE + t0 * ldE + (int64_t)c * HID + n0);
     const uint32_t ld4 = (uint32_t)ldE * 4u;
+    // row factors -> LDS behind the epilogue's transpose area (the first 64 KiB of the staging memory, free after the main loop)
+    float* rw_s = reinterpret_cast<float*>(&sm.B[0][0]);
+    int* ro_s = reinterpret_cast<int*>(&sm.B[0][SPM * 4]);
+    if (pt.scores) {
+        if (tid < SPM) {
+            rw_s[tid] = row_w;
+            ro_s[tid] = row_off;
+        }
+        __syncthreads();
+    }
+    const float* dpb = pt.d_pooled + n0;
     auto emit = [&](int row, int col, const f32x4& v) {
         f32x4* o = reinterpret_cast<f32x4*>(ob + (int64_t)row * ld4 + (uint32_t)col * 4u);
         f32x4 r = v * inv;
-        if (pt.scores) {  // fused A3 term: + w[t,c] * d_pooled[bag(t), c, :]  (cache-resident row)
-            int bag;
-            const float w = pool_term_weight(pt, t0 + row, c, H, bag);
-            const f32x4 dp = *reinterpret_cast<const f32x4*>(pt.d_pooled + ((int64_t)bag * H + c) * HID + n0 + col);
+        if (pt.scores) {  // + w[t,c] * d_pooled[bag(t), c, :]  (cache-resident row)
+            const float w = rw_s[row];
+            const f32x4 dp = *reinterpret_cast<const f32x4*>(dpb + (ro_s[row] + col));
 #pragma unroll
             for (int i = 0; i < 4; ++i) r[i] = fmaf(w, dp[i], r[i]);
         }
