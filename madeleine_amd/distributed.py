@@ -379,6 +379,21 @@ def got_local_extrema(problems, impl=None) -> torch.Tensor:
     return torch.stack(out)
 
 
+def _lane_of(shapes):
+    """Lane per problem for _fan_out: the CHEAPEST chain (k n^3) takes lane 0 = the caller's stream, whose later launches (the InfoNCE
+    section, the loss sum) then wait for the shortest chain, not for an arbitrary one; the others take lanes 1 .. in problem order."""
+    live = [s for s, (vs, _qs) in enumerate(shapes) if vs[0] > 0]
+    if not live:
+        return [0] * len(shapes)
+    first = min(live, key=lambda s: shapes[s][0][0] * shapes[s][0][1] ** 3)
+    lane, nxt = [0] * len(shapes), 1
+    for s in live:
+        if s != first:
+            lane[s] = nxt
+            nxt += 1
+    return lane
+
+
 class _GOTMulti(torch.autograd.Function):
     """S GOT problems (one per stain) in ONE autograd node with global-batch thresholds `ext` [S,6].
 
@@ -393,18 +408,19 @@ class _GOTMulti(torch.autograd.Function):
         probs = [(tensors[2 * s].contiguous(), tensors[2 * s + 1].contiguous()) for s in range(S)]
         dev = tensors[0].device
         outs, states = [], []
+        ctx.shapes = [(V.shape, Q.shape) for V, Q in probs]
+        ctx.lane = lane = _lane_of(ctx.shapes)
         with _fan_out(dev, S) as lanes:   # stains are independent: one HIP stream each (k <= 32 workgroups per problem)
             for s, (V, Q) in enumerate(probs):
                 if V.shape[0] == 0:
                     outs.append(torch.zeros(2, device=dev, dtype=tensors[0].dtype))
                     states.append(None)
                 else:
-                    with lanes(s):
+                    with lanes(lane[s]):
                         o, st = impl.forward(V, Q, ext[s])
                     outs.append(o)
                     states.append(st)
         ctx.impl, ctx.group, ctx.states = impl, group, states
-        ctx.shapes = [(V.shape, Q.shape) for V, Q in probs]
         return torch.stack(outs)
 
     @staticmethod
@@ -418,7 +434,7 @@ class _GOTMulti(torch.autograd.Function):
                 if st is None:
                     parts.append(torch.zeros(6, device=dev, dtype=d_outs.dtype))
                 else:
-                    with lanes(s):
+                    with lanes(ctx.lane[s]):
                         parts.append(impl.backward_begin(st, d_outs[s]))
         dmm = torch.stack(parts)
         if collectives_on():
@@ -429,7 +445,7 @@ class _GOTMulti(torch.autograd.Function):
                 if st is None:
                     grads += [d_outs.new_zeros(ctx.shapes[s][0]), d_outs.new_zeros(ctx.shapes[s][1])]
                 else:
-                    with lanes(s):
+                    with lanes(ctx.lane[s]):
                         grads += list(impl.backward_finish(st, dmm[s]))
         return (None, None, None) + tuple(grads)
 
@@ -527,10 +543,13 @@ def calculate_losses_dp(STAINS, loss_fn_interMod, got_impl, wsi_embs, token_embs
     # THE collective: slide embeddings + presence mask + GOT extrema in one payload
     pad = torch.ones(labels_l.shape[0], 1, dtype=labels_l.dtype)                      # H&E column: always present
     embs_g, _mask_dev, ext_all = gather_packed(wsi_embs, mods, torch.cat([pad, labels_l], dim=1), ext_local, group)
+    # The GOT chains are queued FIRST (lane 0 on this stream, the other stains on side streams): the ~60 small launches of the InfoNCE
+    # section then run behind lane 0's chain, inside the time the longer lanes need anyway, instead of in front of all four
+    # (profiles/r04e_c4_got_concurrency.txt: 0.7 ms of a config-4 rank step).  Same values: nothing below depends on the order.
+    outs = got_multi(problems, got_impl, group, extrema=_reduce_extrema(ext_all)) if problems else None     # [S,2]
     loss_g, flag = calculate_losses(STAINS, loss_fn_interMod, None, loss_fn_intraMod, embs_g, None, labels_g, args)
-    if not flag or not problems:
+    if not flag or outs is None:
         return loss_g, flag
-    outs = got_multi(problems, got_impl, group, extrema=_reduce_extrema(ext_all))     # [S,2]
     local = (outs[:, 1] + outs[:, 0]).sum() * args.local_loss_weight
     loss = (loss_g if torch.is_tensor(loss_g) else 0.0) + float(W) * local
     return loss, flag
