@@ -437,7 +437,7 @@ class _GOTMulti(torch.autograd.Function):
                     with lanes(ctx.lane[s]):
                         parts.append(impl.backward_begin(st, d_outs[s]))
         dmm = torch.stack(parts)
-        if collectives_on():
+        if collectives_on() and ctx.group is not _LOCAL:
             dmm = _all_reduce_sum(dmm, ctx.group)
         grads = []
         with _fan_out(dev, len(states)) as lanes:
@@ -450,14 +450,21 @@ class _GOTMulti(torch.autograd.Function):
         return (None, None, None) + tuple(grads)
 
 
-def got_multi(problems, impl=None, group=None, extrema=None) -> torch.Tensor:
+_LOCAL = object()   # group sentinel: this process's problems only, no collective even when a process group exists
+
+
+def got_multi(problems, impl=None, group=None, extrema=None, local=False) -> torch.Tensor:
     """problems: list of (V, Q) token tensors [k_s, n_s, d] (already sub-sampled) -> [S, 2] = (WD sum, GWD sum).
-    `extrema` [S,6]: the global-batch thresholds (from gather_packed); None -> computed here (one [S,6] all-gather)."""
+    `extrema` [S,6]: the global-batch thresholds (from gather_packed); None -> computed here (one [S,6] all-gather).
+    local=True: S independent reference-semantics GOT calls of THIS process (thresholds from its own problems, no collective in either
+    direction) -- trainer.calculate_losses' per-stain GOT terms, run as concurrent chains."""
     if impl is None:
         from .functional import HipGotImpl as impl  # noqa: N813
+    if local:
+        group = _LOCAL
     if extrema is None:
         extrema = got_local_extrema(problems, impl)
-        if collectives_on():
+        if collectives_on() and not local:
             extrema = _reduce_extrema(_all_gather_cat(extrema, group).view(world_size(group), -1, 6))
     flat = []
     for V, Q in problems:

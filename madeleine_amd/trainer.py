@@ -66,6 +66,26 @@ def _global_terms_batched(criterion, parts: List[_Participant], wsi_embs, symmet
     return {part.column: per_problem[s] for s, part in enumerate(parts)}
 
 
+def _local_terms_batched(parts, token_embs, dev, subsample=256):
+    """{stain column: GOT(he_tokens, stain_tokens, subsample=256)} for every participating stain, the stains' chains running concurrently
+    (one autograd node, one HIP stream per stain).  None when there is nothing to overlap or the tokens are not on a ROCm device."""
+    if len(parts) < 2 or dev.type != "cuda":
+        return None
+    from .distributed import got_multi
+    problems = []
+    for part in parts:
+        he_src, st_src = token_embs["HE"][:, :, :, part.column], token_embs[part.name].squeeze()   # .squeeze() as in trainer.py:43
+        if st_src.dim() != 3:
+            return None
+        rows = h2d(part.rows_cpu, dev)
+        kk = min(int(rows.numel()), he_src.shape[1])          # randperm(k)[:256] < k: the first k tokens are all GOT can read
+        he_tok, st_tok = he_src[:, :kk].index_select(0, rows), st_src[:, :kk].index_select(0, rows)
+        idx = h2d(torch.randperm(he_tok.shape[0])[:subsample], dev)   # loss.py:282 -- the same draw, in the same order, as GOT()
+        problems.append((he_tok.index_select(1, idx).float().contiguous(), st_tok.index_select(1, idx).float().contiguous()))
+    outs = got_multi(problems, local=True)
+    return {part.column: outs[i, 1] + outs[i, 0] for i, part in enumerate(parts)}
+
+
 def calculate_losses(STAINS, loss_fn_interMod, loss_fn_interMod_local, loss_fn_intraMod, wsi_embs, token_embs,
                      modality_labels_withoutHE, args):
     """Sum of the active loss terms over the participating stains; returns (loss, at_least_one_stain_flag)."""
@@ -80,6 +100,9 @@ def calculate_losses(STAINS, loss_fn_interMod, loss_fn_interMod_local, loss_fn_i
         precomputed = _global_terms_batched(loss_fn_interMod, parts, wsi_embs, args.symmetric_cl)
 
     dev = wsi_embs["HE"].device
+    # local terms of all stains as ONE node of concurrent GOT chains (distributed.got_multi(local=True): same arithmetic as the
+    # per-stain calls below -- thresholds from each problem's own cost matrices, torch.randperm consumed in the same stain order)
+    got_terms = _local_terms_batched(parts, token_embs, dev) if loss_fn_interMod_local is _GOT else None
     terms = []
     for part in parts:
         rows = h2d(part.rows_cpu, dev)
@@ -89,7 +112,9 @@ def calculate_losses(STAINS, loss_fn_interMod, loss_fn_interMod_local, loss_fn_i
             else:
                 he, st = _pair(wsi_embs, part, rows, WHOLE_VIEW_POSITION)
                 terms.append(loss_fn_interMod(query=he, positive_key=st, symmetric=args.symmetric_cl))
-        if loss_fn_interMod_local:                               # local: token-level GOT, 256 sub-sampled tokens
+        if loss_fn_interMod_local and got_terms is not None:
+            terms.append(got_terms[part.column] * args.local_loss_weight)
+        elif loss_fn_interMod_local:                             # local: token-level GOT, 256 sub-sampled tokens
             he_src, st_src = token_embs["HE"][:, :, :, part.column], token_embs[part.name].squeeze()   # .squeeze() as in trainer.py:43
             if loss_fn_interMod_local is _GOT and st_src.dim() == 3:
                 # our GOT reads token indices randperm(k)[:256] < k = the number of participating cases (the reference's quirk,

@@ -113,3 +113,32 @@ def test_full_step_forward_untouched_gradients_at_eleven_bits(dev, use_got):
         moved = moved or d > 0
     assert moved and worst < 1e-3, worst
     assert np.isfinite(worst)
+
+
+def test_calculate_losses_batches_the_local_terms_without_changing_them(dev):
+    """trainer.calculate_losses (reference trainer.py:20-77) runs the stains' GOT terms as one node of concurrent chains
+    (distributed.got_multi(local=True)); a callable that is not madeleine_amd.GOT itself takes the per-stain route.  Same randperm
+    draws, same thresholds: loss and every parameter gradient agree to fp32 rounding."""
+    from madeleine_amd import GOT, InfoNCE, calculate_losses
+    from tests.test_model_gpu import build
+    MODS = ["HE", "ER", "PR", "KI67", "HER2"]
+    B, M, N, D = 10, 4, 200, 64
+    feats = t((B, M, N, D), "bl:fs") * 0.5
+    labels = torch.ones(B, M)
+    labels[2, 1] = labels[7, 3] = labels[8, 3] = 0
+    feats = feats * labels[:, :, None, None]
+    args = SimpleNamespace(global_loss="info-nce", symmetric_cl=True, local_loss_weight=0.7)
+    model = build(MODS[:M], D, "wbl", dev).eval()
+    res = []
+    for local in (GOT, lambda v, q, subsample=None: GOT(v, q, subsample=subsample)):
+        model.zero_grad()
+        embs, toks = model({"feats": feats}, device=dev, train=True)
+        torch.manual_seed(5)
+        loss, flag = calculate_losses(MODS[1:M], InfoNCE(temperature=0.1), local, None, embs, toks, labels[:, 1:], args)
+        assert flag
+        loss.backward()
+        res.append((loss.detach().clone(), {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}))
+    assert abs(float(res[0][0]) - float(res[1][0])) <= 2e-6 * abs(float(res[1][0]))
+    top = max(float(v.norm()) for v in res[1][1].values())
+    for k, v in res[1][1].items():
+        assert float((res[0][1][k] - v).norm()) <= 2e-5 * max(float(v.norm()), 1e-3 * top), k
