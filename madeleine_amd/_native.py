@@ -117,8 +117,9 @@ def lib():
     with _LOCK:
         if _LIB is not None:
             return _LIB
-        path = lib_path()
-        if not _build.is_fresh():
+        override = os.environ.get("MADELEINE_LIB")   # a library built elsewhere (A/B of two builds); the ABI check below still applies
+        path = override or lib_path()
+        if not override and not _build.is_fresh():
             try:
                 _build.build()
             except _build.HipccMissing as e:
