@@ -306,6 +306,10 @@ def secondary_c3_leg(dev, D, MF, InfoNCE, MADELEINE, steps=5, warmup=2):
 
 
 F16_MFMA_PEAK_TF = 2500.0   # MI355X_MICROARCH.md: dense fp16 / bf16 matrix peak (v_mfma_f32_32x32x16_f16 / _bf16)
+# What the matrix cores SUSTAIN under the 1400 W package cap with register-only operands of random content (no LDS / HBM traffic at all;
+# tools/micro/mfma_power.hip, profiles/r04h_mfma_power_by_operand_content.txt): the nominal peak needs operands with few toggling bits
+# (2.2-2.4 PF measured with small-integer operands); fp32 MFMA is not power-limited (151.5 of 157.3).
+MFMA_SUSTAINED_RANDOM_TF = {"f16": 1660.0, "bf16": 1820.0, "f32": 151.5}
 
 
 def kernel_rooflines(prof, work, precision="float32", gemm_mode="fp32"):
@@ -765,6 +769,11 @@ def main():
             out["roofline_mfma"] = {"kernel": "abmil_gate fwd + bwd contractions (dX, dW) on " + instr, "bound": "mfma",
                                     "achieved": round(mult * tf, 2), "peak": mpeak, "unit": "TFLOP/s",
                                     "frac": round(mult * tf / mpeak, 4),
+                                    "frac_of_sustained_peak_random_operands": round(
+                                        mult * tf / MFMA_SUSTAINED_RANDOM_TF["bf16" if a.precision != "float32" else ("f16" if splitm else "f32")], 4),
+                                    "sustained_peak_note": "register-only MFMA stream on random operands under the 1400 W cap: fp16 1.66, bf16 1.82 "
+                                                           "PFLOP/s, fp32 151.5 TFLOP/s (profiles/r04h_mfma_power_by_operand_content.txt); "
+                                                           "`peak` / `frac` stay the guide's nominal dense peak",
                                     "algorithmic_fp32_tflops": round(tf, 2), "algorithmic_over_fp32_mfma_peak": round(tf / F32_MFMA_PEAK_TF, 4),
                                     "fwd_tflops": round(tf_f, 2),
                                     "bwd_contractions_tflops": round(tf_b, 2), "fwd_ms": round(msf, 3),

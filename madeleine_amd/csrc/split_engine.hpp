@@ -156,8 +156,13 @@ __device__ __forceinline__ void sp_nt_mainloop(SmemSP& sm, SpAcc& acc, int nblk,
         }
         // last set of the chunk: every read of stage st has been requested -> barrier, then the next chunk's first fragments and
         // the DMA of block ch + 2 between this set's MFMAs (the last two iterations re-fetch the last block: branch-free body)
+        // (MDL_SP_PROBE_*: timing probes of tools/ab -- WRONG results, they only tell what the loop waits for)
+#ifndef MDL_SP_PROBE_NOWAIT
         SP_DMA_WAIT();
+#endif
+#ifndef MDL_SP_PROBE_NOBARRIER
         __syncthreads();
+#endif
         ldA(a0, st ^ 1, 0);
         ldB(b0, st ^ 1, 0);
         SP_SB();
@@ -166,7 +171,9 @@ __device__ __forceinline__ void sp_nt_mainloop(SmemSP& sm, SpAcc& acc, int nblk,
         for (int m = 0; m < SP_NP; ++m) {
             mma1(a1, b2, m);                             // lo hi, s1
             SP_SB();
+#ifndef MDL_SP_PROBE_NODMA
             dma(st, f, m);
+#endif
             SP_SB();
         }
     }
