@@ -54,7 +54,7 @@ const char* mdl_version(void);
 /* ABI revision of this header: bumped whenever an entry point's argument list changes.  A binding compares
  * mdl_abi_version() with the MDL_ABI_VERSION it was written against BEFORE calling anything else, so that a stale
  * shared object fails loudly instead of being called with shifted arguments. */
-#define MDL_ABI_VERSION 19
+#define MDL_ABI_VERSION 20
 int mdl_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -286,6 +286,23 @@ int mdl_got_bwd(const float* V, const float* Q, const float* d_out, float* dV, f
 int mdl_got_bwd_begin(const float* d_out, float* d_minmax, int k, int n, int d, void* ws, void* stream);
 int mdl_got_bwd_finish(const float* V, const float* Q, float* dV, float* dQ, const float* d_minmax_total,
                        int k, int n, int d, void* ws, void* stream);
+/* Several GOT problems in ONE launch sequence (round 4).  The reference calls GOT once per stain (trainer.py:40-49); a data-parallel
+ * rank used to run the stains' chains on one HIP stream each, and a process has four hardware queues: the first stream that is not
+ * ours (a prefetcher's, RCCL's) made two chains share a queue and run one after the other.  Here every launch covers all problems
+ * (a workgroup finds its problem from blockIdx), on the caller's stream alone.  1 <= np <= MDL_GOT_MAX_BATCH, every problem
+ * non-empty (k >= 1, n >= 1) with n <= 256 (MDL_E_UNSUPPORTED above), one d for all; arrays of np entries: V[p], Q[p] [k[p], n[p], d],
+ * ws[p] = mdl_got_ws_bytes(k[p], n[p], d) kept from _fwd_multi to _bwd_finish_multi, out[p] [2], minmax / d_minmax entries [6].
+ * The kernels of the largest problem's size class run every problem: results of a problem equal its single-problem call bit for
+ * bit when it is in that class itself, and to fp32 rounding otherwise (another reduction order). */
+#define MDL_GOT_MAX_BATCH 4
+int mdl_got_extrema_multi(int np, const float* const* V, const float* const* Q, float* const* minmax_out, const int* k, const int* n,
+                          int d, void* const* ws, void* stream);
+int mdl_got_fwd_multi(int np, const float* const* V, const float* const* Q, float* const* out, const float* const* minmax_in,
+                      const int* k, const int* n, int d, void* const* ws, void* stream);
+int mdl_got_bwd_begin_multi(int np, const float* const* d_out, float* const* d_minmax, const int* k, const int* n, int d,
+                            void* const* ws, void* stream);
+int mdl_got_bwd_finish_multi(int np, const float* const* V, const float* const* Q, float* const* dV, float* const* dQ,
+                             const float* const* d_minmax_total, const int* k, const int* n, int d, void* const* ws, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * bf16 mode -- the reference's `precision: bfloat16` runs (torch autocast around the forward,

@@ -13,7 +13,7 @@ from . import _build
 
 _LOCK = threading.Lock()
 _LIB = None
-ABI_VERSION = 19   # == MDL_ABI_VERSION of include/madeleine_amd.h this file's SIGNATURES were written against
+ABI_VERSION = 20   # == MDL_ABI_VERSION of include/madeleine_amd.h this file's SIGNATURES were written against
 
 c_f = ctypes.c_void_p  # float* (device)
 c_p = ctypes.c_void_p
@@ -61,6 +61,11 @@ SIGNATURES = {
     "mdl_got_bwd": (i32, [c_f, c_f, c_f, c_f, c_f, i32, i32, i32, c_p, c_p]),
     "mdl_got_bwd_begin": (i32, [c_f, c_f, i32, i32, i32, c_p, c_p]),
     "mdl_got_bwd_finish": (i32, [c_f, c_f, c_f, c_f, c_f, i32, i32, i32, c_p, c_p]),
+    # several problems per launch: host arrays of np device pointers / ints
+    "mdl_got_extrema_multi": (i32, [i32, c_p, c_p, c_p, c_p, c_p, i32, c_p, c_p]),
+    "mdl_got_fwd_multi": (i32, [i32, c_p, c_p, c_p, c_p, c_p, c_p, i32, c_p, c_p]),
+    "mdl_got_bwd_begin_multi": (i32, [i32, c_p, c_p, c_p, c_p, i32, c_p, c_p]),
+    "mdl_got_bwd_finish_multi": (i32, [i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, i32, c_p, c_p]),
     # bf16 mode (same argument lists as the fp32 entry points; activation pointers are bf16)
     "mdl_ln_gelu_drop_fwd_bf16": (i32, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, i64, i32, f32, f32, u64, c_p, c_p]),
     "mdl_ln_gelu_drop_bwd_bf16": (i32, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i64, i32, f32, u64, c_p, c_p,

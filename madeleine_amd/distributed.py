@@ -326,10 +326,10 @@ class _fan_out:
 
     def __enter__(self):
         if self.on:
-            key = (str(self.device), self.n)
-            if key not in _SIDE_STREAMS:
-                _SIDE_STREAMS[key] = [torch.cuda.Stream(device=self.device) for _ in range(self.n - 1)]
-            self.streams = _SIDE_STREAMS[key]
+            pool = _SIDE_STREAMS.setdefault(str(self.device), [])   # ONE growing pool per device: never more side streams than lanes
+            while len(pool) < self.n - 1:
+                pool.append(torch.cuda.Stream(device=self.device))
+            self.streams = pool[:self.n - 1]
             self.main = torch.cuda.current_stream(self.device)
             self.used = set()
             # the side lanes depend on what the current stream held BEFORE the fan-out, not on lane 0's own launches
@@ -367,6 +367,9 @@ def got_local_extrema(problems, impl=None) -> torch.Tensor:
     dev, dt = problems[0][0].device, problems[0][0].dtype
     # (on the caller's stream: fanning these small cost-matrix passes out over the per-stain streams saved 0.2 ms in the four-stain lab
     # and cost 6.5 ms per config-3 step -- their workspaces then come from the side streams' allocator pools)
+    live = [(V.contiguous(), Q.contiguous()) for V, Q in problems if V.shape[0] > 0]
+    if len(live) == len(problems) and getattr(impl, "can_batch", None) and impl.can_batch(live):
+        return impl.extrema_multi(live)   # two launches for all stains
     empty = None
     out = []
     for V, Q in problems:
@@ -379,18 +382,30 @@ def got_local_extrema(problems, impl=None) -> torch.Tensor:
     return torch.stack(out)
 
 
+GOT_LANES = int(os.environ.get("MADELEINE_GOT_LANES", "4"))   # HIP streams (the caller's included) the GOT chains of a step are spread over
+
+
 def _lane_of(shapes):
-    """Lane per problem for _fan_out: the CHEAPEST chain (k n^3) takes lane 0 = the caller's stream, whose later launches (the InfoNCE
-    section, the loss sum) then wait for the shortest chain, not for an arbitrary one; the others take lanes 1 .. in problem order."""
+    """Lane per problem for _fan_out: the chains (cost ~ k n^3) are packed onto min(#problems, GOT_LANES) lanes, heaviest first onto the
+    lightest lane; the LIGHTEST lane is lane 0 = the caller's stream, whose later launches (the InfoNCE section, the loss sum) then
+    wait for the shortest queue.  ROCm gives a process 4 hardware queues by default: every stream beyond that -- a prefetcher's, RCCL's
+    -- makes two lanes share a queue and their chains run one after the other (profiles/r04i_c4_streams_vs_lanes.txt), so fewer lanes
+    can be the faster choice in such a process (MADELEINE_GOT_LANES)."""
     live = [s for s, (vs, _qs) in enumerate(shapes) if vs[0] > 0]
+    lane = [0] * len(shapes)
     if not live:
-        return [0] * len(shapes)
-    first = min(live, key=lambda s: shapes[s][0][0] * shapes[s][0][1] ** 3)
-    lane, nxt = [0] * len(shapes), 1
-    for s in live:
-        if s != first:
-            lane[s] = nxt
-            nxt += 1
+        return lane
+    cost = {s: float(shapes[s][0][0]) * float(shapes[s][0][1]) ** 3 for s in live}
+    n_l = max(1, min(len(live), GOT_LANES))
+    load, members = [0.0] * n_l, [[] for _ in range(n_l)]
+    for s in sorted(live, key=lambda q: -cost[q]):
+        i = min(range(n_l), key=lambda j: load[j])
+        load[i] += cost[s]
+        members[i].append(s)
+    order = sorted(range(n_l), key=lambda j: load[j])          # lightest bin -> lane 0
+    for new_lane, j in enumerate(order):
+        for s in members[j]:
+            lane[s] = new_lane
     return lane
 
 
@@ -409,8 +424,18 @@ class _GOTMulti(torch.autograd.Function):
         dev = tensors[0].device
         outs, states = [], []
         ctx.shapes = [(V.shape, Q.shape) for V, Q in probs]
+        live = [s for s in range(S) if probs[s][0].shape[0] > 0]
+        ctx.batched = None
+        if getattr(impl, "can_batch", None) and impl.can_batch([probs[s] for s in live]):
+            # ONE launch sequence for all stains on the caller's stream (mdl_got_*_multi): no side streams, no hardware queues to share
+            o, st = impl.forward_multi([probs[s] for s in live], ext[live] if len(live) < S else ext)
+            res = torch.zeros(S, 2, device=dev, dtype=o.dtype)
+            res[live] = o
+            ctx.impl, ctx.group, ctx.batched, ctx.live = impl, group, st, live
+            return res
         ctx.lane = lane = _lane_of(ctx.shapes)
-        with _fan_out(dev, S) as lanes:   # stains are independent: one HIP stream each (k <= 32 workgroups per problem)
+        ctx.n_lanes = max(lane) + 1
+        with _fan_out(dev, ctx.n_lanes) as lanes:   # stains are independent: one HIP stream each (k <= 32 workgroups per problem)
             for s, (V, Q) in enumerate(probs):
                 if V.shape[0] == 0:
                     outs.append(torch.zeros(2, device=dev, dtype=tensors[0].dtype))
@@ -425,11 +450,27 @@ class _GOTMulti(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_outs):
-        impl, states = ctx.impl, ctx.states
+        impl = ctx.impl
         dev = d_outs.device
         d_outs = d_outs.contiguous()
+        if ctx.batched is not None:
+            live, S = ctx.live, len(ctx.shapes)
+            part = impl.backward_begin_multi(ctx.batched, d_outs[live] if len(live) < S else d_outs)
+            dmm = torch.zeros(S, 6, device=dev, dtype=part.dtype)
+            dmm[live] = part
+            if collectives_on() and ctx.group is not _LOCAL:
+                dmm = _all_reduce_sum(dmm, ctx.group)
+            pairs = impl.backward_finish_multi(ctx.batched, dmm[live] if len(live) < S else dmm)
+            grads = []
+            for s in range(S):
+                if s in live:
+                    grads += list(pairs[live.index(s)])
+                else:
+                    grads += [d_outs.new_zeros(ctx.shapes[s][0]), d_outs.new_zeros(ctx.shapes[s][1])]
+            return (None, None, None) + tuple(grads)
+        states = ctx.states
         parts = []
-        with _fan_out(dev, len(states)) as lanes:
+        with _fan_out(dev, ctx.n_lanes) as lanes:
             for s, st in enumerate(states):
                 if st is None:
                     parts.append(torch.zeros(6, device=dev, dtype=d_outs.dtype))
@@ -440,7 +481,7 @@ class _GOTMulti(torch.autograd.Function):
         if collectives_on() and ctx.group is not _LOCAL:
             dmm = _all_reduce_sum(dmm, ctx.group)
         grads = []
-        with _fan_out(dev, len(states)) as lanes:
+        with _fan_out(dev, ctx.n_lanes) as lanes:
             for s, st in enumerate(states):
                 if st is None:
                     grads += [d_outs.new_zeros(ctx.shapes[s][0]), d_outs.new_zeros(ctx.shapes[s][1])]

@@ -1331,3 +1331,80 @@ class HipGotImpl:
             rc = lib.mdl_got_bwd_finish(_ptr(V), _ptr(Q), _ptr(dV), _ptr(dQ), _ptr(dmm_total), k, n, d, _ptr(ws), _stream())
         _native.check(rc, "mdl_got_bwd_finish")
         return dV, dQ
+
+    # ---- several problems per launch (mdl_got_*_multi): every kernel launch covers all problems, on the caller's stream alone ----
+    MAX_BATCH = 4
+
+    @staticmethod
+    def can_batch(problems) -> bool:
+        """2 .. MAX_BATCH non-empty problems on one ROCm device, every n <= 256, one d."""
+        if not 2 <= len(problems) <= HipGotImpl.MAX_BATCH or os.environ.get("MADELEINE_GOT_NO_BATCH"):
+            return False
+        d = problems[0][0].shape[2]
+        return all(V.is_cuda and V.dtype == torch.float32 and V.shape[0] >= 1 and 1 <= V.shape[1] <= 256 and V.shape[2] == d
+                   and V.device == problems[0][0].device for V, _ in problems)
+
+    @staticmethod
+    def _arrays(problems, wss):
+        import ctypes
+        np_ = len(problems)
+        ptrs = lambda ts: (ctypes.c_void_p * np_)(*[t.data_ptr() for t in ts])      # noqa: E731
+        ks = (ctypes.c_int * np_)(*[int(V.shape[0]) for V, _ in problems])
+        ns = (ctypes.c_int * np_)(*[int(V.shape[1]) for V, _ in problems])
+        return np_, ptrs([V for V, _ in problems]), ptrs([Q for _, Q in problems]), ks, ns, int(problems[0][0].shape[2]), ptrs(wss), ptrs
+
+    @staticmethod
+    def _rows(t):
+        import ctypes
+        return (ctypes.c_void_p * t.shape[0])(*[t.data_ptr() + i * t.stride(0) * t.element_size() for i in range(t.shape[0])])
+
+    @staticmethod
+    def extrema_multi(problems):
+        lib = _native.lib()
+        dev = problems[0][0].device
+        wss = [_ws(lib.mdl_got_ws_bytes(*V.shape), dev) for V, _ in problems]
+        np_, Vp, Qp, ks, ns, d, wsp, _ = HipGotImpl._arrays(problems, wss)
+        mm = torch.empty(np_, 6, device=dev, dtype=torch.float32)
+        rc = lib.mdl_got_extrema_multi(np_, Vp, Qp, HipGotImpl._rows(mm), ks, ns, d, wsp, _stream())
+        _native.check(rc, "mdl_got_extrema_multi")
+        return mm
+
+    @staticmethod
+    def forward_multi(problems, minmax):
+        lib = _native.lib()
+        dev = problems[0][0].device
+        for V, _ in problems:
+            if lib.mdl_got_ws_bytes(*V.shape) == -3:
+                raise NotImplementedError("madeleine_amd.GOT supports n <= 512 tokens per bag and d <= 128")
+        wss = [_ws(lib.mdl_got_ws_bytes(*V.shape), dev) for V, _ in problems]
+        np_, Vp, Qp, ks, ns, d, wsp, _ = HipGotImpl._arrays(problems, wss)
+        out = torch.empty(np_, 2, device=dev, dtype=torch.float32)
+        mm = minmax.contiguous()
+        with _timed("got_fwd"):
+            rc = lib.mdl_got_fwd_multi(np_, Vp, Qp, HipGotImpl._rows(out), HipGotImpl._rows(mm), ks, ns, d, wsp, _stream())
+        _native.check(rc, "mdl_got_fwd_multi")
+        return out, (list(problems), wss)
+
+    @staticmethod
+    def backward_begin_multi(state, d_outs):
+        problems, wss = state
+        lib = _native.lib()
+        np_, _Vp, _Qp, ks, ns, d, wsp, _ = HipGotImpl._arrays(problems, wss)
+        d_outs = d_outs.contiguous()
+        dmm = torch.empty(np_, 6, device=d_outs.device, dtype=torch.float32)
+        with _timed("got_bwd"):
+            rc = lib.mdl_got_bwd_begin_multi(np_, HipGotImpl._rows(d_outs), HipGotImpl._rows(dmm), ks, ns, d, wsp, _stream())
+        _native.check(rc, "mdl_got_bwd_begin_multi")
+        return dmm
+
+    @staticmethod
+    def backward_finish_multi(state, dmm_total):
+        problems, wss = state
+        lib = _native.lib()
+        np_, Vp, Qp, ks, ns, d, wsp, ptrs = HipGotImpl._arrays(problems, wss)
+        dVs, dQs = [torch.empty_like(V) for V, _ in problems], [torch.empty_like(Q) for _, Q in problems]
+        dmm_total = dmm_total.contiguous()
+        with _timed("got_bwd_finish"):
+            rc = lib.mdl_got_bwd_finish_multi(np_, Vp, Qp, ptrs(dVs), ptrs(dQs), HipGotImpl._rows(dmm_total), ks, ns, d, wsp, _stream())
+        _native.check(rc, "mdl_got_bwd_finish_multi")
+        return list(zip(dVs, dQs))

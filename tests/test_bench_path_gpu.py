@@ -437,7 +437,7 @@ def test_got_multi_c4_rank_shape_vs_fp64_oracle(dev):
     def run():
         probs = [(v.to(dev).requires_grad_(), q.to(dev).requires_grad_()) for v, q in probs64]
         ext = DP.got_local_extrema([(a.detach(), b.detach()) for a, b in probs], MF.HipGotImpl)
-        outs = DP.got_multi(probs, MF.HipGotImpl, None, extrema=ext)            # [S, 2] on four streams
+        outs = DP.got_multi(probs, MF.HipGotImpl, None, extrema=ext)            # [S, 2]: one batched launch sequence (or four streams)
         (outs[:, 0] + outs[:, 1]).sum().backward()
         torch.cuda.synchronize()
         return outs.detach().clone(), [(a.grad.clone(), b.grad.clone()) for a, b in probs]
@@ -451,9 +451,26 @@ def test_got_multi_c4_rank_shape_vs_fp64_oracle(dev):
         got = float(o1[s].sum())
         assert abs(got - ref) < TOL * abs(ref), (s, got, ref)
         assert rel_err(g1[s][0], dv) < TOL and rel_err(g1[s][1], dq) < TOL, (s, rel_err(g1[s][0], dv), rel_err(g1[s][1], dq))
-    # the same four problems one after the other on the caller's stream: the concurrent result is the sequential one, bit for bit
+    # the same four problems one after the other through the single-problem entry points: the batched launches (mdl_got_*_multi: the
+    # kernels of the LARGEST problem's size class run every problem) give the same bits for the problems of that class (n > 128 here),
+    # and fp32-rounding differences for the n = 112 problem, whose single-problem call takes the fused n <= 128 kernels
     for s, (v, q) in enumerate(probs64):
         vd, qd = v.to(dev).requires_grad_(), q.to(dev).requires_grad_()
         o = MF.got(vd, qd)
         (o[0] + o[1]).backward()
-        assert torch.equal(o, o1[s]) and torch.equal(vd.grad, g1[s][0]) and torch.equal(qd.grad, g1[s][1]), s
+        if C4_SHAPE[s][1] > 128:
+            assert torch.equal(o, o1[s]) and torch.equal(vd.grad, g1[s][0]) and torch.equal(qd.grad, g1[s][1]), s
+        else:
+            assert rel_err(o, o1[s]) < 1e-6 and rel_err(vd.grad, g1[s][0]) < 1e-5 and rel_err(qd.grad, g1[s][1]) < 1e-5, s
+    # and the stream fan-out (the route for problems the batch entry points do not take) still agrees with the batched route
+    import os
+    os.environ["MADELEINE_GOT_NO_BATCH"] = "1"
+    try:
+        o3, g3 = run()
+    finally:
+        del os.environ["MADELEINE_GOT_NO_BATCH"]
+    for s in range(len(C4_SHAPE)):
+        if C4_SHAPE[s][1] > 128:
+            assert torch.equal(o3[s], o1[s]) and torch.equal(g3[s][0], g1[s][0]) and torch.equal(g3[s][1], g1[s][1]), s
+        else:
+            assert rel_err(o3[s], o1[s]) < 1e-6 and rel_err(g3[s][0], g1[s][0]) < 1e-5, s
