@@ -61,11 +61,6 @@ __device__ __forceinline__ const char* sp_uniform(const char* p) {
 }
 
 #define SP_SB() __builtin_amdgcn_sched_barrier(0)
-#ifdef MDL_SP_SETPRIO
-#define SP_PRIO(p) __builtin_amdgcn_s_setprio(p)
-#else
-#define SP_PRIO(p)
-#endif
 #define SP_DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
 __device__ __forceinline__ void sp_zero(SpAcc& acc) {
@@ -119,13 +114,11 @@ __device__ __forceinline__ void sp_nt_mainloop(SmemSP& sm, SpAcc& acc, int nblk,
         acc[rt][ct] = sp_mfma(fa[rt], fb[ct], acc[rt][ct]);
     };
 #define SP_SET(FA, FB, LOADS)                                                   \
-    SP_PRIO(1);                                                                 \
     mma1(FA, FB, 0);                                                            \
     SP_SB();                                                                    \
     LOADS;                                                                      \
     SP_SB();                                                                    \
     _Pragma("unroll") for (int m = 1; m < SP_NP; ++m) mma1(FA, FB, m);          \
-    SP_PRIO(0);                                                                 \
     SP_SB();
     if (nblk <= 0) return;
     u32x4 a0[4], a1[4], a2[4], b0[SPNCT], b1[SPNCT], b2[SPNCT];
@@ -156,13 +149,8 @@ __device__ __forceinline__ void sp_nt_mainloop(SmemSP& sm, SpAcc& acc, int nblk,
         }
         // last set of the chunk: every read of stage st has been requested -> barrier, then the next chunk's first fragments and
         // the DMA of block ch + 2 between this set's MFMAs (the last two iterations re-fetch the last block: branch-free body)
-        // (MDL_SP_PROBE_*: timing probes of tools/ab -- WRONG results, they only tell what the loop waits for)
-#ifndef MDL_SP_PROBE_NOWAIT
         SP_DMA_WAIT();
-#endif
-#ifndef MDL_SP_PROBE_NOBARRIER
         __syncthreads();
-#endif
         ldA(a0, st ^ 1, 0);
         ldB(b0, st ^ 1, 0);
         SP_SB();
@@ -171,9 +159,7 @@ __device__ __forceinline__ void sp_nt_mainloop(SmemSP& sm, SpAcc& acc, int nblk,
         for (int m = 0; m < SP_NP; ++m) {
             mma1(a1, b2, m);                             // lo hi, s1
             SP_SB();
-#ifndef MDL_SP_PROBE_NODMA
             dma(st, f, m);
-#endif
             SP_SB();
         }
     }

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """What does the split NT tile loop wait for?  Times mdl_split_gemm_nt (K = 2048 -> N = 512 and K = 512 -> N = 2048 at T = 262,144)
-with the library given in MADELEINE_LIB: the probe builds of tools/ab (MDL_SP_PROBE_NODMA / NOBARRIER / NOWAIT) drop one ingredient
+with the library given in MADELEINE_LIB: probe builds (tools/micro/loop_probes.patch applied to csrc/split_engine.hpp, then
+tools/ab/build_variant.sh with -DMDL_SP_PROBE_NODMA / _NOBARRIER / _NOWAIT / -DMDL_SP_SETPRIO) drop one ingredient
 of the loop each -- their results are WRONG, only their times mean something.  Usage: exp_loop_probes.py <label>"""
 import os
 import sys
