@@ -254,11 +254,18 @@ def measure_leg(MF, stepf, steps, warmup=2, prof_steps=3):
         stepf()
     torch.cuda.synchronize()
     MF.TIMER = None
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = stepf()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
+    dev = torch.cuda.current_device()
+    for _attempt in range(3):
+        # steady state only: a leg that follows torch.cuda.empty_cache() can still be growing its pools, and a hipMalloc right after tens
+        # of GiB were freed waits for the driver to scrub them (seen: 2-6x the step time in one of four processes) -- time again then
+        a0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = stepf()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if torch.cuda.memory_stats(dev).get("num_device_alloc", 0) == a0:
+            break
     MF.TIMER = MF.KernelTimer()
     try:
         for _ in range(prof_steps):
@@ -382,8 +389,8 @@ def secondary_c4_rank_leg(dev, D, MF, InfoNCE, MADELEINE, world=8, steps=4, warm
             oth = loc.detach().repeat(world - 1, 1, 1) + noise[m]
             full = torch.cat([loc, oth])
             embs_g[m] = full.unsqueeze(3).expand(-1, -1, -1, M - 1) if m == "HE" else full
+        outs = D.got_multi(problems, MF.HipGotImpl, None, extrema=ext)     # queued before the InfoNCE section, as calculate_losses_dp does
         loss_g, flag = calculate_losses(mods[1:], crit, None, None, embs_g, None, lab_g[:, 1:], largs)
-        outs = D.got_multi(problems, MF.HipGotImpl, None, extrema=ext)
         loss = loss_g + float(world) * (outs[:, 0] + outs[:, 1]).sum()
         loss.backward()
         opt.step()
