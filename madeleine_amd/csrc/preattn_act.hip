@@ -280,7 +280,15 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_fwd_kernel(const IO* _
             rmax = fmaxf(rmax, row_mul ? rstd * row_mul[r] : rstd);
         }
     }
-    if (rstd_max && lane == 0 && seg == 0) atomicMax(reinterpret_cast<unsigned int*>(rstd_max), __float_as_uint(rmax));
+    // one atomic per WORKGROUP: at a few ten thousand rows every wave of the grid arrives here at once, and 8192 atomics on one address
+    // took 77 us of a 31-us launch (tools/exp_ln_fwd_atomic.py)
+    if (rstd_max) {   // kernel-uniform
+        __shared__ float bmax[4];
+        if (lane == 0) bmax[wv] = rmax;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            atomicMax(reinterpret_cast<unsigned int*>(rstd_max), __float_as_uint(fmaxf(fmaxf(bmax[0], bmax[1]), fmaxf(bmax[2], bmax[3]))));
+    }
 }
 
 // IMG: dx is written as a split image (rows of 4 W bytes at `img`, scale img_sc[0]) instead of dx

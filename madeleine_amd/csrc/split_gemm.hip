@@ -165,7 +165,13 @@ __global__ __launch_bounds__(256) void sp_image_rows_reg_kernel(const float* __r
             }
         }
     }
-    if (lane == 0 && absmax) atomicMax(reinterpret_cast<unsigned int*>(absmax), __float_as_uint(tot));
+    if (absmax) {   // kernel-uniform; one atomic per workgroup (all waves of a short launch arrive here together)
+        __shared__ float bmax[4];
+        if (lane == 0) bmax[threadIdx.x >> 6] = tot;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            atomicMax(reinterpret_cast<unsigned int*>(absmax), __float_as_uint(fmaxf(fmaxf(bmax[0], bmax[1]), fmaxf(bmax[2], bmax[3]))));
+    }
 }
 // sc = {1, absmax already in sc[1]}: the common factor of a row-scaled image is 1 (the row factors travel in row_inv)
 __global__ void sp_unit_scale_kernel(float* __restrict__ sc) { sc[0] = 1.f; }

@@ -432,12 +432,13 @@ def split_image_rows(x2d, pad_rows=0):
     lib = _native.lib()
     rows, K = x2d.shape
     data = torch.empty(rows + pad_rows, K, device=x2d.device, dtype=torch.float32)
-    scale = torch.empty(2, device=x2d.device, dtype=torch.float32)
     row_inv = torch.empty(rows, device=x2d.device, dtype=torch.float32)
-    with _timed("split_image", ("byte", 8.0 * rows * K)):   # one HBM read (the second pass hits the cache) + write
-        rc = lib.mdl_split_image_rows(_ptr(x2d), x2d.stride(0), rows, K, _ptr(data), K * 4, pad_rows, _ptr(row_inv), _ptr(scale), _stream())
+    # scale = NULL: nothing consumes the tensor-wide maximum of a row-scaled image, and collecting it is a memset, a scale launch and one
+    # atomic per wave on a single address (75 us of a 95-us launch at 30,000 rows: every wave arrives at once)
+    with _timed("split_image", ("byte", 8.0 * rows * K)):   # one HBM read + write
+        rc = lib.mdl_split_image_rows(_ptr(x2d), x2d.stride(0), rows, K, _ptr(data), K * 4, pad_rows, _ptr(row_inv), None, _stream())
     _native.check(rc, "mdl_split_image_rows")
-    return SplitImage(data, scale, rows, K), row_inv
+    return SplitImage(data, _unit_scale(x2d.device), rows, K), row_inv
 
 
 _UNIT_SCALE = {}
@@ -622,7 +623,10 @@ class PreAttnBlockFn(torch.autograd.Function):
         out = torch.empty(T, N, device=dev, dtype=torch.float32) if want_fp32 else None
         mean = torch.empty(T, device=dev, dtype=torch.float32)
         rstd = torch.empty_like(mean)
-        rstd_max = torch.empty(1, device=dev, dtype=torch.float32)   # max_r rstd[r] row_inv[r]: a factor of the backward's image bound
+        # max_r rstd[r] row_inv[r], a factor of the backward's image bound -- only when a backward can follow (inference: not even the
+        # one atomic per workgroup)
+        needs_bwd = any(ctx.needs_input_grad)
+        rstd_max = torch.empty(1, device=dev, dtype=torch.float32) if needs_bwd else None
         with _timed("ln_gelu_drop_fwd", ("byte", (3.0 if want_fp32 else 2.0) * T * N * 4)):
             rc = lib.mdl_ln_gelu_drop_fwd_split(_ptr(y), _ptr(lin_bias), _ptr(gamma), _ptr(beta), _ptr(out), _ptr(img), _ptr(scale),
                                                 _ptr(mean), _ptr(rstd), T, N, float(eps), float(p_drop), int(seed), _ptr(keep),
@@ -631,7 +635,7 @@ class PreAttnBlockFn(torch.autograd.Function):
             raise NotImplementedError("fused LayerNorm-GELU-Dropout supports widths 256/512/1024/2048/4096 (got %d)" % N)
         _native.check(rc, "mdl_ln_gelu_drop_fwd_split")
         ctx.save_for_backward(xi.data, xi.scale, W, y, gamma, beta, mean, rstd, lin_bias if lin_bias is not None else torch.empty(0),
-                              row_inv if row_inv is not None else torch.empty(0), rstd_max)
+                              row_inv if row_inv is not None else torch.empty(0), rstd_max if rstd_max is not None else torch.empty(0))
         ctx.cfg = (float(p_drop), int(seed), keep, lin_bias is not None, bool(want_fp32), T, K, N, x_scale is not None)
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(scale)
@@ -647,6 +651,7 @@ class PreAttnBlockFn(torch.autograd.Function):
         xdata, xscale, W, y, gamma, beta, mean, rstd, lin_bias, row_inv, rstd_max = ctx.saved_tensors
         p_drop, seed, keep, has_bias, want_fp32, T, K, N, x_is_image = ctx.cfg
         lin_bias = lin_bias if has_bias else None
+        rstd_max = rstd_max if rstd_max.numel() else None
         # first block (row-scaled input image): the gradient image carries row_inv[r] dx[r][:], so that the row factors of the two images
         # cancel inside the dW contraction over rows
         row_inv = None if x_is_image else row_inv
