@@ -341,7 +341,7 @@ __global__ __launch_bounds__(SP_THREADS) void sp_gate_dx_kernel(const char* __re
     };
     if (t0 + SPM <= T) sp_epilogue_rows<true, 2>(acc, sm, wave, wm, wn, lane, SPM, emit);
     else sp_epilogue_rows<false, 2>(acc, sm, wave, wm, wn, lane, (int)(T - t0), emit);
-    if (absmax_out) sp_atomic_absmax(absmax_out, amax);
+    if (absmax_out) sp_block_absmax(absmax_out, amax, reinterpret_cast<float*>(&sm.B[1][0]));   // B[0] holds the row factors
 }
 
 // ================================================================================================

@@ -462,6 +462,19 @@ __device__ __forceinline__ void sp_epilogue_rows(const SpAcc& acc, SmemSP& sm, i
 }
 
 // absmax bookkeeping: non-negative floats order like their bit patterns
+// the same with ONE atomic per workgroup: `lds` = SP_WAVES floats nobody else touches until the workgroup ends.  Kernel-uniform call
+// sites only (it synchronises).  The eight waves of a tile -- and the 256 tiles resident at once -- reach this point together.
+__device__ __forceinline__ void sp_block_absmax(float* dst, float v, float* lds) {
+    v = wave_max(v);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = lds[0];
+#pragma unroll
+        for (int w = 1; w < SP_WAVES; ++w) m = fmaxf(m, lds[w]);
+        atomicMax(reinterpret_cast<unsigned int*>(dst), __float_as_uint(m));
+    }
+}
 __device__ __forceinline__ void sp_atomic_absmax(float* dst, float v) {
     v = wave_max(v);
     if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(dst), __float_as_uint(v));

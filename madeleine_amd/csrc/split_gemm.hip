@@ -262,7 +262,7 @@ __global__ __launch_bounds__(SP_THREADS) void sp_nt_kernel(const char* __restric
     };
     if (m0 + SPM <= M) sp_epilogue_rows<true>(acc, sm, wave, wm, wn, lane, SPM, emit);
     else sp_epilogue_rows<false>(acc, sm, wave, wm, wn, lane, (int)(M - m0), emit);
-    if (absmax_out) sp_atomic_absmax(absmax_out, amax);
+    if (absmax_out) sp_block_absmax(absmax_out, amax, reinterpret_cast<float*>(&sm.B[1][0]));   // (B stages: outside the epilogue's transpose areas)
 }
 
 // The same product on the tall tile (512 rows x 128 columns per workgroup) for N <= 128: no row gate (callers with a row gate have wide
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(SP_THREADS) void sp_nt_tall_kernel(const char* __re
     };
     if (m0 + SPT_M <= M) sp_epilogue_rows_tall<true>(acc, sm, wave, lane, SPT_M, emit);
     else sp_epilogue_rows_tall<false>(acc, sm, wave, lane, (int)(M - m0), emit);
-    if (absmax_out) sp_atomic_absmax(absmax_out, amax);
+    if (absmax_out) sp_block_absmax(absmax_out, amax, reinterpret_cast<float*>(&sm.B[1][0]));
 }
 
 // Chunk lists for the TN loop: list[sp][0 .. count[sp]) = the 32-row chunks of split sp whose chunk_max (sp_tile_absmax_kernel over the

@@ -4,7 +4,7 @@ NAME=${1:-prio}
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/r04ab; mkdir -p $OUT
 B="--steps 20 --warmup 5 --no-cpu-baseline --no-pmc --no-extra-legs --no-bf16-leg"
 for rep in 1 2; do
- for V in base $NAME; do
+ for V in $NAME base; do
   if [ $V = base ]; then unset MADELEINE_LIB; else export MADELEINE_LIB=$R/tools/ab/$V.so; fi
   timeout 200 python $R/bench.py $B > $OUT/${V}_$rep.json 2>/dev/null
   python - <<EOF
