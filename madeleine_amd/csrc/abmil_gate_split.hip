@@ -190,12 +190,12 @@ __global__ __launch_bounds__(SP_THREADS) void sp_gate_fwd_kernel(const char* __r
 __global__ __launch_bounds__(64 * MDL_MAX_HEADS) void sp_gate_dz_kernel(const float* __restrict__ wc, const float* __restrict__ act_a,
                                                          const float* __restrict__ act_b, const float* __restrict__ d_scores,
                                                          char* __restrict__ dzi, const float* __restrict__ dz_sc,
-                                                         float* __restrict__ slabV, int64_t T, int H, DropCfg drop) {
+                                                         float* __restrict__ slabV, int64_t T, int H, DropCfg drop, int rows_per_wg) {
     constexpr int VEC = 8;   // 64 groups of 8 columns per head (16-B image stores)
     const int tid = threadIdx.x, q = tid & 63, c = tid >> 6;
     const int64_t bx = blockIdx.x;
-    const int64_t r0 = bx * DZ_ROWS;
-    int64_t r1 = r0 + DZ_ROWS;
+    const int64_t r0 = bx * rows_per_wg;
+    int64_t r1 = r0 + rows_per_wg;
     if (r1 > T) r1 = T;
     const float s = dz_sc[0];
     float vw[VEC], sa[VEC], sb[VEC], sw[VEC];
@@ -401,6 +401,9 @@ int sp_launch_absmax_flat(const float* x, int64_t n, float* out, hipStream_t s);
 int sp_launch_scale(float* sc, hipStream_t s);
 
 static inline int64_t up16s(int64_t b) { return (b + 15) & ~(int64_t)15; }
+// token rows per workgroup of the dz pass: a workgroup walks its rows two at a time (~1.3 us per pair of rows, latency), so 256 rows
+// only pay when there are thousands of workgroups to overlap them; a 2,048-token step (config 1) spent 340 us in 8 workgroups
+static inline int sp_dz_rows(int64_t T) { return T >= 131072 ? DZ_ROWS : (T >= 16384 ? 64 : 16); }
 struct SpBwdWs {
     int S;
     int64_t tps, nblk;
@@ -412,7 +415,7 @@ static inline SpBwdWs sp_bwd_ws(int64_t T, int H) {
     int64_t tps = (T + w.S - 1) / w.S;
     w.tps = ((tps + SPK - 1) / SPK) * SPK;
     if (w.tps < SPK) w.tps = SPK;
-    w.nblk = (T + DZ_ROWS - 1) / DZ_ROWS;
+    w.nblk = (T + sp_dz_rows(T) - 1) / sp_dz_rows(T);
     int64_t o = 0;
     w.oWN = o; o += up16s((int64_t)H * HID * 1024 * 4);
     w.odz = o; o += up16s((T + SPK) * H * 1024 * 4);       // + 32 zero rows: token tail of the dW contraction
@@ -544,7 +547,7 @@ extern "C" int mdl_abmil_attnpool_bwd_split(const void* E_img, int64_t e_rsb, co
         MDL_LAUNCH_CHECK();
         if (T > 0) {
             hipLaunchKernelGGL(sp_gate_dz_kernel, dim3((unsigned)L.nblk), dim3(64 * H), 0, s, wc, act_a, act_b, d_scores, dzi,
-                               (const float*)(sc + 4), slabV, T, H, d);
+                               (const float*)(sc + 4), slabV, T, H, d, sp_dz_rows(T));
             MDL_LAUNCH_CHECK();
         }
         rc = gate_launch_reduce_v(slabV, dba, dbb, dwc, dbc, H, (int)L.nblk, s);
