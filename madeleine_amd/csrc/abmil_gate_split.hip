@@ -403,7 +403,10 @@ int sp_launch_scale(float* sc, hipStream_t s);
 static inline int64_t up16s(int64_t b) { return (b + 15) & ~(int64_t)15; }
 // token rows per workgroup of the dz pass: a workgroup walks its rows two at a time (~1.3 us per pair of rows, latency), so 256 rows
 // only pay when there are thousands of workgroups to overlap them; a 2,048-token step (config 1) spent 340 us in 8 workgroups
-static inline int sp_dz_rows(int64_t T) { return T >= 131072 ? DZ_ROWS : (T >= 16384 ? 64 : 16); }
+#ifndef MDL_DZ_ROWS_BIG
+#define MDL_DZ_ROWS_BIG DZ_ROWS
+#endif
+static inline int sp_dz_rows(int64_t T) { return T >= 131072 ? MDL_DZ_ROWS_BIG : (T >= 16384 ? 64 : 16); }
 struct SpBwdWs {
     int S;
     int64_t tps, nblk;
