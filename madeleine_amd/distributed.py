@@ -409,6 +409,20 @@ def _lane_of(shapes):
     return lane
 
 
+def _rows_of(t, live, S):
+    """t[live] without a host-side index tensor (live: ascending Python ints)."""
+    return t if len(live) == S else torch.stack([t[i] for i in live])
+
+
+def _scatter_rows(part, live, S):
+    """[S, ...] with part's rows at `live` and zeros elsewhere, again without an index tensor."""
+    if len(live) == S:
+        return part
+    zero = torch.zeros_like(part[0])
+    pos = {s: i for i, s in enumerate(live)}
+    return torch.stack([part[pos[s]] if s in pos else zero for s in range(S)])
+
+
 class _GOTMulti(torch.autograd.Function):
     """S GOT problems (one per stain) in ONE autograd node with global-batch thresholds `ext` [S,6].
 
@@ -428,11 +442,11 @@ class _GOTMulti(torch.autograd.Function):
         ctx.batched = None
         if getattr(impl, "can_batch", None) and impl.can_batch([probs[s] for s in live]):
             # ONE launch sequence for all stains on the caller's stream (mdl_got_*_multi): no side streams, no hardware queues to share
-            o, st = impl.forward_multi([probs[s] for s in live], ext[live] if len(live) < S else ext)
-            res = torch.zeros(S, 2, device=dev, dtype=o.dtype)
-            res[live] = o
+            # (rows are picked / scattered by stacking views: indexing a device tensor with a Python list is a pageable H2D copy of the
+            # index, i.e. a host synchronisation in the middle of the loss section -- 1.2 ms of idle device per config-3 step)
+            o, st = impl.forward_multi([probs[s] for s in live], _rows_of(ext, live, S))
             ctx.impl, ctx.group, ctx.batched, ctx.live = impl, group, st, live
-            return res
+            return _scatter_rows(o, live, S)
         ctx.lane = lane = _lane_of(ctx.shapes)
         ctx.n_lanes = max(lane) + 1
         with _fan_out(dev, ctx.n_lanes) as lanes:   # stains are independent: one HIP stream each (k <= 32 workgroups per problem)
@@ -455,12 +469,10 @@ class _GOTMulti(torch.autograd.Function):
         d_outs = d_outs.contiguous()
         if ctx.batched is not None:
             live, S = ctx.live, len(ctx.shapes)
-            part = impl.backward_begin_multi(ctx.batched, d_outs[live] if len(live) < S else d_outs)
-            dmm = torch.zeros(S, 6, device=dev, dtype=part.dtype)
-            dmm[live] = part
+            dmm = _scatter_rows(impl.backward_begin_multi(ctx.batched, _rows_of(d_outs, live, S)), live, S)
             if collectives_on() and ctx.group is not _LOCAL:
                 dmm = _all_reduce_sum(dmm, ctx.group)
-            pairs = impl.backward_finish_multi(ctx.batched, dmm[live] if len(live) < S else dmm)
+            pairs = impl.backward_finish_multi(ctx.batched, _rows_of(dmm, live, S))
             grads = []
             for s in range(S):
                 if s in live:
