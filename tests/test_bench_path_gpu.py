@@ -474,3 +474,43 @@ def test_got_multi_c4_rank_shape_vs_fp64_oracle(dev):
             assert torch.equal(o3[s], o1[s]) and torch.equal(g3[s][0], g1[s][0]) and torch.equal(g3[s][1], g1[s][1]), s
         else:
             assert rel_err(o3[s], o1[s]) < 1e-6 and rel_err(g3[s][0], g1[s][0]) < 1e-5, s
+
+
+def test_train_step_does_not_synchronise_the_host(dev):
+    """A step of the data-parallel loss path (forward, calculate_losses_dp with InfoNCE + GOT on absent-stain batches, backward, AdamW) issues
+    no host-synchronising call once warm: the host must be able to run a whole step ahead of the device (the reference syncs only to print
+    and to collect embeddings, trainer.py:117-136).  torch's sync debug mode raises on pageable copies, .item(), nonzero, list indexing of
+    device tensors ... -- two of the latter sat in the batched GOT node for a while and cost 1.2 ms of idle device per config-3 step."""
+    from madeleine_amd import InfoNCE, MADELEINE
+    from madeleine_amd import distributed as D
+    from madeleine_amd import functional as MF
+    import bench as BN
+    B, M, N, Dm = 8, 4, 256, 512
+    mods = BN.MODS5[:M]
+    torch.manual_seed(0)
+    model = MADELEINE(BN.make_cfg(M, Dm)).to(dev).train()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, fused=True)
+    labels = torch.ones(B, M)
+    labels[1, 2] = labels[5, 1] = labels[6, 3] = 0
+    feats = torch.randn(B, M, N, Dm, device=dev) * labels.to(dev)[:, :, None, None]
+    data = {"feats": feats, "modality_labels": labels}
+    crit = InfoNCE(temperature=0.001)
+    largs = SimpleNamespace(global_loss="info-nce", symmetric_cl=True, local_loss_weight=1.0)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        embs, toks = model(data, device=dev)
+        loss, _ = D.calculate_losses_dp(mods[1:], crit, MF.HipGotImpl, embs, toks, labels[:, 1:], largs)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        loss = step()
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    assert torch.isfinite(loss.detach()).item()
