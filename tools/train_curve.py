@@ -20,8 +20,9 @@ base = torch.randn(4, B, 1, N, D, generator=g)                       # 4 batches
 batches = [(base[i] + 0.5 * torch.randn(B, M, N, D, generator=g)).to(dev) for i in range(4)]
 labels = torch.ones(B, M)
 curves = {}
-for mode in ("float32", "float32-mfma", "bfloat16"):
+for mode in ("float32", "float32-mfma", "float32-g2", "bfloat16"):
     MF.set_gemm_mode("fp32" if mode == "float32-mfma" else "split")
+    MF.set_gradient_terms(2 if mode == "float32-g2" else 3)   # g2: the opt-in two-term backward products (forward unchanged)
     torch.manual_seed(42)
     model = MADELEINE(cfg).to(dev).train()
     opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
@@ -38,8 +39,13 @@ for mode in ("float32", "float32-mfma", "bfloat16"):
         out.append(float(loss.detach()))
     curves[mode] = out
 MF.set_gemm_mode("split")
+MF.set_gradient_terms(3)
 for s in range(0, a.steps, max(1, a.steps // 10)):
-    print(f"step {s:3d}  fp32(split) {curves['float32'][s]:10.5f}   fp32(mfma) {curves['float32-mfma'][s]:10.5f}   bf16 {curves['bfloat16'][s]:10.5f}")
-print(f"last      fp32(split) {curves['float32'][-1]:10.5f}   fp32(mfma) {curves['float32-mfma'][-1]:10.5f}   bf16 {curves['bfloat16'][-1]:10.5f}")
+    print(f"step {s:3d}  fp32(split) {curves['float32'][s]:10.5f}   fp32(mfma) {curves['float32-mfma'][s]:10.5f}   "
+          f"split, 2-term bwd {curves['float32-g2'][s]:10.5f}   bf16 {curves['bfloat16'][s]:10.5f}")
+print(f"last      fp32(split) {curves['float32'][-1]:10.5f}   fp32(mfma) {curves['float32-mfma'][-1]:10.5f}   "
+      f"split, 2-term bwd {curves['float32-g2'][-1]:10.5f}   bf16 {curves['bfloat16'][-1]:10.5f}")
+d2 = [abs(x - y) / max(abs(y), 1e-12) for x, y in zip(curves["float32-g2"], curves["float32"])]
+print("two-term backward vs three terms: max relative loss difference over %d steps %.2e (first 10 steps: %.2e)" % (a.steps, max(d2), max(d2[:10])))
 d = [abs(x - y) / max(abs(y), 1e-12) for x, y in zip(curves["float32"], curves["float32-mfma"])]
 print("split vs exact-fp32 kernels: max relative loss difference over %d steps %.2e (first 10 steps: %.2e)" % (a.steps, max(d), max(d[:10])))
