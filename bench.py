@@ -474,12 +474,29 @@ def main():
                          "mask stains with ACROBAT's presence rates; no effect on c2).  Off by default: the reference encodes them all")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "RANK" not in os.environ:
+        # turnkey N-GPU run: `python bench.py --gpus N ...` without a launcher re-executes itself as N ranks (one per GPU) under
+        # torch.distributed.run on the loopback rendezvous -- the form the driver uses when IT launches (`python -m torch.distributed.run
+        # --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`); rank 0 prints the one JSON line
+        import socket
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL's peer mappings need it on this driver
+        env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // a.gpus)))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execvpe(cmd[0], cmd, env)
+
     from madeleine_amd import InfoNCE, MADELEINE
     from madeleine_amd import distributed as D
     from madeleine_amd import functional as MF
 
     rank, world, local_rank = D.init_from_env()
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher set WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a GPU: the HIP kernels are the only backend"
     n_dev = torch.cuda.device_count()
     dev = torch.device("cuda", local_rank % n_dev)   # (several ranks per GPU only in gloo debug runs)

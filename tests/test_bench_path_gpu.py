@@ -514,3 +514,25 @@ def test_train_step_does_not_synchronise_the_host(dev):
     finally:
         torch.cuda.set_sync_debug_mode("default")
     assert torch.isfinite(loss.detach()).item()
+
+
+def test_bench_gpus_2_without_a_launcher_prints_one_valid_line():
+    """`python bench.py --gpus N` with no RANK in the environment re-executes itself under
+    torch.distributed.run.  Here: N = 2 gloo ranks sharing the one GPU (the collectives are host-staged; on an N-GPU node the same
+    command runs RCCL, one rank per GPU) -- rank 0 prints exactly one JSON line carrying the contract's keys."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["MADELEINE_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                        "--no-extra-legs", "--no-pmc", "--no-bf16-leg"], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["ranks_seen"] == 2 and out["config"]["collective_backend"] == "gloo"
+    assert out["config"]["global_batch"] == 64 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["config"]["grad_sync"] == "flat_all_reduce"

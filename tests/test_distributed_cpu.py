@@ -52,38 +52,60 @@ def _free_port():
         return s.getsockname()[1]
 
 
-B, M, N, D = 6, 4, 14, 64
-LABELS = torch.tensor([[1, 1, 1, 0], [1, 1, 0, 1], [1, 0, 1, 1], [1, 1, 1, 1], [1, 1, 1, 0], [1, 0, 1, 1]], dtype=torch.float32)
-# HER2: k_global 4 (ranks 2/2); PGR: 5 (2/3); KI67: 4 (1/3)
+N, D = 14, 64
+CASES = {
+    # benign sharding: every participating stain has cases on both ranks.  HER2: k_global 4 (ranks 2/2); PGR: 5 (2/3); KI67: 4 (1/3)
+    "benign": torch.tensor([[1, 1, 1, 0], [1, 1, 0, 1], [1, 0, 1, 1], [1, 1, 1, 1], [1, 1, 1, 0], [1, 0, 1, 1]], dtype=torch.float32),
+    # degenerate sharding (the reference gets these for free from the gathered batch, trainer.py:25-26,71-75):
+    #   W = 4 (2 cases per rank): rank 1 = cases 2, 3 is H&E-only; rank 1 owns no case of any participating stain; rank 0 has no ER case
+    #   W = 8 (1 case per rank) : most ranks own zero cases of most stains
+    #   KI67: k_global = 1 (case 7) -> skipped (trainer.py:28); ER: k_global = 2, one case on each of two ranks (4 | 7)
+    "degenerate": torch.tensor([[1, 1, 1, 0, 0],
+                                [1, 1, 0, 0, 0],
+                                [1, 0, 0, 0, 0],
+                                [1, 0, 0, 0, 0],
+                                [1, 1, 1, 0, 1],
+                                [1, 1, 0, 0, 0],
+                                [1, 1, 1, 0, 0],
+                                [1, 0, 1, 1, 1]], dtype=torch.float32),
+    # nothing but H&E anywhere (or single cases): the (-1, False) sentinel on every rank (trainer.py:72-75)
+    "he_only": torch.tensor([[1, 0, 0, 0], [1, 1, 0, 0], [1, 0, 0, 0], [1, 0, 0, 1]], dtype=torch.float32),
+}
 
 
-def _params64():
+def _params64(M):
     """fp64 leaves: the decomposition is exact in real arithmetic, so fp64 pins the LOGIC to ~1e-10 (in fp32 the
     GW fixed point amplifies summation-order noise to ~1e-3 on some gradients, which would hide logic errors)."""
     return {k: v.double().requires_grad_() for k, v in recipe_params(M, D, "wdp").items()}
 
 
-def _single_process(use_got):
+def _single_process(use_got, case="benign"):
+    LABELS = CASES[case]
+    B, M = LABELS.shape
     mods = MODS5[:M]
-    sd = _params64()
+    sd = _params64(M)
     feats = t((B, M, N, D), "dp:feats").double()
     nce = lambda a, b, symmetric=False: R.info_nce(a, b, 0.001, symmetric)  # noqa: E731
     embs, toks = R.madeleine_forward_train(feats, sd, mods)
     # identity token permutation: the value does not depend on the randperm order
     loc = (lambda a, b, subsample=None: R.got(a, b, subsample, perm=torch.arange(a.shape[0]))) if use_got else None
     loss, flag = R.calculate_losses(mods[1:], nce, loc, None, embs, toks, LABELS[:, 1:], True, 0.7)
+    if not flag:
+        return loss, None
     loss.backward()
     return float(loss), {k: (v.grad.clone() if v.grad is not None else torch.zeros_like(v)) for k, v in sd.items()}
 
 
-def _worker(rank, world, port, use_got, ret):
+def _worker(rank, world, port, use_got, ret, case="benign"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    torch.set_num_threads(2)
+    torch.set_num_threads(2 if world <= 2 else 1)
+    LABELS = CASES[case]
+    B, M = LABELS.shape
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from madeleine_amd import distributed as DP
         mods = MODS5[:M]
-        sd = _params64()
+        sd = _params64(M)
         Bl = B // world
         sl = slice(rank * Bl, (rank + 1) * Bl)
         feats = t((B, M, N, D), "dp:feats").double()[sl]
@@ -92,6 +114,9 @@ def _worker(rank, world, port, use_got, ret):
         embs, toks = R.madeleine_forward_train(feats, sd, mods)
         loss, flag = DP.calculate_losses_dp(mods[1:], nce, OracleGotImpl if use_got else None, embs, toks,
                                             LABELS[sl, 1:], args, use_local_loss=use_got)
+        if not flag:       # sentinel: every rank must reach the same verdict without touching a collective it would hang in
+            ret["r%d" % rank] = (loss, bool(flag))
+            return
         loss.backward()
         # the gradient mean over ranks bench.py performs for N > 1: distributed.FlatGradSync (one packed all-reduce); the parameters
         # outside the step's graph (token_projector without the local loss) are excluded on every rank alike
@@ -130,6 +155,46 @@ def test_two_rank_gloo_equals_global_batch(use_got):
         got = torch.from_numpy(ret["grads"][k])
         err = float((got - g).norm())
         assert err <= 1e-8 * float(g.norm()) + 1e-10 * top, (k, err, float(g.norm()))
+
+
+def _check_against_global_batch(world, use_got, case):
+    ref_loss, ref_grads = _single_process(use_got, case)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), use_got, ret, case), nprocs=world, join=True)
+    assert ret["flag"]
+    assert abs(ret["loss"] - ref_loss) < 1e-9 * abs(ref_loss), (ret["loss"], ref_loss)
+    top = max(float(g.norm()) for g in ref_grads.values())
+    for k, g in ref_grads.items():
+        got = torch.from_numpy(ret["grads"][k])
+        err = float((got - g).norm())
+        assert err <= 1e-8 * float(g.norm()) + 1e-10 * top, (world, k, err, float(g.norm()))
+
+
+@pytest.mark.parametrize("use_got", [False, True])
+@pytest.mark.parametrize("world", [4, 8])
+def test_degenerate_sharding_equals_global_batch(world, use_got):
+    """W = 4 and W = 8 on a label matrix whose shards are as uneven as a real batch allows (CASES['degenerate']): a rank that is
+    H&E-only while the global batch is not, ranks with zero local cases of a participating stain (empty GOT problems that still take
+    part in the [S,6] all-reduce), a stain with k_global = 1 (skipped on every rank) and one with k_global = 2 split over two ranks
+    (each rank's GOT problem has ONE case and n = 2 tokens).  The W-rank loss and FlatGradSync-averaged parameter gradients must equal
+    the single-process global-batch ones (reference semantics: nn.DataParallel gathers before the loss, setup_components.py:185-187;
+    trainer.py:25-26,71-75; loss.py:282,289-292)."""
+    _check_against_global_batch(world, use_got, "degenerate")
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_he_only_global_batch_is_the_sentinel_on_every_rank(world):
+    """No stain with more than one case in the GLOBAL batch: every rank returns (-1, False) (trainer.py:72-75) -- and must do so
+    without leaving a peer inside a collective (the ranks that do hold a stain case must not start the GOT extrema exchange)."""
+    ref_loss, ref_grads = _single_process(True, "he_only")
+    assert ref_loss == -1 and ref_grads is None
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), True, ret, "he_only"), nprocs=world, join=True)
+    for r in range(world):
+        loss, flag = ret["r%d" % r]
+        assert loss == -1 and flag is False
 
 
 def test_got_parts_matches_got():

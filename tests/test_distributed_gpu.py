@@ -25,6 +25,10 @@ pytestmark = pytest.mark.gpu
 B, M, N, D = 8, 4, 300, 64
 LABELS = torch.tensor([[1, 1, 1, 0], [1, 1, 0, 1], [1, 0, 1, 1], [1, 1, 1, 1],
                        [1, 1, 1, 0], [1, 0, 1, 1], [1, 1, 1, 1], [1, 0, 0, 1]], dtype=torch.float32)
+# the degenerate sharding of tests/test_distributed_cpu.py (CASES["degenerate"]): at W = 4 rank 1 (cases 2, 3) is H&E-only, ranks own zero
+# cases of participating stains, KI67 has k_global = 1 (skipped), ER has k_global = 2 with one case on each of two ranks
+LABELS_DEGENERATE = torch.tensor([[1, 1, 1, 0, 0], [1, 1, 0, 0, 0], [1, 0, 0, 0, 0], [1, 0, 0, 0, 0],
+                                  [1, 1, 1, 0, 1], [1, 1, 0, 0, 0], [1, 1, 1, 0, 0], [1, 0, 1, 1, 1]], dtype=torch.float32)
 
 
 def _free_port():
@@ -33,16 +37,16 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _build_model(dev):
+def _build_model(dev, n_mod=M):
     from tests.test_model_gpu import build
-    return build(MODS5[:M], D, "wdp", dev).eval()   # eval: dropout off, gradients still flow (parity mode)
+    return build(MODS5[:n_mod], D, "wdp", dev).eval()   # eval: dropout off, gradients still flow (parity mode)
 
 
 def _step(model, feats, labels_local, dev, use_got, labels_global=None, sync=True):
     from madeleine_amd import InfoNCE
     from madeleine_amd import distributed as DP
     from madeleine_amd import functional as MF
-    mods = MODS5[:M]
+    mods = MODS5[:labels_local.shape[1]]
     args = SimpleNamespace(global_loss="info-nce", symmetric_cl=True, local_loss_weight=0.7)
     embs, toks = model({"feats": feats}, device=dev, train=True)
     loss, flag = DP.calculate_losses_dp(mods[1:], InfoNCE(temperature=0.01), MF.HipGotImpl if use_got else None, embs, toks,
@@ -56,14 +60,15 @@ def _step(model, feats, labels_local, dev, use_got, labels_global=None, sync=Tru
     return loss.detach(), flag
 
 
-def _single(dev, use_got):
-    model = _build_model(dev)
-    loss, flag = _step(model, t((B, M, N, D), "dpg:feats"), LABELS, dev, use_got)
+def _single(dev, use_got, labels=LABELS):
+    model = _build_model(dev, labels.shape[1])
+    loss, flag = _step(model, t((B, labels.shape[1], N, D), "dpg:feats"), labels, dev, use_got)
     assert flag
     return float(loss), {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters() if p.grad is not None}
 
 
-def _worker(rank, world, port, backend, use_got, ret, ddp=False):
+def _worker(rank, world, port, backend, use_got, ret, ddp=False, LABELS=LABELS):
+    M = LABELS.shape[1]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       HSA_ENABLE_IPC_MODE_LEGACY="0")
     dev = torch.device("cuda", rank if backend == "nccl" else 0)
@@ -71,7 +76,7 @@ def _worker(rank, world, port, backend, use_got, ret, ddp=False):
     dist.init_process_group(backend, rank=rank, world_size=world)
     try:
         from madeleine_amd import distributed as DP
-        model = _build_model(dev)
+        model = _build_model(dev, M)
         sync = None
         if ddp == "flat":   # what bench.py uses for N > 1: one flat all-reduce (mean) of the packed gradients after backward
             sync = DP.FlatGradSync(model, use_local_loss=use_got)
@@ -147,6 +152,26 @@ def test_two_ranks_under_ddp_equal_global_batch(use_got, ddp):
         err = float((torch.from_numpy(got) - g).norm())
         assert err <= 1e-4 * float(g.norm()) + 1e-6 * top, (k, err, float(g.norm()))
     assert len(ret["grads"]) >= len(ref_grads) - 2
+
+
+@pytest.mark.parametrize("use_got", [False, True])
+def test_four_ranks_degenerate_sharding_equal_global_batch(use_got):
+    """Four gloo ranks sharing cuda:0 through the HIP kernels on the degenerate label matrix (an H&E-only rank, ranks without a case of
+    a participating stain, k_global = 1 skipped, k_global = 2 split over two ranks -> one-case GOT problems with n = 2 tokens), gradient
+    mean by FlatGradSync as bench.py runs it for N > 1 -- against the single-process global-batch HIP step."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    ref_loss, ref_grads = _single(torch.device("cuda:0"), use_got, LABELS_DEGENERATE)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(4, _free_port(), "gloo", use_got, ret, "flat", LABELS_DEGENERATE), nprocs=4, join=True)
+    assert ret["flag"]
+    assert abs(ret["loss"] - ref_loss) < 1e-4 * abs(ref_loss), (ret["loss"], ref_loss)
+    top = max(float(g.norm()) for g in ref_grads.values())
+    for k, g in ref_grads.items():
+        got = torch.from_numpy(ret["grads"][k])
+        err = float((got - g).norm())
+        assert err <= 1e-4 * float(g.norm()) + 1e-6 * top, (k, err, float(g.norm()))
 
 
 def _worker_rccl_w1(rank, port, use_got, ret, flat=False):

@@ -209,3 +209,21 @@ def test_simple_dataset_for_extraction(tmp_path):
     assert set(seen) == {"s_a", "s_b"}
     assert torch.equal(seen["s_a"], torch.from_numpy(arrs["s_a"].squeeze())) and torch.equal(seen["s_b"], torch.from_numpy(arrs["s_b"]))
 
+
+
+def test_bench_gpus_n_relaunches_itself_under_torchrun():
+    """`python bench.py --gpus 2` with no launcher in the environment must start 2 ranks under torch.distributed.run by itself
+    (the bare form used to die on a WORLD_SIZE assertion).  Without a GPU every rank then stops at bench.py's own
+    'needs a GPU' check -- reached only after the relaunch, the rendezvous and init_process_group(gloo) worked."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["MADELEINE_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
+                        "--no-extra-legs"], env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    if torch.cuda.is_available():      # (this file also runs on the GPU box: there the two gloo ranks share the GPU and finish)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return
+    assert r.returncode != 0
+    assert "WORLD_SIZE" not in r.stderr, r.stderr[-2000:]
+    assert r.stderr.count("bench.py needs a GPU") >= 2, r.stderr[-2000:]
