@@ -51,15 +51,20 @@ __device__ __forceinline__ float wave_max(float v) {
 // ---- counter-based dropout RNG ------------------------------------------------------------------
 // keep(idx) is a pure function of (seed, stream, idx): forward and backward regenerate identical
 // masks without storing them.  Two rounds of a xorshift-multiply finaliser over a 64-bit counter folded with the seed.
-// Round 4: the multiplies are 24-bit (v_mul_u32_u24, full rate) instead of v_mul_lo_u32 (quarter rate: 2 of them were a sixth of the
-// gate epilogue's VALU issue time); each fold x ^= x >> s first carries the bits the 24-bit multiply drops into the ones it keeps.
-// tools/rng_quality.py compares the keep masks' statistics (rate, lag / a-b / adjacent-key correlations, bucket chi-square) with the
-// lowbias32 finaliser used before: on par, ample for Bernoulli dropout masks.
+// The multiplies are 24-bit (full-rate VALU; v_mul_lo_u32 is quarter rate and two of them were a sixth of the gate epilogue's issue
+// time) in the multiply-ADD form x <- lo24(x) * K + x (one v_mad_u32_u24, K even): that equals lo24(x) * (K + 1) + (x & 0xFF000000)
+// mod 2^32, which is INJECTIVE on 32-bit counters -- K + 1 is odd, so the low 24 bits of the result determine lo24(x), and the top byte
+// of x then follows from the top byte of the result.  (Round 4's plain v_mul_u32_u24 dropped bits 24-31 after the first fold: idx and
+// idx ^ (d << 24 | d << 8) hashed alike, i.e. keep masks repeated between token rows of any activation tensor above 2^24 elements --
+// ADVICE round 4.)  Constants chosen by tools/rng_quality.py --search over the worst keep-mask correlation under every 1- and 2-bit
+// input difference and the (d << 24 | d << 8) family: 0.22 (lowbias32, the two-multiply finaliser used before round 4: 0.27); the
+// same tool reports rate, lag / a-b / adjacent-key correlations, bucket chi-square at n = 2^25 and the distinct-hash count over 2^26
+// consecutive counters (100 %).
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     x ^= x >> 16;
-    x = __umul24(x, 0xD35A2DU);
+    x = __umul24(x, 0x58E58AU) + x;
     x ^= x >> 13;
-    x = __umul24(x, 0x9E3779U);
+    x = __umul24(x, 0xCA6D40U) + x;
     x ^= x >> 16;
     return x;
 }

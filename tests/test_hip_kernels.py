@@ -744,3 +744,29 @@ def test_batched_abmil_other_geometries_vs_oracle(dev, din, hid, ncls, N):
     assert rel_err(xd.grad, xr.grad) < 1e-4
     for k, p in m.named_parameters():
         assert rel_err(p.grad, ref_p[k].grad) < 1e-4, k
+
+
+def test_dropout_masks_do_not_repeat_beyond_2_pow_24_elements(dev):
+    """the counter hash must spread 32-bit counters.  With round 4's 24-bit multiplies element idx and
+    element idx ^ (d << 24 | d << 8) always shared their keep decision -- the masks of token rows 2^24 / (H * 512) = 8192 tokens apart
+    repeated.  The exported gate masks ([T, H, 512] -> flat index (t * H + c) * 512 + e) of T = 3 * 8192 + 64 tokens: the keep rate is
+    exact, those pairs are no longer tied (a two-multiply finaliser keeps a residual correlation on such structured differences --
+    tools/rng_quality.py: worst 0.22 over all 1- / 2-bit and (d << 24 | d << 8) differences, lowbias32 0.27 -- bounded here at 0.3),
+    and whole token rows 8192 tokens apart agree on no more elements than independent masks do."""
+    from tests.test_bench_path_gpu import _exported_masks
+    T, H, p = 3 * 8192 + 64, 4, 0.25
+    ka, kb = _exported_masks(dev, T, H, p, 987654321)
+    for m in (ka, kb):
+        flat = m.reshape(-1).float()
+        n = flat.numel()
+        assert abs(float(flat.mean()) - 0.75) < 5.0 * (0.75 * 0.25 / n) ** 0.5
+        idx = torch.arange(0, n - (3 << 24) - 4096, 7, device=dev)
+        z = flat - flat.mean()
+        for d in (1, 2, 3):
+            partner = idx ^ ((d << 24) | (d << 8))
+            ok = partner < n
+            c = float((z[idx[ok]] * z[partner[ok]]).mean() / z.var())
+            assert abs(c) < 0.3, (d, c)      # round 4: exactly 1.0
+        # whole 2048-element rows (one token, all heads) 8192 tokens apart
+        rows = m.reshape(T, H * 512)
+        assert float((rows[:8192] == rows[8192:16384]).float().mean()) < 0.64      # independent: 0.75^2 + 0.25^2 = 0.625
