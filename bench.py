@@ -276,10 +276,11 @@ def measure_leg(MF, stepf, steps, warmup=2, prof_steps=3):
     return el, loss, prof, work, prof_steps
 
 
-def secondary_c3_leg(dev, D, MF, InfoNCE, MADELEINE, steps=5, warmup=2):
+def secondary_c3_leg(dev, D, MF, InfoNCE, MADELEINE, steps=5, warmup=2, all_present=False):
     """BASELINE configs[2] as a short secondary measurement beside the headline: 32 slides x 5 stains (ACROBAT presence rates,
     absent stain = all-zero bag) x 4096 x 512, global InfoNCE + local GOT (IPOT Wasserstein + Gromov-Wasserstein, n = k <= 32
-    tokens), AdamW, train mode.  The headline workload (c2) has no GOT: this leg is where the GOT kernels are timed."""
+    tokens), AdamW, train mode.  The headline workload (c2) has no GOT: this leg is where the GOT kernels are timed.
+    all_present: SURVEY 8(d)'s second mask variant -- every case carries every stain (k = 32 for all four GOT problems, no zero bags)."""
     B, M, N, Dm, _, _ = CONFIGS["c3"]
     mods = MODS5[:M]
     torch.manual_seed(42)
@@ -289,6 +290,8 @@ def secondary_c3_leg(dev, D, MF, InfoNCE, MADELEINE, steps=5, warmup=2):
     feats = torch.randn(B, M, N, Dm, device=dev, generator=gen)
     rates = torch.tensor([1.0, 0.46, 0.73, 0.73, 0.73])
     labels = (torch.rand(B, M, generator=torch.Generator().manual_seed(77)) < rates).float()
+    if all_present:
+        labels = torch.ones(B, M)
     labels[:, 0] = 1
     feats = feats * labels.to(dev)[:, :, None, None]
     data = {"feats": feats, "modality_labels": labels}
@@ -306,7 +309,8 @@ def secondary_c3_leg(dev, D, MF, InfoNCE, MADELEINE, steps=5, warmup=2):
     el, loss, prof, work, psteps = measure_leg(MF, step, steps, warmup)
     k = [int(labels[:, s].sum()) for s in range(1, M)]
     return {"value": round(B * steps / el, 3), "unit": "slides/s", "ms_per_step": round(1e3 * el / steps, 3), "steps": steps,
-            "workload": f"c3: {B} slides x {M} stains (cases per stain {k}) x {N} x {Dm}, InfoNCE + GOT, train mode, AdamW",
+            "workload": f"c3{' (all stains present)' if all_present else ''}: {B} slides x {M} stains (cases per stain {k}) x {N} x {Dm}, "
+                        f"InfoNCE + GOT, train mode, AdamW",
             "final_loss": float(loss.detach()),
             "kernel_ms": {n: round(v[0], 4) for n, v in prof.items()}, "kernel_calls_per_step": {n: v[1] // psteps for n, v in prof.items()},
             "kernel_roofline": kernel_rooflines(prof, work, "float32", MF.gemm_mode())}
@@ -346,36 +350,55 @@ def kernel_rooflines(prof, work, precision="float32", gemm_mode="fp32"):
     return out
 
 
-def secondary_c4_rank_leg(dev, D, MF, InfoNCE, MADELEINE, world=8, steps=4, warmup=2):
-    """What ONE rank of BASELINE configs[3] (8 x MI355X, 256-slide global batch, 5 stains) executes per step, on one GPU: its 32
-    local cases through the encoder, the replicated global InfoNCE over k_global <= 256 cases, and its share of GOT with the
-    GLOBAL token count n = min(k_global, 256) (loss.py:282: indices are randperm(k) with k = the number of participating cases of
-    the global batch) and supplied threshold extrema.  The other 7 ranks' contribution to the all-gathered payload is emulated
-    (their presence labels drawn with the same ACROBAT rates; their slide embeddings = detached perturbed copies of the local
-    ones); no collective runs.  Reports the step time and, against the single-rank c3 step, the weak-scaling ceiling that the
-    n = k_global GOT growth alone implies (communication not included)."""
+def secondary_rank_leg(dev, D, MF, InfoNCE, MADELEINE, world=8, steps=4, warmup=2, config="c3", all_present=False):
+    """What ONE rank of an 8 x MI355X configuration (BASELINE configs[3] = 8 ranks x c3, configs[4] = 8 ranks x c5; 256-slide global
+    batch, 5 stains) executes per step, on one GPU: its 32 local cases through the encoder, the replicated global InfoNCE over
+    k_global <= 256 cases, and its share of GOT with the GLOBAL token count n = min(k_global, 256) (loss.py:282: indices are
+    randperm(k) with k = the number of participating cases of the global batch) and supplied threshold extrema.  The other 7 ranks'
+    contribution to the all-gathered payload is emulated (their presence labels drawn with the same rates; their slide embeddings =
+    detached perturbed copies of the local ones); no collective runs.  Reports the step time and, against the single-rank step of the
+    same configuration, the weak-scaling ceiling that the n = k_global GOT growth alone implies (communication not included).
+    config "c3": dense 4096-patch bags, d = 512, ACROBAT presence rates -- or, with all_present (SURVEY 8(d)'s second mask variant,
+    absent-bag rule wsi_dataset.py:66 never firing), every stain on every case: k_global = 256 -> n = 256, the largest GOT size class,
+    four problems of 32 local cases each.  config "c5": ragged bags U[1024, 16384], d = 768, stain-encoding tokens, every stain
+    present (as bench.py --config c5) -> the same four n = 256 problems on top of the ragged encoder."""
     from madeleine_amd.trainer import calculate_losses
-    B, M, N, Dm, _, _ = CONFIGS["c3"]
+    B, M, N, Dm, _, stain_enc = CONFIGS[config]
+    ragged = N == 0
     mods = MODS5[:M]
     torch.manual_seed(42)
-    model = MADELEINE(make_cfg(M, Dm)).to(dev).train()
+    model = MADELEINE(make_cfg(M, Dm), stain_encoding=stain_enc).to(dev).train()
     opt = torch.optim.AdamW(model.parameters(), lr=1e-4, fused=FUSED_ADAMW)
     gen = torch.Generator(device=dev).manual_seed(1234)
-    feats = torch.randn(B, M, N, Dm, device=dev, generator=gen)
     rates = torch.tensor([1.0, 0.46, 0.73, 0.73, 0.73])
     lab_g = (torch.rand(world * B, M, generator=torch.Generator().manual_seed(77)) < rates).float()
+    if all_present or ragged:
+        lab_g = torch.ones(world * B, M)
     lab_g[:, 0] = 1
     labels = lab_g[:B]
-    feats = feats * labels.to(dev)[:, :, None, None]
-    data = {"feats": feats, "modality_labels": labels}
+    if ragged:
+        lens = torch.randint(1024, 16385, (B, M), generator=torch.Generator().manual_seed(4321))
+        data = {"bags": [[torch.randn(int(lens[b, m]), Dm, device=dev, generator=gen) for m in range(M)] for b in range(B)],
+                "modality_labels": labels}
+        shape = f"ragged U[1024,16384] (mean {int(lens.float().mean())}) x {Dm} + stain tokens"
+    else:
+        feats = torch.randn(B, M, N, Dm, device=dev, generator=gen)
+        feats = feats * labels.to(dev)[:, :, None, None]
+        data = {"feats": feats, "modality_labels": labels}
+        shape = f"{N} x {Dm}"
     crit = InfoNCE(temperature=0.001)
     largs = SimpleNamespace(global_loss="info-nce", symmetric_cl=True, local_loss_weight=1.0)
     k_g = [int(lab_g[:, s].sum()) for s in range(1, M)]
     noise = {m: 0.05 * torch.randn((world - 1) * B, 1, 512, device=dev, generator=gen) for m in mods}
 
-    def step():
+    def rank_step(local_only=False):
         opt.zero_grad(set_to_none=True)
         embs, toks = model(data, device=dev)
+        if local_only:   # the single-rank step of the same configuration (the weak-scaling reference: world size 1, n = k_local)
+            loss, _ = D.calculate_losses_dp(mods[1:], crit, MF.HipGotImpl, embs, toks, labels[:, 1:], largs)
+            loss.backward()
+            opt.step()
+            return loss
         problems = []
         for s_idx, stain in enumerate(mods[1:]):
             n = min(k_g[s_idx], 256)
@@ -396,15 +419,21 @@ def secondary_c4_rank_leg(dev, D, MF, InfoNCE, MADELEINE, world=8, steps=4, warm
         opt.step()
         return loss
 
-    el, loss, prof, _work, psteps = measure_leg(MF, step, steps, warmup)
+    el, loss, prof, _work, psteps = measure_leg(MF, rank_step, steps, warmup)
     got_ms = sum(prof[k][0] * prof[k][1] / psteps for k in ("got_fwd", "got_bwd", "got_bwd_finish") if k in prof)
-    return {"ms_per_step": round(1e3 * el / steps, 3), "steps": steps, "emulated_world": world,
-            "workload": f"one rank of c4: {B} local slides x {M} stains x {N} x {Dm}; global batch {world * B} emulated: cases per stain "
-                        f"{k_g} -> GOT token count n = min(k_global, 256) = {[min(k, 256) for k in k_g]}, replicated InfoNCE over "
-                        f"k_global rows; no collective",
-            "final_loss": float(loss.detach()), "got_ms_per_step_sum_over_stains": round(got_ms, 3),
-            "kernel_ms": {n: round(v[0], 4) for n, v in prof.items()},
-            "kernel_calls_per_step": {n: v[1] // psteps for n, v in prof.items()}}
+    out = {"ms_per_step": round(1e3 * el / steps, 3), "steps": steps, "emulated_world": world,
+           "workload": f"one rank of {world} x {config}{' (all stains present)' if all_present and not ragged else ''}: {B} local slides x {M} stains x "
+                       f"{shape}; global batch {world * B} emulated: cases per stain {k_g} -> GOT token count n = min(k_global, 256) = "
+                       f"{[min(k, 256) for k in k_g]}, replicated InfoNCE over k_global rows; no collective",
+           "final_loss": float(loss.detach()), "got_ms_per_step_sum_over_stains": round(got_ms, 3),
+           "kernel_ms": {n: round(v[0], 4) for n, v in prof.items()},
+           "kernel_calls_per_step": {n: v[1] // psteps for n, v in prof.items()}}
+    if ragged or all_present:
+        # the single-rank step of the SAME data (the c3 leg serves the ACROBAT-mask variant): denominator of the weak-scaling ceiling
+        el1, _l1, _p1, _w1, _ = measure_leg(MF, lambda: rank_step(True), steps, warmup, prof_steps=0)
+        out["single_rank_ms_per_step"] = round(1e3 * el1 / steps, 3)
+        out["implied_weak_scaling_ceiling_vs_single_rank"] = round(el1 / el, 4)
+    return out
 
 
 def secondary_inference_leg(dev, MF, MADELEINE, n_patches=30000, bags=20):
@@ -703,7 +732,7 @@ def main():
                 step()
             fence()
         power = ps.summary(skip_s=1.0)
-    c3_leg = infer_leg = c4_leg = None
+    c3_leg = infer_leg = c4_leg = c3ap_leg = c4ap_leg = c5_leg = None
     if a.config == "c2" and a.precision == "float32" and world == 1 and not a.no_extra_legs and host_iter is None:
         # free the c2 working set first (the c3 step keeps ~60 GiB live)
         feats = data = None
@@ -712,8 +741,16 @@ def main():
         torch.cuda.empty_cache()
         infer_leg = secondary_inference_leg(dev, MF, MADELEINE)
         torch.cuda.empty_cache()
-        c4_leg = secondary_c4_rank_leg(dev, D, MF, InfoNCE, MADELEINE)
+        c4_leg = secondary_rank_leg(dev, D, MF, InfoNCE, MADELEINE)
         c4_leg["implied_weak_scaling_ceiling_vs_c3_single_rank"] = round(c3_leg["ms_per_step"] / c4_leg["ms_per_step"], 4)
+        torch.cuda.empty_cache()
+        # the all-present mask variant (every GOT problem in the n = 256 size class on a rank of config 4), and one rank of
+        # config 5 (ragged, d = 768, stain tokens; every stain present -> the same four n = 256 problems)
+        c3ap_leg = secondary_c3_leg(dev, D, MF, InfoNCE, MADELEINE, steps=4, all_present=True)
+        torch.cuda.empty_cache()
+        c4ap_leg = secondary_rank_leg(dev, D, MF, InfoNCE, MADELEINE, all_present=True)
+        torch.cuda.empty_cache()
+        c5_leg = secondary_rank_leg(dev, D, MF, InfoNCE, MADELEINE, config="c5", steps=3)
         torch.cuda.empty_cache()
 
     tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -836,6 +873,12 @@ def main():
             out["inference_mode"] = infer_leg
         if c4_leg is not None:
             out["c4_rank_emulation"] = c4_leg
+        if c3ap_leg is not None:
+            out["c3_all_present"] = c3ap_leg
+        if c4ap_leg is not None:
+            out["c4_rank_emulation_all_present"] = c4ap_leg
+        if c5_leg is not None:
+            out["c5_rank_emulation"] = c5_leg
         if world == 1 and not a.no_cpu_baseline:
             try:
                 nb = min(a.cpu_sample, B)

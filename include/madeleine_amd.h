@@ -394,8 +394,8 @@ int mdl_pool_timer_arm(int slot);
 int mdl_pool_timer_read(int slot, float* ms);
 int mdl_split_image(const float* X, int64_t ldx, int64_t rows, int K, void* img, int64_t rsb, int64_t pad_rows, float* scale,
                     void* stream);
-/* ROW-SCALED image (round 4): row r of X is scaled by its own power of two s_r (max_k |s_r X[r][k]| in [2^13, 2^14); 1 for an all-zero
- * row) -- for the tensor whose rows a CALLER controls, the patch features (Model.py:113, :351): with one common scale a patch 2^20 times
+/* ROW-SCALED image (round 4): row r of X is scaled by its own power of two s_r (max_k |s_r X[r][k]| in [2^13, 2^14); an all-zero
+ * row has no scale: its image row is zero and row_inv = 0 -- do NOT divide by row_inv) -- for the tensor whose rows a CALLER controls, the patch features (Model.py:113, :351): with one common scale a patch 2^20 times
  * larger than the others would cost them their low bits (fp32 nn.Linear has no such coupling between rows).  row_inv (device
  * float[rows]) receives 1 / s_r (0 for an all-zero row: it contributes nothing to any product), scale = {1, max |X|}; scale may be NULL
  * (no bookkeeping launches: the image is ONE kernel -- the weights' images, built every forward; pass a constant {1, .} as its scale).  Consumers: mdl_split_gemm_nt(A = this image, a_row_mul = row_inv) -- the row

@@ -78,8 +78,11 @@ class FlatGradSync:
     per-step bookkeeping measured +5 ms on this step (tools/exp_ddp.py).  Same result as DDP's mean (reference semantics:
     nn.DataParallel's summed replica gradients of a global-batch-mean loss, setup_components.py:185-187).
         sync = FlatGradSync(model, use_local_loss);  ...;  loss.backward();  sync.all_reduce_mean();  optimizer.step()
-    Parameters that did not take part in the step (grad None: the token_projector without the local loss must be excluded through
-    use_local_loss=False so that every rank packs the same set) contribute zeros."""
+    Every packed parameter must have taken part in the step: a missing gradient (p.grad is None) raises.  DDP and the reference leave
+    such a parameter's .grad None and the optimizer skips it; a zero stand-in would make AdamW apply weight decay and moment decay to
+    it, and a set of None gradients that differs between ranks would be averaged silently.  The one parameter that is
+    legitimately outside the graph -- the token_projector without the local loss -- is excluded through use_local_loss=False, on every
+    rank alike."""
 
     def __init__(self, model, use_local_loss: bool = True, group=None):
         # model: an nn.Module, or an iterable of (name, leaf tensor) pairs
@@ -87,6 +90,7 @@ class FlatGradSync:
         if not use_local_loss:
             named = [(n, p) for n, p in named if not n.startswith("token_projector.")]
         self.params = [p for _, p in named]
+        self.names = [n for n, _ in named]
         self.group = group
         total = sum(p.numel() for p in self.params)
         p0 = self.params[0]
@@ -98,11 +102,12 @@ class FlatGradSync:
 
     def all_reduce_mean(self):
         grads = []
-        for p, v in zip(self.params, self.views):
+        for i, (p, v) in enumerate(zip(self.params, self.views)):
             g = p.grad
             if g is None:
-                v.zero_()
-                g = v
+                raise RuntimeError("FlatGradSync: packed parameter %s has no gradient after backward -- it took no part in this step's "
+                                   "graph; exclude it when the sync is built (use_local_loss=False drops the token_projector) instead of "
+                                   "averaging a stand-in" % (self.names[i],))
             grads.append(g)
         src = [g for g, v in zip(grads, self.views) if g.data_ptr() != v.data_ptr()]
         dst = [v for g, v in zip(grads, self.views) if g.data_ptr() != v.data_ptr()]

@@ -562,8 +562,18 @@ class SplitLinearFn(torch.autograd.Function):
 # allocates the sum elsewhere, which misses here) and records the version counter the tensor had when the kernel wrote it (views share
 # the counter: an in-place update by a hook or another consumer shows as a newer version).  A miss or a stale entry returns None and the
 # consumer takes its own one-pass absmax (the dy_absmax = NULL path of mdl_ln_gelu_drop_bwd_split).
+# The strong reference lives only as long as the backward pass that created it: the first entry of a pass queues an engine callback
+# that empties the table when the outermost backward returns, so a consumer that never runs (frozen pre_attn, a hook that replaces the
+# gradient, an exception) cannot pin a multi-GB gradient buffer until the next encoder forward.
 _ABSMAX = {}
 _ABSMAX_LOCK = threading.Lock()
+_ABSMAX_CB = [False]
+
+
+def _absmax_end_of_backward():
+    with _ABSMAX_LOCK:
+        _ABSMAX.clear()
+        _ABSMAX_CB[0] = False
 
 
 def _put_absmax(t, amax):
@@ -571,6 +581,12 @@ def _put_absmax(t, amax):
         if len(_ABSMAX) > 8:
             _ABSMAX.clear()
         _ABSMAX[(t.data_ptr(), t.numel())] = (t, t._version, amax)
+        if not _ABSMAX_CB[0]:
+            try:      # (only callable while the engine is running a backward -- which is where every producer lives)
+                torch.autograd.Variable._execution_engine.queue_callback(_absmax_end_of_backward)
+                _ABSMAX_CB[0] = True
+            except RuntimeError:
+                pass
 
 
 def _take_absmax(t):

@@ -72,11 +72,13 @@ def _local_terms_batched(parts, token_embs, dev, subsample=256):
     if len(parts) < 2 or dev.type != "cuda":
         return None
     from .distributed import got_multi
+    # every part's shape is checked BEFORE the first torch.randperm is drawn: the per-stain fallback draws its own, and a batched attempt
+    # abandoned half-way would have consumed draws the reference's loop never makes
+    if any(token_embs[part.name].squeeze().dim() != 3 for part in parts):
+        return None
     problems = []
     for part in parts:
         he_src, st_src = token_embs["HE"][:, :, :, part.column], token_embs[part.name].squeeze()   # .squeeze() as in trainer.py:43
-        if st_src.dim() != 3:
-            return None
         rows = h2d(part.rows_cpu, dev)
         kk = min(int(rows.numel()), he_src.shape[1])          # randperm(k)[:256] < k: the first k tokens are all GOT can read
         he_tok, st_tok = he_src[:, :kk].index_select(0, rows), st_src[:, :kk].index_select(0, rows)
@@ -88,7 +90,11 @@ def _local_terms_batched(parts, token_embs, dev, subsample=256):
 
 def calculate_losses(STAINS, loss_fn_interMod, loss_fn_interMod_local, loss_fn_intraMod, wsi_embs, token_embs,
                      modality_labels_withoutHE, args):
-    """Sum of the active loss terms over the participating stains; returns (loss, at_least_one_stain_flag)."""
+    """Sum of the active loss terms over the participating stains; returns (loss, at_least_one_stain_flag).
+    With madeleine_amd.GOT as the local loss and two or more participating stains, the stains' GOT terms run as ONE batched launch
+    sequence (distributed.got_multi(local=True)): every problem then runs in the kernels of the size class of the LARGEST n of the
+    batch, so a term can differ from the per-stain GOT() call in fp32 rounding (same arithmetic, other association: <= 1e-5 relative,
+    tests/test_bench_path_gpu.py::test_got_multi_c4_rank_shape_vs_fp64_oracle); torch.randperm is consumed in the same stain order."""
     parts = _participants(STAINS, modality_labels_withoutHE.detach().cpu())
     if not parts:
         return -1, False   # trainer.py:72-75: nothing but H&E in this batch

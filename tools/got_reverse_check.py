@@ -48,6 +48,81 @@ def ipot_bwd(C, inv_beta, iters, Th, dh, sh, gT):
     return -inv_beta * gA * A
 
 
+def ipot_bwd_onepass(C, inv_beta, iters, Th, dh, sh, gT, dtype=None, q_from_plan=False):
+    """The reverse sweep as csrc/got_impl.inc runs it since round 5 (ipot_backward_h): ONE pass over Q_t = A . T_{t-1} per iteration and
+    no matrix-sized state besides the accumulator H.  With Y_t := gQ_t . Q_t (elementwise) the recurrences of ipot_bwd collapse:
+        gq_t = gT_t . Q_t = Y_{t+1} / (delta_t,i sigma_t,j)      (A . Q_t = Q_{t+1} / (delta_t sigma_t), gT_t = gQ_{t+1} . A)
+        gdel_i = rowsum(Y_{t+1})_i / delta_t,i ;  u_j = colsum(Y_{t+1})_j / sigma_t,j        -> only the row / column SUMS of Y travel
+        W_t = Q_t . (delta_t ga_t^T + gr_t sigma_{t-1}^T) ;  Y_t = Y_{t+1} + W_t ;  Y_{iters+1} = gT_in . T_iters
+        dL/dC = -(1/beta) sum_t Y_t = -(1/beta) (iters Y_{iters+1} + sum_t t W_t)
+    q_from_plan: Q_t = T_t / (delta_t sigma_t) from the stored plan (one matrix read per iteration) instead of A . T_{t-1}."""
+    dtp = dtype or dt
+    n = C.shape[0]
+    A = torch.exp(-C.to(dtp) * inv_beta)
+    Y0 = gT.to(dtp) * Th[iters - 1].to(dtp)
+    H = iters * Y0
+    R, Cc = Y0.sum(1), Y0.sum(0)
+    gsig = torch.zeros(n, dtype=dtp)
+    for t in range(iters, 0, -1):
+        dl, sg, so = dh[t - 1].to(dtp), sh[t].to(dtp), sh[t - 1].to(dtp)
+        if q_from_plan:
+            Q = Th[t - 1].to(dtp) * (1.0 / dl)[:, None] * (1.0 / sg)[None, :]
+        else:
+            Q = A * (Th[t - 2].to(dtp) if t >= 2 else torch.ones(n, n, dtype=dtp))
+        ga = -n * sg * (sg * gsig + Cc)
+        rs, rs2 = Q @ ga, Q @ so
+        gr = -n * dl * dl * (R / dl + rs)
+        W = Q * (dl[:, None] * ga[None, :] + gr[:, None] * so[None, :])
+        H = H + t * W
+        gsig = Q.t() @ gr
+        R = R + dl * rs + gr * rs2
+        Cc = Cc + W.sum(0)
+    return -inv_beta * H
+
+
+def check_onepass():
+    global dt
+    for n, inv_beta, iters in ((7, 2.0, 30), (33, 10.0, 20), (96, 10.0, 20)):
+        C = torch.rand(n, n, dtype=dt) * 0.8
+        gT = torch.randn(n, n, dtype=dt)
+        Th, dh, sh = ipot_fwd(C, inv_beta, iters)
+        ref = ipot_bwd(C, inv_beta, iters, Th, dh, sh, gT)
+        Cr = C.clone().requires_grad_()
+        A = torch.exp(-Cr * inv_beta)
+        sig = torch.full((n,), 1.0 / n, dtype=dt)
+        T = torch.ones(n, n, dtype=dt)
+        for _ in range(iters):
+            Q = A * T
+            de = 1.0 / (n * (Q @ sig))
+            sig = 1.0 / (n * (Q.t() @ de))
+            T = de[:, None] * Q * sig[None, :]
+        (auto,) = torch.autograd.grad((T * gT).sum(), Cr)
+        for qp in (False, True):
+            new = ipot_bwd_onepass(C, inv_beta, iters, Th, dh, sh, gT, q_from_plan=qp)
+            e1 = float((new - auto).norm() / auto.norm())
+            e0 = float((ref - auto).norm() / auto.norm())
+            # the same two sweeps in fp32 on fp32-rounded histories (what the kernels hold), against the fp64 autograd result
+            f32 = lambda x: x.float()  # noqa: E731
+            Th32, dh32, sh32 = [f32(x) for x in Th], [f32(x) for x in dh], [f32(x) for x in sh]
+            new32 = ipot_bwd_onepass(f32(C), inv_beta, iters, Th32, dh32, sh32, f32(gT), dtype=torch.float32, q_from_plan=qp)
+            e32 = float((new32.double() - auto).norm() / auto.norm())
+            print(f"one-pass sweep n={n} iters={iters} q_from_plan={qp}: fp64 vs autograd {e1:.1e} (two-pass {e0:.1e}); fp32 arithmetic {e32:.1e}")
+            assert e1 < 1e-9
+    keep = dt
+    dt = torch.float32
+    try:
+        C = torch.rand(96, 96) * 0.8
+        gT = torch.randn(96, 96)
+        Th, dh, sh = ipot_fwd(C, 10.0, 20)
+        old32 = ipot_bwd(C, 10.0, 20, Th, dh, sh, gT)
+    finally:
+        dt = keep
+    Cd, gTd = C.double(), gT.double()
+    Thd, dhd, shd = ipot_fwd(Cd, 10.0, 20)
+    ref = ipot_bwd(Cd, 10.0, 20, Thd, dhd, shd, gTd)
+    print(f"two-pass sweep in fp32 (round-4 kernels' arithmetic), n=96: {float((old32.double() - ref).norm() / ref.norm()):.1e}")
+
+
 def got_manual(V, Q):
     k, n, d = V.shape
     rV, rQ = V.norm(dim=2), Q.norm(dim=2)
@@ -117,6 +192,7 @@ def got_manual(V, Q):
     return wd_tot + gw_tot, nb(V, Vh, rV, gVh), nb(Q, Qh, rQ, gQh)
 
 
+check_onepass()
 for (k, n) in ((2, 5), (3, 9), (4, 16)):
     V = torch.randn(k, n, 16, dtype=dt)
     Q = torch.randn(k, n, 16, dtype=dt) + 0.7 * V
