@@ -54,7 +54,7 @@ const char* mdl_version(void);
 /* ABI revision of this header: bumped whenever an entry point's argument list changes.  A binding compares
  * mdl_abi_version() with the MDL_ABI_VERSION it was written against BEFORE calling anything else, so that a stale
  * shared object fails loudly instead of being called with shifted arguments. */
-#define MDL_ABI_VERSION 20
+#define MDL_ABI_VERSION 21
 int mdl_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -392,6 +392,11 @@ int mdl_abmil_pool_dscores_img(const void* E_img, int64_t e_rsb, const float* e_
  * first to end of the second} in milliseconds (MDL_E_ARG for a slot that was never used).  Process-wide state, one training thread. */
 int mdl_pool_timer_arm(int slot);
 int mdl_pool_timer_read(int slot, float* ms);
+/* A HIP stream restricted to a subset of the compute units (hipExtStreamCreateWithCUMask): mask = n_words x 32 bits, bit i = CU i may run
+ * this stream's kernels.  For partitioning the chip between a matrix-core-bound and an HBM-bound chain that run concurrently (the dW
+ * products of the backward beside the LayerNorm / dz passes).  *stream_out receives the hipStream_t; mdl_stream_destroy releases it. */
+int mdl_stream_create_cu_mask(uint32_t n_words, const uint32_t* mask, void** stream_out);
+int mdl_stream_destroy(void* stream);
 int mdl_split_image(const float* X, int64_t ldx, int64_t rows, int K, void* img, int64_t rsb, int64_t pad_rows, float* scale,
                     void* stream);
 /* ROW-SCALED image (round 4): row r of X is scaled by its own power of two s_r (max_k |s_r X[r][k]| in [2^13, 2^14); an all-zero
@@ -447,7 +452,11 @@ int mdl_ln_gelu_drop_bwd_split(const float* x, const float* bias, const float* g
 /* A2 on the split engine (csrc/abmil_gate_split.hip): mdl_abmil_gate_fwd / mdl_abmil_attnpool_bwd(_phases) with E given as a split
  * image (rows of e_rsb bytes holding the H*512 head-major channels, scale e_scale) -- everything else (parameters, scores, saved
  * activations, gradients, dropout, pooling term, `accumulate`) as in the fp32 entry points.  scores == NULL in the backward: no
- * pooling term (plain gate backward).  dE_absmax (device float, may be NULL, zeroed by the caller) is raised to max |dE|. */
+ * pooling term (plain gate backward).  dE_absmax (device float, may be NULL, zeroed by the caller) is raised to max |dE|.
+ * phases of mdl_abmil_attnpool_bwd_split (bit mask, 1 .. 15): 1 = the dz pass (+ bias / wc column sums), 2 = both contractions,
+ * 4 = the dX contraction alone, 8 = the dW contraction alone (dWa, dWb) -- the two contractions only read what the dz pass wrote into
+ * `ws`, so a caller may queue 8 on another stream behind an event recorded after 1 while 4 and the rest of the backward proceed
+ * (functional.set_dw_stream: the dW half of the backward off the critical path). */
 int64_t mdl_abmil_gate_fwd_split_ws_bytes(int64_t T, int H);
 int mdl_abmil_gate_fwd_split(const void* E_img, int64_t e_rsb, const float* e_scale, const float* Wa, const float* ba, const float* Wb,
                              const float* bb, const float* wc, const float* bc, float* scores, float* act_a, float* act_b, int64_t T,

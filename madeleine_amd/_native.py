@@ -13,7 +13,7 @@ from . import _build
 
 _LOCK = threading.Lock()
 _LIB = None
-ABI_VERSION = 20   # == MDL_ABI_VERSION of include/madeleine_amd.h this file's SIGNATURES were written against
+ABI_VERSION = 21   # == MDL_ABI_VERSION of include/madeleine_amd.h this file's SIGNATURES were written against
 
 c_f = ctypes.c_void_p  # float* (device)
 c_p = ctypes.c_void_p
@@ -90,6 +90,8 @@ SIGNATURES = {
     # split-fp16 engine
     "mdl_pool_timer_arm": (i32, [i32]),
     "mdl_pool_timer_read": (i32, [i32, c_f]),
+    "mdl_stream_create_cu_mask": (i32, [ctypes.c_uint32, c_p, c_p]),
+    "mdl_stream_destroy": (i32, [c_p]),
     "mdl_split_image": (i32, [c_f, i64, i64, i32, c_p, i64, i64, c_f, c_p]),
     "mdl_abmil_pool_fwd_img": (i32, [c_p, i64, c_f, c_f, c_f, c_f, c_f, i64, i64, c_p, i64, i32, c_p, c_p]),
     "mdl_abmil_pool_dscores_img": (i32, [c_p, i64, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, i64, i64, c_p, i64, i32, c_p]),

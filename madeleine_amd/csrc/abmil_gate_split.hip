@@ -508,7 +508,8 @@ extern "C" int mdl_abmil_attnpool_bwd_split(const void* E_img, int64_t e_rsb, co
     if (terms != 2 && terms != 3) return MDL_E_ARG;
     if (!E_img || !e_scale || !Wa || !Wb || !wc || !act_a || !act_b || !d_scores || !dE || !dWa || !dWb || !dba || !dbb || !dwc || !ws)
         return MDL_E_ARG;
-    if (phases < 1 || phases > 3) return MDL_E_ARG;
+    if (phases < 1 || phases > 15) return MDL_E_ARG;
+    const bool do_dx = (phases & (2 | 4)) != 0, do_dw = (phases & (2 | 8)) != 0;   // bit 1 = both contractions; bit 2 = dX only, bit 3 = dW only
     if ((keep_a == nullptr) != (keep_b == nullptr)) return MDL_E_ARG;
     if (scores && (!stat_m || !stat_l || !d_pooled || (!row_bag && N < 1))) return MDL_E_ARG;
     if (T < 0 || H < 1 || H > MDL_MAX_HEADS || ldE < (int64_t)H * HID || (ldE & 3) || e_rsb < (int64_t)H * HID * 4 || (e_rsb & 15) ||
@@ -556,17 +557,17 @@ extern "C" int mdl_abmil_attnpool_bwd_split(const void* E_img, int64_t e_rsb, co
         rc = gate_launch_reduce_v(slabV, dba, dbb, dwc, dbc, H, (int)L.nblk, s);
         if (rc) return rc;
     }
-    if (phases & 2) {
-        if (T > 0) {
-            hipLaunchKernelGGL(sp_gate_wn_kernel, dim3(16, 32, H), dim3(256), 0, s, Wa, Wb, WN, (const float*)sc);
-            MDL_LAUNCH_CHECK();
-            const int64_t n_tt = (T + SPM - 1) / SPM;
-            const int64_t grid = xcd_head_grid(n_tt, 2, H);
-            if (grid > 0x7fffffff) return MDL_E_UNSUPPORTED;
-            hipLaunchKernelGGL(terms == 2 ? sp_gate_dx_kernel<2> : sp_gate_dx_kernel<3>, dim3((unsigned)grid), dim3(SP_THREADS), 0, s, (const char*)dzi, (const float*)(sc + 4),
-                               (const char*)WN, (const float*)sc, dE, ldE, accumulate, T, H, pt, dE_absmax);
-            MDL_LAUNCH_CHECK();
-        }
+    if (do_dx && T > 0) {
+        hipLaunchKernelGGL(sp_gate_wn_kernel, dim3(16, 32, H), dim3(256), 0, s, Wa, Wb, WN, (const float*)sc);
+        MDL_LAUNCH_CHECK();
+        const int64_t n_tt = (T + SPM - 1) / SPM;
+        const int64_t grid = xcd_head_grid(n_tt, 2, H);
+        if (grid > 0x7fffffff) return MDL_E_UNSUPPORTED;
+        hipLaunchKernelGGL(terms == 2 ? sp_gate_dx_kernel<2> : sp_gate_dx_kernel<3>, dim3((unsigned)grid), dim3(SP_THREADS), 0, s, (const char*)dzi, (const float*)(sc + 4),
+                           (const char*)WN, (const float*)sc, dE, ldE, accumulate, T, H, pt, dE_absmax);
+        MDL_LAUNCH_CHECK();
+    }
+    if (do_dw) {
         hipLaunchKernelGGL(terms == 2 ? sp_gate_dw_kernel<2> : sp_gate_dw_kernel<3>, dim3((unsigned)xcd_head_grid(L.S, 8, H)), dim3(SP_THREADS), 0, s, (const char*)E_img, e_rsb, e_scale,
                            (const char*)dzi, (const float*)(sc + 4), slabW, T, H, L.tps, L.S);
         MDL_LAUNCH_CHECK();

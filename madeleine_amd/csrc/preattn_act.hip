@@ -194,6 +194,21 @@ __device__ __forceinline__ void row_allreduce2(float& a, float& b, float (*red)[
     }
 }
 
+// Rows of one workgroup: [base0, base1) in steps of `step` row blocks of RPB rows.  Default: the grid-stride order;
+// -DMDL_ACT_CONTIG: a contiguous range per workgroup (A/B through tools/ab: null, see the forward kernel).
+struct ActRange {
+    int64_t base0, base1, step;
+};
+__device__ __forceinline__ ActRange act_range(int64_t rows, int RPB) {
+#ifndef MDL_ACT_CONTIG
+    return ActRange{(int64_t)blockIdx.x * RPB, rows, (int64_t)gridDim.x * RPB};
+#else
+    const int64_t nrb = (rows + RPB - 1) / RPB, per = (nrb + gridDim.x - 1) / gridDim.x;
+    const int64_t b0 = (int64_t)blockIdx.x * per, b1 = b0 + per < nrb ? b0 + per : nrb;
+    return ActRange{b0 * RPB, b1 * RPB, (int64_t)RPB};
+#endif
+}
+
 // IMG: 0 = y only; 1 = split image only (the output feeds contractions of the split engine only); 2 = both (fp32 kernels only)
 template <int NV, int WPR, class IO, int IMG = 0>
 __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_fwd_kernel(const IO* __restrict__ x,
@@ -224,12 +239,17 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_fwd_kernel(const IO* _
     // the next row's loads are issued before the current row's reductions / epilogue: a wave always has a row in flight
     // (one row at a time left the kernel latency-bound at ~50 % of the HBM rate)
     f32x4 vn[NV];
+    // Row order: grid-stride (row block b, b + grid, ...).  Round 5 tried one CONTIGUOUS range of rows per workgroup (-DMDL_ACT_CONTIG),
+    // because a plain 1 read : 1 write float4 stream gains 15-25 % from it (tools/micro/hbm_rate.hip: 4.6-5.0 -> 5.8-6.1 TB/s at 8-16
+    // workgroups per CU); in these kernels it is a null -- forward 0.436 / 0.441 vs 0.437 / 0.427 ms, backward 0.657 / 0.659 vs 0.637 /
+    // 0.653 ms in a same-box A/B (profiles/r05d_contig_rows_and_dw_stream_ab.txt): they are not at the streaming ceiling the order moves.
+    const ActRange rg = act_range(rows, RPB);
     {
-        const int64_t r = (int64_t)blockIdx.x * RPB + slot;
-        if (r < rows) row_load<IO, NV>(x + r * W + cb, lane, vn);
+        const int64_t r = rg.base0 + slot;
+        if (rg.base0 < rg.base1 && r < rows) row_load<IO, NV>(x + r * W + cb, lane, vn);
         else row_zero<NV>(vn);
     }
-    for (int64_t base = (int64_t)blockIdx.x * RPB; base < rows; base += (int64_t)gridDim.x * RPB) {
+    for (int64_t base = rg.base0; base < rg.base1; base += rg.step) {
         const int64_t r = base + slot;
         const bool live = r < rows;
         f32x4 v[NV];
@@ -237,8 +257,8 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_fwd_kernel(const IO* _
 #pragma unroll
         for (int i = 0; i < NV; ++i) v[i] = vn[i] + lb[i];
         {
-            const int64_t rn = r + (int64_t)gridDim.x * RPB;
-            if (rn < rows) row_load<IO, NV>(x + rn * W + cb, lane, vn);
+            const int64_t rn = r + rg.step;
+            if (base + rg.step < rg.base1 && rn < rows) row_load<IO, NV>(x + rn * W + cb, lane, vn);
             else row_zero<NV>(vn);
         }
 #pragma unroll
@@ -321,9 +341,10 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_bwd_kernel(const IO* _
         sx[i] = sg[i];
     }
     f32x4 xn[NV], gn[NV];   // next row, prefetched (see the forward kernel)
+    const ActRange rg = act_range(rows, RPB);   // one contiguous range of rows per workgroup (see the forward kernel)
     {
-        const int64_t r = (int64_t)blockIdx.x * RPB + slot;
-        if (r < rows) {
+        const int64_t r = rg.base0 + slot;
+        if (rg.base0 < rg.base1 && r < rows) {
             row_load<IO, NV>(x + r * W + cb, lane, xn);
             row_load<IO, NV>(dy + r * W + cb, lane, gn);
         } else {
@@ -331,7 +352,7 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_bwd_kernel(const IO* _
             row_zero<NV>(gn);
         }
     }
-    for (int64_t base = (int64_t)blockIdx.x * RPB; base < rows; base += (int64_t)gridDim.x * RPB) {
+    for (int64_t base = rg.base0; base < rg.base1; base += rg.step) {
         const int64_t r = base + slot;
         const bool live = r < rows;
         const float mean = live ? mean_i[r] : 0.f, rstd = live ? rstd_i[r] : 0.f;
@@ -342,8 +363,8 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_bwd_kernel(const IO* _
             gc[i] = gn[i];
         }
         {
-            const int64_t rn = r + (int64_t)gridDim.x * RPB;
-            if (rn < rows) {
+            const int64_t rn = r + rg.step;
+            if (base + rg.step < rg.base1 && rn < rows) {
                 row_load<IO, NV>(x + rn * W + cb, lane, xn);
                 row_load<IO, NV>(dy + rn * W + cb, lane, gn);
             } else {

@@ -118,8 +118,16 @@ __global__ __launch_bounds__(256) void sp_image_rows_reg_kernel(const float* __r
                                                                 float* __restrict__ absmax) {
     const int lane = threadIdx.x & 63;
     float tot = 0.f;
-    const int64_t stride = (int64_t)gridDim.x * 4 * ROWS;
-    for (int64_t r0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS; r0 < rows; r0 += stride) {
+    // -DMDL_ACT_CONTIG: one contiguous range of row groups per workgroup, its four waves interleaved inside it (round-5 experiment: a plain
+    // 1 read : 1 write stream gains 15-25 % from that order, tools/micro/hbm_rate.hip; this kernel does not -- 0.207 vs 0.202 ms)
+#ifndef MDL_ACT_CONTIG
+    const int64_t stride = (int64_t)gridDim.x * 4 * ROWS, r_begin = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS, r_end = rows;
+#else
+    const int64_t ng = (rows + ROWS - 1) / ROWS, per = ((ng + gridDim.x - 1) / gridDim.x + 3) / 4 * 4;
+    const int64_t g0 = (int64_t)blockIdx.x * per, g1 = g0 + per < ng ? g0 + per : ng;
+    const int64_t stride = 4 * ROWS, r_begin = (g0 + (threadIdx.x >> 6)) * ROWS, r_end = g1 * ROWS < rows ? g1 * ROWS : rows;
+#endif
+    for (int64_t r0 = r_begin; r0 < r_end; r0 += stride) {
         f32x4 v[ROWS][SEG][2];
 #pragma unroll
         for (int j = 0; j < ROWS; ++j) {

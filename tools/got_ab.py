@@ -38,14 +38,19 @@ def rel(a, b):
 
 
 if __name__ == "__main__":
-    old = load(sys.argv[1])
-    new = load(sys.argv[2]) if len(sys.argv) > 2 else load(_native.lib_path())
+    import json
+    paths = sys.argv[1:] or [_native.lib_path()]
+    libs = [(os.path.basename(p), load(p)) for p in paths]
     dev = torch.device("cuda:0")
-    for (k, n) in ((4, 129), (32, 160), (32, 192), (32, 256)):
+    geoms = json.loads(os.environ.get("GOT_GEOMS", "[[4,129],[32,160],[32,192],[32,256]]"))
+    for (k, n) in geoms:
         g = torch.Generator(device=dev).manual_seed(k * 1000 + n)
         v = torch.randn(k, n, 128, device=dev, generator=g)
         q = torch.randn(k, n, 128, device=dev, generator=g) + 0.7 * v
-        oo, dvo, dqo, to = run(old, v, q)
-        on, dvn, dqn, tn = run(new, v, q)
-        print(f"k={k:3d} n={n:3d}  wd {float(oo[0]):.6f}/{float(on[0]):.6f} gw {float(oo[1]):.6f}/{float(on[1]):.6f}  "
-              f"dV rel {rel(dvn, dvo):.2e} dQ rel {rel(dqn, dqo):.2e}   old {to[0]:7.2f}+{to[1]:7.2f} ms  new {tn[0]:7.2f}+{tn[1]:7.2f} ms", flush=True)
+        ref = None
+        for name, L in libs:
+            o, dv, dq, t = run(L, v, q, reps=3)
+            if ref is None:
+                ref = (o, dv, dq)
+            print(f"k={k:3d} n={n:3d} {name:<24} wd {float(o[0]):.6f} gw {float(o[1]):.6f}  dV rel {rel(dv, ref[1]):.2e} dQ rel {rel(dq, ref[2]):.2e}   "
+                  f"{t[0]:7.3f} + {t[1]:7.3f} ms", flush=True)

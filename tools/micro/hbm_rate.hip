@@ -53,6 +53,77 @@ __global__ void k(const f32x4* __restrict__ a, const f32x4* __restrict__ b, f32x
     if (MODE == 0 && acc.x == 12345.678f) sink[0] = acc.y;
 }
 
+// Store patterns of the product's image-writing passes (1 read : 1 write in bytes), contiguous range per workgroup, U float4 in flight:
+//   PAT 0: plain float4 copy (reference)
+//   PAT 1: "split planes, 8 B": a lane's float4 goes out as 8 B into the hi plane and 8 B into the lo plane of its 128-B image block
+//          (LayerNorm kernels' img_store4: one store instruction covers the 64-B halves of 8 lines)
+//   PAT 2: "split planes, 16 B": a lane reads 32 B (two float4) and writes 16 B + 16 B (the dz pass / row-scaled image: 64-B halves of 16 lines)
+//   PAT 3: as 2, but lanes L and L^4 exchange their lo halves through DPP so that every store instruction writes whole 128-B lines
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+template <int PAT, int U>
+__global__ void kp(const f32x4* __restrict__ a, char* __restrict__ o, long n4) {
+    const long bd = blockDim.x;
+    const long per = ((n4 + gridDim.x - 1) / gridDim.x + 2 * U * bd - 1) / (2 * U * bd) * (2 * U * bd);
+    const long i0 = (long)blockIdx.x * per, end = i0 + per < n4 ? i0 + per : n4;
+    const int lane = threadIdx.x & 63;
+    if (PAT <= 1) {
+        for (long i = i0 + threadIdx.x; i < end; i += U * bd) {
+            f32x4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = i + u * bd < end ? __builtin_nontemporal_load(a + i + u * bd) : f32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const long j = i + u * bd;
+                if (j >= end) continue;
+                if (PAT == 0) *reinterpret_cast<f32x4*>(o + j * 16) = v[u];
+                else {   // float4 j = columns 4j .. 4j+3: block (4j / 32) of 128 B, 8 B at (4j % 32) * 2 and the same + 64
+                    char* p = o + (j >> 3) * 128 + (j & 7) * 8;
+                    const u32x4 w = __builtin_bit_cast(u32x4, v[u]);
+                    *reinterpret_cast<u32x2*>(p) = u32x2{w.x, w.y};
+                    *reinterpret_cast<u32x2*>(p + 64) = u32x2{w.z, w.w};
+                }
+            }
+        }
+    } else {
+        const long n8 = n4 / 2, e8 = end / 2;
+        for (long i = i0 / 2 + threadIdx.x; i < e8; i += U * bd) {   // i = index of a 32-B piece (8 floats)
+            f32x4 v[U][2];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const long j = i + u * bd < e8 ? i + u * bd : i;
+                v[u][0] = __builtin_nontemporal_load(a + 2 * j);
+                v[u][1] = __builtin_nontemporal_load(a + 2 * j + 1);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const long j = i + u * bd;
+                if (j >= e8) continue;
+                char* p = o + (j >> 2) * 128 + (j & 3) * 16;   // piece j = 8 columns: block j / 4, 16 B at (j % 4) * 16 and + 64
+                u32x4 hi = __builtin_bit_cast(u32x4, v[u][0]), lo = __builtin_bit_cast(u32x4, v[u][1]);
+                if (PAT == 2) {
+                    *reinterpret_cast<u32x4*>(p) = hi;
+                    *reinterpret_cast<u32x4*>(p + 64) = lo;
+                } else {
+                    // lanes L (L % 8 < 4, piece in line A) and L + 4 (same position in line A + 1) swap their lo halves: instruction 1 then
+                    // writes line A whole (hi from the low lanes, lo from the high lanes), instruction 2 line A + 1
+                    const bool low = (lane & 4) == 0;
+                    u32x4 got;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int shr = __builtin_amdgcn_update_dpp(0, (int)lo[e], 0x114, 0xF, 0xF, false);   // row_shr:4 (from lane - 4)
+                        const int shl = __builtin_amdgcn_update_dpp(0, (int)lo[e], 0x104, 0xF, 0xF, false);   // row_shl:4 (from lane + 4)
+                        got[e] = (unsigned)(low ? shl : shr);
+                    }
+                    *reinterpret_cast<u32x4*>(low ? p : p - 128 + 64) = low ? hi : got;
+                    *reinterpret_cast<u32x4*>(low ? p + 128 + 64 : p) = low ? got : hi;
+                }
+            }
+        }
+        (void)n8;
+    }
+}
+
 typedef void (*kern_t)(const f32x4*, const f32x4*, f32x4*, long, float*);
 template <int MODE, int U>
 kern_t pick(bool nt, bool contig) {
@@ -111,6 +182,28 @@ int main(int argc, char** argv) {
                                     snprintf(best[si][mode].what, 160, "U=%d wg=%d wg/CU=%d %s %s", U, bd, wgcu, contig ? "contig" : "stride", nt ? "nt-store" : "plain-store");
                                 }
                             }
+    }
+    {
+        printf("\n== store patterns of the image-writing passes (copy, 2 GiB, contiguous range per workgroup) ==\n");
+        const long bytes = 2L << 30, n4 = bytes / 16;
+        const char* pn[4] = {"float4 copy", "split planes 8 B", "split planes 16 B", "split planes 16 B, whole lines (DPP swap)"};
+        for (int pat = 0; pat < 4; ++pat)
+            for (int bd : {256, 512})
+                for (int wgcu : {2, 8, 16}) {
+                    float bestms = 1e9f;
+                    for (int rep = 0; rep < 4; ++rep) {
+                        hipEventRecord(e0);
+                        const dim3 g(256 * wgcu), b(bd);
+                        if (pat == 0) hipLaunchKernelGGL((kp<0, 4>), g, b, 0, 0, a, (char*)o, n4);
+                        else if (pat == 1) hipLaunchKernelGGL((kp<1, 4>), g, b, 0, 0, a, (char*)o, n4);
+                        else if (pat == 2) hipLaunchKernelGGL((kp<2, 4>), g, b, 0, 0, a, (char*)o, n4);
+                        else hipLaunchKernelGGL((kp<3, 4>), g, b, 0, 0, a, (char*)o, n4);
+                        hipEventRecord(e1); hipEventSynchronize(e1);
+                        float ms; hipEventElapsedTime(&ms, e0, e1);
+                        if (ms < bestms) bestms = ms;
+                    }
+                    printf("%-44s wg=%-4d wg/CU=%-2d  %.3f ms  %.2f TB/s\n", pn[pat], bd, wgcu, bestms, 2.0 * bytes / bestms / 1e9);
+                }
     }
     printf("\n== best per access mix and working set ==\n");
     for (int si = 0; si < 4; ++si)
