@@ -136,10 +136,10 @@ class ABMILEmbedder(nn.Module):
                 seed = MF.new_dropout_seed()
         return p, seed, keep
 
-    def _block_split(self, x, x_scale, blk, perm=None, want_fp32=False):
+    def _block_split(self, x, x_scale, blk, perm=None, want_fp32=False, weight=None):
         """Linear + LayerNorm + GELU + Dropout of block `blk` as one node on the split engine (functional.PreAttnBlockFn)."""
         lin, ln = self.pre_attn[4 * blk], self.pre_attn[4 * blk + 1]
-        W, lb, g, b = lin.weight, lin.bias, ln.weight, ln.bias
+        W, lb, g, b = (lin.weight if weight is None else weight), lin.bias, ln.weight, ln.bias
         if perm is not None:
             W, lb, g, b = self.permuted(W, 0), self.permuted(lb, 0), self.permuted(g, 0), self.permuted(b, 0)
         p, seed, keep = self._drop_cfg(blk, perm)
@@ -167,23 +167,33 @@ class ABMILEmbedder(nn.Module):
         the bf16 mode of the HIP kernels; LayerNorm statistics, GELU and every reduction stay fp32 inside the kernels."""
         pa = self.pre_attn
         perm = self._perm
+        # Any patch_embedding_dim (Model.py:351 is a plain nn.Linear): the kernels contract over 32-column blocks, so an input width that
+        # is not a multiple of 32 is zero-padded -- features and the columns of the first weight alike, which leaves every product
+        # unchanged (exact) and costs one padded copy of the bags per forward; autograd slices the weight gradient back.  The usual
+        # encoders (512 / 768 / 1024 / 1536 / 2048 / 2560, + 32 stain channels) never take this branch.
+        W0 = pa[0].weight
+        k_in = bags.shape[-1]
+        if k_in % 32:
+            padc = 32 - k_in % 32
+            bags = F.pad(bags, (0, padc))
+            W0 = F.pad(W0, (0, padc))
         if bf16_mode():
             with torch.autocast(device_type="cuda", enabled=False):
                 bf = torch.bfloat16
-                x = self._act(MF.linear(bags.to(bf), pa[0].weight), pa[1], 0, None, pa[0].bias)
+                x = self._act(MF.linear(bags.to(bf), W0), pa[1], 0, None, pa[0].bias)
                 x = self._act(MF.linear(x, pa[4].weight), pa[5], 1, None, pa[4].bias)
                 E = self._act(MF.linear(x, self.permuted(pa[8].weight, 0)), pa[9], 2, perm, pa[8].bias)
                 return (E, None) if return_image else E
         x2d = bags.reshape(-1, bags.shape[-1])
         if MF.preattn_split_supported(x2d, x2d.shape[-1]) and pa[0].weight.shape[0] % 32 == 0:
             # split GEMM mode: three fused blocks; the activations between them exist as split images only
-            img, sc, _ = self._block_split(x2d.float().contiguous(), None, 0)
+            img, sc, _ = self._block_split(x2d.float().contiguous(), None, 0, weight=W0)
             img, sc, _ = self._block_split(img, sc, 1)
             keep_fp32 = want_fp32 or not return_image
             img, sc, E = self._block_split(img, sc, 2, perm, want_fp32=keep_fp32)
             E = (E if keep_fp32 else img).view(*bags.shape[:-1], img.shape[-1])
             return (E, (img, sc)) if return_image else E
-        x = self._act(MF.linear(bags.float(), pa[0].weight), pa[1], 0, None, pa[0].bias)
+        x = self._act(MF.linear(bags.float(), W0), pa[1], 0, None, pa[0].bias)
         x = self._act(MF.linear(x, pa[4].weight), pa[5], 1, None, pa[4].bias)
         E = self._act(MF.linear(x, self.permuted(pa[8].weight, 0)), pa[9], 2, perm, pa[8].bias)
         return (E, None) if return_image else E
@@ -334,12 +344,8 @@ class MADELEINE(nn.Module):
         else:
             self.stain_encoding_dim = 0
         if self.config.wsi_encoder == "abmil":
-            in_dim = self.config.patch_embedding_dim + self.stain_encoding_dim
-            if in_dim % 32:
-                # fail at construction with the reason, not at the first big bag with a kernel return code
-                raise ValueError("madeleine_amd: patch_embedding_dim%s must be a multiple of 32 (got %d): the encoder's Linears run on "
-                                 "hand-written HIP kernels (32-column blocks) and there is no library-GEMM fallback"
-                                 % (" + 32 stain-encoding channels" if self.stain_encoding else "", in_dim))
+            # (any patch_embedding_dim: widths that are not a multiple of 32 are zero-padded at the encoder's entry, ABMILEmbedder.
+            # embed_tokens_headmajor -- round 4 raised here)
             pre_params = {'input_dim': self.config.patch_embedding_dim + self.stain_encoding_dim,
                           'hidden_dim': self.config.wsi_encoder_hidden_dim}
             attention_params = {'model': 'ABMIL',

@@ -652,3 +652,42 @@ def test_forward_ragged_unequal_backward_vs_oracle(dev, use_got):
             continue
         cos = float(torch.dot(grads_b[k].flatten(), g.flatten()) / (grads_b[k].norm() * g.norm()).clamp_min(1e-30))
         assert cos > (0.99 if g.dim() >= 2 else 0.9), (k, cos)
+
+
+@pytest.mark.parametrize("gemm", ["split", "fp32"])
+@pytest.mark.parametrize("d_in", [500, 1000, 77])
+def test_any_patch_embedding_dim_vs_oracle(dev, d_in, gemm):
+    """Model.py:351 is a plain nn.Linear: any patch_embedding_dim works in the reference.  Here an input width that is not a multiple of
+    32 is zero-padded at the encoder's entry (features and first-weight columns alike: exact).  d = 500 / 1000
+    and an odd width, full step (InfoNCE at T = 0.01) against the CPU oracle: loss, slide embeddings, every parameter gradient --
+    the first Linear's weight gradient in its reference shape [512, d]."""
+    from madeleine_amd import InfoNCE, calculate_losses
+    from madeleine_amd import functional as MF
+    mods = MODS5[:3]
+    B, M, N = 4, 3, 300
+    keep = MF.gemm_mode()
+    MF.set_gemm_mode(gemm)
+    try:
+        model = build(mods, d_in, "anyd", dev).eval()
+        feats = t((B, M, N, d_in), "anyd:feats")
+        labels = torch.tensor([[1, 1, 1], [1, 1, 0], [1, 1, 1], [1, 0, 1]], dtype=torch.float32)
+        args = SimpleNamespace(global_loss="info-nce", symmetric_cl=True, local_loss_weight=1.0)
+        embs, toks = model({"feats": feats}, device=dev, train=True)
+        loss, flag = calculate_losses(mods[1:], InfoNCE(temperature=0.01), None, None, embs, toks, labels[:, 1:], args)
+        model.zero_grad()
+        loss.backward()
+    finally:
+        MF.set_gemm_mode(keep)
+    sd = {k: v.detach().cpu().clone().requires_grad_() for k, v in model.state_dict().items()}
+    ref_loss, _, ref_embs = R.pretrain_step_loss(feats, labels, sd, mods, 0.01, True, use_got=False)
+    ref_loss.backward()
+    assert flag and abs(float(loss) - float(ref_loss)) < TOL * abs(float(ref_loss))
+    for m in mods[1:]:
+        assert rel_err(embs[m], ref_embs[m]) < TOL
+    top = max(float(v.grad.norm()) for v in sd.values() if v.grad is not None)
+    for k, p in model.named_parameters():
+        if sd[k].grad is None:
+            continue
+        assert p.grad is not None and p.grad.shape == sd[k].shape, k
+        err = float((p.grad.cpu() - sd[k].grad).norm())
+        assert err <= TOL * float(sd[k].grad.norm()) + 1e-5 * top, (k, err, float(sd[k].grad.norm()))
