@@ -418,6 +418,25 @@ class MADELEINE(nn.Module):
         pooled, _, _ = self.wsi_embedders.forward_headmajor(feats, need_tokens=False)
         return self._project_slide(pooled)
 
+    def encode_he_bags(self, bags, device):
+        """encode_he (Model.py:97-107) for SEVERAL bags of different lengths in one launch set: `bags` = list of [N_i, D] (or [1, N_i, D])
+        tensors -> [len(bags), 512].  The tokens are packed [sum N_i, D] and pooled through the ragged kernels (cu_seqlens); every kernel
+        of the path is row-local and the pooling merges a bag's 128-token chunks in bag order, so each row equals encode_he of that bag
+        alone BIT FOR BIT as long as every bag is on the same kernel path alone as in the pack (more than 256 patches: the large-M
+        engines; run_inference sends smaller bags one by one).  For the extraction loop (utils.run_inference): one bag per call leaves a
+        30,000-patch bag on 235 pooling workgroups and the host bound by ~40 launches per bag."""
+        emb = self.wsi_embedders
+        if emb.attn[0].activation != 'softmax' or len(bags) == 1:     # (the ragged pooling kernels serve the softmax activation)
+            return torch.cat([self.encode_he(b.reshape(1, -1, b.shape[-1]), device) for b in bags])
+        flat = [b.reshape(-1, b.shape[-1]) for b in bags]
+        lens = [int(x.shape[0]) for x in flat]
+        cu = torch.zeros(len(flat) + 1, dtype=torch.int64)
+        cu[1:] = torch.cumsum(torch.tensor(lens, dtype=torch.int64), 0)
+        x = torch.cat([f.to(device) for f in flat], dim=0)
+        E, e_img = emb.embed_tokens_headmajor(x, return_image=True, want_fp32=False)
+        pooled, _ = emb.pool_headmajor_ragged(E, MF.h2d(cu, device), max(lens), e_img=e_img)
+        return self._project_slide(pooled)
+
     def forward_ragged(self, bags, device, n_loss_tokens=None):
         """Variable-length bags (BASELINE config 5) -- NEW functionality: the reference can only torch.stack equal-N
         bags (wsi_dataset.py:89-92).  `bags` is a list over cases of lists over modalities of [N_bm, D] tensors.

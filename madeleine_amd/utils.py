@@ -12,22 +12,46 @@ import torch
 DEVICE = torch.device("cuda" if torch.cuda.is_available() else "cpu")
 
 
-def run_inference(ssl_model, val_dataloader, config=None, torch_precision=None):
-    """Slide-embedding extraction loop (utils.py:27-66): eval mode, no gradients, one full bag per batch through
-    `ssl_model.encode_he` under the configured precision; returns ({"embeds": [n,512] fp32 array, "slide_ids": [...]},
-    smooth rank of the embeddings).  The dataloader yields (feats [1,N,D], slide_ids) like the reference's SimpleDataset
-    (wsi_dataset.py:102-124).  Forward-only use of the HIP path: nothing is saved for backward."""
+def run_inference(ssl_model, val_dataloader, config=None, torch_precision=None, bags_per_launch=4):
+    """Slide-embedding extraction loop (utils.py:27-66): eval mode, no gradients, full bags through `ssl_model.encode_he` under the
+    configured precision; returns ({"embeds": [n,512] fp32 array, "slide_ids": [...]}, smooth rank of the embeddings).  The dataloader
+    yields (feats [1,N,D], slide_ids) like the reference's SimpleDataset (wsi_dataset.py:102-124).  Forward-only use of the HIP path:
+    nothing is saved for backward.
+    Organisation (same embeddings, bit for bit, as one encode_he call per bag): up to `bags_per_launch` bags go through ONE launch set
+    (MADELEINE.encode_he_bags: packed tokens + cu_seqlens; bags of at most 256 patches go alone, they take the small-M kernels), and
+    the embeddings stay on the device until the loop ends -- the reference's per-bag `.cpu()` is a device synchronisation per slide,
+    which leaves the GPU idle while the host prepares the next bag."""
     ssl_model.eval()
     precision = torch_precision if torch_precision is not None else set_model_precision(config.precision)
     reduced = precision in (torch.bfloat16, torch.float16)      # for fp32 / fp64 torch disables autocast (SURVEY.md section 5)
-    embeds, slide_ids = [], []
+    batched = bags_per_launch > 1 and hasattr(ssl_model, "encode_he_bags")
+    outs, slide_ids, pending = [], [], []
+
+    def flush():
+        if not pending:
+            return
+        with torch.amp.autocast(device_type="cuda", dtype=precision, enabled=reduced):
+            if len(pending) == 1:
+                emb = ssl_model.encode_he(pending[0], device=DEVICE)
+            else:
+                emb = ssl_model.encode_he_bags(pending, device=DEVICE)
+        outs.append(emb.float())
+        pending.clear()
+
     with torch.no_grad():
         for feats, ids in val_dataloader:
-            with torch.amp.autocast(device_type="cuda", dtype=precision, enabled=reduced):
-                wsi_embed = ssl_model.encode_he(feats, device=DEVICE)
-            embeds.extend(wsi_embed.float().cpu().numpy())
             slide_ids.append(ids[0])
-    embeds = np.array(embeds)
+            n_patches = feats.shape[-2]
+            if not batched or n_patches <= 256:
+                flush()
+                pending.append(feats)
+                flush()
+                continue
+            pending.append(feats)
+            if len(pending) >= bags_per_launch:
+                flush()
+        flush()
+        embeds = torch.cat(outs).cpu().numpy() if outs else np.zeros((0, 512), dtype=np.float32)
     return {"embeds": embeds, "slide_ids": slide_ids}, smooth_rank_measure(torch.Tensor(embeds))
 
 

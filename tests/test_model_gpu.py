@@ -462,6 +462,19 @@ def test_inference_full_bag_vs_oracle_and_run_inference(dev):
     with torch.no_grad():
         direct = model.encode_he(bag, dev)
     assert torch.equal(direct.cpu()[0], torch.from_numpy(res["embeds"][0]))
+    # several bags per launch set (run_inference's default) == one encode_he call per bag, bit for bit -- also across a bag of at most
+    # 256 patches (sent alone: it takes the small-M kernels) and a ragged mix of lengths.  Under bf16 autocast the Linear / gate kernels
+    # pick their tile (128 / 256 rows, 32 / 64-deep chunks) by the number of token rows of the call, so a packed call may round
+    # differently from a single-bag call: equal to bf16 accuracy there, not bit for bit
+    many = loader + [(t((1, 200, D), "inf:bag4"), ["slide_d"]), (t((1, 12345, D), "inf:bag5"), ["slide_e"]),
+                     (t((1, 257, D), "inf:bag6"), ["slide_f"]), (t((1, 5000, D), "inf:bag7"), ["slide_g"])]
+    one_by_one, _ = run_inference(model, many, config=SimpleNamespace(precision="float32"), bags_per_launch=1)
+    packed, _ = run_inference(model, many, config=SimpleNamespace(precision="float32"), bags_per_launch=4)
+    assert packed["slide_ids"] == one_by_one["slide_ids"] == [ids[0] for _, ids in many]
+    assert np.array_equal(packed["embeds"], one_by_one["embeds"]) and np.array_equal(packed["embeds"][:3], res["embeds"])
+    p16, _ = run_inference(model, many, torch_precision=torch.bfloat16, bags_per_launch=3)
+    o16, _ = run_inference(model, many, torch_precision=torch.bfloat16, bags_per_launch=1)
+    assert rel_err(p16["embeds"], o16["embeds"]) < 1e-2
     # the reference's bf16 extraction (extract_slide_embeddings.py:49 passes torch_precision): same loop under autocast
     res16, _ = run_inference(model, loader[1:], torch_precision=torch.bfloat16)
     assert rel_err(res16["embeds"], res["embeds"][1:]) < 3e-2
