@@ -8,13 +8,22 @@ synthetic bags: per rank B=32 slides x M stains x N=409
 (weak scaling: per-GPU work fixed).  N=1 workload = BASELINE.json configs[1] ("c2": 2 stains, ABMIL pool +
 global InfoNCE), the configuration the metric is quoted on.  Rank 0 prints ONE JSON line.
 
-Extra objects on that line:
-  roofline      -- A3 softmax-pool forward kernel (the HBM-bound kernel north_star targets at >= 60 %):
-                   algorithmic bytes (8,208 B/token + 8 KiB/bag) / HIP-event duration inside the timed region.
-  roofline_mfma -- A2 gate kernels (fwd + dX + dW), the time-dominant fp32-MFMA contractions: algorithmic
-                   FLOP / HIP-event duration vs the 157.3 TFLOP/s fp32 matrix peak.
-  cpu_baseline  -- the CPU oracle (oracle/restatement.py, kind "port") timed on this box's host cores on a
-                   bounded sample of the same workload (rank 0, N=1 only).
+`python bench.py --gpus N` with no launcher in the environment re-executes itself as N ranks under torch.distributed.run (loopback
+rendezvous); under a launcher (RANK / WORLD_SIZE set) it joins the group it was given.
+
+Extra objects on that line (the headline's per-kernel figures come FIRST so that a truncated tail still shows them):
+  roofline        -- A3 softmax-pool forward kernel (the HBM-bound kernel north_star targets at >= 60 %): algorithmic bytes
+                     (8,208 B/token + 8 KiB/bag) / the dispatches' own start-stop HIP events inside the timed region; `traffic` from
+                     two in-run rocprofv3 PMC passes.
+  kernel_ms / kernel_roofline -- every kernel family of the headline step: ms per call, achieved TFLOP/s against the dense MFMA peak
+                     of the instruction it runs on (split mode: 3 fp16 MFMA FLOPs per algorithmic fp32 FLOP against the 2.5 PFLOP/s
+                     fp16 peak) or GB/s against the 8 TB/s HBM peak.
+  roofline_mfma   -- A2 gate kernels (fwd + dX + dW), the time-dominant contractions: the same accounting, plus the fraction of what
+                     the matrix cores sustain on random operands under the power cap.
+  cpu_baseline    -- the CPU oracle (oracle/restatement.py, kind "port") timed on this box's host cores on the full 32-slide step
+                     (rank 0, N=1 only), + variants.
+  secondary legs  -- bf16 / exact-fp32 / two-term modes, PCIe-inclusive feed, config 3 (ACROBAT mask and all stains present), one rank
+                     of config 4 (both masks) and of config 5, inference (1 and 4 bags per launch set).
 """
 import argparse
 import json
@@ -925,6 +934,11 @@ def main():
                 except Exception as e2:
                     out["cpu_baseline"] = {"value": None, "unit": "slides/s", "cores": usable_cores(), "kind": "port",
                                            "sample": f"failed: {type(e2).__name__}: {e2}"}
+        # LAST on the line (a reader that keeps only the tail still sees the headline's figures): step time, per-kernel ms and fractions
+        out["headline_summary"] = {"value_slides_per_s": out["value"], "ms_per_step": out["ms_per_step"],
+                                   "pool_fwd_hbm_frac": out.get("roofline", {}).get("frac"),
+                                   "kernel_ms": out.get("kernel_ms"),
+                                   "kernel_frac_of_peak": {k: v["frac"] for k, v in out.get("kernel_roofline", {}).items()}}
         print(json.dumps(out), flush=True)
 
     if dist_on:
