@@ -50,20 +50,6 @@ __global__ __launch_bounds__(256) void gate_wt_kernel(const float* __restrict__ 
 
 // DM: dropout mode 0 = off, 1 = counter-hash RNG, 2 = explicit uint8 masks (one code path per instantiation: the
 // three-way runtime choice per element cost 12 arch VGPRs, i.e. the third wave per SIMD).  SAVE: store the activations.
-template <int DM>
-__device__ __forceinline__ void fwd_keep2(const DropCfg& d, int64_t idx, uint32_t row_key, bool& ka, bool& kb) {
-    if (DM == 0) {
-        ka = kb = true;
-    } else if (DM == 2) {
-        ka = d.ka[idx] != 0;
-        kb = d.kb[idx] != 0;
-    } else {
-        const uint32_t h = mix32((uint32_t)idx ^ row_key);   // = rng_u32(d.key, idx), high-word part hoisted (drop_row_key)
-        ka = (h & 0xFFFFu) >= d.thr;
-        kb = (h >> 16) >= d.thr;
-    }
-}
-
 template <int DM, bool SAVE>
 __global__ __launch_bounds__(256) void gate_fwd_kernel(const float* __restrict__ E, int64_t ldE,
                                                        const float* __restrict__ WT, const float* __restrict__ ba,
@@ -110,17 +96,18 @@ __global__ __launch_bounds__(256) void gate_fwd_kernel(const float* __restrict__
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
             const int jc = j0 + wn * 64 + ct * 32;                 // first gate column of this pass
-            const float bav = ba[c * HID + jc + l32], bbv = bb[c * HID + jc + l32];
+            // (bias and the exponent's scaling folded into one FMA: gate_tanh_pre / gate_sigmoid_pre, common.hpp)
+            const float ta = 2.f * MDL_LOG2E * ba[c * HID + jc + l32], tb = -MDL_LOG2E * bb[c * HID + jc + l32];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float za, zb;
                 asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(za) : "a"(acc[rt][ct][r]));
                 asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(zb) : "a"(acc[rt][2 + ct][r]));
-                tile[acc_row(r, lane) * 64 + l32] = fast_tanh(za + bav);
-                tile[acc_row(r, lane) * 64 + 32 + l32] = fast_sigmoid(zb + bbv);
+                tile[acc_row(r, lane) * 64 + l32] = gate_tanh_pre(za, 2.f * MDL_LOG2E, ta);
+                tile[acc_row(r, lane) * 64 + 32 + l32] = gate_sigmoid_pre(zb, -MDL_LOG2E, tb);
                 if ((r & 3) == 3) TILE_SB();
             }
-            const f32x4 wc4 = *reinterpret_cast<const f32x4*>(wc + c * HID + jc + g8 * 4);
+            const f32x4 wc4 = *reinterpret_cast<const f32x4*>(wc + c * HID + jc + g8 * 4) * (drop.inv * drop.inv);   // both dropout factors
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = i * 8 + r8;
@@ -138,10 +125,9 @@ __global__ __launch_bounds__(256) void gate_fwd_kernel(const float* __restrict__
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         bool keep_a, keep_b;
-                        fwd_keep2<DM>(drop, idx + e, rkey, keep_a, keep_b);
-                        const float ad = keep_a ? a4[e] * drop.inv : 0.f;
-                        const float bd = keep_b ? b4[e] * drop.inv : 0.f;
-                        sum += ad * bd * wc4[e];
+                        gate_keep2_fwd<DM>(drop, idx, e, rkey, keep_a, keep_b);
+                        const float ab = a4[e] * b4[e];
+                        sum = fmaf((keep_a && keep_b) ? ab : 0.f, wc4[e], sum);
                     }
                 }
                 sum += __shfl_xor(sum, 1, 64);
@@ -391,11 +377,12 @@ __global__ __launch_bounds__(256) void gate_reduce_v_kernel(const float* __restr
     }
 }
 
-__global__ void gate_mask_kernel(uint8_t* __restrict__ keep, int64_t n, int which, uint32_t key, uint32_t thr) {
+__global__ void gate_mask_kernel(uint8_t* __restrict__ keep, int64_t n, int which, DropCfg d) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
-        const uint32_t h = rng_u32(key, (uint64_t)i);
-        keep[i] = ((which ? (h >> 16) : (h & 0xFFFFu)) >= thr) ? 1 : 0;
+        bool ka, kb;
+        drop_keep2(d, i, drop_row_key(d, i), ka, kb);     // the very function the forward / backward kernels evaluate (either field width)
+        keep[i] = (which ? kb : ka) ? 1 : 0;
     }
 }
 
@@ -451,17 +438,19 @@ extern "C" int mdl_abmil_gate_fwd(const float* E, int64_t ldE, const float* Wa, 
     float* part = WT + (int64_t)H * HID * 1024;
     hipLaunchKernelGGL(gate_wt_kernel, dim3(16, 32, H), dim3(256), 0, s, Wa, Wb, WT);
     MDL_LAUNCH_CHECK();
-    const int dm = !d.on ? 0 : (d.ka ? 2 : 1);
+    const int dm = gate_drop_mode(d);
 #define MDL_GATE_FWD(DM, SAVE)                                                                                                  \
     hipLaunchKernelGGL((gate_fwd_kernel<DM, SAVE>), dim3((unsigned)grid), dim3(256), 0, s, E, ldE, (const float*)WT, ba, bb, wc, part, \
                        act_a, act_b, T, H, (int)n_tt, d)
     if (act_a) {
         if (dm == 0) MDL_GATE_FWD(0, true);
         else if (dm == 1) MDL_GATE_FWD(1, true);
+        else if (dm == 3) MDL_GATE_FWD(3, true);
         else MDL_GATE_FWD(2, true);
     } else {
         if (dm == 0) MDL_GATE_FWD(0, false);
         else if (dm == 1) MDL_GATE_FWD(1, false);
+        else if (dm == 3) MDL_GATE_FWD(3, false);
         else MDL_GATE_FWD(2, false);
     }
 #undef MDL_GATE_FWD
@@ -577,8 +566,9 @@ extern "C" int mdl_abmil_gate_dropout_mask(uint8_t* keep, int64_t T, int H, int 
     if (!(p_drop >= 0.f && p_drop < 1.f)) return MDL_E_ARG;
     const int64_t n = T * H * HID;
     if (n == 0) return MDL_OK;
-    hipLaunchKernelGGL(gate_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, keep, n, which,
-                       make_drop(p_drop, seed, nullptr, nullptr).key, drop_threshold(p_drop));
+    DropCfg d = make_drop(p_drop, seed, nullptr, nullptr);
+    d.on = 1;   // (p = 0: threshold 0, every element kept)
+    hipLaunchKernelGGL(gate_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, keep, n, which, d);
     MDL_LAUNCH_CHECK();
     return MDL_OK;
 }

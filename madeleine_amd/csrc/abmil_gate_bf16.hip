@@ -50,20 +50,6 @@ __global__ __launch_bounds__(256) void gate_wn_bf16_kernel(const float* __restri
 // ================================================================================================
 // DM: dropout mode 0 = off, 1 = counter-hash RNG, 2 = explicit uint8 masks; SAVE: store the activations (one code path per
 // instantiation keeps the unrolled epilogue inside the register budget).
-template <int DM>
-__device__ __forceinline__ void fwd_keep2_bf16(const DropCfg& d, int64_t idx, uint32_t row_key, bool& ka, bool& kb) {
-    if (DM == 0) {
-        ka = kb = true;
-    } else if (DM == 2) {
-        ka = d.ka[idx] != 0;
-        kb = d.kb[idx] != 0;
-    } else {
-        const uint32_t h = mix32((uint32_t)idx ^ row_key);   // = rng_u32(d.key, idx), high-word part hoisted (drop_row_key)
-        ka = (h & 0xFFFFu) >= d.thr;
-        kb = (h >> 16) >= d.thr;
-    }
-}
-
 template <int DM, bool SAVE>
 __global__ __launch_bounds__(256, 2) void gate_fwd_bf16_kernel(const bf16_t* __restrict__ E, int64_t ldE,
                                                                const bf16_t* __restrict__ WK, const float* __restrict__ ba,
@@ -124,15 +110,16 @@ __global__ __launch_bounds__(256, 2) void gate_fwd_bf16_kernel(const bf16_t* __r
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
             const int jc = j0 + wn * 64 + ct * 32;                 // first gate column of this pass
-            const float bav = ba[c * HID + jc + l32], bbv = bb[c * HID + jc + l32];
+            const float ta = 2.f * MDL_LOG2E * ba[c * HID + jc + l32], tb = -MDL_LOG2E * bb[c * HID + jc + l32];   // (folded, see common.hpp)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                tile[acc_row(r, lane) * 64 + l32] = (float)(bf16_t)fast_tanh(acc[rt][ct][r] + bav);
-                tile[acc_row(r, lane) * 64 + 32 + l32] = (float)(bf16_t)fast_sigmoid(acc[rt][2 + ct][r] + bbv);
+                tile[acc_row(r, lane) * 64 + l32] = (float)(bf16_t)gate_tanh_pre(acc[rt][ct][r], 2.f * MDL_LOG2E, ta);
+                tile[acc_row(r, lane) * 64 + 32 + l32] = (float)(bf16_t)gate_sigmoid_pre(acc[rt][2 + ct][r], -MDL_LOG2E, tb);
                 if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
-            const f32x4 wlo = *reinterpret_cast<const f32x4*>(wc + c * HID + jc + g4 * 8);
-            const f32x4 whi = *reinterpret_cast<const f32x4*>(wc + c * HID + jc + g4 * 8 + 4);
+            const float inv2 = drop.inv * drop.inv;   // both dropout factors folded into wc: one select per (a, b) pair
+            const f32x4 wlo = *reinterpret_cast<const f32x4*>(wc + c * HID + jc + g4 * 8) * inv2;
+            const f32x4 whi = *reinterpret_cast<const f32x4*>(wc + c * HID + jc + g4 * 8 + 4) * inv2;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int row = i * 16 + r16;
@@ -151,12 +138,10 @@ __global__ __launch_bounds__(256, 2) void gate_fwd_bf16_kernel(const bf16_t* __r
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         bool keep_a, keep_b;
-                        fwd_keep2_bf16<DM>(drop, idx + e, rkey, keep_a, keep_b);
+                        gate_keep2_fwd<DM>(drop, idx, e, rkey, keep_a, keep_b);
                         const float a = e < 4 ? alo[e & 3] : ahi[e & 3], b = e < 4 ? blo[e & 3] : bhi[e & 3];
                         const float w = e < 4 ? wlo[e & 3] : whi[e & 3];
-                        const float ad = keep_a ? a * drop.inv : 0.f;
-                        const float bd = keep_b ? b * drop.inv : 0.f;
-                        sum += ad * bd * w;
+                        sum = fmaf((keep_a && keep_b) ? a * b : 0.f, w, sum);
                     }
                 }
                 sum += __shfl_xor(sum, 1, 64);
@@ -223,15 +208,16 @@ __global__ __launch_bounds__(512) void gate_fwd256_bf16_kernel(const bf16_t* __r
     float* sred = reinterpret_cast<float*>(&sm) + 8 * (32 * 64) + wn * QM + wm * 128;   // [4 (wn)][256 rows]
     const int g4 = lane & 3, r16 = lane >> 2;
     const int jc = j0 + wn * 32;
-    const float bav = ba[c * HID + jc + l32], bbv = bb[c * HID + jc + l32];
-    const f32x4 wlo = *reinterpret_cast<const f32x4*>(wc + c * HID + jc + g4 * 8);
-    const f32x4 whi = *reinterpret_cast<const f32x4*>(wc + c * HID + jc + g4 * 8 + 4);
+    const float ta = 2.f * MDL_LOG2E * ba[c * HID + jc + l32], tb = -MDL_LOG2E * bb[c * HID + jc + l32];   // (folded, see common.hpp)
+    const float inv2 = drop.inv * drop.inv;   // both dropout factors folded into wc: one select per (a, b) pair
+    const f32x4 wlo = *reinterpret_cast<const f32x4*>(wc + c * HID + jc + g4 * 8) * inv2;
+    const f32x4 whi = *reinterpret_cast<const f32x4*>(wc + c * HID + jc + g4 * 8 + 4) * inv2;
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            tile[acc_row(r, lane) * 64 + l32] = (float)(bf16_t)fast_tanh(acc[rt][0][r] + bav);
-            tile[acc_row(r, lane) * 64 + 32 + l32] = (float)(bf16_t)fast_sigmoid(acc[rt][1][r] + bbv);
+            tile[acc_row(r, lane) * 64 + l32] = (float)(bf16_t)gate_tanh_pre(acc[rt][0][r], 2.f * MDL_LOG2E, ta);
+            tile[acc_row(r, lane) * 64 + 32 + l32] = (float)(bf16_t)gate_sigmoid_pre(acc[rt][1][r], -MDL_LOG2E, tb);
             if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
@@ -252,12 +238,10 @@ __global__ __launch_bounds__(512) void gate_fwd256_bf16_kernel(const bf16_t* __r
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     bool keep_a, keep_b;
-                    fwd_keep2_bf16<DM>(drop, idx + e, rkey, keep_a, keep_b);
+                    gate_keep2_fwd<DM>(drop, idx, e, rkey, keep_a, keep_b);
                     const float a = e < 4 ? alo[e & 3] : ahi[e & 3], b = e < 4 ? blo[e & 3] : bhi[e & 3];
                     const float w = e < 4 ? wlo[e & 3] : whi[e & 3];
-                    const float ad = keep_a ? a * drop.inv : 0.f;
-                    const float bd = keep_b ? b * drop.inv : 0.f;
-                    sum += ad * bd * w;
+                    sum = fmaf((keep_a && keep_b) ? a * b : 0.f, w, sum);
                 }
             }
             sum += __shfl_xor(sum, 1, 64);
@@ -574,7 +558,7 @@ extern "C" int mdl_abmil_gate_fwd_bf16(const uint16_t* E, int64_t ldE, const flo
     float* part = (float*)((char*)ws + (int64_t)H * 1024 * HID * 2);
     hipLaunchKernelGGL(gate_wk_bf16_kernel, dim3((unsigned)((int64_t)H * 1024 * HID / 4 / 256)), dim3(256), 0, s, Wa, Wb, WK, H);
     MDL_LAUNCH_CHECK();
-    const int dm = !d.on ? 0 : (d.ka ? 2 : 1);
+    const int dm = gate_drop_mode(d);
 #define MDL_GATE_FWD16(DM, SAVE)                                                                                                   \
     hipLaunchKernelGGL((gate_fwd_bf16_kernel<DM, SAVE>), dim3((unsigned)grid), dim3(256), 0, s, (const bf16_t*)E, ldE, (const bf16_t*)WK, \
                        ba, bb, wc, part, (bf16_t*)act_a, (bf16_t*)act_b, T, H, (int)n_tt, d)
@@ -588,19 +572,23 @@ extern "C" int mdl_abmil_gate_fwd_bf16(const uint16_t* E, int64_t ldE, const flo
         if (act_a) {
             if (dm == 0) MDL_GATE_FWD256(0, true);
             else if (dm == 1) MDL_GATE_FWD256(1, true);
+            else if (dm == 3) MDL_GATE_FWD256(3, true);
             else MDL_GATE_FWD256(2, true);
         } else {
             if (dm == 0) MDL_GATE_FWD256(0, false);
             else if (dm == 1) MDL_GATE_FWD256(1, false);
+            else if (dm == 3) MDL_GATE_FWD256(3, false);
             else MDL_GATE_FWD256(2, false);
         }
     } else if (act_a) {
         if (dm == 0) MDL_GATE_FWD16(0, true);
         else if (dm == 1) MDL_GATE_FWD16(1, true);
+        else if (dm == 3) MDL_GATE_FWD16(3, true);
         else MDL_GATE_FWD16(2, true);
     } else {
         if (dm == 0) MDL_GATE_FWD16(0, false);
         else if (dm == 1) MDL_GATE_FWD16(1, false);
+        else if (dm == 3) MDL_GATE_FWD16(3, false);
         else MDL_GATE_FWD16(2, false);
     }
 #undef MDL_GATE_FWD256

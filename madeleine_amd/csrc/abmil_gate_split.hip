@@ -62,20 +62,6 @@ __global__ void sp_bound_scale_kernel(const float* __restrict__ in, float mult, 
 // ================================================================================================
 // forward
 // ================================================================================================
-template <int DM>
-__device__ __forceinline__ void sp_keep2(const DropCfg& d, int64_t idx, uint32_t row_key, bool& ka, bool& kb) {
-    if (DM == 0) {
-        ka = kb = true;
-    } else if (DM == 2) {
-        ka = d.ka[idx] != 0;
-        kb = d.kb[idx] != 0;
-    } else {
-        const uint32_t h = mix32((uint32_t)idx ^ row_key);
-        ka = (h & 0xFFFFu) >= d.thr;
-        kb = (h >> 16) >= d.thr;
-    }
-}
-
 // Tile: 256 tokens x (128 a | 128 b) gate columns j0 .. j0 + 127 of head c.  Tile column n = wn * SP_WCOLS + ct * 32 + l with the first
 // SPNCT / 2 column tiles of a wave = a columns j0 + wn * (16 SPNCT) + ct * 32 + l and the second half = the b columns of the same j, so that
 // a wave holds za and zb of the same (token, j) in acc[rt][cp] / acc[rt][SPNCT / 2 + cp].
@@ -131,14 +117,17 @@ __global__ __launch_bounds__(SP_THREADS) void sp_gate_fwd_kernel(const char* __r
 #pragma unroll
         for (int cp = 0; cp < HALF; ++cp) {
             const int jc = j0 + wn * (32 * HALF) + cp * 32;   // first gate column of this pass
-            const float bav = ba[c * HID + jc + l32], bbv = bb[c * HID + jc + l32];
+            // pre-activation = acc * inv + bias, folded into the exponent's FMA (gate_tanh_pre / gate_sigmoid_pre, common.hpp)
+            const float ta = 2.f * MDL_LOG2E * ba[c * HID + jc + l32], tb = -MDL_LOG2E * bb[c * HID + jc + l32];
+            const float sa2 = 2.f * MDL_LOG2E * inv, sb1 = -MDL_LOG2E * inv;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                tile[acc_row(r, lane) * 64 + l32] = fast_tanh(fmaf(acc[rt][cp][r], inv, bav));
-                tile[acc_row(r, lane) * 64 + 32 + l32] = fast_sigmoid(fmaf(acc[rt][HALF + cp][r], inv, bbv));
+                tile[acc_row(r, lane) * 64 + l32] = gate_tanh_pre(acc[rt][cp][r], sa2, ta);
+                tile[acc_row(r, lane) * 64 + 32 + l32] = gate_sigmoid_pre(acc[rt][HALF + cp][r], sb1, tb);
                 if ((r & 3) == 3) SP_SB();
             }
-            const f32x4 wc4 = *reinterpret_cast<const f32x4*>(wc + c * HID + jc + g8 * 4);
+            // score term of an element: keep_a keep_b / (1-p)^2 a b wc -- the two dropout factors folded into wc, ONE select per pair
+            const f32x4 wc4 = *reinterpret_cast<const f32x4*>(wc + c * HID + jc + g8 * 4) * (drop.inv * drop.inv);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = i * 8 + r8;
@@ -155,10 +144,9 @@ __global__ __launch_bounds__(SP_THREADS) void sp_gate_fwd_kernel(const char* __r
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         bool keep_a, keep_b;
-                        sp_keep2<DM>(drop, idx + e, rkey, keep_a, keep_b);
-                        const float ad = keep_a ? a4[e] * drop.inv : 0.f;
-                        const float bd = keep_b ? b4[e] * drop.inv : 0.f;
-                        sum += ad * bd * wc4[e];
+                        gate_keep2_fwd<DM>(drop, idx, e, rkey, keep_a, keep_b);
+                        const float ab = a4[e] * b4[e];
+                        sum = fmaf((keep_a && keep_b) ? ab : 0.f, wc4[e], sum);
                     }
                 }
                 sum += __shfl_xor(sum, 1, 64);
@@ -473,17 +461,19 @@ extern "C" int mdl_abmil_gate_fwd_split(const void* E_img, int64_t e_rsb, const 
     if (rc) return rc;
     hipLaunchKernelGGL(sp_gate_wk_kernel, dim3((unsigned)((int64_t)H * 1024 * 64 / 256)), dim3(256), 0, s, Wa, Wb, WK, H, (const float*)sc);
     MDL_LAUNCH_CHECK();
-    const int dm = !d.on ? 0 : (d.ka ? 2 : 1);
+    const int dm = gate_drop_mode(d);
 #define MDL_GATE_FWD_SP(DM, SAVE)                                                                                                     \
     hipLaunchKernelGGL((sp_gate_fwd_kernel<DM, SAVE>), dim3((unsigned)grid), dim3(SP_THREADS), 0, s, (const char*)E_img, e_rsb, e_scale, \
                        (const char*)WK, (const float*)sc, ba, bb, wc, part, act_a, act_b, T, H, (int)n_tt, d)
     if (act_a) {
         if (dm == 0) MDL_GATE_FWD_SP(0, true);
         else if (dm == 1) MDL_GATE_FWD_SP(1, true);
+        else if (dm == 3) MDL_GATE_FWD_SP(3, true);
         else MDL_GATE_FWD_SP(2, true);
     } else {
         if (dm == 0) MDL_GATE_FWD_SP(0, false);
         else if (dm == 1) MDL_GATE_FWD_SP(1, false);
+        else if (dm == 3) MDL_GATE_FWD_SP(3, false);
         else MDL_GATE_FWD_SP(2, false);
     }
 #undef MDL_GATE_FWD_SP

@@ -102,6 +102,18 @@ __host__ __device__ __forceinline__ uint32_t drop_threshold(float p) {
 // instructions and the epilogue is VALU-bound beside the MFMA stream)
 __device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 __device__ __forceinline__ float fast_tanh(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)); }
+// The same two activations of a pre-activation z = acc * s + bias with the scaling of the exponent folded into the FMA that forms z
+// (round 5: the gate epilogue is VALU-bound beside the matrix cores, every instruction removed is wall time):
+//   tanh(z)    = 1 - 2 / (1 + 2^(acc * (2 log2e s) + 2 log2e bias))       -> gate_tanh_pre(acc, 2 log2e s, 2 log2e bias)
+//   sigmoid(z) = 1 / (1 + 2^(acc * (-log2e s) - log2e bias))              -> gate_sigmoid_pre(acc, -log2e s, -log2e bias)
+// one fma + v_exp_f32 + add + v_rcp_f32 (+ fma): 5 and 4 instructions instead of 7 and 6.
+constexpr float MDL_LOG2E = 1.4426950408889634f;
+__device__ __forceinline__ float gate_tanh_pre(float acc, float s2, float b2) {
+    return fmaf(-2.f, __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(fmaf(acc, s2, b2))), 1.f);
+}
+__device__ __forceinline__ float gate_sigmoid_pre(float acc, float s1, float b1) {
+    return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(fmaf(acc, s1, b1)));
+}
 
 // XCD-aware remap (8 XCDs; block b runs on XCD b % 8): returns a logical id such that logical ids
 // [x*per, (x+1)*per) all run on XCD x, i.e. consecutive logical tiles share one L2.  Bijective for

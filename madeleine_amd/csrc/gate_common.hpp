@@ -1,5 +1,6 @@
 // gate_common.hpp -- pieces shared by the fp32 (abmil_gate.hip) and bf16 (abmil_gate_bf16.hip) gate kernels
 #pragma once
+#include <stdlib.h>
 #include "common.hpp"
 
 namespace mdl {
@@ -34,6 +35,7 @@ struct DropCfg {
     const uint8_t* ka;
     const uint8_t* kb;
     int on;
+    int bytes;      // byte-field mode of the counter hash (see gate_keep2_bytes): thr is a multiple of 256
 };
 
 // rng_u32(key, idx) = mix32(lo32(idx) ^ key ^ (hi32(idx) * golden)): the part that depends on the high word only, hoisted once per
@@ -41,13 +43,52 @@ struct DropCfg {
 __device__ __forceinline__ uint32_t drop_row_key(const DropCfg& d, int64_t idx0) {
     return d.key ^ ((uint32_t)((uint64_t)idx0 >> 32) * 0x9E3779B9U);
 }
-// keep decisions of one gate element (tanh branch, sigmoid branch); row_key = drop_row_key of an index with the same high word
+// Counter-hash keep decisions of one gate element (tanh branch, sigmoid branch).  Two field widths:
+//   16-bit fields (any p):  h = mix32(lo32(idx) ^ row_key);  ka = h[15:0] >= thr,  kb = h[31:16] >= thr
+//   byte fields (round 5; DropCfg.bytes: thr % 256 == 0, e.g. the gate's p = 0.25 -> P(keep) exact): ONE hash serves the element PAIR
+//   (2q, 2q + 1):  h = mix32((lo32(idx) >> 1) ^ row_key);  element 2q: ka = h[7:0] >= thr >> 8, kb = h[15:8] >= ...;  element 2q + 1:
+//   bytes 2 and 3 -- half of the hash instructions of the VALU-bound forward epilogue.  Forward, dz pass and mask export all come here.
+// gate_keep2_hash<BYTES>(d, idx_even, e, row_key, ...): element idx_even + e with idx_even even and e a compile-time offset, so that the
+// two elements of a pair share the hash after common-subexpression elimination.
+template <bool BYTES>
+__device__ __forceinline__ void gate_keep2_hash(const DropCfg& d, int64_t idx_even, int e, uint32_t row_key, bool& ka, bool& kb) {
+    if (BYTES) {
+        const uint32_t h = mix32((((uint32_t)idx_even >> 1) + (uint32_t)(e >> 1)) ^ row_key);
+        const uint32_t f = (e & 1) ? (h >> 16) : h, t8 = d.thr >> 8;
+        ka = (f & 0xFFu) >= t8;
+        kb = ((f >> 8) & 0xFFu) >= t8;
+    } else {
+        const uint32_t h = mix32(((uint32_t)idx_even + (uint32_t)e) ^ row_key);
+        ka = (h & 0xFFFFu) >= d.thr;
+        kb = (h >> 16) >= d.thr;
+    }
+}
+// DM: dropout mode of a forward-kernel instantiation: 0 = off, 1 = counter hash with 16-bit fields, 2 = explicit uint8 masks, 3 = counter
+// hash with byte fields
+template <int DM>
+__device__ __forceinline__ void gate_keep2_fwd(const DropCfg& d, int64_t idx_even, int e, uint32_t row_key, bool& ka, bool& kb) {
+    if (DM == 0) {
+        ka = kb = true;
+    } else if (DM == 2) {
+        ka = d.ka[idx_even + e] != 0;
+        kb = d.kb[idx_even + e] != 0;
+    } else {
+        gate_keep2_hash<DM == 3>(d, idx_even, e, row_key, ka, kb);
+    }
+}
+static inline int gate_drop_mode(const DropCfg& d) { return !d.on ? 0 : (d.ka ? 2 : (d.bytes ? 3 : 1)); }
+// run-time form (dz passes, mask export): any idx; row_key = drop_row_key of an index with the same high word
 __device__ __forceinline__ void drop_keep2(const DropCfg& d, int64_t idx, uint32_t row_key, bool& ka, bool& kb) {
     if (!d.on) {
         ka = kb = true;
     } else if (d.ka) {
         ka = d.ka[idx] != 0;
         kb = d.kb[idx] != 0;
+    } else if (d.bytes) {
+        const uint32_t h = mix32(((uint32_t)idx >> 1) ^ row_key);
+        const uint32_t f = ((uint32_t)idx & 1u) ? (h >> 16) : h, t8 = d.thr >> 8;
+        ka = (f & 0xFFu) >= t8;
+        kb = ((f >> 8) & 0xFFu) >= t8;
     } else {
         const uint32_t h = mix32((uint32_t)idx ^ row_key);
         ka = (h & 0xFFFFu) >= d.thr;
@@ -94,6 +135,7 @@ static inline DropCfg make_drop(float p, uint64_t seed, const uint8_t* ka, const
     d.p = p;
     d.inv = d.on ? 1.f / (1.f - p) : 1.f;
     d.thr = drop_threshold(p);
+    d.bytes = (d.on && d.thr > 0 && (d.thr & 0xFFu) == 0 && !getenv("MADELEINE_DROP_16BIT")) ? 1 : 0;
     d.key = (uint32_t)(seed * 0x9E3779B97F4A7C15ULL >> 32) ^ (uint32_t)seed;
     d.ka = ka;
     d.kb = kb;
