@@ -573,10 +573,21 @@ static int ln_fwd_launch(const IO* x, const float* bias, const float* gamma, con
         return MDL_E_ALIGN;
     if (rows == 0) return MDL_OK;
     const ActDrop d = make_act_drop(p_drop, seed, keep);
+// (geometry of the 2048-wide kernels as macros: round 5 swept forward <4,2> / <2,4>, backward <8,1> / <2,4> and grid caps 768 / 1024 on fp32
+// and bf16 storage -- the shipped <8,1> / <4,2> / 2048 is the best or within noise everywhere, profiles/r05i_ln_2048_geometry_variants.txt;
+// the bf16 kernels (4.0 / 3.9 TB/s) are bound by their ~20 VALU issue slots per element -- two quarter-rate transcendentals of the
+// GELU, the counter hash -- not by the row geometry)
+#ifndef MDL_LN_F_NV
+#define MDL_LN_F_NV 8
+#define MDL_LN_F_WPR 1
+#endif
+#ifndef MDL_LN_GRID_CAP
+#define MDL_LN_GRID_CAP 2048
+#endif
     if (W == 2048) {  // forward: a whole 2048-wide row per wave (153 VGPRs, no block barriers) beats 4 waves per row
-        int64_t nb = (rows + 3) / 4;
-        if (nb > 2048) nb = 2048;
-        hipLaunchKernelGGL((ln_gelu_drop_fwd_kernel<8, 1, IO>), dim3((unsigned)nb), dim3(ACT_BLOCK), 0, (hipStream_t)stream, x,
+        int64_t nb = (rows + 4 / MDL_LN_F_WPR - 1) / (4 / MDL_LN_F_WPR);
+        if (nb > MDL_LN_GRID_CAP) nb = MDL_LN_GRID_CAP;
+        hipLaunchKernelGGL((ln_gelu_drop_fwd_kernel<MDL_LN_F_NV, MDL_LN_F_WPR, IO>), dim3((unsigned)nb), dim3(ACT_BLOCK), 0, (hipStream_t)stream, x,
                            bias, gamma, beta, y, mean, rstd, rows, eps, d);
         MDL_LAUNCH_CHECK();
         return MDL_OK;
@@ -604,10 +615,14 @@ static int ln_bwd_launch(const IO* x, const float* bias, const float* gamma, con
     if (W == 2048 && nb > 0) {
         // 2048 wide: 2 waves per row (NV = 4, ~226 VGPRs) instead of 4 -- the 4-wave version was bound by its per-row block barriers
         // rather than by VALU or HBM: bf16 0.97 -> 0.82 ms, fp32 1.35 -> 1.25 ms at config 2 (tools/exp_ln.py)
-        int64_t b2 = (rows + 1) / 2;
-        if (b2 > 2048) b2 = 2048;
+#ifndef MDL_LN_B_NV
+#define MDL_LN_B_NV 4
+#define MDL_LN_B_WPR 2
+#endif
+        int64_t b2 = (rows + 4 / MDL_LN_B_WPR - 1) / (4 / MDL_LN_B_WPR);
+        if (b2 > MDL_LN_GRID_CAP) b2 = MDL_LN_GRID_CAP;
         nb = (int)b2;
-        hipLaunchKernelGGL((ln_gelu_drop_bwd_kernel<4, 2, IO>), dim3(nb), dim3(ACT_BLOCK), 0, s, x, bias, gamma, beta, mean, rstd, dy, dx,
+        hipLaunchKernelGGL((ln_gelu_drop_bwd_kernel<MDL_LN_B_NV, MDL_LN_B_WPR, IO>), dim3(nb), dim3(ACT_BLOCK), 0, s, x, bias, gamma, beta, mean, rstd, dy, dx,
                            (float*)ws, rows, d);
         MDL_LAUNCH_CHECK();
     } else
