@@ -285,15 +285,18 @@ def measure_leg(MF, stepf, steps, warmup=2, prof_steps=3):
     return el, loss, prof, work, prof_steps
 
 
-def secondary_c3_leg(dev, D, MF, InfoNCE, MADELEINE, steps=5, warmup=2, all_present=False):
+def secondary_c3_leg(dev, D, MF, InfoNCE, MADELEINE, steps=5, warmup=2, all_present=False, skip_absent=False):
     """BASELINE configs[2] as a short secondary measurement beside the headline: 32 slides x 5 stains (ACROBAT presence rates,
     absent stain = all-zero bag) x 4096 x 512, global InfoNCE + local GOT (IPOT Wasserstein + Gromov-Wasserstein, n = k <= 32
     tokens), AdamW, train mode.  The headline workload (c2) has no GOT: this leg is where the GOT kernels are timed.
-    all_present: SURVEY 8(d)'s second mask variant -- every case carries every stain (k = 32 for all four GOT problems, no zero bags)."""
+    all_present: SURVEY 8(d)'s second mask variant -- every case carries every stain (k = 32 for all four GOT problems, no zero bags).
+    skip_absent: SURVEY 8(f) N4 -- the all-zero bag of an absent stain (wsi_dataset.py:66; no loss term reads its outputs, trainer.py:27-29)
+    is encoded once instead of once per case (MADELEINE.skip_absent_stains; never the default: the reference encodes them all)."""
     B, M, N, Dm, _, _ = CONFIGS["c3"]
     mods = MODS5[:M]
     torch.manual_seed(42)
     model = MADELEINE(make_cfg(M, Dm)).to(dev).train()
+    model.skip_absent_stains = bool(skip_absent)
     opt = torch.optim.AdamW(model.parameters(), lr=1e-4, fused=FUSED_ADAMW)
     gen = torch.Generator(device=dev).manual_seed(1234)
     feats = torch.randn(B, M, N, Dm, device=dev, generator=gen)
@@ -319,7 +322,8 @@ def secondary_c3_leg(dev, D, MF, InfoNCE, MADELEINE, steps=5, warmup=2, all_pres
     k = [int(labels[:, s].sum()) for s in range(1, M)]
     return {"value": round(B * steps / el, 3), "unit": "slides/s", "ms_per_step": round(1e3 * el / steps, 3), "steps": steps,
             "workload": f"c3{' (all stains present)' if all_present else ''}: {B} slides x {M} stains (cases per stain {k}) x {N} x {Dm}, "
-                        f"InfoNCE + GOT, train mode, AdamW",
+                        f"InfoNCE + GOT, train mode, AdamW" + (f"; absent-stain zero bags encoded once ({int(labels.sum())} of {B * M} bags "
+                                                               f"present)" if skip_absent else ""),
             "final_loss": float(loss.detach()),
             "kernel_ms": {n: round(v[0], 4) for n, v in prof.items()}, "kernel_calls_per_step": {n: v[1] // psteps for n, v in prof.items()},
             "kernel_roofline": kernel_rooflines(prof, work, "float32", MF.gemm_mode())}
@@ -764,7 +768,7 @@ def main():
                 step()
             fence()
         power = ps.summary(skip_s=1.0)
-    c3_leg = infer_leg = c4_leg = c3ap_leg = c4ap_leg = c5_leg = None
+    c3_leg = infer_leg = c4_leg = c3ap_leg = c4ap_leg = c5_leg = c3skip_leg = None
     if a.config == "c2" and a.precision == "float32" and world == 1 and not a.no_extra_legs and host_iter is None:
         # free the c2 working set first (the c3 step keeps ~60 GiB live)
         feats = data = None
@@ -779,6 +783,8 @@ def main():
         # the all-present mask variant (every GOT problem in the n = 256 size class on a rank of config 4), and one rank of
         # config 5 (ragged, d = 768, stain tokens; every stain present -> the same four n = 256 problems)
         c3ap_leg = secondary_c3_leg(dev, D, MF, InfoNCE, MADELEINE, steps=4, all_present=True)
+        torch.cuda.empty_cache()
+        c3skip_leg = secondary_c3_leg(dev, D, MF, InfoNCE, MADELEINE, steps=4, skip_absent=True)
         torch.cuda.empty_cache()
         c4ap_leg = secondary_rank_leg(dev, D, MF, InfoNCE, MADELEINE, all_present=True)
         torch.cuda.empty_cache()
@@ -907,6 +913,8 @@ def main():
             out["c4_rank_emulation"] = c4_leg
         if c3ap_leg is not None:
             out["c3_all_present"] = c3ap_leg
+        if c3skip_leg is not None:
+            out["c3_skip_absent_optin"] = c3skip_leg
         if c4ap_leg is not None:
             out["c4_rank_emulation_all_present"] = c4ap_leg
         if c5_leg is not None:
