@@ -54,7 +54,7 @@ const char* mdl_version(void);
 /* ABI revision of this header: bumped whenever an entry point's argument list changes.  A binding compares
  * mdl_abi_version() with the MDL_ABI_VERSION it was written against BEFORE calling anything else, so that a stale
  * shared object fails loudly instead of being called with shifted arguments. */
-#define MDL_ABI_VERSION 21
+#define MDL_ABI_VERSION 22
 int mdl_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -423,6 +423,13 @@ int mdl_split_tile_absmax(const float* X, int64_t ldx, int64_t rows, int K, floa
 int mdl_split_gemm_nt(const void* A, int64_t a_rsb, const float* a_scale, const void* B, int64_t b_rsb, const float* b_scale, float* C,
                       int64_t ldc, int64_t M, int N, int K, const float* bias, int accumulate, float* absmax_out, const float* row_gate,
                       const float* a_row_mul, const float* b_col_mul, int terms, void* stream);
+/* (round 5) The same product with a bias row per GROUP of output rows: C[m][:] += group_bias[row_group[m]][:]; group_bias [G][N]
+ * contiguous fp32, row_group device int32 [M] with values in [0, G).  MADELEINE's stain encoding (Model.py:125-132) concatenates ONE
+ * 32-vector per bag to every patch feature before the first Linear (:351): [x | e_g] W^T = x Wx^T + e_g We^T, so the concat never has to
+ * exist -- the bag's row e_g We^T enters here, and mdl_ln_gelu_drop_bwd_split_groups returns its gradient. */
+int mdl_split_gemm_nt_group_bias(const void* A, int64_t a_rsb, const float* a_scale, const void* B, int64_t b_rsb, const float* b_scale,
+                                 float* C, int64_t ldc, int64_t M, int N, int K, const float* bias, const float* a_row_mul,
+                                 const float* b_col_mul, const float* group_bias, const int32_t* row_group, int terms, void* stream);
 int64_t mdl_split_gemm_tn_ws_bytes(int64_t T, int Mi, int N);
 /* b_chunk_max (float [ceil(T / 32)], may be NULL): per-32-row maxima of |X| for B = image(X) (mdl_split_tile_absmax) -- chunks whose
  * entry is 0 are skipped (the token_projector's dW: the local loss reads the first <= 256 tokens of a bag, the rest of d_tok is zero). */
@@ -448,6 +455,15 @@ int mdl_ln_gelu_drop_bwd_split(const float* x, const float* bias, const float* g
                                const float* rstd, const float* dy, const float* dy_absmax, void* dx_img, float* dx_scale, float* dgamma,
                                float* dbeta, float* dbias, int64_t rows, int W, float p_drop, uint64_t seed, const uint8_t* keep,
                                const float* row_mul, const float* rstd_max, void* ws, void* stream);
+/* (round 5) mdl_ln_gelu_drop_bwd_split for a pre-LN tensor whose rows carry a per-group bias row (see mdl_split_gemm_nt_group_bias): the
+ * rows of a group are contiguous, cu_groups = device int64 [G + 1] row offsets, G <= 2048.  Additionally dgroup_bias [G][W] = the sum
+ * of dx over the rows of each group.  ws: mdl_ln_gelu_drop_bwd_groups_ws_bytes(rows, W, G). */
+int64_t mdl_ln_gelu_drop_bwd_groups_ws_bytes(int64_t rows, int W, int G);
+int mdl_ln_gelu_drop_bwd_split_groups(const float* x, const float* bias, const float* gamma, const float* beta, const float* mean,
+                                      const float* rstd, const float* dy, const float* dy_absmax, void* dx_img, float* dx_scale,
+                                      float* dgamma, float* dbeta, float* dbias, int64_t rows, int W, float p_drop, uint64_t seed,
+                                      const uint8_t* keep, const float* row_mul, const float* rstd_max, const int64_t* cu_groups, int G,
+                                      float* dgroup_bias, void* ws, void* stream);
 
 /* A2 on the split engine (csrc/abmil_gate_split.hip): mdl_abmil_gate_fwd / mdl_abmil_attnpool_bwd(_phases) with E given as a split
  * image (rows of e_rsb bytes holding the H*512 head-major channels, scale e_scale) -- everything else (parameters, scores, saved

@@ -13,7 +13,7 @@ from . import _build
 
 _LOCK = threading.Lock()
 _LIB = None
-ABI_VERSION = 21   # == MDL_ABI_VERSION of include/madeleine_amd.h this file's SIGNATURES were written against
+ABI_VERSION = 22   # == MDL_ABI_VERSION of include/madeleine_amd.h this file's SIGNATURES were written against
 
 c_f = ctypes.c_void_p  # float* (device)
 c_p = ctypes.c_void_p
@@ -97,6 +97,10 @@ SIGNATURES = {
     "mdl_abmil_pool_dscores_img": (i32, [c_p, i64, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, i64, i64, c_p, i64, i32, c_p]),
     "mdl_split_tile_absmax": (i32, [c_f, i64, i64, i32, c_f, c_f, c_p]),
     "mdl_split_gemm_nt": (i32, [c_p, i64, c_f, c_p, i64, c_f, c_f, i64, i64, i32, i32, c_f, i32, c_f, c_f, c_f, c_f, i32, c_p]),
+    "mdl_split_gemm_nt_group_bias": (i32, [c_p, i64, c_f, c_p, i64, c_f, c_f, i64, i64, i32, i32, c_f, c_f, c_f, c_f, c_p, i32, c_p]),
+    "mdl_ln_gelu_drop_bwd_groups_ws_bytes": (i64, [i64, i32, i32]),
+    "mdl_ln_gelu_drop_bwd_split_groups": (i32, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_f, c_f, c_f, c_f, i64, i32, f32, u64, c_p, c_f, c_f,
+                                                c_p, i32, c_f, c_p, c_p]),
     "mdl_split_image_rows": (i32, [c_f, i64, i64, i32, c_p, i64, i64, c_f, c_f, c_p]),
     "mdl_split_gemm_tn_ws_bytes": (i64, [i64, i32, i32]),
     "mdl_split_gemm_tn": (i32, [c_p, i64, c_f, i32, c_p, i64, c_f, i32, c_f, i64, c_f, c_p, i32, c_p]),

@@ -199,13 +199,14 @@ __device__ __forceinline__ void row_allreduce2(float& a, float& b, float (*red)[
 struct ActRange {
     int64_t base0, base1, step;
 };
-__device__ __forceinline__ ActRange act_range(int64_t rows, int RPB) {
+// rows [lo, hi) of this workgroup's row group (the whole tensor, or -- grouped backward -- the rows of group blockIdx.y)
+__device__ __forceinline__ ActRange act_range(int64_t lo, int64_t hi, int RPB) {
 #ifndef MDL_ACT_CONTIG
-    return ActRange{(int64_t)blockIdx.x * RPB, rows, (int64_t)gridDim.x * RPB};
+    return ActRange{lo + (int64_t)blockIdx.x * RPB, hi, (int64_t)gridDim.x * RPB};
 #else
-    const int64_t nrb = (rows + RPB - 1) / RPB, per = (nrb + gridDim.x - 1) / gridDim.x;
+    const int64_t nrb = (hi - lo + RPB - 1) / RPB, per = (nrb + gridDim.x - 1) / gridDim.x;
     const int64_t b0 = (int64_t)blockIdx.x * per, b1 = b0 + per < nrb ? b0 + per : nrb;
-    return ActRange{b0 * RPB, b1 * RPB, (int64_t)RPB};
+    return ActRange{lo + b0 * RPB, lo + b1 * RPB, (int64_t)RPB};
 #endif
 }
 
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_fwd_kernel(const IO* _
     // because a plain 1 read : 1 write float4 stream gains 15-25 % from it (tools/micro/hbm_rate.hip: 4.6-5.0 -> 5.8-6.1 TB/s at 8-16
     // workgroups per CU); in these kernels it is a null -- forward 0.436 / 0.441 vs 0.437 / 0.427 ms, backward 0.657 / 0.659 vs 0.637 /
     // 0.653 ms in a same-box A/B (profiles/r05d_contig_rows_and_dw_stream_ab.txt): they are not at the streaming ceiling the order moves.
-    const ActRange rg = act_range(rows, RPB);
+    const ActRange rg = act_range(0, rows, RPB);
     {
         const int64_t r = rg.base0 + slot;
         if (rg.base0 < rg.base1 && r < rows) row_load<IO, NV>(x + r * W + cb, lane, vn);
@@ -320,11 +321,15 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_bwd_kernel(const IO* _
                                                                      const float* __restrict__ mean_i,
                                                                      const float* __restrict__ rstd_i,
                                                                      const IO* __restrict__ dy, IO* __restrict__ dx,
-                                                                     float* __restrict__ part, int64_t rows, ActDrop drop,
+                                                                     float* __restrict__ part, int64_t rows_all, ActDrop drop,
                                                                      char* __restrict__ img = nullptr,
                                                                      const float* __restrict__ img_sc = nullptr,
-                                                                     const float* __restrict__ row_mul = nullptr) {
+                                                                     const float* __restrict__ row_mul = nullptr,
+                                                                     const int64_t* __restrict__ cu = nullptr) {
+    // cu (grouped backward, round 5): rows [cu[g], cu[g + 1]) of group g = blockIdx.y are this workgroup's; its partial column sums
+    // (slot blockIdx.y * gridDim.x + blockIdx.x) then belong to ONE group: the dbias third of them is the gradient of that group's bias row
     constexpr int W = NV * 256 * WPR, RPB = 4 / WPR;
+    const int64_t row_lo = cu ? cu[blockIdx.y] : 0, rows = cu ? cu[blockIdx.y + 1] : rows_all;
     __shared__ float red[1][4][2];
     __shared__ float csum[WPR < 4 ? 3 * W : 1];  // WPR < 4: several waves own the same columns -> merged through LDS
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, slot = wv / WPR, seg = wv % WPR;
@@ -341,7 +346,7 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_bwd_kernel(const IO* _
         sx[i] = sg[i];
     }
     f32x4 xn[NV], gn[NV];   // next row, prefetched (see the forward kernel)
-    const ActRange rg = act_range(rows, RPB);   // one contiguous range of rows per workgroup (see the forward kernel)
+    const ActRange rg = act_range(row_lo, rows, RPB);   // (row order: see the forward kernel)
     {
         const int64_t r = rg.base0 + slot;
         if (rg.base0 < rg.base1 && r < rows) {
@@ -416,7 +421,7 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_bwd_kernel(const IO* _
             }
         }
     }
-    float* __restrict__ prow = part + (int64_t)blockIdx.x * 3 * W;  // [block][dgamma W | dbeta W | dbias W]
+    float* __restrict__ prow = part + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 3 * W;  // [block][dgamma W | dbeta W | dbias W]
     if (WPR == 4) {  // every wave owns its own column segment
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -707,11 +712,29 @@ extern "C" int mdl_ln_gelu_drop_fwd_split(const float* x, const float* bias, con
  * dx_scale[2] = {scale, bound} from the rigorous bound rstd_max 1.13 max|gamma| max|dy| (2 + sqrt(W)) / (1-p).  dy_absmax: device
  * float holding max |dy| (e.g. from the epilogue of the kernel that produced dy), or NULL: computed here by one pass over dy.
  * ws: mdl_ln_gelu_drop_bwd_ws_bytes(rows, W) + 64 bytes. */
-extern "C" int mdl_ln_gelu_drop_bwd_split(const float* x, const float* bias, const float* gamma, const float* beta, const float* mean,
-                                          const float* rstd, const float* dy, const float* dy_absmax, void* dx_img, float* dx_scale,
-                                          float* dgamma, float* dbeta, float* dbias, int64_t rows, int W, float p_drop, uint64_t seed,
-                                          const uint8_t* keep, const float* row_mul, const float* rstd_max, void* ws, void* stream) {
+// gradient of the group bias rows: dgb[g][c] = sum over the nbx partial slots of group g of their dbias third
+__global__ __launch_bounds__(256) void ln_group_bias_kernel(const float* __restrict__ part, float* __restrict__ dgb, int nbx, int W) {
+    const int g = blockIdx.x;
+    for (int c = threadIdx.x; c < W; c += 256) {
+        float v = 0.f;
+        for (int b = 0; b < nbx; ++b) v += part[((int64_t)g * nbx + b) * 3 * W + 2 * W + c];
+        dgb[(int64_t)g * W + c] = v;
+    }
+}
+static inline int ln_group_nbx(int64_t rows, int W, int G) {   // workgroups per group: G * nbx <= 2048 partial slots
+    int nbx = 2048 / (G > 0 ? G : 1);
+    const int64_t per = (rows / (G > 0 ? G : 1) + act_rpb(W) - 1) / act_rpb(W);   // no more than an average group has row blocks
+    if (nbx > per) nbx = (int)per;
+    return nbx < 1 ? 1 : nbx;
+}
+
+static int ln_bwd_split_impl(const float* x, const float* bias, const float* gamma, const float* beta, const float* mean,
+                             const float* rstd, const float* dy, const float* dy_absmax, void* dx_img, float* dx_scale,
+                             float* dgamma, float* dbeta, float* dbias, int64_t rows, int W, float p_drop, uint64_t seed,
+                             const uint8_t* keep, const float* row_mul, const float* rstd_max, void* ws, void* stream,
+                             const int64_t* cu_groups, int G, float* dgroup_bias) {
     if (!x || !gamma || !beta || !mean || !rstd || !dy || !dx_img || !dx_scale || !dgamma || !dbeta || !ws || rows < 0) return MDL_E_ARG;
+    if (cu_groups && (G < 1 || G > 2048 || !dgroup_bias)) return MDL_E_ARG;
     if (!(p_drop >= 0.f && p_drop < 1.f)) return MDL_E_ARG;
     if (!act_width_ok(W) || W > 4096) return MDL_E_UNSUPPORTED;
     if (!host_aligned16(x) || !host_aligned16(dy) || !host_aligned16(dx_img) || !host_aligned16(gamma) || !host_aligned16(beta) ||
@@ -725,8 +748,16 @@ extern "C" int mdl_ln_gelu_drop_bwd_split(const float* x, const float* bias, con
         if (b2 > 2048) b2 = 2048;
         nb = (int)b2;
     }
+    int slots = act_blocks(rows, W);
+    dim3 grid(nb > 0 ? nb : 1);
+    if (cu_groups) {   // nbx workgroups per group, one partial slot each: [G][nbx][3 W]
+        const int nbx = ln_group_nbx(rows, W, G);
+        grid = dim3(nbx, G);
+        nb = nbx * G;
+        slots = slots > nb ? slots : nb;
+    }
     float* part = (float*)ws;
-    float* aux = (float*)((char*)ws + (((int64_t)act_blocks(rows, W) * 3 * W * 4 + 15) & ~(int64_t)15));   // [0] max rstd, [1] max |dy|
+    float* aux = (float*)((char*)ws + (((int64_t)slots * 3 * W * 4 + 15) & ~(int64_t)15));   // [0] max rstd, [1] max |dy|
     hipError_t e = hipMemsetAsync((char*)dx_img + rows * (int64_t)W * 4, 0, (size_t)32 * W * 4, s);
     if (e != hipSuccess) return (int)e;
     int rc = MDL_OK;
@@ -763,18 +794,53 @@ extern "C" int mdl_ln_gelu_drop_bwd_split(const float* x, const float* bias, con
         MDL_LAUNCH_CHECK();
     }
     if (W == 2048 && nb > 0) {
-        hipLaunchKernelGGL((ln_gelu_drop_bwd_kernel<4, 2, float, true>), dim3(nb), dim3(ACT_BLOCK), 0, s, x, bias, gamma, beta, mean, rstd, dy,
-                           (float*)nullptr, part, rows, d, (char*)dx_img, (const float*)dx_scale, row_mul);
+        hipLaunchKernelGGL((ln_gelu_drop_bwd_kernel<4, 2, float, true>), grid, dim3(ACT_BLOCK), 0, s, x, bias, gamma, beta, mean, rstd, dy,
+                           (float*)nullptr, part, rows, d, (char*)dx_img, (const float*)dx_scale, row_mul, cu_groups);
         MDL_LAUNCH_CHECK();
     } else
     MDL_DISPATCH_W(W, {
         if (nb > 0) {
-            hipLaunchKernelGGL((ln_gelu_drop_bwd_kernel<NV, WPR, float, true>), dim3(nb), dim3(ACT_BLOCK), 0, s, x, bias, gamma, beta, mean,
-                               rstd, dy, (float*)nullptr, part, rows, d, (char*)dx_img, (const float*)dx_scale, row_mul);
+            hipLaunchKernelGGL((ln_gelu_drop_bwd_kernel<NV, WPR, float, true>), grid, dim3(ACT_BLOCK), 0, s, x, bias, gamma, beta, mean,
+                               rstd, dy, (float*)nullptr, part, rows, d, (char*)dx_img, (const float*)dx_scale, row_mul, cu_groups);
             MDL_LAUNCH_CHECK();
         }
     });
     hipLaunchKernelGGL(ln_reduce_kernel, dim3((3 * W + 31) / 32), dim3(256), 0, s, (const float*)part, dgamma, dbeta, dbias, nb, W);
     MDL_LAUNCH_CHECK();
+    if (cu_groups) {
+        hipLaunchKernelGGL(ln_group_bias_kernel, dim3(G), dim3(256), 0, s, (const float*)part, dgroup_bias, nb / G, W);
+        MDL_LAUNCH_CHECK();
+    }
     return MDL_OK;
+}
+
+extern "C" int mdl_ln_gelu_drop_bwd_split(const float* x, const float* bias, const float* gamma, const float* beta, const float* mean,
+                                          const float* rstd, const float* dy, const float* dy_absmax, void* dx_img, float* dx_scale,
+                                          float* dgamma, float* dbeta, float* dbias, int64_t rows, int W, float p_drop, uint64_t seed,
+                                          const uint8_t* keep, const float* row_mul, const float* rstd_max, void* ws, void* stream) {
+    return ln_bwd_split_impl(x, bias, gamma, beta, mean, rstd, dy, dy_absmax, dx_img, dx_scale, dgamma, dbeta, dbias, rows, W, p_drop, seed, keep,
+                             row_mul, rstd_max, ws, stream, nullptr, 0, nullptr);
+}
+
+/* The same for a pre-LN tensor that carries a per-GROUP bias row (x[r] = product[r] + group_bias[g(r)], rows of a group contiguous:
+ * cu_groups int64 [G + 1] on the device, G <= 2048): additionally dgroup_bias [G][W] = sum over the rows of each group of dx -- the
+ * gradient of the group rows (MADELEINE's stain-encoding columns folded out of the first Linear: Model.py:125-132, :351).  The launch
+ * is organised by group (rows of one group per workgroup), so the per-group sums are the existing per-workgroup dbias partials, merged
+ * in a fixed order.  ws: mdl_ln_gelu_drop_bwd_groups_ws_bytes(rows, W, G). */
+extern "C" int64_t mdl_ln_gelu_drop_bwd_groups_ws_bytes(int64_t rows, int W, int G) {
+    if (rows < 0 || G < 1 || G > 2048) return MDL_E_ARG;
+    if (!act_width_ok(W)) return MDL_E_UNSUPPORTED;
+    int64_t slots = act_blocks(rows, W);
+    const int64_t nb = (int64_t)ln_group_nbx(rows, W, G) * G;
+    if (nb > slots) slots = nb;
+    return slots * 3 * W * 4 + 128;
+}
+extern "C" int mdl_ln_gelu_drop_bwd_split_groups(const float* x, const float* bias, const float* gamma, const float* beta, const float* mean,
+                                                 const float* rstd, const float* dy, const float* dy_absmax, void* dx_img, float* dx_scale,
+                                                 float* dgamma, float* dbeta, float* dbias, int64_t rows, int W, float p_drop, uint64_t seed,
+                                                 const uint8_t* keep, const float* row_mul, const float* rstd_max, const int64_t* cu_groups,
+                                                 int G, float* dgroup_bias, void* ws, void* stream) {
+    if (!cu_groups) return MDL_E_ARG;
+    return ln_bwd_split_impl(x, bias, gamma, beta, mean, rstd, dy, dy_absmax, dx_img, dx_scale, dgamma, dbeta, dbias, rows, W, p_drop, seed, keep,
+                             row_mul, rstd_max, ws, stream, cu_groups, G, dgroup_bias);
 }

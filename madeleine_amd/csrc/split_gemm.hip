@@ -221,7 +221,10 @@ __global__ __launch_bounds__(SP_THREADS) void sp_nt_kernel(const char* __restric
                                                     float* __restrict__ C, int64_t ldc, int64_t M, int N, int nblk, int n_tiles,
                                                     const float* __restrict__ bias, int accumulate, float* __restrict__ absmax_out,
                                                     const float* __restrict__ row_gate, const float* __restrict__ a_row_mul,
-                                                    const float* __restrict__ b_col_mul) {
+                                                    const float* __restrict__ b_col_mul, const float* __restrict__ group_bias = nullptr,
+                                                    const int32_t* __restrict__ row_group = nullptr) {
+    // group_bias [G][N] + row_group [M] (round 5): C[m][:] += group_bias[row_group[m]][:] -- a bias row per GROUP of rows (MADELEINE's
+    // stain-encoding columns of the first Linear as a per-bag bias: [x | e_g] W^T = x Wx^T + e_g We^T, Model.py:132, :351)
     __shared__ SmemSP sm;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -263,6 +266,7 @@ __global__ __launch_bounds__(SP_THREADS) void sp_nt_kernel(const char* __restric
         f32x4 r = v * (a_row_mul ? inv * a_row_mul[m0 + row] : inv);   // row-scaled A image: its row factor (a power of two) comes back here
         if (b_col_mul) r *= *reinterpret_cast<const f32x4*>(b_col_mul + n0 + col);   // row-scaled B image (a weight: one factor per output column)
         if (bias) r += *reinterpret_cast<const f32x4*>(bias + n0 + col);
+        if (group_bias) r += *reinterpret_cast<const f32x4*>(group_bias + (int64_t)row_group[m0 + row] * N + n0 + col);
         f32x4* o = reinterpret_cast<f32x4*>(cb + (int64_t)row * ldc4 + (uint32_t)col * 4u);
         if (accumulate) r += *o;
         *o = r;
@@ -507,16 +511,19 @@ extern "C" int mdl_split_tile_absmax(const float* X, int64_t ldx, int64_t rows, 
     return MDL_OK;
 }
 
-extern "C" int mdl_split_gemm_nt(const void* A, int64_t a_rsb, const float* a_scale, const void* B, int64_t b_rsb, const float* b_scale,
-                                 float* C, int64_t ldc, int64_t M, int N, int K, const float* bias, int accumulate, float* absmax_out,
-                                 const float* row_gate, const float* a_row_mul, const float* b_col_mul, int terms, void* stream) {
+static int sp_gemm_nt_impl(const void* A, int64_t a_rsb, const float* a_scale, const void* B, int64_t b_rsb, const float* b_scale,
+                           float* C, int64_t ldc, int64_t M, int N, int K, const float* bias, int accumulate, float* absmax_out,
+                           const float* row_gate, const float* a_row_mul, const float* b_col_mul, int terms, void* stream,
+                           const float* group_bias, const int32_t* row_group) {
+    if ((group_bias == nullptr) != (row_group == nullptr)) return MDL_E_ARG;
+    if (group_bias && !host_aligned16(group_bias)) return MDL_E_ALIGN;
     if (terms != 2 && terms != 3) return MDL_E_ARG;
     if (row_gate && (!accumulate || bias)) return MDL_E_ARG;   // skipping a tile is only the identity when it would add zeros
     if (!A || !B || !C || !a_scale || !b_scale || M < 0 || N < 4 || (N & 3) || K < 32 || (K % 32) || ldc < N || (ldc & 3)) return MDL_E_ARG;
     if (a_rsb < (int64_t)K * 4 || b_rsb < (int64_t)K * 4 || (a_rsb & 15) || (b_rsb & 15)) return MDL_E_ARG;
     if (!host_aligned16(A) || !host_aligned16(B) || !host_aligned16(C) || !host_aligned16(bias)) return MDL_E_ALIGN;
     if (M == 0) return MDL_OK;
-    if (N <= SPT_N && !row_gate && M > SPM) {   // narrow output (the token_projector): the 512 x 128 tile
+    if (N <= SPT_N && !row_gate && !group_bias && M > SPM) {   // narrow output (the token_projector): the 512 x 128 tile
         const int64_t tt = (M + SPT_M - 1) / SPT_M;
         if (tt > 0x7fffffff || a_rsb * SPT_M > 0x7fffffff || b_rsb * SPT_N > 0x7fffffff) return MDL_E_UNSUPPORTED;
         hipLaunchKernelGGL(terms == 2 ? sp_nt_tall_kernel<2> : sp_nt_tall_kernel<3>, dim3((unsigned)tt), dim3(SP_THREADS), 0, (hipStream_t)stream,
@@ -529,9 +536,25 @@ extern "C" int mdl_split_gemm_nt(const void* A, int64_t a_rsb, const float* a_sc
     if (tiles > 0x7fffffff || a_rsb * SPM > 0x7fffffff || b_rsb * SPN > 0x7fffffff) return MDL_E_UNSUPPORTED;
     hipLaunchKernelGGL(terms == 2 ? sp_nt_kernel<2> : sp_nt_kernel<3>, dim3((unsigned)tiles), dim3(SP_THREADS), 0, (hipStream_t)stream,
                        (const char*)A, a_rsb, a_scale, (const char*)B, b_rsb, b_scale, C, ldc, M, N, K / 32, (int)tiles, bias, accumulate,
-                       absmax_out, row_gate, a_row_mul, b_col_mul);
+                       absmax_out, row_gate, a_row_mul, b_col_mul, group_bias, row_group);
     MDL_LAUNCH_CHECK();
     return MDL_OK;
+}
+extern "C" int mdl_split_gemm_nt(const void* A, int64_t a_rsb, const float* a_scale, const void* B, int64_t b_rsb, const float* b_scale,
+                                 float* C, int64_t ldc, int64_t M, int N, int K, const float* bias, int accumulate, float* absmax_out,
+                                 const float* row_gate, const float* a_row_mul, const float* b_col_mul, int terms, void* stream) {
+    return sp_gemm_nt_impl(A, a_rsb, a_scale, B, b_rsb, b_scale, C, ldc, M, N, K, bias, accumulate, absmax_out, row_gate, a_row_mul, b_col_mul,
+                           terms, stream, nullptr, nullptr);
+}
+/* mdl_split_gemm_nt with a bias row per GROUP of rows: C[m][:] += group_bias[row_group[m]][:] (group_bias [G][N] contiguous fp32,
+ * row_group int32 [M] with values in [0, G)). */
+extern "C" int mdl_split_gemm_nt_group_bias(const void* A, int64_t a_rsb, const float* a_scale, const void* B, int64_t b_rsb,
+                                            const float* b_scale, float* C, int64_t ldc, int64_t M, int N, int K, const float* bias,
+                                            const float* a_row_mul, const float* b_col_mul, const float* group_bias,
+                                            const int32_t* row_group, int terms, void* stream) {
+    if (!group_bias || !row_group) return MDL_E_ARG;
+    return sp_gemm_nt_impl(A, a_rsb, a_scale, B, b_rsb, b_scale, C, ldc, M, N, K, bias, 0, nullptr, nullptr, a_row_mul, b_col_mul, terms, stream,
+                           group_bias, row_group);
 }
 
 extern "C" int64_t mdl_split_gemm_tn_ws_bytes(int64_t T, int Mi, int N) {

@@ -497,6 +497,27 @@ def split_gemm_nt(A: SplitImage, B: SplitImage, bias=None, out=None, accumulate=
     return C
 
 
+def split_gemm_nt_group_bias(A: SplitImage, B: SplitImage, group_bias, row_group, bias=None, a_row_mul=None, name="split_nt"):
+    """split_gemm_nt with a bias row per GROUP of output rows: C[m] = A[m] B^T (+ bias) + group_bias[row_group[m]] (mdl_split_gemm_nt_group_bias;
+    group_bias [G, B.rows] fp32, row_group int32 [A.rows])."""
+    lib = _native.lib()
+    M, N, K = A.rows, B.rows, A.K
+    if B.K != K:
+        raise ValueError("split_gemm_nt_group_bias: contraction lengths differ")
+    _require(group_bias, "group_bias")
+    _require(row_group, "row_group", torch.int32)
+    if group_bias.dim() != 2 or group_bias.shape[1] != N or row_group.numel() != M:
+        raise ValueError("split_gemm_nt_group_bias: group_bias must be [G, %d] and row_group [%d]" % (N, M))
+    if a_row_mul is None:
+        a_row_mul = A.row_inv
+    C = torch.empty(M, N, device=A.data.device, dtype=torch.float32)
+    with _timed(name, ("flop", 2.0 * M * N * K)):
+        rc = lib.mdl_split_gemm_nt_group_bias(_ptr(A.data), K * 4, _ptr(A.scale), _ptr(B.data), K * 4, _ptr(B.scale), _ptr(C), C.stride(0), M, N, K,
+                                              _ptr(bias), _ptr(a_row_mul), _ptr(B.row_inv), _ptr(group_bias), _ptr(row_group), 3, _stream())
+    _native.check(rc, "mdl_split_gemm_nt_group_bias")
+    return C
+
+
 def split_gemm_tn(A: SplitImage, B: SplitImage, name="split_tn", b_chunk_max=None, terms=3):
     """out [B.K, A.K] = B^T A summed over the rows (tokens) of the two images; B must carry >= 32 zero pad rows.  b_chunk_max: the
     per-32-row maxima (split_tile_absmax(x, chunks=True)) of the tensor B is the image of -- its all-zero chunks are skipped."""
@@ -614,7 +635,10 @@ class PreAttnBlockFn(torch.autograd.Function):
     contractions read it -- no conversion pass anywhere (scales come from rigorous bounds, include/madeleine_amd.h)."""
 
     @staticmethod
-    def forward(ctx, x, x_scale, W, lin_bias, gamma, beta, eps, p_drop, seed, keep, want_fp32):
+    def forward(ctx, x, x_scale, W, lin_bias, gamma, beta, eps, p_drop, seed, keep, want_fp32, gbias=None, row_group=None, cu_groups=None):
+        # gbias [G, N] + row_group int32 [T] + cu_groups int64 [G + 1] (first block only, round 5): a bias row per GROUP of rows (= bag), rows of
+        # a group contiguous -- the stain-encoding columns of MADELEINE's first Linear folded out of the contraction:
+        # [x | e_g] W^T = x Wx^T + e_g We^T (Model.py:125-132, :351).  The concat [T, D + 32] never exists; the backward returns d(gbias).
         _require(x, "x")
         for t_, n_ in ((W, "weight"), (gamma, "gamma"), (beta, "beta")):
             _require(t_, n_)
@@ -633,7 +657,11 @@ class PreAttnBlockFn(torch.autograd.Function):
             xi = SplitImage(x, x_scale, T, K)
         else:
             xi, row_inv = split_image_rows(x)
-        y = split_gemm_nt(xi, weight_image(W), name="linear_fwd", a_row_mul=row_inv)   # pre-LN values (the Linear's bias is added by the LN kernel)
+        if gbias is not None:
+            _require(cu_groups, "cu_groups", torch.int64)
+            y = split_gemm_nt_group_bias(xi, weight_image(W), gbias.contiguous(), row_group, a_row_mul=row_inv, name="linear_fwd")
+        else:
+            y = split_gemm_nt(xi, weight_image(W), name="linear_fwd", a_row_mul=row_inv)   # pre-LN values (the Linear's bias is added by the LN kernel)
         img = torch.empty(T, N, device=dev, dtype=torch.float32)
         scale = torch.empty(2, device=dev, dtype=torch.float32)
         out = torch.empty(T, N, device=dev, dtype=torch.float32) if want_fp32 else None
@@ -653,6 +681,7 @@ class PreAttnBlockFn(torch.autograd.Function):
         ctx.save_for_backward(xi.data, xi.scale, W, y, gamma, beta, mean, rstd, lin_bias if lin_bias is not None else torch.empty(0),
                               row_inv if row_inv is not None else torch.empty(0), rstd_max if rstd_max is not None else torch.empty(0))
         ctx.cfg = (float(p_drop), int(seed), keep, lin_bias is not None, bool(want_fp32), T, K, N, x_scale is not None)
+        ctx.groups = None if gbias is None else (cu_groups, int(gbias.shape[0]))
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(scale)
         if want_fp32:
@@ -681,13 +710,25 @@ class PreAttnBlockFn(torch.autograd.Function):
         dxscale = torch.empty(2, device=dev, dtype=torch.float32)
         dg, db = torch.empty_like(gamma), torch.empty_like(beta)
         dbias = torch.empty_like(lin_bias) if has_bias else None
-        ws = _ws(lib.mdl_ln_gelu_drop_bwd_ws_bytes(T, N), dev)
         amax = _take_absmax(dy)
-        with _timed("ln_gelu_drop_bwd", ("byte", (3.0 if amax is not None else 4.0) * T * N * 4)):
-            rc = lib.mdl_ln_gelu_drop_bwd_split(_ptr(y), _ptr(lin_bias), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(dy), _ptr(amax),
-                                                _ptr(dximg), _ptr(dxscale), _ptr(dg), _ptr(db), _ptr(dbias), T, N, p_drop, seed, _ptr(keep),
-                                                _ptr(row_inv), _ptr(rstd_max), _ptr(ws), _stream())
-        _native.check(rc, "mdl_ln_gelu_drop_bwd_split")
+        d_gbias = None
+        if ctx.groups is not None:
+            cu_groups, G = ctx.groups
+            d_gbias = torch.empty(G, N, device=dev, dtype=torch.float32)
+            ws = _ws(lib.mdl_ln_gelu_drop_bwd_groups_ws_bytes(T, N, G), dev)
+            with _timed("ln_gelu_drop_bwd", ("byte", (3.0 if amax is not None else 4.0) * T * N * 4)):
+                rc = lib.mdl_ln_gelu_drop_bwd_split_groups(_ptr(y), _ptr(lin_bias), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(dy),
+                                                           _ptr(amax), _ptr(dximg), _ptr(dxscale), _ptr(dg), _ptr(db), _ptr(dbias), T, N, p_drop, seed,
+                                                           _ptr(keep), _ptr(row_inv), _ptr(rstd_max), _ptr(cu_groups), G, _ptr(d_gbias), _ptr(ws),
+                                                           _stream())
+            _native.check(rc, "mdl_ln_gelu_drop_bwd_split_groups")
+        else:
+            ws = _ws(lib.mdl_ln_gelu_drop_bwd_ws_bytes(T, N), dev)
+            with _timed("ln_gelu_drop_bwd", ("byte", (3.0 if amax is not None else 4.0) * T * N * 4)):
+                rc = lib.mdl_ln_gelu_drop_bwd_split(_ptr(y), _ptr(lin_bias), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(dy), _ptr(amax),
+                                                    _ptr(dximg), _ptr(dxscale), _ptr(dg), _ptr(db), _ptr(dbias), T, N, p_drop, seed, _ptr(keep),
+                                                    _ptr(row_inv), _ptr(rstd_max), _ptr(ws), _stream())
+            _native.check(rc, "mdl_ln_gelu_drop_bwd_split")
         dyi = SplitImage(dximg, dxscale, T, N)
         dx = None
         if ctx.needs_input_grad[0]:
@@ -710,12 +751,13 @@ class PreAttnBlockFn(torch.autograd.Function):
             if x_is_image:       # the consumer is the previous block's LayerNorm backward (this node's input was its image)
                 _put_absmax(dx, am)
         dW = split_gemm_tn(SplitImage(xdata, xscale, T, K), dyi, name="linear_bwd", terms=GRAD_TERMS)
-        return dx, None, dW, dbias, dg, db, None, None, None, None, None
+        return dx, None, dW, dbias, dg, db, None, None, None, None, None, d_gbias, None, None
 
 
-def preattn_block(x, x_scale, W, lin_bias, gamma, beta, eps=1e-5, p_drop=0.0, seed=0, keep=None, want_fp32=False):
+def preattn_block(x, x_scale, W, lin_bias, gamma, beta, eps=1e-5, p_drop=0.0, seed=0, keep=None, want_fp32=False, group_bias=None,
+                  row_group=None, cu_groups=None):
     return PreAttnBlockFn.apply(x, x_scale, W.contiguous(), None if lin_bias is None else lin_bias.contiguous(), gamma.contiguous(),
-                                beta.contiguous(), float(eps), float(p_drop), int(seed), keep, bool(want_fp32))
+                                beta.contiguous(), float(eps), float(p_drop), int(seed), keep, bool(want_fp32), group_bias, row_group, cu_groups)
 
 
 def preattn_split_supported(x2d, K) -> bool:

@@ -136,7 +136,7 @@ class ABMILEmbedder(nn.Module):
                 seed = MF.new_dropout_seed()
         return p, seed, keep
 
-    def _block_split(self, x, x_scale, blk, perm=None, want_fp32=False, weight=None):
+    def _block_split(self, x, x_scale, blk, perm=None, want_fp32=False, weight=None, group_bias=None):
         """Linear + LayerNorm + GELU + Dropout of block `blk` as one node on the split engine (functional.PreAttnBlockFn)."""
         lin, ln = self.pre_attn[4 * blk], self.pre_attn[4 * blk + 1]
         W, lb, g, b = (lin.weight if weight is None else weight), lin.bias, ln.weight, ln.bias
@@ -145,7 +145,8 @@ class ABMILEmbedder(nn.Module):
         p, seed, keep = self._drop_cfg(blk, perm)
         if keep is not None:
             keep = keep.reshape(-1, keep.shape[-1])
-        return MF.preattn_block(x, x_scale, W, lb, g, b, ln.eps, p, seed, keep, want_fp32)
+        gb, rg, cu = group_bias if group_bias is not None else (None, None, None)
+        return MF.preattn_block(x, x_scale, W, lb, g, b, ln.eps, p, seed, keep, want_fp32, gb, rg, cu)
 
     def _act(self, x, ln, blk, perm=None, lin_bias=None):
         """(+ bias of the preceding Linear) -> LayerNorm -> GELU -> Dropout(.1) of block `blk` in ONE fused HIP pass each
@@ -156,7 +157,7 @@ class ABMILEmbedder(nn.Module):
         p, seed, keep = self._drop_cfg(blk, perm)
         return MF.ln_gelu_drop(x if x.dtype == torch.bfloat16 else x.float(), g, b, ln.eps, p, seed, keep, lin_bias)
 
-    def embed_tokens_headmajor(self, bags: torch.Tensor, return_image: bool = False, want_fp32: bool = True):
+    def embed_tokens_headmajor(self, bags: torch.Tensor, return_image: bool = False, want_fp32: bool = True, stain=None):
         """pre_attn(bags) with the 2048 output channels in head-major order: [BM, N, H*512]  (with return_image: (E, image of E or
         None) -- in the split GEMM mode the last block's kernel writes the split image the gate contractions read).  want_fp32 = False
         (with return_image, split GEMM mode only): no fp32 copy of E is written -- the returned "E" IS the image tensor (an opaque
@@ -167,6 +168,27 @@ class ABMILEmbedder(nn.Module):
         the bf16 mode of the HIP kernels; LayerNorm statistics, GELU and every reduction stay fp32 inside the kernels."""
         pa = self.pre_attn
         perm = self._perm
+        # stain = (e [G, 32], row_group int32 [T], cu_groups int64 [G + 1]): MADELEINE's stain encoding concatenates ONE 32-vector per bag to
+        # every patch feature in front of the first Linear (Model.py:125-132, :351).  [x | e_g] W^T = x Wx^T + e_g We^T: on the split engine the
+        # concat never exists -- the bag's row e_g We^T ([G, 512], a small HIP Linear with autograd) enters the first product as a per-group
+        # bias (mdl_split_gemm_nt_group_bias) and its gradient comes back from the grouped LayerNorm backward.  The other engines concatenate.
+        group_bias = None
+        if stain is not None:
+            e_rows, row_group, cu_groups = stain
+            d_feat = bags.shape[-1]
+            x_flat = bags.reshape(-1, d_feat)
+            if (not bf16_mode()) and MF.preattn_split_supported(x_flat, d_feat) and pa[0].weight.shape[0] % 32 == 0 \
+                    and e_rows.shape[1] % 4 == 0 and e_rows.shape[0] <= 2048:
+                Wfull = pa[0].weight
+                img, sc, _ = self._block_split(x_flat.float().contiguous(), None, 0, weight=Wfull[:, :d_feat],
+                                               group_bias=(MF.linear(e_rows.float(), Wfull[:, d_feat:].contiguous()), row_group, cu_groups))
+                img, sc, _ = self._block_split(img, sc, 1)
+                keep_fp32 = want_fp32 or not return_image
+                img, sc, E = self._block_split(img, sc, 2, perm, want_fp32=keep_fp32)
+                E = (E if keep_fp32 else img).view(*bags.shape[:-1], img.shape[-1])
+                return (E, (img, sc)) if return_image else E
+            enc = e_rows.index_select(0, row_group.long()).view(*bags.shape[:-1], e_rows.shape[1])
+            bags = torch.cat([bags, enc.to(bags.dtype)], dim=-1)
         # Any patch_embedding_dim (Model.py:351 is a plain nn.Linear): the kernels contract over 32-column blocks, so an input width that
         # is not a multiple of 32 is zero-padded -- features and the columns of the first weight alike, which leaves every product
         # unchanged (exact) and costs one padded copy of the bags per forward; autograd slices the weight gradient back.  The usual
@@ -262,7 +284,7 @@ class ABMILEmbedder(nn.Module):
         lead = pooled_hm.shape[:-1]
         return pooled_hm.view(*lead, self.n_heads, -1).transpose(-1, -2).contiguous()  # [...,512,H]
 
-    def forward_headmajor(self, bags, n_views=1, tok_proj=None, need_tokens=True):
+    def forward_headmajor(self, bags, n_views=1, tok_proj=None, need_tokens=True, stain=None):
         """Fast path used by MADELEINE: returns (pooled_hm [BM,(V,)H*512], E_hm, raw scores [BM,N,H]) and, with tok_proj = (W, bias)
         of a Linear over the head-major token embeddings (MADELEINE's token_projector), its output [BM,N,P] as a fourth result.
         need_tokens = False: the caller does not read E_hm (it is returned as None when the split GEMM mode then keeps E as an image
@@ -273,7 +295,7 @@ class ABMILEmbedder(nn.Module):
         fused = act == 'softmax' and n_views == 1
         tok_on_image = tok_proj is None or MF.split_linear_supported(bags.numel() // bags.shape[-1], tok_proj[0].shape[0],
                                                                      tok_proj[0].shape[1])
-        E, e_img = self.embed_tokens_headmajor(bags, return_image=True, want_fp32=need_tokens or not fused or not tok_on_image)
+        E, e_img = self.embed_tokens_headmajor(bags, return_image=True, want_fp32=need_tokens or not fused or not tok_on_image, stain=stain)
         if self.image_only(E, e_img):
             out = self.pool_headmajor(E, tok_proj=tok_proj, e_img=e_img)
             return (out[0], None, out[1]) + tuple(out[2:])
@@ -370,10 +392,13 @@ class MADELEINE(nn.Module):
         with torch.autocast(device_type="cuda", enabled=False):
             return MF.linear(E_hm, self.wsi_embedders.permuted(self.token_projector.weight, 1), self.token_projector.bias)
 
-    def _cat_stain(self, feats, idx):
-        """feats [R,N,D], idx LongTensor [R] -> cat([feats, embedding[idx] broadcast over N])."""
-        enc = self.embedding(MF.h2d(idx, feats.device)).unsqueeze(1).expand(-1, feats.shape[1], -1)
-        return torch.cat([feats, enc.to(feats.dtype)], dim=-1)
+    def _stain_groups(self, idx, n_bags, n_tokens, device):
+        """(embedding rows [n_bags, 32], row_group int32 [n_bags * n_tokens], cu_groups int64 [n_bags + 1]) for dense bags of n_tokens rows:
+        what ABMILEmbedder.embed_tokens_headmajor(stain=...) folds into the first Linear instead of a concatenated copy of the bags."""
+        e_rows = self.embedding(MF.h2d(idx, device))
+        row_group = torch.arange(n_bags * n_tokens, device=device, dtype=torch.int32).div_(n_tokens, rounding_mode="floor")
+        cu = torch.arange(n_bags + 1, device=device, dtype=torch.int64) * n_tokens
+        return e_rows, row_group, cu
 
     @staticmethod
     def _absent_stain_plan(modality_labels, input_key_of_row):
@@ -457,21 +482,24 @@ class MADELEINE(nn.Module):
         cu = torch.zeros(len(flat) + 1, dtype=torch.int64)
         cu[1:] = torch.cumsum(torch.tensor(lens, dtype=torch.int64), 0)
         x = torch.cat([f.to(device) for f in flat], dim=0)                     # packed [T, D]
+        stain = None
         if self.stain_encoding:
             row_stain = torch.arange(bs * n_mod) // bs                          # the train-branch quirk
-            # one embedding row per BAG, broadcast to its tokens by a gather: an embedding lookup per token makes the backward sort
-            # 1.4 M indices per config-5 step (9 ms); the gather's backward is one index_add over [T, 32]
-            bag_of_tok = MF.h2d(torch.repeat_interleave(torch.arange(bs * n_mod), torch.tensor(lens)), device)
-            x = torch.cat([x, self.embedding(MF.h2d(row_stain, device)).index_select(0, bag_of_tok).to(x.dtype)], dim=-1)
+            # one embedding row per BAG; the bag of every packed token as an int32 map (folded into the first Linear on the split engine,
+            # gathered + concatenated by the other engines: ABMILEmbedder.embed_tokens_headmajor)
+            bag_of_tok = MF.h2d(torch.repeat_interleave(torch.arange(bs * n_mod, dtype=torch.int32), torch.tensor(lens)), device)
+            stain = (self.embedding(MF.h2d(row_stain, device)), bag_of_tok, None)
         emb = self.wsi_embedders
         cu_d = MF.h2d(cu, device)
+        if stain is not None:
+            stain = (stain[0], stain[1], cu_d)
         head = MF.h2d((cu[:-1].unsqueeze(1) + torch.arange(n_loss_tokens).unsqueeze(0)).reshape(-1), device)
         tp = (emb.permuted(self.token_projector.weight, 1), self.token_projector.bias)
         # Split GEMM mode: the token projection is part of the pooling node (every token, on the image of E) and the head tokens are
         # gathered from ITS output -- gathering rows of E instead makes autograd fill a zero [T, 2048] tensor and add it to the node's dE
         # (3 x 11 GB of traffic per config-5 step), and E need not exist in fp32 at all.
         fuse_tok = (not bf16_mode()) and MF.split_linear_supported(x.shape[0], tp[0].shape[0], tp[0].shape[1])
-        E, e_img = emb.embed_tokens_headmajor(x, return_image=True, want_fp32=not fuse_tok)   # [T, H*512]
+        E, e_img = emb.embed_tokens_headmajor(x, return_image=True, want_fp32=not fuse_tok, stain=stain)   # [T, H*512]
         if fuse_tok and e_img is not None:
             pooled, _, tok_all = emb.pool_headmajor_ragged(E, cu_d, max(lens), e_img=e_img, tok_proj=tp)
             tok = tok_all.index_select(0, head).view(bs, n_mod, n_loss_tokens, -1)          # [B,M,n,128]
@@ -510,10 +538,9 @@ class MADELEINE(nn.Module):
                 if expand is not None:   # encode every present bag + ONE all-zero bag per distinct input among the absent ones
                     x = x.index_select(0, MF.h2d(compact, device))
                     stain_of_row = stain_of_row[compact]
-            if self.stain_encoding:
-                x = self._cat_stain(x, stain_of_row)
+            stain = self._stain_groups(stain_of_row, x.shape[0], n_tokens, device) if self.stain_encoding else None
             # token_projector (Model.py:140) inside the pooling node: the two gradients of E are accumulated in the gate dX epilogue
-            pooled, _, _, tok = emb.forward_headmajor(x, n_views=n_views, need_tokens=False, tok_proj=(
+            pooled, _, _, tok = emb.forward_headmajor(x, n_views=n_views, need_tokens=False, stain=stain, tok_proj=(
                 emb.permuted(self.token_projector.weight, 1), self.token_projector.bias))   # tok [rows,N,128]
             slide = self._project_slide(pooled.view(x.shape[0], -1, pooled.shape[-1]))  # [rows,V,512]
             if expand is not None:       # absent rows take the outputs of their all-zero representative
@@ -540,10 +567,11 @@ class MADELEINE(nn.Module):
             for stain_idx in range(n_mod):
                 stain_name = self.modalities[custom_stain_idx] if custom_stain_idx else self.modalities[stain_idx]
                 cur = all_wsi_feats[:, stain_idx]
+                stain = None
                 if self.stain_encoding:
                     key = custom_stain_idx if custom_stain_idx else stain_idx
-                    cur = self._cat_stain(cur, torch.full((bs,), key, dtype=torch.long))
-                pooled, _, _ = emb.forward_headmajor(cur, need_tokens=False)
+                    stain = self._stain_groups(torch.full((bs,), key, dtype=torch.long), bs, n_tokens, device)
+                pooled, _, _ = emb.forward_headmajor(cur, need_tokens=False, stain=stain)
                 # the reference's .view(bs*n_mod, ...) / .view(bs, n_mod, d) only type-checks for n_mod == 1
                 all_embeddings[stain_name] = self._project_slide(pooled).view(bs, n_mod, -1)
             return all_embeddings
