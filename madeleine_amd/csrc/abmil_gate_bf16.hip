@@ -167,24 +167,29 @@ __global__ __launch_bounds__(256, 2) void gate_fwd_bf16_kernel(const bf16_t* __r
 // j0 + wn * 32 + l, ct = 1 -> the b column of the same j, so a wave holds za and zb of the same (token, j) in acc[rt][0] / acc[rt][1]
 // (the layout of abmil_gate_split.hip).  Epilogue as above: 4 passes of 32 rows x (32 a | 32 b) through the wave's LDS tile.
 // ------------------------------------------------------------------------------------------------
-template <int DM, bool SAVE>
+// Round 5: PERSIST = one workgroup runs the GATE_JT column tiles of its (token tile, head) back to back (grid / GATE_JT workgroups): with
+// one workgroup per CU (128 KiB of stages) nothing overlaps a tile's prologue -- workgroup launch, first chunk's memory latency --
+// with the previous tile, and K = 512 is only 8 chunks.  The persistent loop requests the NEXT tile's first chunk into stage 0 before
+// the epilogue of the current one; the epilogue stages through stage 1's memory (waves 0-3: A[1], waves 4-7: B[1]) and the row sums
+// have their own 4 KiB.  The E tile is re-read by the same CU four times in a row (L2 hits).
+template <int DM, bool SAVE, bool PERSIST>
 __global__ __launch_bounds__(512) void gate_fwd256_bf16_kernel(const bf16_t* __restrict__ E, int64_t ldE, const bf16_t* __restrict__ WK,
                                                                const float* __restrict__ ba, const float* __restrict__ bb,
                                                                const float* __restrict__ wc, float* __restrict__ part,
                                                                bf16_t* __restrict__ act_a, bf16_t* __restrict__ act_b, int64_t T, int H,
                                                                int n_ttiles, DropCfg drop) {
     __shared__ SmemQ sm;
+    __shared__ float sred_s[4 * QM];   // [4 (wn)][256 rows]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const XcdHead xh = xcd_head(blockIdx.x, H);
-    const int jt = xh.li % GATE_JT, c = xh.c, tt = (xh.li / GATE_JT) * xh.nshare + xh.share;
+    const int c = xh.c;
+    const int tt = (PERSIST ? xh.li : xh.li / GATE_JT) * xh.nshare + xh.share;
     if (tt >= n_ttiles) return;  // block-uniform
     const int64_t t0 = (int64_t)tt * QM;
-    const int j0 = jt * 128;
 
     const char* baseA = reinterpret_cast<const char*>(E + t0 * ldE + (int64_t)c * HID);
-    const char* baseB = reinterpret_cast<const char*>(WK + (int64_t)c * 1024 * HID);
     uint32_t voA[4], voB[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -193,23 +198,38 @@ __global__ __launch_bounds__(512) void gate_fwd256_bf16_kernel(const bf16_t* __r
         int64_t ra = row;
         if (t0 + ra > T - 1) ra = T - 1 - t0;
         voA[i] = (uint32_t)(ra * ldE * 2 + ch * 16);
-        const int wrow = ((row >> 5) & 1) * HID + j0 + (row >> 6) * 32 + (row & 31);
+        const int wrow = ((row >> 5) & 1) * HID + (row >> 6) * 32 + (row & 31);   // relative to the tile's first gate column j0
         voB[i] = (uint32_t)(wrow * (HID * 2) + ch * 16);
     }
-    f32x16 acc[4][2];
-    nt256_mainloop(sm, acc, HID / QK, wm, wn, lane, [&](int st, int64_t f, int piece) {
+    const int l32 = lane & 31;
+    float* tile = reinterpret_cast<float*>(wave < 4 ? &sm.A[1][wave * 8192] : &sm.B[1][(wave - 4) * 8192]);
+    float* sred = sred_s + wn * QM + wm * 128;
+    const int g4 = lane & 3, r16 = lane >> 2;
+    const float inv2 = drop.inv * drop.inv;   // both dropout factors folded into wc: one select per (a, b) pair
+
+    const int jt_lo = PERSIST ? 0 : xh.li % GATE_JT, jt_hi = PERSIST ? GATE_JT : jt_lo + 1;
+    for (int jt = jt_lo; jt < jt_hi; ++jt) {
+    const int j0 = jt * 128;
+    const char* baseB = reinterpret_cast<const char*>(WK + ((int64_t)c * 1024 + j0) * HID);
+    auto dma = [&](int st, int64_t f, int piece) {
         const int i = piece & 3;
         if (piece < 4) glds16_s(voA[i], baseA + f * (QK * 2), lds_addr_of(&sm.A[st][(wave * 4 + i) * 1024]));
         else glds16_s(voB[i], baseB + f * (QK * 2), lds_addr_of(&sm.B[st][(wave * 4 + i) * 1024]));
-    });
+    };
+    f32x16 acc[4][2];
+    nt256_mainloop(sm, acc, HID / QK, wm, wn, lane, dma, PERSIST && jt > jt_lo);
+    if (PERSIST && jt + 1 < jt_hi) {   // the next tile's first chunk travels during this epilogue (stage 0 is free, the epilogue is in stage 1)
+        const char* baseBn = baseB + (int64_t)128 * HID * 2;
+#pragma unroll
+        for (int piece = 0; piece < 8; ++piece) {
+            const int i = piece & 3;
+            if (piece < 4) glds16_s(voA[i], baseA, lds_addr_of(&sm.A[0][(wave * 4 + i) * 1024]));
+            else glds16_s(voB[i], baseBn, lds_addr_of(&sm.B[0][(wave * 4 + i) * 1024]));
+        }
+    }
 
-    const int l32 = lane & 31;
-    float* tile = reinterpret_cast<float*>(&sm) + wave * (32 * 64);
-    float* sred = reinterpret_cast<float*>(&sm) + 8 * (32 * 64) + wn * QM + wm * 128;   // [4 (wn)][256 rows]
-    const int g4 = lane & 3, r16 = lane >> 2;
     const int jc = j0 + wn * 32;
     const float ta = 2.f * MDL_LOG2E * ba[c * HID + jc + l32], tb = -MDL_LOG2E * bb[c * HID + jc + l32];   // (folded, see common.hpp)
-    const float inv2 = drop.inv * drop.inv;   // both dropout factors folded into wc: one select per (a, b) pair
     const f32x4 wlo = *reinterpret_cast<const f32x4*>(wc + c * HID + jc + g4 * 8) * inv2;
     const f32x4 whi = *reinterpret_cast<const f32x4*>(wc + c * HID + jc + g4 * 8 + 4) * inv2;
 #pragma unroll
@@ -253,9 +273,10 @@ __global__ __launch_bounds__(512) void gate_fwd256_bf16_kernel(const bf16_t* __r
     __syncthreads();
     if (tid < QM) {
         const int64_t t = t0 + tid;
-        const float* sr = reinterpret_cast<const float*>(&sm) + 8 * (32 * 64);
+        const float* sr = sred_s;
         if (t < T) part[(t * H + c) * GATE_JT + jt] = ((sr[tid] + sr[QM + tid]) + sr[2 * QM + tid]) + sr[3 * QM + tid];
     }
+    }   // jt (the next tile's main loop has barriers between these reads of sred_s and its epilogue's writes)
 }
 
 // ================================================================================================
@@ -563,10 +584,17 @@ extern "C" int mdl_abmil_gate_fwd_bf16(const uint16_t* E, int64_t ldE, const flo
     hipLaunchKernelGGL((gate_fwd_bf16_kernel<DM, SAVE>), dim3((unsigned)grid), dim3(256), 0, s, (const bf16_t*)E, ldE, (const bf16_t*)WK, \
                        ba, bb, wc, part, (bf16_t*)act_a, (bf16_t*)act_b, T, H, (int)n_tt, d)
     const int64_t n_tt256 = (T + QM - 1) / QM;
-    const int64_t grid256 = xcd_head_grid(n_tt256, GATE_JT, H);
+    static const bool persist = !getenv("MADELEINE_BF16_GATE_NO_PERSIST");   // (A/B switch: one workgroup per column tile, as in round 4)
+    const int64_t grid256 = xcd_head_grid(n_tt256, persist ? 1 : GATE_JT, H);
 #define MDL_GATE_FWD256(DM, SAVE)                                                                                                  \
-    hipLaunchKernelGGL((gate_fwd256_bf16_kernel<DM, SAVE>), dim3((unsigned)grid256), dim3(512), 0, s, (const bf16_t*)E, ldE,       \
-                       (const bf16_t*)WK, ba, bb, wc, part, (bf16_t*)act_a, (bf16_t*)act_b, T, H, (int)n_tt256, d)
+    do {                                                                                                                           \
+        if (persist)                                                                                                               \
+            hipLaunchKernelGGL((gate_fwd256_bf16_kernel<DM, SAVE, true>), dim3((unsigned)grid256), dim3(512), 0, s, (const bf16_t*)E, ldE, \
+                               (const bf16_t*)WK, ba, bb, wc, part, (bf16_t*)act_a, (bf16_t*)act_b, T, H, (int)n_tt256, d);         \
+        else                                                                                                                       \
+            hipLaunchKernelGGL((gate_fwd256_bf16_kernel<DM, SAVE, false>), dim3((unsigned)grid256), dim3(512), 0, s, (const bf16_t*)E, ldE, \
+                               (const bf16_t*)WK, ba, bb, wc, part, (bf16_t*)act_a, (bf16_t*)act_b, T, H, (int)n_tt256, d);         \
+    } while (0)
     const bool big = T >= 4096 && !getenv("MADELEINE_BF16_GATE128");
     if (big) {   // 256 x 256 x 64 tile
         if (act_a) {

@@ -17,6 +17,10 @@
 
 #include "split_engine.hpp"
 
+#ifndef MDL_POOL_PRE
+#define MDL_POOL_PRE 1   // pool_partial_kernel: request the first rows of a chunk before its softmax statistics
+#endif
+
 namespace mdl {
 
 // Element types of E: float, bf16_t, or img_t = a split-fp16 image row (csrc/split_engine.hpp) addressed in channel units (4 bytes per
@@ -28,18 +32,27 @@ struct img_t {
 };
 template <class TE>
 struct PoolLd {
+    // ld == decode(ld_raw): the two halves of a load, so that a kernel can request rows long before it consumes them
+    typedef f32x4 raw_t;
     static __device__ __forceinline__ f32x4 ld(const TE* __restrict__ rowp, int col, float) { return ld4_nt(rowp + col); }
+    static __device__ __forceinline__ raw_t ld_raw(const TE* __restrict__ rowp, int col) { return ld4_nt(rowp + col); }
+    static __device__ __forceinline__ f32x4 decode(const raw_t& r, int, float) { return r; }
 };
 template <>
 struct PoolLd<img_t> {
     // col = 4 x (lane index of a full wave): lanes 2k, 2k+1 own channels [8k, 8k+4), [8k+4, 8k+8) of one 32-channel block.  ONE 16-B load
     // per lane -- the even lane fetches the hi plane of the 8 channels, the odd lane their lo plane -- and the halves each lane is
     // missing come from its neighbour by DPP (two 8-B loads per lane cost the pooling kernels 12 %).  Every lane of the wave must call.
-    static __device__ __forceinline__ f32x4 ld(const img_t* __restrict__ rowp, int col, float inv) {   // col % 4 == 0
-        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    typedef u32x4 raw_t;
+    static __device__ __forceinline__ raw_t ld_raw(const img_t* __restrict__ rowp, int col) {   // col % 4 == 0
         const bool odd = (col >> 2) & 1;
         const char* p = reinterpret_cast<const char*>(rowp) + (col >> 5) * 128 + ((col & 31) & ~7) * 2 + (odd ? 64 : 0);
-        const u32x4 w = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+        return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+    }
+    static __device__ __forceinline__ f32x4 ld(const img_t* __restrict__ rowp, int col, float inv) { return decode(ld_raw(rowp, col), col, inv); }
+    static __device__ __forceinline__ f32x4 decode(const raw_t& w, int col, float inv) {
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        const bool odd = (col >> 2) & 1;
         // even: w = hi[0..7]: keeps hi[0..3] = w.xy, sends hi[4..7] = w.zw;  odd: w = lo[0..7]: keeps lo[4..7] = w.zw, sends lo[0..3] = w.xy
         const uint32_t s0 = odd ? w.x : w.z, s1 = odd ? w.y : w.w;
         const uint32_t r0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s0, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]: lane ^ 1
@@ -80,8 +93,13 @@ __device__ __forceinline__ BagSpan bag_span(int b, int64_t N, const int64_t* cu,
 // LIN: `scores` already ARE the (un-normalised) weights -- the relu / leaky_relu / sigmoid attention activations of
 // abmil.py:56-61, which the reference pools without a softmax: p = s, chunk statistics (m, l) = (0, [chunk == 0]) so that
 // pool_combine's merge is the plain sum (M = 0, L = 1).
+#ifdef MDL_POOL_WPE   // A/B: occupancy target of the forward kernel (waves per SIMD)
+#define POOL_FWD_ATTR __attribute__((amdgpu_waves_per_eu(MDL_POOL_WPE, MDL_POOL_WPE)))
+#else
+#define POOL_FWD_ATTR
+#endif
 template <int H, class TE, bool IDX = false, bool LIN = false>
-__global__ __launch_bounds__(H * 128) void pool_partial_kernel(const TE* __restrict__ E, int64_t ldE,
+__global__ __launch_bounds__(H * 128) POOL_FWD_ATTR void pool_partial_kernel(const TE* __restrict__ E, int64_t ldE,
                                                                const float* __restrict__ scores,
                                                                float* __restrict__ part_acc,
                                                                float* __restrict__ part_m,
@@ -107,6 +125,26 @@ __global__ __launch_bounds__(H * 128) void pool_partial_kernel(const TE* __restr
     const int64_t prow = (st < nt) ? (IDX ? (int64_t)idx[t0 + st] : t0 + st) : 0;
     if (IDX && sc == 0 && st < nt) tok_s[st] = (int32_t)prow;
     const float s = (st < nt) ? scores[(sp.start + prow) * H + sc] : (LIN ? 0.f : -INFINITY);
+
+    // The first U token rows of the chunk are requested BEFORE the softmax statistics (round 5): that phase -- two block reductions,
+    // three barriers -- is a latency bubble at the head of every workgroup, and the row stream does not depend on it.  The requests follow
+    // the score load (loads return in order: the statistics then wait for vmcnt(U), not 0), they are unconditional (a branch around them
+    // would make the join wait for vmcnt(0): a short tail chunk re-requests its last row for u >= nt, which meets p_s == 0 below), and
+    // the phase's barriers (POOL_SYNC) wait for the LDS traffic only -- __syncthreads would drain the row loads in flight.
+    constexpr int U = 8;
+    typedef PoolLd<TE> L;
+    constexpr bool PRE = MDL_POOL_PRE && !IDX;
+    const TE* __restrict__ Er = E + (sp.start + (IDX ? 0 : t0)) * ldE;
+    typename L::raw_t r0[U];
+    if constexpr (PRE) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) r0[u] = L::ld_raw(Er + (int64_t)(u < nt ? u : nt - 1) * ldE, tid * 4);
+    }
+#if MDL_POOL_PRE
+#define POOL_SYNC() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#else
+#define POOL_SYNC() __syncthreads()
+#endif
     if (LIN) {
         p_s[st * H + sc] = s;
         if (tid < H) {
@@ -114,7 +152,7 @@ __global__ __launch_bounds__(H * 128) void pool_partial_kernel(const TE* __restr
             part_m[o] = 0.f;
             part_l[o] = chunk == 0 ? 1.f : 0.f;
         }
-        __syncthreads();
+        POOL_SYNC();
     }
     float mx = s;
     if (!LIN) {
@@ -122,7 +160,7 @@ __global__ __launch_bounds__(H * 128) void pool_partial_kernel(const TE* __restr
     for (int o = 32; o >= H; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
     const int lane = tid & 63, wave = tid >> 6;
     if (lane < H) red_s[wave * H + lane] = mx;
-    __syncthreads();
+    POOL_SYNC();
     float m = red_s[sc];
 #pragma unroll
     for (int w = 1; w < NW; ++w) m = fmaxf(m, red_s[w * H + sc]);
@@ -131,9 +169,9 @@ __global__ __launch_bounds__(H * 128) void pool_partial_kernel(const TE* __restr
     float sm = p;
 #pragma unroll
     for (int o = 32; o >= H; o >>= 1) sm += __shfl_xor(sm, o, 64);
-    __syncthreads();  // red_s reads done; p_s written
+    POOL_SYNC();  // red_s reads done; p_s written
     if (lane < H) red_s[wave * H + lane] = sm;
-    __syncthreads();
+    POOL_SYNC();
     if (tid < H) {
         float l = 0.f;
 #pragma unroll
@@ -147,10 +185,13 @@ __global__ __launch_bounds__(H * 128) void pool_partial_kernel(const TE* __restr
     // ---- weighted accumulation: thread owns one float4 column, loops over the chunk's tokens -----
     const int ca = tid / 128;
     const float inv = e_scale ? 1.f / e_scale[0] : 1.f;
-    const TE* __restrict__ Er = E + (sp.start + (IDX ? 0 : t0)) * ldE;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    constexpr int U = 8;
     int t = 0;
+    if constexpr (PRE) {   // the rows requested at the top: the arithmetic and order of the loop below (p_s is 0 for tokens >= nt)
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc += p_s[u * H + ca] * L::decode(r0[u], tid * 4, inv);
+        t = U;
+    }
     for (; t + U <= nt; t += U) {
         f32x4 x[U];
 #pragma unroll
@@ -166,6 +207,7 @@ __global__ __launch_bounds__(H * 128) void pool_partial_kernel(const TE* __restr
         acc += p_s[t * H + ca] * x;
     }
     *reinterpret_cast<f32x4*>(part_acc + ((int64_t)b * max_chunks + chunk) * (H * HID) + (int64_t)tid * 4) = acc;
+#undef POOL_SYNC
 }
 
 template <int H>

@@ -172,7 +172,10 @@ __device__ __forceinline__ void nt256_slot(int wave, int i, int lane, int& row, 
 }
 // dma(stage, chunk, piece): piece 0..3 = this wave's A row blocks, 4..7 = its B row blocks (glds16_s).  acc is zeroed here.
 template <class Dma>
-__device__ __forceinline__ void nt256_mainloop(SmemQ& sm, f32x16 (&acc)[4][2], int64_t nch, int wm, int wn, int lane, Dma&& dma) {
+// chunk0_in_flight: the caller already issued this wave's 8 pieces of chunk 0 into stage 0 (a persistent workgroup requests the next
+// tile's first chunk before the epilogue of the current one, see gate_fwd256_bf16_kernel).
+__device__ __forceinline__ void nt256_mainloop(SmemQ& sm, f32x16 (&acc)[4][2], int64_t nch, int wm, int wn, int lane, Dma&& dma,
+                                               bool chunk0_in_flight = false) {
     const int l32 = lane & 31, kh = lane >> 5;
     uint32_t offA[4], offB[2];
 #pragma unroll
@@ -211,8 +214,10 @@ __device__ __forceinline__ void nt256_mainloop(SmemQ& sm, f32x16 (&acc)[4][2], i
     _Pragma("unroll") for (int m = 1; m < 8; ++m) mma1(FA, FB, m);              \
     NT256_SB();
     if (nch <= 0) return;
+    if (!chunk0_in_flight) {
 #pragma unroll
-    for (int p = 0; p < 8; ++p) dma(0, (int64_t)0, p);
+        for (int p = 0; p < 8; ++p) dma(0, (int64_t)0, p);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     {
