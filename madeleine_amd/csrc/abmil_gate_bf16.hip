@@ -167,12 +167,16 @@ __global__ __launch_bounds__(256, 2) void gate_fwd_bf16_kernel(const bf16_t* __r
 // j0 + wn * 32 + l, ct = 1 -> the b column of the same j, so a wave holds za and zb of the same (token, j) in acc[rt][0] / acc[rt][1]
 // (the layout of abmil_gate_split.hip).  Epilogue as above: 4 passes of 32 rows x (32 a | 32 b) through the wave's LDS tile.
 // ------------------------------------------------------------------------------------------------
-// Round 5: PERSIST = one workgroup runs the GATE_JT column tiles of its (token tile, head) back to back (grid / GATE_JT workgroups): with
-// one workgroup per CU (128 KiB of stages) nothing overlaps a tile's prologue -- workgroup launch, first chunk's memory latency --
-// with the previous tile, and K = 512 is only 8 chunks.  The persistent loop requests the NEXT tile's first chunk into stage 0 before
-// the epilogue of the current one; the epilogue stages through stage 1's memory (waves 0-3: A[1], waves 4-7: B[1]) and the row sums
-// have their own 4 KiB.  The E tile is re-read by the same CU four times in a row (L2 hits).
-template <int DM, bool SAVE, bool PERSIST>
+// Round 5: persistent workgroups.  With one workgroup per CU (128 KiB of stages) nothing overlaps a tile's prologue -- workgroup launch,
+// first chunk's memory latency -- with the previous tile, and K = 512 is only 8 chunks.  A persistent workgroup runs several tiles back
+// to back and requests the NEXT tile's first chunk into stage 0 before the epilogue of the current one; the epilogue stages through
+// stage 1's memory (waves 0-3: A[1], waves 4-7: B[1]) and the row sums have their own 4 KiB.  PMODE as in abmil_gate_split.hip:
+// 0 = one tile per workgroup, 1 = the GATE_JT column tiles of a token tile, 2 = GATE_PT16 token tiles of one column tile.
+#ifndef MDL_GATE_BF16_PMODE
+#define MDL_GATE_BF16_PMODE 1
+#endif
+constexpr int GATE_PT16 = 4;
+template <int DM, bool SAVE, int PMODE>
 __global__ __launch_bounds__(512) void gate_fwd256_bf16_kernel(const bf16_t* __restrict__ E, int64_t ldE, const bf16_t* __restrict__ WK,
                                                                const float* __restrict__ ba, const float* __restrict__ bb,
                                                                const float* __restrict__ wc, float* __restrict__ part,
@@ -185,45 +189,61 @@ __global__ __launch_bounds__(512) void gate_fwd256_bf16_kernel(const bf16_t* __r
     const int wm = wave >> 2, wn = wave & 3;
     const XcdHead xh = xcd_head(blockIdx.x, H);
     const int c = xh.c;
-    const int tt = (PERSIST ? xh.li : xh.li / GATE_JT) * xh.nshare + xh.share;
-    if (tt >= n_ttiles) return;  // block-uniform
-    const int64_t t0 = (int64_t)tt * QM;
+    constexpr int n_k = PMODE == 1 ? GATE_JT : PMODE == 2 ? GATE_PT16 : 1;
+    auto tt_of = [&](int k) { return (PMODE == 1 ? xh.li : PMODE == 2 ? (xh.li / GATE_JT) * GATE_PT16 + k : xh.li / GATE_JT) * xh.nshare + xh.share; };
+    auto jt_of = [&](int k) { return PMODE == 1 ? k : xh.li % GATE_JT; };
+    if (tt_of(0) >= n_ttiles) return;  // block-uniform
 
-    const char* baseA = reinterpret_cast<const char*>(E + t0 * ldE + (int64_t)c * HID);
-    uint32_t voA[4], voB[4];
+    uint32_t voB[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         int row, ch;
         nt256_slot(wave, i, lane, row, ch);
-        int64_t ra = row;
-        if (t0 + ra > T - 1) ra = T - 1 - t0;
-        voA[i] = (uint32_t)(ra * ldE * 2 + ch * 16);
         const int wrow = ((row >> 5) & 1) * HID + (row >> 6) * 32 + (row & 31);   // relative to the tile's first gate column j0
         voB[i] = (uint32_t)(wrow * (HID * 2) + ch * 16);
     }
+    auto a_offsets = [&](int64_t t0, uint32_t (&vo)[4]) {   // rows past T re-read the last valid row (discarded)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int row, ch;
+            nt256_slot(wave, i, lane, row, ch);
+            int64_t ra = row;
+            if (t0 + ra > T - 1) ra = T - 1 - t0;
+            vo[i] = (uint32_t)(ra * ldE * 2 + ch * 16);
+        }
+    };
     const int l32 = lane & 31;
     float* tile = reinterpret_cast<float*>(wave < 4 ? &sm.A[1][wave * 8192] : &sm.B[1][(wave - 4) * 8192]);
     float* sred = sred_s + wn * QM + wm * 128;
     const int g4 = lane & 3, r16 = lane >> 2;
     const float inv2 = drop.inv * drop.inv;   // both dropout factors folded into wc: one select per (a, b) pair
 
-    const int jt_lo = PERSIST ? 0 : xh.li % GATE_JT, jt_hi = PERSIST ? GATE_JT : jt_lo + 1;
-    for (int jt = jt_lo; jt < jt_hi; ++jt) {
+    for (int k = 0; k < n_k; ++k) {
+    const int tt = tt_of(k), jt = jt_of(k);
+    if (tt >= n_ttiles) break;   // block-uniform (PMODE 2: a short last group)
+    const int64_t t0 = (int64_t)tt * QM;
     const int j0 = jt * 128;
+    const char* baseA = reinterpret_cast<const char*>(E + t0 * ldE + (int64_t)c * HID);
     const char* baseB = reinterpret_cast<const char*>(WK + ((int64_t)c * 1024 + j0) * HID);
+    uint32_t voA[4];
+    a_offsets(t0, voA);
     auto dma = [&](int st, int64_t f, int piece) {
         const int i = piece & 3;
         if (piece < 4) glds16_s(voA[i], baseA + f * (QK * 2), lds_addr_of(&sm.A[st][(wave * 4 + i) * 1024]));
         else glds16_s(voB[i], baseB + f * (QK * 2), lds_addr_of(&sm.B[st][(wave * 4 + i) * 1024]));
     };
     f32x16 acc[4][2];
-    nt256_mainloop(sm, acc, HID / QK, wm, wn, lane, dma, PERSIST && jt > jt_lo);
-    if (PERSIST && jt + 1 < jt_hi) {   // the next tile's first chunk travels during this epilogue (stage 0 is free, the epilogue is in stage 1)
-        const char* baseBn = baseB + (int64_t)128 * HID * 2;
+    nt256_mainloop(sm, acc, HID / QK, wm, wn, lane, dma, k > 0);
+    if (k + 1 < n_k && tt_of(k + 1) < n_ttiles) {   // the next tile's first chunk travels during this epilogue (stage 0 is free, the epilogue is in stage 1)
+        const int64_t t0n = (int64_t)tt_of(k + 1) * QM;
+        const char* baseAn = reinterpret_cast<const char*>(E + t0n * ldE + (int64_t)c * HID);
+        const char* baseBn = reinterpret_cast<const char*>(WK + ((int64_t)c * 1024 + jt_of(k + 1) * 128) * HID);
+        uint32_t voAn[4];
+        a_offsets(t0n, voAn);
 #pragma unroll
         for (int piece = 0; piece < 8; ++piece) {
             const int i = piece & 3;
-            if (piece < 4) glds16_s(voA[i], baseA, lds_addr_of(&sm.A[0][(wave * 4 + i) * 1024]));
+            if (piece < 4) glds16_s(voAn[i], baseAn, lds_addr_of(&sm.A[0][(wave * 4 + i) * 1024]));
             else glds16_s(voB[i], baseBn, lds_addr_of(&sm.B[0][(wave * 4 + i) * 1024]));
         }
     }
@@ -276,7 +296,7 @@ __global__ __launch_bounds__(512) void gate_fwd256_bf16_kernel(const bf16_t* __r
         const float* sr = sred_s;
         if (t < T) part[(t * H + c) * GATE_JT + jt] = ((sr[tid] + sr[QM + tid]) + sr[2 * QM + tid]) + sr[3 * QM + tid];
     }
-    }   // jt (the next tile's main loop has barriers between these reads of sred_s and its epilogue's writes)
+    }   // k (the next tile's main loop has barriers between these reads of sred_s and its epilogue's writes)
 }
 
 // ================================================================================================
@@ -584,16 +604,22 @@ extern "C" int mdl_abmil_gate_fwd_bf16(const uint16_t* E, int64_t ldE, const flo
     hipLaunchKernelGGL((gate_fwd_bf16_kernel<DM, SAVE>), dim3((unsigned)grid), dim3(256), 0, s, (const bf16_t*)E, ldE, (const bf16_t*)WK, \
                        ba, bb, wc, part, (bf16_t*)act_a, (bf16_t*)act_b, T, H, (int)n_tt, d)
     const int64_t n_tt256 = (T + QM - 1) / QM;
-    static const bool persist = !getenv("MADELEINE_BF16_GATE_NO_PERSIST");   // (A/B switch: one workgroup per column tile, as in round 4)
-    const int64_t grid256 = xcd_head_grid(n_tt256, persist ? 1 : GATE_JT, H);
+    // persistent workgroups (round 5, see gate_fwd256_bf16_kernel): MADELEINE_BF16_GATE_PERSIST = 0 | 1 | 2 picks the mode (A/B switch)
+    static const int pmode_env = getenv("MADELEINE_BF16_GATE_PERSIST") ? atoi(getenv("MADELEINE_BF16_GATE_PERSIST")) : MDL_GATE_BF16_PMODE;
+    const int64_t grid_tiles = xcd_head_grid(n_tt256, GATE_JT, H);
+    int pmode = pmode_env;
+    if (pmode == 1 && !gate_persist_pays(grid_tiles, 0.93)) pmode = 0;
+    if (pmode == 2 && !gate_persist_pays(grid_tiles, 0.93, GATE_PT16)) pmode = 0;
+    const int64_t per_share = (n_tt256 + 8 / H - 1) / (8 / H);
+    const int64_t grid256 = pmode == 1 ? grid_tiles / GATE_JT : pmode == 2 ? 8 * ((per_share + GATE_PT16 - 1) / GATE_PT16) * GATE_JT : grid_tiles;
+#define MDL_GATE_FWD256_1(DM, SAVE, PM)                                                                                            \
+    hipLaunchKernelGGL((gate_fwd256_bf16_kernel<DM, SAVE, PM>), dim3((unsigned)grid256), dim3(512), 0, s, (const bf16_t*)E, ldE,   \
+                       (const bf16_t*)WK, ba, bb, wc, part, (bf16_t*)act_a, (bf16_t*)act_b, T, H, (int)n_tt256, d)
 #define MDL_GATE_FWD256(DM, SAVE)                                                                                                  \
     do {                                                                                                                           \
-        if (persist)                                                                                                               \
-            hipLaunchKernelGGL((gate_fwd256_bf16_kernel<DM, SAVE, true>), dim3((unsigned)grid256), dim3(512), 0, s, (const bf16_t*)E, ldE, \
-                               (const bf16_t*)WK, ba, bb, wc, part, (bf16_t*)act_a, (bf16_t*)act_b, T, H, (int)n_tt256, d);         \
-        else                                                                                                                       \
-            hipLaunchKernelGGL((gate_fwd256_bf16_kernel<DM, SAVE, false>), dim3((unsigned)grid256), dim3(512), 0, s, (const bf16_t*)E, ldE, \
-                               (const bf16_t*)WK, ba, bb, wc, part, (bf16_t*)act_a, (bf16_t*)act_b, T, H, (int)n_tt256, d);         \
+        if (pmode == 1) MDL_GATE_FWD256_1(DM, SAVE, 1);                                                                            \
+        else if (pmode == 2) MDL_GATE_FWD256_1(DM, SAVE, 2);                                                                       \
+        else MDL_GATE_FWD256_1(DM, SAVE, 0);                                                                                       \
     } while (0)
     const bool big = T >= 4096 && !getenv("MADELEINE_BF16_GATE128");
     if (big) {   // 256 x 256 x 64 tile
@@ -620,6 +646,7 @@ extern "C" int mdl_abmil_gate_fwd_bf16(const uint16_t* E, int64_t ldE, const flo
         else MDL_GATE_FWD16(2, false);
     }
 #undef MDL_GATE_FWD256
+#undef MDL_GATE_FWD256_1
 #undef MDL_GATE_FWD16
     MDL_LAUNCH_CHECK();
     return gate_launch_finalize(part, bc, scores, T * H, H, s);

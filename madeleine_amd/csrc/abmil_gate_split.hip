@@ -65,7 +65,19 @@ __global__ void sp_bound_scale_kernel(const float* __restrict__ in, float mult, 
 // Tile: 256 tokens x (128 a | 128 b) gate columns j0 .. j0 + 127 of head c.  Tile column n = wn * SP_WCOLS + ct * 32 + l with the first
 // SPNCT / 2 column tiles of a wave = a columns j0 + wn * (16 SPNCT) + ct * 32 + l and the second half = the b columns of the same j, so that
 // a wave holds za and zb of the same (token, j) in acc[rt][cp] / acc[rt][SPNCT / 2 + cp].
-template <int DM, bool SAVE>
+// Round 5: persistent workgroups.  With one workgroup per CU (128 KiB of stages) nothing overlaps a tile's prologue -- workgroup launch,
+// the first block's memory latency -- with the previous tile.  A persistent workgroup runs PER tiles back to back and requests the NEXT
+// tile's first block into stage 0 before the epilogue of the current one; the epilogue stages through stage 1 (sp_stage1_tile) and the
+// row sums have their own LDS.  Same arithmetic in the same order: bit-identical to one workgroup per tile.
+//   PMODE 0: one tile per workgroup (round 4)
+//   PMODE 1: the GATE_JT column tiles of one (token tile, head): the E tile is re-read by the same CU GATE_JT times in a row
+//   PMODE 2: GATE_PT consecutive token tiles of one (column tile, head): the weight tile stays, and the GATE_JT workgroups of the same
+//            token tiles still run side by side on one XCD (they share each E tile through its L2, as in PMODE 0)
+#ifndef MDL_GATE_SP_PMODE
+#define MDL_GATE_SP_PMODE 0
+#endif
+constexpr int GATE_PT = 4;
+template <int DM, bool SAVE, int PMODE>
 __global__ __launch_bounds__(SP_THREADS) void sp_gate_fwd_kernel(const char* __restrict__ Ei, int64_t e_rsb, const float* __restrict__ e_sc,
                                                           const char* __restrict__ WK, const float* __restrict__ w_sc,
                                                           const float* __restrict__ ba, const float* __restrict__ bb,
@@ -73,45 +85,76 @@ __global__ __launch_bounds__(SP_THREADS) void sp_gate_fwd_kernel(const char* __r
                                                           float* __restrict__ act_a, float* __restrict__ act_b, int64_t T, int H,
                                                           int n_ttiles, DropCfg drop) {
     __shared__ SmemSP sm;
+    __shared__ float sred_s[SP_WN * SPM];   // [SP_WN][256 rows]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / SP_WN, wn = wave % SP_WN;
     const XcdHead xh = xcd_head(blockIdx.x, H);
-    const int jt = xh.li % GATE_JT, c = xh.c, tt = (xh.li / GATE_JT) * xh.nshare + xh.share;
-    if (tt >= n_ttiles) return;  // block-uniform
-    const int64_t t0 = (int64_t)tt * SPM;
-    const int j0 = jt * 128;
+    const int c = xh.c;
+    // the workgroup's tiles: (token tile tt_of(k), column tile jt_of(k)), k = 0 .. n_k - 1
+    constexpr int n_k = PMODE == 1 ? GATE_JT : PMODE == 2 ? GATE_PT : 1;
+    auto tt_of = [&](int k) { return (PMODE == 1 ? xh.li : PMODE == 2 ? (xh.li / GATE_JT) * GATE_PT + k : xh.li / GATE_JT) * xh.nshare + xh.share; };
+    auto jt_of = [&](int k) { return PMODE == 1 ? k : xh.li % GATE_JT; };
+    if (tt_of(0) >= n_ttiles) return;  // block-uniform
 
-    const char* baseA = Ei + t0 * e_rsb + (int64_t)c * (HID * 4);
-    const char* baseB = WK + (int64_t)c * 1024 * (HID * 4);
     constexpr int HALF = SPNCT / 2;   // a (= b) column tiles per wave
-    uint32_t voA[SP_PW], voB[SP_PW];
+    uint32_t voB[SP_PW];
 #pragma unroll
     for (int i = 0; i < SP_PW; ++i) {
         int row, ch;
         sp_nt_slot(wave, i, lane, row, ch);
-        int64_t ra = row;
-        if (t0 + ra > T - 1) ra = T - 1 - t0;
-        voA[i] = (uint32_t)(ra * e_rsb + ch * 16);
-        // tile row (= tile column of the product) -> row of the head's [a | b] weight block
+        // tile row (= tile column of the product) -> row of the head's [a | b] weight block, relative to the tile's first gate column j0
         const int wv = row / SP_WCOLS, ct = (row >> 5) % SPNCT;
-        const int wrow = (ct / HALF) * HID + j0 + wv * (32 * HALF) + (ct % HALF) * 32 + (row & 31);
+        const int wrow = (ct / HALF) * HID + wv * (32 * HALF) + (ct % HALF) * 32 + (row & 31);
         voB[i] = (uint32_t)(wrow * (HID * 4) + ch * 16);
     }
+    auto a_offsets = [&](int64_t t0, uint32_t (&vo)[SP_PW]) {   // rows past T re-read the last valid row (discarded)
+#pragma unroll
+        for (int i = 0; i < SP_PW; ++i) {
+            int row, ch;
+            sp_nt_slot(wave, i, lane, row, ch);
+            int64_t ra = row;
+            if (t0 + ra > T - 1) ra = T - 1 - t0;
+            vo[i] = (uint32_t)(ra * e_rsb + ch * 16);
+        }
+    };
+    const float inv = 1.f / (e_sc[0] * w_sc[0]);
+    const int l32 = lane & 31;
+    float* tile = sp_stage1_tile(sm, wave);
+    float* sred = sred_s + wn * SPM + wm * 128;
+    const int g8 = lane & 7, r8 = lane >> 3;
+
+    for (int k = 0; k < n_k; ++k) {
+    const int tt = tt_of(k), jt = jt_of(k);
+    if (tt >= n_ttiles) break;   // block-uniform (PMODE 2: a short last group)
+    const int64_t t0 = (int64_t)tt * SPM;
+    const int j0 = jt * 128;
+    const char* baseA = Ei + t0 * e_rsb + (int64_t)c * (HID * 4);
+    const char* baseB = WK + ((int64_t)c * 1024 + j0) * (HID * 4);
+    uint32_t voA[SP_PW];
+    a_offsets(t0, voA);
     SpAcc acc;
     sp_zero(acc);
     sp_nt_mainloop(sm, acc, HID / 32, wm, wn, lane, [&](int st, int f, int piece) {
         const int i = piece % SP_PW;
         if (piece < SP_PW) glds16_s(voA[i], sp_uniform(baseA + (int64_t)f * 128), lds_addr_of(&sm.A[st][(wave * SP_PW + i) * 1024]));
         else glds16_s(voB[i], sp_uniform(baseB + (int64_t)f * 128), lds_addr_of(&sm.B[st][(wave * SP_PW + i) * 1024]));
-    });
+    }, k > 0);
+    if (k + 1 < n_k && tt_of(k + 1) < n_ttiles) {   // the next tile's first block travels during this epilogue
+        const int64_t t0n = (int64_t)tt_of(k + 1) * SPM;
+        const char* baseAn = Ei + t0n * e_rsb + (int64_t)c * (HID * 4);
+        const char* baseBn = WK + ((int64_t)c * 1024 + jt_of(k + 1) * 128) * (HID * 4);
+        uint32_t voAn[SP_PW];
+        a_offsets(t0n, voAn);
+#pragma unroll
+        for (int piece = 0; piece < SP_NP; ++piece) {
+            const int i = piece % SP_PW;
+            if (piece < SP_PW) glds16_s(voAn[i], sp_uniform(baseAn), lds_addr_of(&sm.A[0][(wave * SP_PW + i) * 1024]));
+            else glds16_s(voB[i], sp_uniform(baseBn), lds_addr_of(&sm.B[0][(wave * SP_PW + i) * 1024]));
+        }
+    }
 
     // ---- epilogue: 4 x HALF passes (rt, cp) of a 32-row x (32 a | 32 b)-column block through the wave's LDS tile (as abmil_gate.hip)
-    const float inv = 1.f / (e_sc[0] * w_sc[0]);
-    const int l32 = lane & 31;
-    float* tile = reinterpret_cast<float*>(&sm) + wave * (32 * 64);
-    float* sred = reinterpret_cast<float*>(&sm) + SP_WAVES * (32 * 64) + wn * SPM + wm * 128;   // [SP_WN][256 rows]
-    const int g8 = lane & 7, r8 = lane >> 3;
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
@@ -162,12 +205,12 @@ __global__ __launch_bounds__(SP_THREADS) void sp_gate_fwd_kernel(const char* __r
     __syncthreads();
     for (int rr = tid; rr < SPM; rr += SP_THREADS) {
         const int64_t t = t0 + rr;
-        const float* sr = reinterpret_cast<const float*>(&sm) + SP_WAVES * (32 * 64);
-        float v = sr[rr];
+        float v = sred_s[rr];
 #pragma unroll
-        for (int w = 1; w < SP_WN; ++w) v += sr[w * SPM + rr];
+        for (int w = 1; w < SP_WN; ++w) v += sred_s[w * SPM + rr];
         if (t < T) part[(t * H + c) * GATE_JT + jt] = v;
     }
+    }   // k (the next tile's main loop has barriers between these reads of sred_s and its epilogue's writes)
 }
 
 // ================================================================================================
@@ -462,9 +505,23 @@ extern "C" int mdl_abmil_gate_fwd_split(const void* E_img, int64_t e_rsb, const 
     hipLaunchKernelGGL(sp_gate_wk_kernel, dim3((unsigned)((int64_t)H * 1024 * 64 / 256)), dim3(256), 0, s, Wa, Wb, WK, H, (const float*)sc);
     MDL_LAUNCH_CHECK();
     const int dm = gate_drop_mode(d);
+    // persistent workgroups (round 5, see sp_gate_fwd_kernel): MADELEINE_GATE_PERSIST = 0 | 1 | 2 picks the mode (A/B switch)
+    static const int pmode_env = getenv("MADELEINE_GATE_PERSIST") ? atoi(getenv("MADELEINE_GATE_PERSIST")) : MDL_GATE_SP_PMODE;
+    const int nshare = 8 / H;
+    const int64_t per_share = (n_tt + nshare - 1) / nshare;
+    int pmode = pmode_env;
+    if (pmode == 1 && !gate_persist_pays(grid, 0.96)) pmode = 0;
+    if (pmode == 2 && !gate_persist_pays(grid, 0.96, GATE_PT)) pmode = 0;
+    const int64_t pgrid = pmode == 1 ? grid / GATE_JT : pmode == 2 ? 8 * ((per_share + GATE_PT - 1) / GATE_PT) * GATE_JT : grid;
+#define MDL_GATE_FWD_SP1(DM, SAVE, PM)                                                                                                 \
+    hipLaunchKernelGGL((sp_gate_fwd_kernel<DM, SAVE, PM>), dim3((unsigned)pgrid), dim3(SP_THREADS), 0, s, (const char*)E_img, e_rsb,   \
+                       e_scale, (const char*)WK, (const float*)sc, ba, bb, wc, part, act_a, act_b, T, H, (int)n_tt, d)
 #define MDL_GATE_FWD_SP(DM, SAVE)                                                                                                     \
-    hipLaunchKernelGGL((sp_gate_fwd_kernel<DM, SAVE>), dim3((unsigned)grid), dim3(SP_THREADS), 0, s, (const char*)E_img, e_rsb, e_scale, \
-                       (const char*)WK, (const float*)sc, ba, bb, wc, part, act_a, act_b, T, H, (int)n_tt, d)
+    do {                                                                                                                              \
+        if (pmode == 1) MDL_GATE_FWD_SP1(DM, SAVE, 1);                                                                                \
+        else if (pmode == 2) MDL_GATE_FWD_SP1(DM, SAVE, 2);                                                                           \
+        else MDL_GATE_FWD_SP1(DM, SAVE, 0);                                                                                           \
+    } while (0)
     if (act_a) {
         if (dm == 0) MDL_GATE_FWD_SP(0, true);
         else if (dm == 1) MDL_GATE_FWD_SP(1, true);
@@ -477,6 +534,7 @@ extern "C" int mdl_abmil_gate_fwd_split(const void* E_img, int64_t e_rsb, const 
         else MDL_GATE_FWD_SP(2, false);
     }
 #undef MDL_GATE_FWD_SP
+#undef MDL_GATE_FWD_SP1
     MDL_LAUNCH_CHECK();
     return gate_launch_finalize(part, bc, scores, T * H, H, s);
 }

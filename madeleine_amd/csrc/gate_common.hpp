@@ -28,6 +28,13 @@ static inline int64_t xcd_head_grid(int64_t units, int per_unit, int H) {  // un
     return 8 * ((units + nshare - 1) / nshare) * per_unit;
 }
 
+// Persistent gate forward (one workgroup runs the GATE_JT column tiles of a token tile): a tile costs `gain` of a tile launched as its own
+// workgroup (measured: 0.96 split, 0.93 bf16), but the last wave of workgroups is GATE_JT tiles long.  256 CUs, one workgroup each.
+static inline bool gate_persist_pays(int64_t grid_tiles, double gain, int per = 4) {
+    const int64_t rounds_tiles = (grid_tiles + 255) / 256, rounds_persist = (grid_tiles / per + 255) / 256;
+    return (double)rounds_persist * per * gain < (double)rounds_tiles;
+}
+
 struct DropCfg {
     float p, inv;
     uint32_t thr;   // 16-bit threshold

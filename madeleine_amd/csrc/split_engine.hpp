@@ -87,8 +87,11 @@ __device__ __forceinline__ void sp_nt_slot(int wave, int i, int lane, int& row, 
 // dma(stage, block, piece): piece < SP_PW = this wave's A row groups, SP_PW .. SP_NP - 1 = its B row groups (glds16_s).
 // TERMS = 3: ah bh + ah bl + al bh.  TERMS = 2 drops ah bl, i.e. the B operand enters rounded to its hi plane (11 bits): four MFMA sets
 // per chunk instead of six.  For gradient products whose B operand is a weight (dX = dY W); never the default.
+// chunk0_in_flight: the caller already issued this wave's pieces of block 0 into stage 0 (a persistent workgroup requests the next
+// tile's first block before the epilogue of the current one and keeps its epilogue staging inside stage 1: sp_stage1_tile).
 template <int TERMS = 3, class Dma>
-__device__ __forceinline__ void sp_nt_mainloop(SmemSP& sm, SpAcc& acc, int nblk, int wm, int wn, int lane, Dma&& dma) {
+__device__ __forceinline__ void sp_nt_mainloop(SmemSP& sm, SpAcc& acc, int nblk, int wm, int wn, int lane, Dma&& dma,
+                                               bool chunk0_in_flight = false) {
     const int l32 = lane & 31, kh = lane >> 5;
     uint32_t offA[4], offB[SPNCT];
 #pragma unroll
@@ -122,8 +125,10 @@ __device__ __forceinline__ void sp_nt_mainloop(SmemSP& sm, SpAcc& acc, int nblk,
     SP_SB();
     if (nblk <= 0) return;
     u32x4 a0[4], a1[4], a2[4], b0[SPNCT], b1[SPNCT], b2[SPNCT];
+    if (!chunk0_in_flight) {
 #pragma unroll
-    for (int p = 0; p < SP_NP; ++p) dma(0, 0, p);
+        for (int p = 0; p < SP_NP; ++p) dma(0, 0, p);
+    }
     SP_DMA_WAIT();
     __syncthreads();
     {
@@ -166,6 +171,13 @@ __device__ __forceinline__ void sp_nt_mainloop(SmemSP& sm, SpAcc& acc, int nblk,
     SP_DMA_WAIT();
     __syncthreads();   // staging memory is free for the epilogue
 #undef SP_SET
+}
+
+// the wave's [32][64]-float epilogue staging tile inside STAGE 1 of the ring (waves 0 .. SP_WAVES/2 - 1: A[1], the rest: B[1]), for
+// persistent workgroups whose stage 0 already receives the next tile's first block during the epilogue
+__device__ __forceinline__ float* sp_stage1_tile(SmemSP& sm, int wave) {
+    static_assert(SP_WAVES / 2 * 8192 <= SP_STAGE, "staging tiles of half the waves fit one operand stage");
+    return reinterpret_cast<float*>(wave < SP_WAVES / 2 ? &sm.A[1][wave * 8192] : &sm.B[1][(wave - SP_WAVES / 2) * 8192]);
 }
 
 // ---- NT, tall tile (round 4): 512 x 128 outputs -----------------------------------------------------------------------------------
