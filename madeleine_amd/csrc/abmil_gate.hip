@@ -502,8 +502,11 @@ static int gate_bwd_impl(const float* E, int64_t ldE, const float* Wa, const flo
         }
         if (T > 0) {
             if (nblk * H > 0x7fffffff) return MDL_E_UNSUPPORTED;
-            hipLaunchKernelGGL((gate_dz_kernel<float, float>), dim3((unsigned)(nblk * H)), dim3(256), 0, s, wc, act_a, act_b, d_scores, dz, slabV,
-                               T, H, d);
+#define MDL_GATE_DZ(DM)                                                                                                              \
+    hipLaunchKernelGGL((gate_dz_kernel<float, float, DM>), dim3((unsigned)nblk), dim3(64 * H), 0, s, wc, act_a, act_b, d_scores, dz, slabV, \
+                       T, H, d)
+            MDL_DISPATCH_DM(gate_drop_mode(d), MDL_GATE_DZ);
+#undef MDL_GATE_DZ
             MDL_LAUNCH_CHECK();
         }
         hipLaunchKernelGGL(gate_reduce_v_kernel, dim3((H * 4 * HID + 31) / 32), dim3(256), 0, s, (const float*)slabV, dba, dbb,

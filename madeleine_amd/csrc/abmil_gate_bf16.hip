@@ -687,8 +687,11 @@ static int gate_bwd_bf16_impl(const uint16_t* E, int64_t ldE, const float* Wa, c
             if (e != hipSuccess) return (int)e;
         }
         if (T > 0) {
-            hipLaunchKernelGGL((gate_dz_kernel<bf16_t, bf16_t>), dim3((unsigned)(L.nblk * H)), dim3(256), 0, s, wc, (const bf16_t*)act_a,
-                               (const bf16_t*)act_b, d_scores, dz, slabV, T, H, d);
+#define MDL_GATE_DZ16(DM)                                                                                                            \
+    hipLaunchKernelGGL((gate_dz_kernel<bf16_t, bf16_t, DM>), dim3((unsigned)L.nblk), dim3(64 * H), 0, s, wc, (const bf16_t*)act_a,        \
+                       (const bf16_t*)act_b, d_scores, dz, slabV, T, H, d)
+            MDL_DISPATCH_DM(gate_drop_mode(d), MDL_GATE_DZ16);
+#undef MDL_GATE_DZ16
             MDL_LAUNCH_CHECK();
         }
         const int rc = gate_launch_reduce_v(slabV, dba, dbb, dwc, dbc, H, (int)L.nblk, s);

@@ -218,78 +218,78 @@ __global__ __launch_bounds__(SP_THREADS) void sp_gate_fwd_kernel(const char* __r
 // ================================================================================================
 // Workgroup = DZ_ROWS token rows x ALL heads (64 H threads: thread = (head, 8 columns)): every row is one contiguous 2 KB H read of
 // each activation and one contiguous 4 KB H write of the image (a workgroup per head touched 2 KB of every 8 KB).
+template <int DM>   // dropout mode, as the forward kernels (gate_keep2_fwd)
 __global__ __launch_bounds__(64 * MDL_MAX_HEADS) void sp_gate_dz_kernel(const float* __restrict__ wc, const float* __restrict__ act_a,
                                                          const float* __restrict__ act_b, const float* __restrict__ d_scores,
                                                          char* __restrict__ dzi, const float* __restrict__ dz_sc,
                                                          float* __restrict__ slabV, int64_t T, int H, DropCfg drop, int rows_per_wg) {
-    constexpr int VEC = 8;   // 64 groups of 8 columns per head (16-B image stores)
+    // Round 5: lane q of head c owns columns 4q .. 4q + 3 and 256 + 4q .. 256 + 4q + 3 of its head (fully coalesced float4 loads: one
+    // instruction of the wave = 1 KiB), and the image goes out through sp_img_store4's pair exchange (whole 128-B lines per store
+    // instruction).  Round 4 had 8 consecutive columns per lane: 32-B loads and 16 B + 16 B stores, the half-line pattern that streams
+    // 4.8 TB/s where this order streams 5.2-5.4 (tools/micro/hbm_rate.hip patterns).  Same values, same summation order per column.
+    constexpr int NH = 2, VEC = 4;   // column halves per lane x columns per float4
     const int tid = threadIdx.x, q = tid & 63, c = tid >> 6;
     const int64_t bx = blockIdx.x;
     const int64_t r0 = bx * rows_per_wg;
     int64_t r1 = r0 + rows_per_wg;
     if (r1 > T) r1 = T;
     const float s = dz_sc[0];
-    float vw[VEC], sa[VEC], sb[VEC], sw[VEC];
+    f32x4 vw[NH], sa[NH], sb[NH], sw[NH];
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-        vw[i] = wc[c * HID + q * VEC + i];
-        sa[i] = sb[i] = sw[i] = 0.f;
+    for (int h = 0; h < NH; ++h) {
+        vw[h] = *reinterpret_cast<const f32x4*>(wc + c * HID + h * 256 + q * VEC);
+        sa[h] = sb[h] = sw[h] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     float sds = 0.f;
-    const int64_t offa = sp_img_off(q * VEC, 0), offb = sp_img_off(HID + q * VEC, 0);
     constexpr int UNR = 2;   // 2 rows x (a, b) x 2 x 16 B = 8 loads in flight per thread
     for (int64_t rb = r0; rb < r1; rb += UNR) {
-        float va[UNR][VEC], vb[UNR][VEC], ds[UNR];
+        f32x4 va[UNR][NH], vb[UNR][NH];
+        float ds[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             const int64_t r = rb + u;
             const bool ok = r < r1;
             const int64_t o = ((ok ? r : rb) * H + c) * HID + q * VEC;
-            const f32x4 a0 = ld4_nt(act_a + o), a1 = ld4_nt(act_a + o + 4), b0 = ld4_nt(act_b + o), b1 = ld4_nt(act_b + o + 4);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                va[u][i] = a0[i];
-                va[u][4 + i] = a1[i];
-                vb[u][i] = b0[i];
-                vb[u][4 + i] = b1[i];
+            for (int h = 0; h < NH; ++h) {
+                va[u][h] = ld4_nt(act_a + o + h * 256);
+                vb[u][h] = ld4_nt(act_b + o + h * 256);
             }
             ds[u] = ok ? d_scores[r * H + c] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             const int64_t r = rb + u;
-            if (r < r1) {
+            if (r < r1) {   // block-uniform
                 const int64_t o = (r * H + c) * HID + q * VEC;
-                const uint32_t rkey = drop_row_key(drop, o);   // the 8 elements share the high word (o % 512 + i < 512)
-                float za[VEC], zb[VEC];
+                const uint32_t rkey = drop_row_key(drop, o);   // the head's 512 elements share the high word
+                char* row = dzi + (r * H + c) * (int64_t)(1024 * 4);
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) {
-                    float w;
-                    gate_dz(drop, ds[u], vw[i], va[u][i], vb[u][i], o + i, rkey, za[i], zb[i], w);
-                    sw[i] += w;
-                    sa[i] += za[i];
-                    sb[i] += zb[i];
-                    za[i] *= s;
-                    zb[i] *= s;
+                for (int h = 0; h < NH; ++h) {
+                    f32x4 za, zb;
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) {
+                        float w, a, b;
+                        gate_dz_t<DM>(drop, ds[u], vw[h][i], va[u][h][i], vb[u][h][i], o + h * 256, i, rkey, a, b, w);
+                        sw[h][i] += w;
+                        sa[h][i] += a;
+                        sb[h][i] += b;
+                        za[i] = a;
+                        zb[i] = b;
+                    }
+                    sp_img_store4(row, h * 256 + q * VEC, za, s);
+                    sp_img_store4(row, HID + h * 256 + q * VEC, zb, s);
                 }
                 sds += ds[u];
-                u32x4 ha, la, hb, lb;
-                sp_split8(za, ha, la);
-                sp_split8(zb, hb, lb);
-                char* row = dzi + (r * H + c) * (int64_t)(1024 * 4);
-                *reinterpret_cast<u32x4*>(row + offa) = ha;
-                *reinterpret_cast<u32x4*>(row + offa + 64) = la;
-                *reinterpret_cast<u32x4*>(row + offb) = hb;
-                *reinterpret_cast<u32x4*>(row + offb + 64) = lb;
             }
         }
     }
     float* __restrict__ o = slabV + (bx * H + c) * 4 * HID + q * VEC;
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-        o[i] = sa[i];
-        o[HID + i] = sb[i];
-        o[2 * HID + i] = sw[i];
+    for (int h = 0; h < NH; ++h) {
+        *reinterpret_cast<f32x4*>(o + h * 256) = sa[h];
+        *reinterpret_cast<f32x4*>(o + HID + h * 256) = sb[h];
+        *reinterpret_cast<f32x4*>(o + 2 * HID + h * 256) = sw[h];
     }
     if (q == 0) o[3 * HID] = sds;
 }
@@ -598,8 +598,15 @@ extern "C" int mdl_abmil_attnpool_bwd_split(const void* E_img, int64_t e_rsb, co
         hipLaunchKernelGGL(sp_bound_scale_kernel, dim3(1), dim3(1), 0, s, (const float*)(sc + 2), d.inv * d.inv, sc + 4);
         MDL_LAUNCH_CHECK();
         if (T > 0) {
-            hipLaunchKernelGGL(sp_gate_dz_kernel, dim3((unsigned)L.nblk), dim3(64 * H), 0, s, wc, act_a, act_b, d_scores, dzi,
-                               (const float*)(sc + 4), slabV, T, H, d, sp_dz_rows(T));
+            const int dm = gate_drop_mode(d);
+#define MDL_GATE_DZ_SP(DM)                                                                                                    \
+    hipLaunchKernelGGL(sp_gate_dz_kernel<DM>, dim3((unsigned)L.nblk), dim3(64 * H), 0, s, wc, act_a, act_b, d_scores, dzi,    \
+                       (const float*)(sc + 4), slabV, T, H, d, sp_dz_rows(T))
+            if (dm == 0) MDL_GATE_DZ_SP(0);
+            else if (dm == 1) MDL_GATE_DZ_SP(1);
+            else if (dm == 3) MDL_GATE_DZ_SP(3);
+            else MDL_GATE_DZ_SP(2);
+#undef MDL_GATE_DZ_SP
             MDL_LAUNCH_CHECK();
         }
         rc = gate_launch_reduce_v(slabV, dba, dbb, dwc, dbc, H, (int)L.nblk, s);

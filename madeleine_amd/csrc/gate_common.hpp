@@ -136,6 +136,22 @@ __device__ __forceinline__ void gate_dz(const DropCfg& d, float ds, float wcv, f
     pab = ds * ad * bd;
 }
 
+// the same with the dropout mode fixed at compile time (DM as gate_keep2_fwd): element idx_even + e, idx_even even, e a compile-time
+// offset -- no mode branches per element, and in byte-field mode the two elements of a pair share one hash
+template <int DM>
+__device__ __forceinline__ void gate_dz_t(const DropCfg& d, float ds, float wcv, float a, float b, int64_t idx_even, int e, uint32_t row_key,
+                                          float& dza, float& dzb, float& pab) {
+    bool keep_a, keep_b;
+    gate_keep2_fwd<DM>(d, idx_even, e, row_key, keep_a, keep_b);
+    const float ka = keep_a ? d.inv : 0.f;
+    const float kb = keep_b ? d.inv : 0.f;
+    const float ad = a * ka, bd = b * kb;
+    const float g = ds * wcv;
+    dza = g * bd * ka * (1.f - a * a);
+    dzb = g * ad * kb * (b * (1.f - b));
+    pab = ds * ad * bd;
+}
+
 static inline DropCfg make_drop(float p, uint64_t seed, const uint8_t* ka, const uint8_t* kb) {
     DropCfg d;
     d.on = (p > 0.f) ? 1 : 0;
@@ -169,10 +185,16 @@ static inline int splits_for(int64_t T, int tiles_per_split, int64_t slots = 768
 static inline int gate_splits(int64_t T, int H) { return splits_for(T, 16 * H); }  // 4 k-tiles x 4 column tiles per head
 
 constexpr int DZ_ROWS = 256;  // token rows per workgroup
+// launches KERNEL<..., DM> for the run-time dropout mode dm (gate_drop_mode)
+#define MDL_DISPATCH_DM(dm, LAUNCH) \
+    do {                            \
+        if ((dm) == 0) LAUNCH(0);   \
+        else if ((dm) == 1) LAUNCH(1); \
+        else if ((dm) == 3) LAUNCH(3); \
+        else LAUNCH(2);             \
+    } while (0)
 
-// grid (row blocks, H), 256 threads = (512 / VEC) column groups x PH row phases, VEC = 16 B / sizeof(TI) columns per thread (4 fp32,
-// 8 bf16: every memory instruction moves 16 B per lane -- with 8-B accesses the bf16 pass issued twice the memory instructions per
-// byte).  slabV [nblk][H][4][512]: dba | dbb | dwc | (dbc at [0]).
+// dz pass of the fp32-MFMA / bf16 modes (gate_dz_kernel below).  slabV [nblk][H][4][512]: dba | dbb | dwc | (dbc at [0]).
 template <class T>
 __device__ __forceinline__ void ldv(const T* p, float (&v)[16 / sizeof(T)]);
 template <>
@@ -200,91 +222,89 @@ __device__ __forceinline__ void stv(float* p, const float (&v)[8]) {
     *reinterpret_cast<f32x4*>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
 }
 
-template <class TI, class TO>
-__global__ __launch_bounds__(256) void gate_dz_kernel(const float* __restrict__ wc, const TI* __restrict__ act_a,
-                                                      const TI* __restrict__ act_b, const float* __restrict__ d_scores,
-                                                      TO* __restrict__ dz, float* __restrict__ slabV, int64_t T, int H,
-                                                      DropCfg drop) {
-    constexpr int VEC = 16 / sizeof(TI), NQ = HID / VEC, PH = 256 / NQ;
-    __shared__ float red[PH - 1][NQ][3 * VEC + 1];
-    // 1-D grid, head fastest: the H workgroups covering the same rows run together (see sp_gate_dz_kernel)
-    const int tid = threadIdx.x, q = tid % NQ, ph = tid / NQ, c = blockIdx.x % H;
-    const int64_t bx = blockIdx.x / H;
+template <class T> struct DzRaw;
+template <> struct DzRaw<float> { typedef f32x4 type; };
+template <> struct DzRaw<bf16_t> { typedef bf16x8 type; };
+#ifndef MDL_DZ_UNROLL
+#define MDL_DZ_UNROLL 2   // rows in flight per thread (measured: 2 -> 0.80 ms, 4 -> 0.81 ms for the bf16 pass of config 2)
+#endif
+// Round 5: workgroup = DZ_ROWS token rows x ALL heads (64 H threads: thread = (head c, lane q)), as sp_gate_dz_kernel: every row is one
+// contiguous H x 512-element read of each activation and one contiguous H x 1024-element write of dz (a workgroup per (rows, head)
+// touched 1 KiB of every 4 KiB of a bf16 row: 2.5 TB/s).  Lane q owns VEC = 16 B / sizeof(TI) columns at q VEC + h (64 VEC), h < NH:
+// every memory instruction of the wave moves 1 KiB contiguous.  Rows in order, MDL_DZ_UNROLL rows of raw loads in flight.
+// DM: dropout mode fixed at compile time (gate_keep2_fwd; the run-time form cost ~50 instructions per element).
+template <class TI, class TO, int DM>
+__global__ __launch_bounds__(64 * MDL_MAX_HEADS) void gate_dz_kernel(const float* __restrict__ wc, const TI* __restrict__ act_a,
+                                                                    const TI* __restrict__ act_b, const float* __restrict__ d_scores,
+                                                                    TO* __restrict__ dz, float* __restrict__ slabV, int64_t T, int H,
+                                                                    DropCfg drop) {
+    constexpr int VEC = 16 / sizeof(TI), NH = HID / (64 * VEC);
+    typedef typename DzRaw<TI>::type raw_t;
+    const int tid = threadIdx.x, q = tid & 63, c = tid >> 6;
+    const int64_t bx = blockIdx.x;
     const int64_t r0 = bx * DZ_ROWS;
     int64_t r1 = r0 + DZ_ROWS;
     if (r1 > T) r1 = T;
-    float vw[VEC], sa[VEC], sb[VEC], sw[VEC];
+    float vw[NH][VEC], sa[NH][VEC], sb[NH][VEC], sw[NH][VEC];
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-        vw[i] = wc[c * HID + q * VEC + i];
-        sa[i] = sb[i] = sw[i] = 0.f;
-    }
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            vw[h][i] = wc[c * HID + h * 64 * VEC + q * VEC + i];
+            sa[h][i] = sb[h][i] = sw[h][i] = 0.f;
+        }
     float sds = 0.f;
-    // DZ_UNROLL rows per trip, all loads issued before the arithmetic
-    constexpr int DZ_UNROLL = 16 / VEC;   // 4 (fp32) / 2 (bf16): 8 x 16 B in flight per thread either way
-    for (int64_t rb = r0 + ph; rb < r1; rb += PH * DZ_UNROLL) {
-        float va[DZ_UNROLL][VEC], vb[DZ_UNROLL][VEC], ds[DZ_UNROLL];
+    constexpr int UNR = MDL_DZ_UNROLL;   // UNR rows x NH x (a, b) x 16 B in flight per thread
+    for (int64_t rb = r0; rb < r1; rb += UNR) {
+        raw_t ra[UNR][NH], rv[UNR][NH];
+        float ds[UNR];
 #pragma unroll
-        for (int u = 0; u < DZ_UNROLL; ++u) {
-            const int64_t r = rb + PH * u;
+        for (int u = 0; u < UNR; ++u) {
+            const int64_t r = rb + u;
             const bool ok = r < r1;
             const int64_t o = ((ok ? r : rb) * H + c) * HID + q * VEC;
-            ldv<TI>(act_a + o, va[u]);
-            ldv<TI>(act_b + o, vb[u]);
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                ra[u][h] = __builtin_nontemporal_load(reinterpret_cast<const raw_t*>(act_a + o + h * 64 * VEC));
+                rv[u][h] = __builtin_nontemporal_load(reinterpret_cast<const raw_t*>(act_b + o + h * 64 * VEC));
+            }
             ds[u] = ok ? d_scores[r * H + c] : 0.f;
         }
 #pragma unroll
-        for (int u = 0; u < DZ_UNROLL; ++u) {
-            const int64_t r = rb + PH * u;
-            if (r < r1) {
+        for (int u = 0; u < UNR; ++u) {
+            const int64_t r = rb + u;
+            if (r < r1) {   // block-uniform
                 const int64_t o = (r * H + c) * HID + q * VEC;
-                const uint32_t rkey = drop_row_key(drop, o);   // o % 512 + i < 512: the VEC elements share the high word
-                float za[VEC], zb[VEC];
+                const uint32_t rkey = drop_row_key(drop, o);   // the head's 512 elements share the high word
+                TO* __restrict__ out = dz + (r * H + c) * 1024 + q * VEC;
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) {
-                    float w;
-                    gate_dz(drop, ds[u], vw[i], va[u][i], vb[u][i], o + i, rkey, za[i], zb[i], w);
-                    sw[i] += w;
-                    sa[i] += za[i];
-                    sb[i] += zb[i];
+                for (int h = 0; h < NH; ++h) {
+                    float za[VEC], zb[VEC];
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) {
+                        float w;
+                        gate_dz_t<DM>(drop, ds[u], vw[h][i], (float)ra[u][h][i], (float)rv[u][h][i], o + h * 64 * VEC, i, rkey, za[i], zb[i], w);
+                        sw[h][i] += w;
+                        sa[h][i] += za[i];
+                        sb[h][i] += zb[i];
+                    }
+                    stv(out + h * 64 * VEC, za);
+                    stv(out + HID + h * 64 * VEC, zb);
                 }
                 sds += ds[u];
-                TO* __restrict__ out = dz + (r * H + c) * 1024 + q * VEC;
-                stv(out, za);
-                stv(out + HID, zb);
             }
         }
     }
-    if (ph > 0) {
+    float* __restrict__ o = slabV + (bx * H + c) * 4 * HID + q * VEC;
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
-            red[ph - 1][q][i] = sa[i];
-            red[ph - 1][q][VEC + i] = sb[i];
-            red[ph - 1][q][2 * VEC + i] = sw[i];
+            o[h * 64 * VEC + i] = sa[h][i];
+            o[HID + h * 64 * VEC + i] = sb[h][i];
+            o[2 * HID + h * 64 * VEC + i] = sw[h][i];
         }
-        red[ph - 1][q][3 * VEC] = sds;
-    }
-    __syncthreads();
-    if (ph == 0) {
-        float* __restrict__ o = slabV + (bx * H + c) * 4 * HID + q * VEC;
-#pragma unroll
-        for (int p = 0; p < PH - 1; ++p) {
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) {
-                sa[i] += red[p][q][i];
-                sb[i] += red[p][q][VEC + i];
-                sw[i] += red[p][q][2 * VEC + i];
-            }
-            sds += red[p][0][3 * VEC];
-        }
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) {
-            o[i] = sa[i];
-            o[HID + i] = sb[i];
-            o[2 * HID + i] = sw[i];
-        }
-        if (q == 0) o[3 * HID] = sds;
-    }
+    if (q == 0) o[3 * HID] = sds;
 }
 
 

@@ -153,21 +153,9 @@ __device__ __forceinline__ void group_store(IO* __restrict__ p, int lane, int i,
     }
 }
 
-// split-image store of 4 consecutive columns c .. c + 3 (c % 4 == 0) of an image row: 8 B of the hi plane, 8 B of the lo plane
-__device__ __forceinline__ void img_store4(char* __restrict__ row, int c, const f32x4& v, float s) {
-    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-    uint32_t h[2], l[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const float a0 = v[2 * i] * s, a1 = v[2 * i + 1] * s;
-        const _Float16 h0 = (_Float16)a0, h1 = (_Float16)a1;
-        h[i] = __builtin_bit_cast(uint32_t, h2{h0, h1});
-        l[i] = __builtin_bit_cast(uint32_t, h2{(_Float16)(a0 - (float)h0), (_Float16)(a1 - (float)h1)});
-    }
-    char* p = row + (int64_t)(c >> 5) * 128 + (c & 31) * 2;
-    *reinterpret_cast<u32x2*>(p) = u32x2{h[0], h[1]};
-    *reinterpret_cast<u32x2*>(p + 64) = u32x2{l[0], l[1]};
-}
+// split-image store of 4 consecutive columns c .. c + 3 of an image row: sp_img_store4 (split_engine.hpp) -- the fp32 column map gives lane l
+// columns i * 256 + 4 l, which is the lane order its pair exchange needs; every lane of the wave stores (rows are wave-uniform)
+__device__ __forceinline__ void img_store4(char* __restrict__ row, int c, const f32x4& v, float s) { sp_img_store4(row, c, v, s); }
 
 // Geometry: a 256-thread block = 4 waves.  WPR waves share one row (each owns a 256*NV-column segment), so a block
 // works on 4/WPR rows at a time: W = 512 -> NV 2, WPR 1 (one wave per row); W = 2048 -> NV 2, WPR 4 (one block per

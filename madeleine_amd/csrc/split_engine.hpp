@@ -515,4 +515,40 @@ __device__ __forceinline__ void sp_split8(const float (&v)[8], u32x4& hi, u32x4&
 // byte offset of the 16-B group holding columns k .. k + 7 (k % 8 == 0) of plane p within an image row
 __device__ __forceinline__ int64_t sp_img_off(int k, int p) { return (int64_t)(k >> 5) * 128 + p * 64 + (k & 31) * 2; }
 
+// Split-image store of 4 consecutive channels per lane, WHOLE LINES per store instruction (round 5).  Lane l of a full wave owns channels
+// c .. c + 3 of an image row with c = c0 + 4 l (c0 % 256 == 0): lanes 2k and 2k + 1 hold the two halves of channels 8k' .. 8k' + 7.  The
+// even lane hands its lo-plane 8 B to the odd lane and receives the odd lane's hi-plane 8 B (DPP quad_perm [1,0,3,2]); then the even lane
+// writes 16 B of the hi plane and the odd lane 16 B of the lo plane: one store instruction of the wave = 8 whole 128-B lines, after fully
+// coalesced float4 loads.  (8 B + 8 B per lane writes the 64-B halves of 8 lines per instruction, 16 B + 16 B from 32-B loads the halves
+// of 16: 5.1-5.3 / 4.8 TB/s against 5.2-5.4 for this order and for a plain float4 copy on the same box, tools/micro/hbm_rate.hip
+// patterns.)  The mirror image of the pooling kernels' image loads (abmil_pool.hip PoolLd<img_t>).  Every lane of the wave must call, with
+// the same row.  v is scaled by s first.
+// MEASURED in the product (profiles/r05q): no gain -- the dz pass gained its 5 % from the coalesced float4 loads alone (1.87 -> 1.77 ms with
+// either store), the LayerNorm kernels are 1.5 % faster with the plain 8 B + 8 B stores.  Default MDL_IMG_PAIR=0 = those; =1 is the exchange.
+#ifndef MDL_IMG_PAIR
+#define MDL_IMG_PAIR 0
+#endif
+__device__ __forceinline__ void sp_img_store4(char* __restrict__ row, int c, const f32x4& v, float s) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    uint32_t h[2], l[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float a0 = v[2 * i] * s, a1 = v[2 * i + 1] * s;
+        const _Float16 h0 = (_Float16)a0, h1 = (_Float16)a1;
+        h[i] = __builtin_bit_cast(uint32_t, h2{h0, h1});
+        l[i] = __builtin_bit_cast(uint32_t, h2{(_Float16)(a0 - (float)h0), (_Float16)(a1 - (float)h1)});
+    }
+#if MDL_IMG_PAIR
+    const bool odd = (c >> 2) & 1;
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(odd ? h[0] : l[0]), 0xB1, 0xF, 0xF, false);
+    const uint32_t r1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(odd ? h[1] : l[1]), 0xB1, 0xF, 0xF, false);
+    char* p = row + (int64_t)(c >> 5) * 128 + ((c & 31) & ~7) * 2 + (odd ? 64 : 0);
+    *reinterpret_cast<u32x4*>(p) = odd ? u32x4{r0, r1, l[0], l[1]} : u32x4{h[0], h[1], r0, r1};
+#else
+    char* p = row + (int64_t)(c >> 5) * 128 + (c & 31) * 2;
+    *reinterpret_cast<u32x2*>(p) = u32x2{h[0], h[1]};
+    *reinterpret_cast<u32x2*>(p + 64) = u32x2{l[0], l[1]};
+#endif
+}
+
 }  // namespace mdl

@@ -59,6 +59,9 @@ __global__ void k(const f32x4* __restrict__ a, const f32x4* __restrict__ b, f32x
 //          (LayerNorm kernels' img_store4: one store instruction covers the 64-B halves of 8 lines)
 //   PAT 2: "split planes, 16 B": a lane reads 32 B (two float4) and writes 16 B + 16 B (the dz pass / row-scaled image: 64-B halves of 16 lines)
 //   PAT 3: as 2, but lanes L and L^4 exchange their lo halves through DPP so that every store instruction writes whole 128-B lines
+//   PAT 4: "pair swap": fully coalesced float4 loads (lane l = columns 4l .. 4l+3); lanes 2k, 2k+1 exchange 8 B by DPP (the even lane ends
+//          up with the hi plane of channels 8k .. 8k+7, the odd lane with their lo plane) and ONE 16-B store per lane writes whole lines
+//          (the mirror image of the pooling kernels' image loads)
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 template <int PAT, int U>
@@ -67,7 +70,7 @@ __global__ void kp(const f32x4* __restrict__ a, char* __restrict__ o, long n4) {
     const long per = ((n4 + gridDim.x - 1) / gridDim.x + 2 * U * bd - 1) / (2 * U * bd) * (2 * U * bd);
     const long i0 = (long)blockIdx.x * per, end = i0 + per < n4 ? i0 + per : n4;
     const int lane = threadIdx.x & 63;
-    if (PAT <= 1) {
+    if (PAT <= 1 || PAT == 4) {
         for (long i = i0 + threadIdx.x; i < end; i += U * bd) {
             f32x4 v[U];
 #pragma unroll
@@ -77,7 +80,15 @@ __global__ void kp(const f32x4* __restrict__ a, char* __restrict__ o, long n4) {
                 const long j = i + u * bd;
                 if (j >= end) continue;
                 if (PAT == 0) *reinterpret_cast<f32x4*>(o + j * 16) = v[u];
-                else {   // float4 j = columns 4j .. 4j+3: block (4j / 32) of 128 B, 8 B at (4j % 32) * 2 and the same + 64
+                else if (PAT == 4) {   // (n4 even and every range even-aligned: a lane and its partner are live together)
+                    const bool odd = j & 1;
+                    const u32x4 w = __builtin_bit_cast(u32x4, v[u]);
+                    const unsigned s0 = odd ? w.x : w.z, s1 = odd ? w.y : w.w;
+                    const unsigned r0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s0, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+                    const unsigned r1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s1, 0xB1, 0xF, 0xF, false);
+                    char* p = o + (j >> 3) * 128 + ((j & 7) >> 1) * 16 + (odd ? 64 : 0);
+                    *reinterpret_cast<u32x4*>(p) = odd ? u32x4{r0, r1, w.z, w.w} : u32x4{w.x, w.y, r0, r1};
+                } else {   // float4 j = columns 4j .. 4j+3: block (4j / 32) of 128 B, 8 B at (4j % 32) * 2 and the same + 64
                     char* p = o + (j >> 3) * 128 + (j & 7) * 8;
                     const u32x4 w = __builtin_bit_cast(u32x4, v[u]);
                     *reinterpret_cast<u32x2*>(p) = u32x2{w.x, w.y};
@@ -140,6 +151,7 @@ kern_t pick_all(int mode, int U, bool nt, bool contig) {
 
 int main(int argc, char** argv) {
     const bool quick = argc > 1 && !strcmp(argv[1], "quick");
+    const bool patterns_only = argc > 1 && !strcmp(argv[1], "patterns");
     const long maxbytes = 6L << 30;
     f32x4 *a, *b, *o; float* sink;
     if (hipMalloc(&a, maxbytes) != hipSuccess || hipMalloc(&b, maxbytes) != hipSuccess || hipMalloc(&o, maxbytes) != hipSuccess) { printf("alloc failed\n"); return 1; }
@@ -151,7 +163,7 @@ int main(int argc, char** argv) {
     for (int w = 0; w < 20; ++w) hipLaunchKernelGGL((k<2, 8, false, false>), dim3(2048), dim3(256), 0, 0, a, b, o, (2L << 30) / 16, sink);
     struct Best { float tbs = 0; char what[160]; } best[4][4];
     const long sizes[4] = {256L << 20, 1L << 30, 2L << 30, 6L << 30};
-    for (int si = 0; si < 4; ++si) {
+    for (int si = 0; si < (patterns_only ? 0 : 4); ++si) {
         const long bytes = sizes[si], n4 = bytes / 16;
         if (quick && si != 2) continue;
         for (int mode = 0; mode < 4; ++mode)
@@ -186,8 +198,9 @@ int main(int argc, char** argv) {
     {
         printf("\n== store patterns of the image-writing passes (copy, 2 GiB, contiguous range per workgroup) ==\n");
         const long bytes = 2L << 30, n4 = bytes / 16;
-        const char* pn[4] = {"float4 copy", "split planes 8 B", "split planes 16 B", "split planes 16 B, whole lines (DPP swap)"};
-        for (int pat = 0; pat < 4; ++pat)
+        const char* pn[5] = {"float4 copy", "split planes 8 B", "split planes 16 B", "split planes 16 B, whole lines (DPP swap)",
+                             "float4 loads, pair swap, whole-line 16-B stores"};
+        for (int pat = 0; pat < 5; ++pat)
             for (int bd : {256, 512})
                 for (int wgcu : {2, 8, 16}) {
                     float bestms = 1e9f;
@@ -197,7 +210,8 @@ int main(int argc, char** argv) {
                         if (pat == 0) hipLaunchKernelGGL((kp<0, 4>), g, b, 0, 0, a, (char*)o, n4);
                         else if (pat == 1) hipLaunchKernelGGL((kp<1, 4>), g, b, 0, 0, a, (char*)o, n4);
                         else if (pat == 2) hipLaunchKernelGGL((kp<2, 4>), g, b, 0, 0, a, (char*)o, n4);
-                        else hipLaunchKernelGGL((kp<3, 4>), g, b, 0, 0, a, (char*)o, n4);
+                        else if (pat == 3) hipLaunchKernelGGL((kp<3, 4>), g, b, 0, 0, a, (char*)o, n4);
+                        else hipLaunchKernelGGL((kp<4, 4>), g, b, 0, 0, a, (char*)o, n4);
                         hipEventRecord(e1); hipEventSynchronize(e1);
                         float ms; hipEventElapsedTime(&ms, e0, e1);
                         if (ms < bestms) bestms = ms;
