@@ -9,6 +9,7 @@ Organisation differs from the reference where it costs device syncs or launches:
     indexing of device tensors forces a sync per stain);
   * when the global loss is madeleine_amd.InfoNCE, all participating stains go through ONE batched launch set.
 """
+import os
 import time
 from typing import Dict, List, NamedTuple, Optional
 
@@ -24,6 +25,10 @@ from .utils import set_model_precision, smooth_rank_measure
 DEVICE = torch.device("cuda" if torch.cuda.is_available() else "cpu")
 HE_POSITION = 0
 WHOLE_VIEW_POSITION = 0
+
+
+# A/B switch (tools/runs/r05_t.sh): MADELEINE_LOSS_GATHER_ALWAYS=1 restores the unconditional gathers / zero-padded problem tensors
+_SKIP_IDENTITY_GATHERS = not os.environ.get("MADELEINE_LOSS_GATHER_ALWAYS")
 
 
 class _Participant(NamedTuple):
@@ -42,31 +47,57 @@ def _participants(STAINS, labels_cpu: torch.Tensor) -> List[_Participant]:
     return out
 
 
+def _all_cases(part: _Participant, batch: int) -> bool:
+    """Every case of the batch carries this stain: the row gather is the identity (rows_cpu is ascending and unique)."""
+    return _SKIP_IDENTITY_GATHERS and part.rows_cpu.numel() == batch
+
+
+def _take_rows(x, part: _Participant, rows):
+    """x.index_select(0, rows) -- skipped when every case participates (same values; the gather and, in the backward, its zero fill +
+    index_add are ~6 launches of a few microseconds each per stain and side, on a device that is never idle)."""
+    return x if _all_cases(part, x.shape[0]) else x.index_select(0, rows(part) if callable(rows) else rows)
+
+
 def _pair(wsi_embs, part: _Participant, rows, view: int):
-    """(H&E embedding matched to this stain, stain embedding) of view `view` for the participating cases."""
-    he = wsi_embs["HE"][:, view, :, part.column].index_select(0, rows)
-    st = wsi_embs[part.name][:, view, :].index_select(0, rows)
+    """(H&E embedding matched to this stain, stain embedding) of view `view` for the participating cases.  `rows`: the device index
+    tensor, or a callable part -> tensor (a _RowIndex: only called when a gather is needed)."""
+    he = _take_rows(wsi_embs["HE"][:, view, :, part.column], part, rows)
+    st = _take_rows(wsi_embs[part.name][:, view, :], part, rows)
     return he, st
 
 
-def _global_terms_batched(criterion, parts: List[_Participant], wsi_embs, symmetric) -> Dict[int, torch.Tensor]:
+class _RowIndex:
+    """Device copies of the participants' row lists, uploaded at most once per calculate_losses call and only when a gather needs them."""
+
+    def __init__(self, dev):
+        self.dev, self._on_dev = dev, {}
+
+    def __call__(self, part: _Participant):
+        if part.column not in self._on_dev:
+            self._on_dev[part.column] = h2d(part.rows_cpu, self.dev)
+        return self._on_dev[part.column]
+
+
+def _global_terms_batched(criterion, parts: List[_Participant], wsi_embs, symmetric, rows_of) -> Dict[int, torch.Tensor]:
     """All participating stains in one InfoNCE.batched call: padded [S, k_max, d] problems + live-row counts."""
     he_all = wsi_embs["HE"]
     dev, d = he_all.device, he_all.shape[2]
     k_max = max(p.rows_cpu.numel() for p in parts)
-    Q = he_all.new_zeros(len(parts), k_max, d)
-    P = he_all.new_zeros(len(parts), k_max, d)
-    for s, part in enumerate(parts):
-        rows = h2d(part.rows_cpu, dev)
-        q, p = _pair(wsi_embs, part, rows, WHOLE_VIEW_POSITION)
-        Q[s, :rows.numel()] = q
-        P[s, :rows.numel()] = p
+    pairs = [_pair(wsi_embs, part, rows_of, WHOLE_VIEW_POSITION) for part in parts]
+    if _SKIP_IDENTITY_GATHERS and all(p.rows_cpu.numel() == k_max for p in parts):   # nothing to pad: no zero fill, no slice assignments (and none of their backwards)
+        Q, P = torch.stack([q for q, _ in pairs]), torch.stack([p for _, p in pairs])
+    else:
+        Q = he_all.new_zeros(len(parts), k_max, d)
+        P = he_all.new_zeros(len(parts), k_max, d)
+        for s, (part, (q, p)) in enumerate(zip(parts, pairs)):
+            Q[s, :part.rows_cpu.numel()] = q
+            P[s, :part.rows_cpu.numel()] = p
     counts = h2d(torch.tensor([p.rows_cpu.numel() for p in parts], dtype=torch.int32), dev)
     per_problem = criterion.batched(Q, P, counts, symmetric=symmetric)
     return {part.column: per_problem[s] for s, part in enumerate(parts)}
 
 
-def _local_terms_batched(parts, token_embs, dev, subsample=256):
+def _local_terms_batched(parts, token_embs, dev, rows_of, subsample=256):
     """{stain column: GOT(he_tokens, stain_tokens, subsample=256)} for every participating stain, the stains' chains running concurrently
     (one autograd node, one HIP stream per stain).  None when there is nothing to overlap or the tokens are not on a ROCm device."""
     if len(parts) < 2 or dev.type != "cuda":
@@ -79,9 +110,8 @@ def _local_terms_batched(parts, token_embs, dev, subsample=256):
     problems = []
     for part in parts:
         he_src, st_src = token_embs["HE"][:, :, :, part.column], token_embs[part.name].squeeze()   # .squeeze() as in trainer.py:43
-        rows = h2d(part.rows_cpu, dev)
-        kk = min(int(rows.numel()), he_src.shape[1])          # randperm(k)[:256] < k: the first k tokens are all GOT can read
-        he_tok, st_tok = he_src[:, :kk].index_select(0, rows), st_src[:, :kk].index_select(0, rows)
+        kk = min(int(part.rows_cpu.numel()), he_src.shape[1])  # randperm(k)[:256] < k: the first k tokens are all GOT can read
+        he_tok, st_tok = _take_rows(he_src[:, :kk], part, rows_of), _take_rows(st_src[:, :kk], part, rows_of)
         idx = h2d(torch.randperm(he_tok.shape[0])[:subsample], dev)   # loss.py:282 -- the same draw, in the same order, as GOT()
         problems.append((he_tok.index_select(1, idx).float().contiguous(), st_tok.index_select(1, idx).float().contiguous()))
     outs = got_multi(problems, local=True)
@@ -101,17 +131,18 @@ def calculate_losses(STAINS, loss_fn_interMod, loss_fn_interMod_local, loss_fn_i
 
     if loss_fn_interMod and args.global_loss != "info-nce":
         raise AssertionError("invalid global loss")   # the reference asserts the same (trainer.py:36)
+    dev = wsi_embs["HE"].device
+    rows_of = _RowIndex(dev)
     precomputed: Optional[Dict[int, torch.Tensor]] = None
     if isinstance(loss_fn_interMod, _HipInfoNCE) and loss_fn_interMod.reduction == 'mean':
-        precomputed = _global_terms_batched(loss_fn_interMod, parts, wsi_embs, args.symmetric_cl)
+        precomputed = _global_terms_batched(loss_fn_interMod, parts, wsi_embs, args.symmetric_cl, rows_of)
 
-    dev = wsi_embs["HE"].device
     # local terms of all stains as ONE node of concurrent GOT chains (distributed.got_multi(local=True): same arithmetic as the
     # per-stain calls below -- thresholds from each problem's own cost matrices, torch.randperm consumed in the same stain order)
-    got_terms = _local_terms_batched(parts, token_embs, dev) if loss_fn_interMod_local is _GOT else None
+    got_terms = _local_terms_batched(parts, token_embs, dev, rows_of) if loss_fn_interMod_local is _GOT else None
     terms = []
     for part in parts:
-        rows = h2d(part.rows_cpu, dev)
+        rows = rows_of
         if loss_fn_interMod:                                     # global: slide-level InfoNCE, whole-bag view
             if precomputed is not None:
                 terms.append(precomputed[part.column])
@@ -126,9 +157,9 @@ def calculate_losses(STAINS, loss_fn_interMod, loss_fn_interMod_local, loss_fn_i
                 # our GOT reads token indices randperm(k)[:256] < k = the number of participating cases (the reference's quirk,
                 # loss.py:282): narrowing to the first k tokens BEFORE the row gather is exact and keeps the gathers and their
                 # backward at [B, k, 128] instead of [B, N, 128]
-                kk = min(int(rows.numel()), he_src.shape[1])
+                kk = min(int(part.rows_cpu.numel()), he_src.shape[1])
                 he_src, st_src = he_src[:, :kk], st_src[:, :kk]
-            he_tok, st_tok = he_src.index_select(0, rows), st_src.index_select(0, rows)
+            he_tok, st_tok = _take_rows(he_src, part, rows), _take_rows(st_src, part, rows)
             terms.append(loss_fn_interMod_local(he_tok, st_tok, subsample=256) * args.local_loss_weight)
         if loss_fn_intraMod:                                     # intra: the two half-bag views of each modality
             he1, st1 = _pair(wsi_embs, part, rows, 1)
