@@ -511,6 +511,18 @@ def secondary_inference_leg(dev, MF, MADELEINE, n_patches=30000, bags=20):
                                    "kernel_ms_per_call": {n: round(v[0], 4) for n, v in prof4.items()}}
     if "pool_fwd" in prof4:
         out["four_bags_per_launch"]["pool_fwd_GBs"] = round(4 * alg / (prof4["pool_fwd"][0] * 1e-3) / 1e9, 1)
+    # ... under bf16 autocast: what utils.run_inference does by default for the released checkpoint (`precision: bfloat16`, 4 bags per launch)
+    with torch.no_grad(), torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+        for _ in range(2):
+            model.encode_he_bags(group, dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(bags // 4):
+            model.encode_he_bags(group, dev)
+        torch.cuda.synchronize()
+        el416 = time.perf_counter() - t0
+    out["four_bags_per_launch_bf16_autocast"] = {"value": round(nb4 / el416, 2), "unit": "bags/s", "ms_per_bag": round(1e3 * el416 / nb4, 3),
+                                                 "patches_per_sec": round(nb4 * n_patches / el416)}
     return out
 
 

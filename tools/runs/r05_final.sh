@@ -15,4 +15,7 @@ print(d.get("power_clock")); print(d["headline_summary"])
 PY
 bash tools/runs/r04_prof_c2.sh $TAG > $OUT/prof_c2.log 2>&1; tail -5 $OUT/prof_c2.log
 bash tools/collect_profiles.sh $TAG got > /dev/null 2>&1
+# bf16 mode: kernel stats of the same step under torch.autocast(bfloat16)
+( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_c2b && BENCH_NO_TIMER=1 rocprofv3 --kernel-trace --stats -d /tmp/prof_c2b -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-bf16-leg --no-pmc --no-extra-legs --precision bfloat16 > /tmp/prof_c2b.log 2>&1
+  { echo "# $TAG bench_c2_bf16_kernel_stats: BENCH_NO_TIMER=1 rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-bf16-leg --no-pmc --no-extra-legs --precision bfloat16"; python $R/tools/rocpd_summary.py /tmp/prof_c2b/*/*.db 45; } > $R/gpurun_out/prof_txt/${TAG}_bench_c2_bf16_kernel_stats.txt 2>&1 )
 ls $R/gpurun_out/prof_txt | grep $TAG
