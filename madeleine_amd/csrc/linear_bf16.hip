@@ -109,6 +109,10 @@ __global__ __launch_bounds__(256, 2) void linb_nt_kernel(const bf16_t* __restric
 // 128 KiB, one workgroup per CU; the in-wave pipeline of the fp32 engine (fragments of k-step s+1 requested behind the first MFMA
 // of step s, one barrier per chunk before its last step, the next-but-one chunk's 8 LDS-DMA pieces between that step's MFMAs).
 // Used for T >= 4096 rows, output width % 256 == 0, contraction >= 1024 and % 64 == 0 (the dX of the 512 -> 2048 Linear); the 128 x 256 x 32 kernel covers the rest.
+// Round 5: PER > 1 = persistent workgroup over PER consecutive column tiles of one row tile (n_ct % PER == 0): the next tile's first
+// chunk (same A rows, next 256 weight rows) is requested before the epilogue of the current one, which then stages through stage 1
+// only (see gate_fwd256_bf16_kernel).  With the prologue hidden the tile also serves contractions of 512 (linb_use_q).
+template <int PER>
 __global__ __launch_bounds__(512) void linb_nt256_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B,
                                                          const float* __restrict__ bias, bf16_t* __restrict__ C, int64_t ldc,
                                                          int64_t T, int Kc, int n_ct, int n_tiles) {
@@ -116,14 +120,11 @@ __global__ __launch_bounds__(512) void linb_nt256_kernel(const bf16_t* __restric
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;   // rows wm*128 + rt*32 (rt < 4), columns wn*64 + ct*32 (ct < 2)
-    const int lid = xcd_remap(blockIdx.x, n_tiles);
-    const int ct_id = lid % n_ct;
+    const int lid = xcd_remap(blockIdx.x, n_tiles / PER) * PER;   // first tile of this workgroup
     const int64_t t0 = (int64_t)(lid / n_ct) * QM;
-    const int n0 = ct_id * QN;
 
     // DMA: one instruction = 8 rows x 128 B; wave w issues row blocks 4w .. 4w+3 of each operand
     const char* baseA = reinterpret_cast<const char*>(A + t0 * lda);
-    const char* baseB = reinterpret_cast<const char*>(B + (int64_t)n0 * Kc);
     uint32_t voA[4], voB[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -134,25 +135,50 @@ __global__ __launch_bounds__(512) void linb_nt256_kernel(const bf16_t* __restric
         voA[i] = (uint32_t)(ra * lda * 2 + c * 16);
         voB[i] = (uint32_t)((int64_t)row * Kc * 2 + c * 16);
     }
-    auto dma = [&](int st, int64_t f, int piece) {   // piece 0..7: 0-3 = A row blocks, 4-7 = B row blocks
-        const int i = piece & 3;
-        if (piece < 4) glds16_s(voA[i], baseA + f * (QK * 2), lds_addr_of(&sm.A[st][(wave * 4 + i) * 1024]));
-        else glds16_s(voB[i], baseB + f * (QK * 2), lds_addr_of(&sm.B[st][(wave * 4 + i) * 1024]));
-    };
-    f32x16 acc[4][2];
-    nt256_mainloop(sm, acc, Kc / QK, wm, wn, lane, dma);
-
-    bf16_t* ob = C + t0 * ldc + n0;
-    auto emit = [&](int row_u, int rl, int lane_col, const f32x4& lo, const f32x4& hi, int) {
-        bf16_t* o = ob + (int64_t)row_u * ldc + ((uint32_t)rl * (uint32_t)ldc + (uint32_t)lane_col);
-        f32x4 a = lo, b = hi;
-        if (bias) {
-            a += *reinterpret_cast<const f32x4*>(bias + n0 + lane_col);
-            b += *reinterpret_cast<const f32x4*>(bias + n0 + lane_col + 4);
+#pragma unroll 1
+    for (int k = 0; k < PER; ++k) {
+        const int n0 = (lid % n_ct + k) * QN;
+        const char* baseB = reinterpret_cast<const char*>(B + (int64_t)n0 * Kc);
+        auto dma = [&](int st, int64_t f, int piece) {   // piece 0..7: 0-3 = A row blocks, 4-7 = B row blocks
+            const int i = piece & 3;
+            if (piece < 4) glds16_s(voA[i], uniform_ptr(baseA + f * (QK * 2)), lds_addr_of(&sm.A[st][(wave * 4 + i) * 1024]));
+            else glds16_s(voB[i], uniform_ptr(baseB + f * (QK * 2)), lds_addr_of(&sm.B[st][(wave * 4 + i) * 1024]));
+        };
+        f32x16 acc[4][2];
+        nt256_mainloop(sm, acc, Kc / QK, wm, wn, lane, dma, k > 0);
+        if (k + 1 < PER) {   // the next column tile's first chunk travels during this epilogue
+            const char* baseBn = baseB + (int64_t)QN * Kc * 2;
+#pragma unroll
+            for (int piece = 0; piece < 8; ++piece) {
+                const int i = piece & 3;
+                if (piece < 4) glds16_s(voA[i], uniform_ptr(baseA), lds_addr_of(&sm.A[0][(wave * 4 + i) * 1024]));
+                else glds16_s(voB[i], uniform_ptr(baseBn), lds_addr_of(&sm.B[0][(wave * 4 + i) * 1024]));
+            }
         }
-        st8_bf16(o, a, b);
-    };
-    nt256_epilogue(acc, sm, wave, wm, wn, lane, (int)((T - t0 < QM) ? (T - t0) : QM), emit);
+        bf16_t* ob = C + t0 * ldc + n0;
+        auto emit = [&](int row_u, int rl, int lane_col, const f32x4& lo, const f32x4& hi, int) {
+            bf16_t* o = ob + (int64_t)row_u * ldc + ((uint32_t)rl * (uint32_t)ldc + (uint32_t)lane_col);
+            f32x4 a = lo, b = hi;
+            if (bias) {
+                a += *reinterpret_cast<const f32x4*>(bias + n0 + lane_col);
+                b += *reinterpret_cast<const f32x4*>(bias + n0 + lane_col + 4);
+            }
+            st8_bf16(o, a, b);
+        };
+        nt256_epilogue(acc, sm, wave, wm, wn, lane, (int)((T - t0 < QM) ? (T - t0) : QM), emit, PER > 1);
+    }
+}
+// Launches the 256-tile NT kernel.  Measured at config 2 (profiles/r05v): persistence pays on the SHORT contraction with many column tiles
+// (K = 512, N = 2048: 0.706 -> 0.655 ms, and beats the 128 x 256 x 32 kernel there), and costs on the long one (K = 2048, 2 column tiles:
+// 0.61 -> 0.67 ms: the 1-MiB A tile is re-read in sequence instead of side by side) -- so PER = 4 below 1024, 1 from there on.
+// MADELEINE_BF16_LIN_PERSIST=0 forces PER = 1 (A/B switch).
+static inline void linb_launch_nt256(hipStream_t s, const bf16_t* A, int64_t lda, const bf16_t* B, const float* bias, bf16_t* C, int64_t ldc,
+                                     int64_t T, int Kc, int n_ct, int64_t tiles) {
+    static const bool persist = !(getenv("MADELEINE_BF16_LIN_PERSIST") && atoi(getenv("MADELEINE_BF16_LIN_PERSIST")) == 0);
+    const int per = (persist && Kc < 1024 && n_ct % 4 == 0) ? 4 : 1;
+    const dim3 grid((unsigned)(tiles / per));
+    if (per == 4) hipLaunchKernelGGL(linb_nt256_kernel<4>, grid, dim3(512), 0, s, A, lda, B, bias, C, ldc, T, Kc, n_ct, (int)tiles);
+    else hipLaunchKernelGGL(linb_nt256_kernel<1>, grid, dim3(512), 0, s, A, lda, B, bias, C, ldc, T, Kc, n_ct, (int)tiles);
 }
 
 // ---- TN product: slab[sp][n0 + m][k0 + n] = sum_{t in split sp} dY[t][n0 + m] X[t][k0 + n] --------------
@@ -301,7 +327,14 @@ static inline LinbWs linb_ws(int64_t T, int N, int K) {
     w.total = o + 64;
     return w;
 }
-static inline bool linb_use_q(int64_t T, int64_t Kc) { return T >= 4096 && Kc >= 1024 && (Kc % QK) == 0; }   // 256 x 256 x 64 tile: wins on long contractions (measured: K = 2048 0.70 -> 0.61 ms; K = 512 loses, one workgroup per CU exposes prologue + epilogue)
+// 256 x 256 x 64 tile: contractions >= 1024 (measured: K = 2048 0.70 -> 0.61 ms), and -- persistent over 4 column tiles, see
+// linb_launch_nt256 -- contractions of 512..1023 when the output has a multiple of 4 column tiles.  MADELEINE_BF16_LIN256_MINK=1024
+// restores the round-4 rule (A/B switch).
+static inline bool linb_use_q(int64_t T, int64_t Kc, int64_t n_out) {
+    static const int64_t mink = getenv("MADELEINE_BF16_LIN256_MINK") ? atoll(getenv("MADELEINE_BF16_LIN256_MINK")) : 512;
+    if (T < 4096 || (Kc % QK) != 0 || (n_out % QN) != 0) return false;
+    return Kc >= 1024 || (Kc >= mink && (n_out / QN) % 4 == 0);
+}
 static inline bool linb_geom_fwd(int64_t N, int64_t K) { return N > 0 && K > 0 && N % 128 == 0 && K % BBK == 0 && N <= (1 << 20) && K <= (1 << 20); }
 static inline bool linb_geom_bwd(int64_t N, int64_t K) { return linb_geom_fwd(N, K); }
 
@@ -330,12 +363,11 @@ extern "C" int mdl_linear_fwd_bf16(const uint16_t* X, int64_t ldx, const float* 
     hipLaunchKernelGGL(linb_w_cast_kernel, dim3((unsigned)((N * K / 4 + 255) / 256)), dim3(256), 0, s, W, Wb, N * K);
     MDL_LAUNCH_CHECK();
     const bool wide = (N % BBN) == 0;
-    if (wide && linb_use_q(T, K)) {
+    if (wide && linb_use_q(T, K, N)) {
         const int n_ct = (int)(N / QN);
         const int64_t tiles = ((T + QM - 1) / QM) * n_ct;
         if (tiles > 0x7fffffff) return MDL_E_UNSUPPORTED;
-        hipLaunchKernelGGL(linb_nt256_kernel, dim3((unsigned)tiles), dim3(512), 0, s, (const bf16_t*)X, ldx, (const bf16_t*)Wb, bias,
-                           (bf16_t*)Y, ldy, T, (int)K, n_ct, (int)tiles);
+        linb_launch_nt256(s, (const bf16_t*)X, ldx, (const bf16_t*)Wb, bias, (bf16_t*)Y, ldy, T, (int)K, n_ct, tiles);
         MDL_LAUNCH_CHECK();
         return MDL_OK;
     }
@@ -387,12 +419,11 @@ extern "C" int mdl_linear_bwd_bf16(const uint16_t* X, int64_t ldx, const float* 
     if (dX) {   // dX = dY W: NT with B = W^T rows [K][N]
         hipLaunchKernelGGL(linb_w_transpose_kernel, dim3((unsigned)(K / 32), (unsigned)(N / 32)), dim3(256), 0, s, W, WT, (int)N, (int)K);
         MDL_LAUNCH_CHECK();
-        if ((K % QN) == 0 && linb_use_q(T, N)) {
+        if ((K % QN) == 0 && linb_use_q(T, N, K)) {
             const int n_ct = (int)(K / QN);
             const int64_t tiles = ((T + QM - 1) / QM) * n_ct;
             if (tiles > 0x7fffffff) return MDL_E_UNSUPPORTED;
-            hipLaunchKernelGGL(linb_nt256_kernel, dim3((unsigned)tiles), dim3(512), 0, s, (const bf16_t*)dY, lddy, (const bf16_t*)WT,
-                               (const float*)nullptr, (bf16_t*)dX, lddx, T, (int)N, n_ct, (int)tiles);
+            linb_launch_nt256(s, (const bf16_t*)dY, lddy, (const bf16_t*)WT, nullptr, (bf16_t*)dX, lddx, T, (int)N, n_ct, tiles);
             MDL_LAUNCH_CHECK();
         } else {
         const int n_ct = (int)((K + BBN - 1) / BBN);

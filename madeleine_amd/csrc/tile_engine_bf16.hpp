@@ -159,6 +159,12 @@ __device__ __forceinline__ void nt_mainloop_ring(SmemNTR<NS>& sm, f32x16 (&acc)[
 // 128 KiB, one workgroup per CU; the in-wave pipeline of the fp32 engine (fragments of k-step s+1 requested behind the first MFMA
 // of step s, one barrier per chunk before its last step, the next-but-one chunk's 8 LDS-DMA pieces between that step's MFMAs).
 // It wins on long contractions (K >= 1024); on K = 512 one workgroup per CU exposes the tile prologue and epilogue.
+// a wave-uniform pointer the compiler must keep in SGPRs (saddr operand of the LDS-DMA; loop-variant bases otherwise land in VGPRs)
+__device__ __forceinline__ const char* uniform_ptr(const char* p) {
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+}
 constexpr int QM = 256, QN = 256, QK = 64, Q_STAGE = QM * QK * 2;
 struct __attribute__((aligned(16))) SmemQ {
     char A[2][Q_STAGE];
@@ -252,9 +258,12 @@ __device__ __forceinline__ void nt256_mainloop(SmemQ& sm, f32x16 (&acc)[4][2], i
 // epilogue of the 256-tile: the wave's 128 x 64 sub-tile through its private 32 x 64 LDS transpose tile, as two 64-row halves of
 // epilogue_rows8 (emit sees tile-relative rows / columns)
 template <class Emit>
+// stage1 = true: the transpose tiles live in stage 1's memory only (waves 0-3: A[1], 4-7: B[1]) -- for persistent workgroups whose stage 0
+// already receives the next tile's first chunk during this epilogue
 __device__ __forceinline__ void nt256_epilogue(const f32x16 (&acc)[4][2], SmemQ& sm, int wave, int wm, int wn, int lane, int rows_valid,
-                                               Emit&& emit) {
-    float* tile = reinterpret_cast<float*>(&sm) + wave * (32 * 64);
+                                               Emit&& emit, bool stage1 = false) {
+    float* tile = stage1 ? reinterpret_cast<float*>(wave < 4 ? &sm.A[1][wave * 8192] : &sm.B[1][(wave - 4) * 8192])
+                         : reinterpret_cast<float*>(&sm) + wave * (32 * 64);
     const int colb[2] = {wn * 64, wn * 64 + 32};
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
