@@ -77,6 +77,59 @@ __device__ __forceinline__ float act_gelu_grad(float v) {
     else return gelu_grad_f(v);
 }
 
+// Round 5, bf16 mode: the sigmoid form above still spends two quarter-rate transcendentals per element (v_exp_f32, v_rcp_f32 = 8 of its
+// 15 issue slots), and the bf16 LayerNorm kernels are VALU-bound (forward 35 slots per element against 24 at the HBM rate).  Polynomials
+// instead -- nothing but FMAs, which the compiler packs two elements per instruction (v_pk_fma_f32):
+//     GELU(x)  = x (1/2 + xc P(xc^2)),   GELU'(x) = 1/2 + xc R(xc^2),   xc = clamp(x, -4, 4),   P, R of degree 7 in xc^2
+// minimax fits on [-4, 4] (tools/fit_gelu_poly.py): |GELU error| <= 3.8e-5, |GELU' error| <= 2.6e-4 -- an order of magnitude below the
+// bf16 grid of the O(1) values these kernels store (2^-9 relative); beyond +-4 the clamped argument leaves an error of <= 4.2e-5 |x|
+// (x Phi(-4) instead of ~0 on the far negative side; 3.3e-4 at |x| = 8, profiles/r05x_gelu_polynomial_fit.txt).
+// 6 issue slots per element instead of 15 (forward) / 21 (backward).  -DMDL_GELU_POLY=0 keeps the sigmoid form.
+#ifndef MDL_GELU_POLY
+#define MDL_GELU_POLY 1
+#endif
+constexpr float GP_P[8] = {3.986733996e-01f, -6.588784796e-02f, 9.505400654e-03f, -1.006490985e-03f,
+                           7.485512461e-05f, -3.657138657e-06f, 1.041962646e-07f, -1.301297819e-09f};
+constexpr float GP_R[8] = {7.967216592e-01f, -2.620298841e-01f, 5.591485367e-02f, -7.687450676e-03f,
+                           6.876469145e-04f, -3.845970028e-05f, 1.213811852e-06f, -1.641988682e-08f};
+__device__ __forceinline__ f32x4 clamp4(const f32x4& x, float lim) {
+    f32x4 c;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) c[e] = __builtin_amdgcn_fmed3f(x[e], -lim, lim);
+    return c;
+}
+__device__ __forceinline__ f32x4 poly7(const f32x4& x2, const float (&c)[8]) {
+    f32x4 p = x2 * c[7] + c[6];
+#pragma unroll
+    for (int k = 5; k >= 0; --k) p = p * x2 + c[k];
+    return p;
+}
+// element-wise over a float4 (the LayerNorm kernels work on groups of 4 columns)
+template <class IO>
+__device__ __forceinline__ f32x4 act_gelu4(const f32x4& t) {
+    f32x4 o;
+    if constexpr (sizeof(IO) == 2 && MDL_GELU_POLY) {
+        const f32x4 xc = clamp4(t, 4.f);
+        o = t * (xc * poly7(xc * xc, GP_P) + 0.5f);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = act_gelu<IO>(t[e]);
+    }
+    return o;
+}
+template <class IO>
+__device__ __forceinline__ f32x4 act_gelu_grad4(const f32x4& t) {
+    f32x4 o;
+    if constexpr (sizeof(IO) == 2 && MDL_GELU_POLY) {
+        const f32x4 xc = clamp4(t, 4.f);
+        o = xc * poly7(xc * xc, GP_R) + 0.5f;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = act_gelu_grad<IO>(t[e]);
+    }
+    return o;
+}
+
 struct ActDrop {
     float inv;
     uint32_t thr, key;
@@ -105,6 +158,35 @@ __device__ __forceinline__ void act_keep4(const ActDrop& d, uint32_t row_key, ui
         k[3] = (h1 >> 16) >= d.thr ? d.inv : 0.f;
     }
 }
+// DM >= 0 fixes the mode at compile time (0 off, 1 counter hash, 2 uint8 masks): no mode branch inside the column loop, which otherwise
+// cuts the row's arithmetic into a dozen basic blocks the scheduler cannot interleave; DM < 0 = the run-time form above
+template <int DM>
+__device__ __forceinline__ f32x4 act_keep4_t(const ActDrop& d, uint32_t row_key, uint32_t lo4, int64_t idx4) {
+    float k[4];
+    if constexpr (DM < 0) {
+        act_keep4(d, row_key, lo4, idx4, k);
+    } else if constexpr (DM == 0) {
+        k[0] = k[1] = k[2] = k[3] = 1.f;
+    } else if constexpr (DM == 2) {
+        const uint32_t m = *reinterpret_cast<const uint32_t*>(d.keep + idx4);
+        k[0] = (m & 0xFFu) ? d.inv : 0.f;
+        k[1] = (m & 0xFF00u) ? d.inv : 0.f;
+        k[2] = (m & 0xFF0000u) ? d.inv : 0.f;
+        k[3] = (m >> 24) ? d.inv : 0.f;
+    } else {
+        const uint32_t h0 = mix32(lo4 ^ row_key), h1 = mix32((lo4 + 2u) ^ row_key);
+        k[0] = (h0 & 0xFFFFu) >= d.thr ? d.inv : 0.f;
+        k[1] = (h0 >> 16) >= d.thr ? d.inv : 0.f;
+        k[2] = (h1 & 0xFFFFu) >= d.thr ? d.inv : 0.f;
+        k[3] = (h1 >> 16) >= d.thr ? d.inv : 0.f;
+    }
+    return f32x4{k[0], k[1], k[2], k[3]};
+}
+static inline int act_drop_mode(const ActDrop& d) { return !d.on ? 0 : (d.keep ? 2 : 1); }
+// the launchers' choice: compile-time mode for the (VALU-bound) bf16 kernels, the run-time form for fp32 storage (HBM-bound; measured
+// no gain there)
+template <class IO>
+static inline int ln_dm(const ActDrop& d) { return sizeof(IO) == 2 ? act_drop_mode(d) : -1; }
 __device__ __forceinline__ uint32_t act_row_key(const ActDrop& d, int64_t row_base) {
     return d.key ^ ((uint32_t)((uint64_t)row_base >> 32) * 0x9E3779B9U);
 }
@@ -199,7 +281,7 @@ __device__ __forceinline__ ActRange act_range(int64_t lo, int64_t hi, int RPB) {
 }
 
 // IMG: 0 = y only; 1 = split image only (the output feeds contractions of the split engine only); 2 = both (fp32 kernels only)
-template <int NV, int WPR, class IO, int IMG = 0>
+template <int NV, int WPR, class IO, int IMG = 0, int DM = -1>
 __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_fwd_kernel(const IO* __restrict__ x,
                                                                      const float* __restrict__ bias,
                                                                      const float* __restrict__ gamma,
@@ -269,15 +351,10 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_fwd_kernel(const IO* _
             f32x4 prev = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
-                f32x4 o;
-                float kp[4];
                 const int ci = cb + CM::off(i, lane);
-                act_keep4(drop, rkey, (uint32_t)rb + (uint32_t)ci, rb + ci, kp);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float t = (v[i][e] - mean) * rstd * g[i][e] + b[i][e];
-                    o[e] = act_gelu<IO>(t) * kp[e];
-                }
+                const f32x4 kp = act_keep4_t<DM>(drop, rkey, (uint32_t)rb + (uint32_t)ci, rb + ci);
+                const f32x4 t = (v[i] - mean) * rstd * g[i] + b[i];
+                const f32x4 o = act_gelu4<IO>(t) * kp;
                 if (IMG != 1) group_store<IO, NV>(yr, lane, i, prev, o);
                 if (IMG != 0) img_store4(img + r * (int64_t)(W * 4), ci, o, img_sc[0]);
                 prev = o;
@@ -301,7 +378,7 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_fwd_kernel(const IO* _
 }
 
 // IMG: dx is written as a split image (rows of 4 W bytes at `img`, scale img_sc[0]) instead of dx
-template <int NV, int WPR, class IO, bool IMG = false>
+template <int NV, int WPR, class IO, bool IMG = false, int DM = -1>
 __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_bwd_kernel(const IO* __restrict__ x,
                                                                      const float* __restrict__ bias,
                                                                      const float* __restrict__ gamma,
@@ -372,21 +449,20 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_bwd_kernel(const IO* _
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const f32x4 xv = xc[i] + lb[i], gv = gc[i];
-            float kp[4];
             const int ci = cb + CM::off(i, lane);
-            act_keep4(drop, rkey, (uint32_t)rb + (uint32_t)ci, rb + ci, kp);
+            const f32x4 kp = act_keep4_t<DM>(drop, rkey, (uint32_t)rb + (uint32_t)ci, rb + ci);
+            const f32x4 h = (xv - mean) * rstd;
+            const f32x4 t = h * g[i] + b[i];
+            const f32x4 dt = gv * kp * act_gelu_grad4<IO>(t);  // d/d(LN output); rows past the end carry gv = 0
+            sg[i] += dt * h;
+            sb[i] += dt;
+            const f32x4 dh = dt * g[i];
+            xh[i] = h;
+            dxh[i] = dh;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float h = (xv[e] - mean) * rstd;
-                const float t = h * g[i][e] + b[i][e];
-                const float dt = gv[e] * kp[e] * act_gelu_grad<IO>(t);  // d/d(LN output); rows past the end carry gv = 0
-                sg[i][e] += dt * h;
-                sb[i][e] += dt;
-                const float dh = dt * g[i][e];
-                xh[i][e] = h;
-                dxh[i][e] = dh;
-                s1 += dh;
-                s2 += dh * h;
+                s1 += dh[e];
+                s2 += dh[e] * h[e];
             }
         }
         row_allreduce2<WPR>(s1, s2, red, slot * WPR, wv);
@@ -580,16 +656,29 @@ static int ln_fwd_launch(const IO* x, const float* bias, const float* gamma, con
     if (W == 2048) {  // forward: a whole 2048-wide row per wave (153 VGPRs, no block barriers) beats 4 waves per row
         int64_t nb = (rows + 4 / MDL_LN_F_WPR - 1) / (4 / MDL_LN_F_WPR);
         if (nb > MDL_LN_GRID_CAP) nb = MDL_LN_GRID_CAP;
-        hipLaunchKernelGGL((ln_gelu_drop_fwd_kernel<MDL_LN_F_NV, MDL_LN_F_WPR, IO>), dim3((unsigned)nb), dim3(ACT_BLOCK), 0, (hipStream_t)stream, x,
-                           bias, gamma, beta, y, mean, rstd, rows, eps, d);
+#define MDL_LN_FWD(NVV, WPRV, DMV)                                                                                                  \
+    hipLaunchKernelGGL((ln_gelu_drop_fwd_kernel<NVV, WPRV, IO, 0, DMV>), dim3((unsigned)nb), dim3(ACT_BLOCK), 0, (hipStream_t)stream, x, \
+                       bias, gamma, beta, y, mean, rstd, rows, eps, d)
+#define MDL_LN_FWD_DM(NVV, WPRV)                  \
+    do {                                          \
+        if (dm < 0) MDL_LN_FWD(NVV, WPRV, -1);    \
+        else if (dm == 0) MDL_LN_FWD(NVV, WPRV, 0); \
+        else if (dm == 1) MDL_LN_FWD(NVV, WPRV, 1); \
+        else MDL_LN_FWD(NVV, WPRV, 2);            \
+    } while (0)
+        const int dm = ln_dm<IO>(d);
+        MDL_LN_FWD_DM(MDL_LN_F_NV, MDL_LN_F_WPR);
         MDL_LAUNCH_CHECK();
         return MDL_OK;
     }
     MDL_DISPATCH_W(W, {
-        hipLaunchKernelGGL((ln_gelu_drop_fwd_kernel<NV, WPR, IO>), dim3(act_blocks(rows, W)), dim3(ACT_BLOCK), 0,
-                           (hipStream_t)stream, x, bias, gamma, beta, y, mean, rstd, rows, eps, d);
+        const int nb = act_blocks(rows, W);
+        const int dm = ln_dm<IO>(d);
+        MDL_LN_FWD_DM(NV, WPR);
         MDL_LAUNCH_CHECK();
     });
+#undef MDL_LN_FWD_DM
+#undef MDL_LN_FWD
     return MDL_OK;
 }
 
@@ -615,17 +704,29 @@ static int ln_bwd_launch(const IO* x, const float* bias, const float* gamma, con
         int64_t b2 = (rows + 4 / MDL_LN_B_WPR - 1) / (4 / MDL_LN_B_WPR);
         if (b2 > MDL_LN_GRID_CAP) b2 = MDL_LN_GRID_CAP;
         nb = (int)b2;
-        hipLaunchKernelGGL((ln_gelu_drop_bwd_kernel<MDL_LN_B_NV, MDL_LN_B_WPR, IO>), dim3(nb), dim3(ACT_BLOCK), 0, s, x, bias, gamma, beta, mean, rstd, dy, dx,
-                           (float*)ws, rows, d);
+#define MDL_LN_BWD(NVV, WPRV, DMV)                                                                                                  \
+    hipLaunchKernelGGL((ln_gelu_drop_bwd_kernel<NVV, WPRV, IO, false, DMV>), dim3(nb), dim3(ACT_BLOCK), 0, s, x, bias, gamma, beta, mean, \
+                       rstd, dy, dx, (float*)ws, rows, d)
+#define MDL_LN_BWD_DM(NVV, WPRV)                  \
+    do {                                          \
+        if (dm < 0) MDL_LN_BWD(NVV, WPRV, -1);    \
+        else if (dm == 0) MDL_LN_BWD(NVV, WPRV, 0); \
+        else if (dm == 1) MDL_LN_BWD(NVV, WPRV, 1); \
+        else MDL_LN_BWD(NVV, WPRV, 2);            \
+    } while (0)
+        const int dm = ln_dm<IO>(d);
+        MDL_LN_BWD_DM(MDL_LN_B_NV, MDL_LN_B_WPR);
         MDL_LAUNCH_CHECK();
     } else
     MDL_DISPATCH_W(W, {
         if (nb > 0) {
-            hipLaunchKernelGGL((ln_gelu_drop_bwd_kernel<NV, WPR, IO>), dim3(nb), dim3(ACT_BLOCK), 0, s, x, bias, gamma, beta, mean, rstd, dy,
-                               dx, (float*)ws, rows, d);
+            const int dm = ln_dm<IO>(d);
+            MDL_LN_BWD_DM(NV, WPR);
             MDL_LAUNCH_CHECK();
         }
     });
+#undef MDL_LN_BWD_DM
+#undef MDL_LN_BWD
     hipLaunchKernelGGL(ln_reduce_kernel, dim3((3 * W + 31) / 32), dim3(256), 0, s, (const float*)ws, dgamma, dbeta, dbias, nb, W);
     MDL_LAUNCH_CHECK();
     return MDL_OK;
