@@ -85,6 +85,14 @@ __device__ __forceinline__ float act_gelu_grad(float v) {
 // bf16 grid of the O(1) values these kernels store (2^-9 relative); beyond +-4 the clamped argument leaves an error of <= 4.2e-5 |x|
 // (x Phi(-4) instead of ~0 on the far negative side; 3.3e-4 at |x| = 8, profiles/r05x_gelu_polynomial_fit.txt).
 // 6 issue slots per element instead of 15 (forward) / 21 (backward).  -DMDL_GELU_POLY=0 keeps the sigmoid form.
+// split-mode (fp32 storage, image out) kernels with the hash dropout mode fixed at compile time.  Same-box A/B at config 2
+// (profiles/r05z): forward 0.447 -> 0.435 ms avg (3 of 3 pairs), backward 0.660 -> 0.678 (3 of 3 the other way) -- so forward only.
+#ifndef MDL_LN_IMG_DM_FWD
+#define MDL_LN_IMG_DM_FWD 1
+#endif
+#ifndef MDL_LN_IMG_DM
+#define MDL_LN_IMG_DM 0   // the backward
+#endif
 #ifndef MDL_GELU_POLY
 #define MDL_GELU_POLY 1
 #endif
@@ -782,6 +790,9 @@ extern "C" int mdl_ln_gelu_drop_fwd_split(const float* x, const float* bias, con
     do {                                                                                                                               \
         if (y) hipLaunchKernelGGL((ln_gelu_drop_fwd_kernel<NVV, WPRV, float, 2>), dim3((unsigned)(NB)), dim3(ACT_BLOCK), 0, s, x, bias, \
                                   gamma, beta, y, mean, rstd, rows, eps, d, (char*)img, (const float*)scale, row_mul, rstd_max);        \
+        else if (MDL_LN_IMG_DM_FWD && act_drop_mode(d) == 1)                                                                            \
+            hipLaunchKernelGGL((ln_gelu_drop_fwd_kernel<NVV, WPRV, float, 1, MDL_LN_IMG_DM_FWD ? 1 : -1>), dim3((unsigned)(NB)), dim3(ACT_BLOCK), 0, \
+                               s, x, bias, gamma, beta, y, mean, rstd, rows, eps, d, (char*)img, (const float*)scale, row_mul, rstd_max); \
         else hipLaunchKernelGGL((ln_gelu_drop_fwd_kernel<NVV, WPRV, float, 1>), dim3((unsigned)(NB)), dim3(ACT_BLOCK), 0, s, x, bias,   \
                                 gamma, beta, y, mean, rstd, rows, eps, d, (char*)img, (const float*)scale, row_mul, rstd_max);          \
     } while (0)
@@ -882,18 +893,28 @@ static int ln_bwd_split_impl(const float* x, const float* bias, const float* gam
                            (const float*)nullptr);
         MDL_LAUNCH_CHECK();
     }
+    const bool hash_dm = MDL_LN_IMG_DM && act_drop_mode(d) == 1;   // (A/B: the counter-hash mode fixed at compile time)
+#define MDL_LN_BWD_IMG(NVV, WPRV)                                                                                                       \
+    do {                                                                                                                                \
+        if (hash_dm)                                                                                                                    \
+            hipLaunchKernelGGL((ln_gelu_drop_bwd_kernel<NVV, WPRV, float, true, MDL_LN_IMG_DM ? 1 : -1>), grid, dim3(ACT_BLOCK), 0, s, x, bias, \
+                               gamma, beta, mean, rstd, dy, (float*)nullptr, part, rows, d, (char*)dx_img, (const float*)dx_scale, row_mul, \
+                               cu_groups);                                                                                              \
+        else                                                                                                                            \
+            hipLaunchKernelGGL((ln_gelu_drop_bwd_kernel<NVV, WPRV, float, true>), grid, dim3(ACT_BLOCK), 0, s, x, bias, gamma, beta, mean, \
+                               rstd, dy, (float*)nullptr, part, rows, d, (char*)dx_img, (const float*)dx_scale, row_mul, cu_groups);    \
+    } while (0)
     if (W == 2048 && nb > 0) {
-        hipLaunchKernelGGL((ln_gelu_drop_bwd_kernel<4, 2, float, true>), grid, dim3(ACT_BLOCK), 0, s, x, bias, gamma, beta, mean, rstd, dy,
-                           (float*)nullptr, part, rows, d, (char*)dx_img, (const float*)dx_scale, row_mul, cu_groups);
+        MDL_LN_BWD_IMG(4, 2);
         MDL_LAUNCH_CHECK();
     } else
     MDL_DISPATCH_W(W, {
         if (nb > 0) {
-            hipLaunchKernelGGL((ln_gelu_drop_bwd_kernel<NV, WPR, float, true>), grid, dim3(ACT_BLOCK), 0, s, x, bias, gamma, beta, mean,
-                               rstd, dy, (float*)nullptr, part, rows, d, (char*)dx_img, (const float*)dx_scale, row_mul, cu_groups);
+            MDL_LN_BWD_IMG(NV, WPR);
             MDL_LAUNCH_CHECK();
         }
     });
+#undef MDL_LN_BWD_IMG
     hipLaunchKernelGGL(ln_reduce_kernel, dim3((3 * W + 31) / 32), dim3(256), 0, s, (const float*)part, dgamma, dbeta, dbias, nb, W);
     MDL_LAUNCH_CHECK();
     if (cu_groups) {
