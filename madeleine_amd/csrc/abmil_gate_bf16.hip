@@ -546,6 +546,66 @@ __global__ __launch_bounds__(256, 2) void gate_dw_bf16_kernel(const bf16_t* __re
 // ---- workspace layouts -------------------------------------------------------------------------------
 static inline int64_t up16(int64_t b) { return (b + 15) & ~(int64_t)15; }
 
+// dW on the 256 x 256 tile (round 5; tn256_mainloop, 64-token chunks): tile = 256 of the head's 512 E columns x 256 of its 1024 dz columns,
+// 8 tiles per head and split.  E rows past T - 1 re-read row T - 1: their dz rows are the zero pad (TQK rows).
+__global__ __launch_bounds__(512) void gate_dw256_bf16_kernel(const bf16_t* __restrict__ E, int64_t ldE, const bf16_t* __restrict__ dz,
+                                                              float* __restrict__ slabW, int64_t T, int H, int64_t tok_per_split,
+                                                              int n_splits) {
+    __shared__ SmemQ sm;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const XcdHead xh = xcd_head(blockIdx.x, H);
+    const int kt = xh.li % 2, ntile = (xh.li / 2) % 4, c = xh.c, sp = (xh.li / 8) * xh.nshare + xh.share;
+    if (sp >= n_splits) return;  // block-uniform
+    const int k0 = kt * 256, n0 = ntile * 256;
+    const int64_t ts = (int64_t)sp * tok_per_split;
+    int64_t te = ts + tok_per_split;
+    if (te > T) te = T;
+    const int64_t nch = (te > ts) ? (te - ts + TQK - 1) / TQK : 0;
+
+    const char* baseA = reinterpret_cast<const char*>(E + ts * ldE + (int64_t)c * HID + k0);
+    const char* baseB = reinterpret_cast<const char*>(dz + (ts * H + c) * 1024 + n0);
+    const uint32_t ldA2 = (uint32_t)ldE * 2u, ldB2 = (uint32_t)H * 1024u * 2u;
+    uint32_t rowq[4], cs[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int row, src;
+        tn256_slot(wave, q, lane, row, src);
+        rowq[q] = (uint32_t)row;
+        cs[q] = (uint32_t)src << 4;
+    }
+    auto dma = [&](int st, int64_t f, int piece) {
+        const int q = piece & 3;
+        if (piece < 4) {
+            uint32_t k = rowq[q];
+            const int64_t left = T - 1 - (ts + f * TQK);
+            if (left < TQK) k = k < (uint32_t)left ? k : (uint32_t)left;   // uniform branch: only the chunk at the end of E
+            glds16_s(k * ldA2 + cs[q], uniform_ptr(baseA + f * TQK * (int64_t)ldA2), lds_addr_of(&sm.A[st][(wave * 4 + q) * 1024]));
+        } else {
+            glds16_s(rowq[q] * ldB2 + cs[q], uniform_ptr(baseB + f * TQK * (int64_t)ldB2), lds_addr_of(&sm.B[st][(wave * 4 + q) * 1024]));
+        }
+    };
+    f32x16 acc[4][2];
+    tn256_mainloop(sm, acc, nch, wm, wn, lane, dma);
+
+    // slabW [split][head][k' 512][1024: a-cols 0..511 | b-cols 512..1023]
+    float* __restrict__ so = slabW + (((int64_t)sp * H + c) * HID) * 1024;
+    const int l32 = lane & 31;
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kr = k0 + wm * 128 + rt * 32 + acc_row(r, lane);
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) so[(int64_t)kr * 1024 + n0 + wn * 64 + ct * 32 + l32] = acc[rt][ct][r];
+        }
+}
+static inline bool gate_dw_use_q(int64_t T) {
+    static const bool off = getenv("MADELEINE_BF16_TN256") && atoi(getenv("MADELEINE_BF16_TN256")) == 0;   // A/B switch
+    return !off && T >= 16384;
+}
+
 struct BwdWs {
     int S;
     int64_t tps, Tpad, nblk;
@@ -553,15 +613,18 @@ struct BwdWs {
 };
 static inline BwdWs bwd_ws(int64_t T, int H) {
     BwdWs w;
-    w.S = splits_for(T, 16 * H, 512);   // gate_dw_bf16_kernel: 200 VGPRs = two workgroups per CU
+    const bool q = gate_dw_use_q(T);
+    const int chunk = q ? TQK : TNK;
+    w.S = q ? splits_for(T, 8 * H, 256)     // gate_dw256_bf16_kernel: one workgroup per CU
+            : splits_for(T, 16 * H, 512);   // gate_dw_bf16_kernel: 200 VGPRs = two workgroups per CU
     int64_t tps = (T + w.S - 1) / w.S;
-    w.tps = ((tps + TNK - 1) / TNK) * TNK;  // whole 32-token chunks: a chunk never straddles two splits
-    if (w.tps < TNK) w.tps = TNK;
+    w.tps = ((tps + chunk - 1) / chunk) * chunk;  // whole chunks of tokens: a chunk never straddles two splits
+    if (w.tps < chunk) w.tps = chunk;
     w.Tpad = w.tps * w.S;
     w.nblk = (T + DZ_ROWS - 1) / DZ_ROWS;
     int64_t o = 0;
     w.oWN = o; o += up16((int64_t)H * HID * 1024 * 2);
-    w.odz = o; o += up16((T + TNK) * H * 1024 * 2);   // + TNK zero rows: K-tail of the dW contraction
+    w.odz = o; o += up16((T + TQK) * H * 1024 * 2);   // + TQK zero rows: K-tail of the dW contraction
     w.oslabW = o; o += up16((int64_t)w.S * H * HID * 1024 * 4);
     w.oslabV = o; o += up16(w.nblk * H * 4 * HID * 4);
     w.total = o + 64;
@@ -683,7 +746,7 @@ static int gate_bwd_bf16_impl(const uint16_t* E, int64_t ldE, const float* Wa, c
     if (L.nblk * H > 0x7fffffff) return MDL_E_UNSUPPORTED;
     if (phases & 1) {
         {   // zero pad rows of dz (K-tail of the dW contraction)
-            const hipError_t e = hipMemsetAsync(dz + T * H * 1024, 0, (size_t)TNK * H * 1024 * 2, s);
+            const hipError_t e = hipMemsetAsync(dz + T * H * 1024, 0, (size_t)TQK * H * 1024 * 2, s);
             if (e != hipSuccess) return (int)e;
         }
         if (T > 0) {
@@ -716,6 +779,10 @@ static int gate_bwd_bf16_impl(const uint16_t* E, int64_t ldE, const float* Wa, c
             }
             MDL_LAUNCH_CHECK();
         }
+        if (gate_dw_use_q(T))
+            hipLaunchKernelGGL(gate_dw256_bf16_kernel, dim3((unsigned)xcd_head_grid(L.S, 8, H)), dim3(512), 0, s, (const bf16_t*)E, ldE,
+                               (const bf16_t*)dz, slabW, T, H, L.tps, L.S);
+        else
         hipLaunchKernelGGL(gate_dw_bf16_kernel, dim3((unsigned)xcd_head_grid(L.S, 16, H)), dim3(256), 0, s, (const bf16_t*)E, ldE,
                            (const bf16_t*)dz, slabW, T, H, L.tps, L.S);
         MDL_LAUNCH_CHECK();

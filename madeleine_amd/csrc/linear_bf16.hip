@@ -304,18 +304,90 @@ __global__ __launch_bounds__(256) void linb_colsum_final_kernel(const float* __r
 static inline int64_t up16l(int64_t b) { return (b + 15) & ~(int64_t)15; }
 constexpr int LINB_COLSUM_BLOCKS = 1024;
 
+// ---- TN product on the 256 x 256 tile (round 5): tn256_mainloop, 64-token chunks; N % 256 == 0 (rows of the slab = dY columns), ragged K
+// tail as above.  Token rows past T: dY reads the zero row (per-lane address form, last chunk only), X re-reads row T - 1.
+__global__ __launch_bounds__(512) void linb_tn256_kernel(const bf16_t* __restrict__ dY, int64_t lddy, const bf16_t* __restrict__ X,
+                                                         int64_t ldx, const bf16_t* __restrict__ zrow, float* __restrict__ slab,
+                                                         int64_t T, int N, int K, int64_t tok_per_split, int n_splits, int n_tiles) {
+    __shared__ SmemQ sm;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int lid = xcd_remap(blockIdx.x, n_tiles);
+    const int n_kt = (K + 255) / 256, n_nt = N / 256;
+    const int kt = lid % n_kt, ntile = (lid / n_kt) % n_nt, sp = lid / (n_kt * n_nt);
+    if (sp >= n_splits) return;
+    const int n0 = ntile * 256, k0 = kt * 256;
+    const int64_t ts = (int64_t)sp * tok_per_split;
+    int64_t te = ts + tok_per_split;
+    if (te > T) te = T;
+    const int64_t nch = (te > ts) ? (te - ts + TQK - 1) / TQK : 0;
+
+    const char* baseA = reinterpret_cast<const char*>(dY + ts * lddy + n0);
+    const char* baseB = reinterpret_cast<const char*>(X + ts * ldx + k0);
+    const uint32_t ldA2 = (uint32_t)lddy * 2u, ldB2 = (uint32_t)ldx * 2u;
+    uint32_t rowq[4], csA[4], csB[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int row, src;
+        tn256_slot(wave, q, lane, row, src);
+        rowq[q] = (uint32_t)row;
+        csA[q] = (uint32_t)src << 4;
+        csB[q] = (k0 + src * 8 >= K) ? 0u : ((uint32_t)src << 4);   // ragged last column tile: re-read chunk 0, those columns are not stored
+    }
+    auto dma = [&](int st, int64_t f, int piece) {
+        const int q = piece & 3;
+        const int64_t left = T - 1 - (ts + f * TQK);   // index of the last valid token row within this chunk
+        if (piece < 4) {
+            if (left < TQK - 1) {   // uniform: only the chunk that crosses T
+                const char* p = ((int64_t)rowq[q] <= left) ? baseA + (f * TQK + rowq[q]) * (int64_t)ldA2 + csA[q] : reinterpret_cast<const char*>(zrow);
+                glds16(p, &sm.A[st][(wave * 4 + q) * 1024]);
+            } else {
+                glds16_s(rowq[q] * ldA2 + csA[q], uniform_ptr(baseA + f * TQK * (int64_t)ldA2), lds_addr_of(&sm.A[st][(wave * 4 + q) * 1024]));
+            }
+        } else {
+            uint32_t k = rowq[q];
+            if (left < TQK - 1) k = ((int64_t)k <= left) ? k : (uint32_t)(left > 0 ? left : 0);
+            glds16_s(k * ldB2 + csB[q], uniform_ptr(baseB + f * TQK * (int64_t)ldB2), lds_addr_of(&sm.B[st][(wave * 4 + q) * 1024]));
+        }
+    };
+    f32x16 acc[4][2];
+    tn256_mainloop(sm, acc, nch, wm, wn, lane, dma);
+
+    float* __restrict__ so = slab + (int64_t)sp * N * K;
+    const int l32 = lane & 31;
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int nr = n0 + wm * 128 + rt * 32 + acc_row(r, lane);
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                const int kc = k0 + wn * 64 + ct * 32 + l32;
+                if (kc < K) so[(int64_t)nr * K + kc] = acc[rt][ct][r];
+            }
+        }
+}
+
 struct LinbWs {
     int S;
     int64_t tps;
     int64_t oW, oWT, oslab, ozrow, ocpart, total;
 };
+// the 256-tile TN kernel: output rows (N) in whole 256-row tiles and enough tokens to amortise one workgroup per CU
+static inline bool linb_tn_use_q(int64_t T, int N) {
+    static const bool off = getenv("MADELEINE_BF16_TN256") && atoi(getenv("MADELEINE_BF16_TN256")) == 0;   // A/B switch
+    return !off && T >= 16384 && N % 256 == 0;
+}
 static inline LinbWs linb_ws(int64_t T, int N, int K) {
     LinbWs w;
-    const int tiles = (N / 128) * ((K + 255) / 256);
-    w.S = splits_for(T, tiles > 0 ? tiles : 1, 512);
+    const bool q = linb_tn_use_q(T, N);
+    const int tiles = (N / (q ? 256 : 128)) * ((K + 255) / 256);
+    const int chunk = q ? TQK : TNK;
+    w.S = splits_for(T, tiles > 0 ? tiles : 1, q ? 256 : 512);
     int64_t tps = (T + w.S - 1) / w.S;
-    w.tps = ((tps + TNK - 1) / TNK) * TNK;
-    if (w.tps < TNK) w.tps = TNK;
+    w.tps = ((tps + chunk - 1) / chunk) * chunk;
+    if (w.tps < chunk) w.tps = chunk;
     w.S = (int)((T + w.tps - 1) / w.tps);
     if (w.S < 1) w.S = 1;
     int64_t o = 0;
@@ -435,8 +507,13 @@ extern "C" int mdl_linear_bwd_bf16(const uint16_t* X, int64_t ldx, const float* 
         }
     }
     {
-        const int64_t tiles = (int64_t)L.S * (N / 128) * ((K + 255) / 256);
+        const bool q = linb_tn_use_q(T, (int)N);
+        const int64_t tiles = (int64_t)L.S * (N / (q ? 256 : 128)) * ((K + 255) / 256);
         if (tiles > 0x7fffffff) return MDL_E_UNSUPPORTED;
+        if (q)
+            hipLaunchKernelGGL(linb_tn256_kernel, dim3((unsigned)tiles), dim3(512), 0, s, (const bf16_t*)dY, lddy, (const bf16_t*)X, ldx,
+                               (const bf16_t*)zrow, slab, T, (int)N, (int)K, L.tps, L.S, (int)tiles);
+        else
         hipLaunchKernelGGL(linb_tn_kernel, dim3((unsigned)tiles), dim3(256), 0, s, (const bf16_t*)dY, lddy, (const bf16_t*)X, ldx,
                            (const bf16_t*)zrow, slab, T, (int)N, (int)K, L.tps, L.S, (int)tiles);
         MDL_LAUNCH_CHECK();

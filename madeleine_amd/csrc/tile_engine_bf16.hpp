@@ -388,4 +388,130 @@ __device__ __forceinline__ void tn_mainloop(SmemTN& sm, f32x16 (&acc)[2][4], int
     __syncthreads();
 }
 
+
+// ---- TN on the 256 x 256 tile (round 5) -------------------------------------------------------------------------------------------------
+// The 128 x 256 x 32 loop above stages 24.5 KB per 2.1 MFLOP (85 flop per byte through L2 -> LDS) and takes a barrier every 16 MFMAs per
+// wave: the Linear / gate dW products ran at 320-455 TF where the 256-tile NT products reach 780-890.  Here: 8 waves (2 x 4), each 128 x 64
+// = 4 x 2 MFMA tiles, chunks of TQK = 64 tokens, stage = [64 tokens][256 columns] bf16 per operand (512-B rows, 64-B unit u of token row
+// t stored at unit u ^ (t & 3)), two stages = SmemQ's 128 KiB -- the image and the fragment reads of the split engine's TN loop
+// (split_engine.hpp sp_tn_mainloop) with one bf16 plane of 64 tokens instead of two fp16 planes of 32: 128 flop per staged byte, a barrier
+// every 32 MFMAs.  k-step KS (16 tokens) = + KS * 8192 B; the second half of a k-step's fragment = + 4 rows = 2048 B.
+// DMA piece q (< 4) of wave w for one operand: token rows (4 w + q) * 2 + (lane >> 5); the stored 16-B chunk position lane & 31 holds
+// the global chunk (lane & 31) ^ ((row & 3) << 2) (8 columns each)  ->  LDS bytes (4 w + q) * 1024 + lane * 16.
+constexpr int TQK = 64;
+struct Tn256Frag {
+    u32x2 a[4][2], b[2][2];
+};
+template <int KS>
+__device__ __forceinline__ void tn256_load(Tn256Frag& f, const uint32_t (&aA)[4], const uint32_t (&aB)[2]) {
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+        f.a[rt][0] = ds_tr16<KS * 8192>(aA[rt]);
+        f.a[rt][1] = ds_tr16<KS * 8192 + 2048>(aA[rt]);
+    }
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        f.b[ct][0] = ds_tr16<KS * 8192>(aB[ct]);
+        f.b[ct][1] = ds_tr16<KS * 8192 + 2048>(aB[ct]);
+    }
+}
+__device__ __forceinline__ void tn256_mma(f32x16 (&acc)[4][2], const Tn256Frag& f, int m) {
+    const int rt = m >> 1, ct = m & 1;
+    const u32x4 av = {f.a[rt][0].x, f.a[rt][0].y, f.a[rt][1].x, f.a[rt][1].y};
+    const u32x4 bv = {f.b[ct][0].x, f.b[ct][0].y, f.b[ct][1].x, f.b[ct][1].y};
+    acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc[rt][ct], 0,
+                                                          0, 0);
+}
+// this lane's token row and source chunk (x 16 B) of DMA piece q
+__device__ __forceinline__ void tn256_slot(int wave, int q, int lane, int& row, int& src_chunk) {
+    row = (wave * 4 + q) * 2 + (lane >> 5);
+    src_chunk = (lane & 31) ^ ((row & 3) << 2);
+}
+// acc[rt][ct] += sum over nch chunks of 64 tokens of A[t][wm*128 + rt*32 ..] B[t][wn*64 + ct*32 ..];  dma(stage, chunk, piece < 8):
+// pieces 0-3 = this wave's A token-row pairs, 4-7 = its B pairs (glds16_s).  acc is zeroed here.
+template <class Dma>
+__device__ __forceinline__ void tn256_mainloop(SmemQ& sm, f32x16 (&acc)[4][2], int64_t nch, int wm, int wn, int lane, Dma&& dma) {
+    const int g = lane >> 4, r = lane & 15;
+    const int kb = (g >> 1) * 8 + (r >> 2);
+    uint32_t a_0[4], b_0[2];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+        a_0[rt] = lds_addr_of(&sm.A[0][0]) + kb * 512 + (((wm * 128 + rt * 32 + (g & 1) * 16 + (r & 3) * 4) * 2) ^ ((kb & 3) << 6));
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+        b_0[ct] = lds_addr_of(&sm.B[0][0]) + kb * 512 + (((wn * 64 + ct * 32 + (g & 1) * 16 + (r & 3) * 4) * 2) ^ ((kb & 3) << 6));
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    if (nch <= 0) return;
+#define TQ_SB() __builtin_amdgcn_sched_barrier(0)
+#define TQ_LGKM() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#pragma unroll
+    for (int p = 0; p < 8; ++p) dma(0, (int64_t)0, p);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    {
+        const int64_t f = nch > 1 ? 1 : 0;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) dma(1, f, p);
+    }
+    Tn256Frag f0, f1;
+    tn256_load<0>(f0, a_0, b_0);
+    TQ_LGKM();
+    TQ_SB();
+    // one k-step: its first MFMA, the fragment requests of the next k-step behind it, the other 7 MFMAs, then the wait for those requests
+    // (inline-asm LDS reads are not tracked by the compiler's s_waitcnt insertion)
+#define TQ_SET(F, LOADS)                                                \
+    tn256_mma(acc, F, 0);                                               \
+    TQ_SB();                                                            \
+    LOADS;                                                              \
+    TQ_SB();                                                            \
+    _Pragma("unroll") for (int m = 1; m < 8; ++m) tn256_mma(acc, F, m); \
+    TQ_SB();                                                            \
+    TQ_LGKM();                                                          \
+    TQ_SB();
+    for (int64_t ch = 0; ch < nch; ++ch) {
+        const int st = (int)(ch & 1);
+        uint32_t aA[4], aB[2], nA[4], nB[2];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+            aA[rt] = a_0[rt] + st * Q_STAGE;
+            nA[rt] = a_0[rt] + (st ^ 1) * Q_STAGE;
+        }
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            aB[ct] = b_0[ct] + st * Q_STAGE;
+            nB[ct] = b_0[ct] + (st ^ 1) * Q_STAGE;
+        }
+        TQ_SET(f0, tn256_load<1>(f1, aA, aB))
+        TQ_SET(f1, tn256_load<2>(f0, aA, aB))
+        TQ_SET(f0, tn256_load<3>(f1, aA, aB))
+        // last k-step of the chunk: every read of stage st has been requested and waited for -> this wave's DMA of the next chunk must
+        // have landed, barrier, then the next chunk's first fragments and the DMA of chunk ch + 2 between this k-step's MFMAs
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        TQ_SB();
+        __syncthreads();
+        tn256_load<0>(f0, nA, nB);
+        TQ_SB();
+        const int64_t f = (ch + 2 < nch) ? ch + 2 : nch - 1;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            tn256_mma(acc, f1, m);
+            TQ_SB();
+            dma(st, f, m);
+            TQ_SB();
+        }
+        TQ_LGKM();
+        TQ_SB();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped re-fetches of the tail
+    __syncthreads();
+#undef TQ_SET
+#undef TQ_LGKM
+#undef TQ_SB
+}
+
 }  // namespace mdl

@@ -53,7 +53,8 @@ def test_ln_gelu_drop_bf16_vs_fp32_kernel(dev, W, rows):
 @pytest.mark.parametrize("T,N,K,bias", [(1000, 512, 512, False), (4133, 256, 512, True), (257, 2048, 256, True),
                                          (20000, 512, 1024, False), (1500, 128, 2048, True), (700, 384, 256, False),
                                          (3000, 512, 800, False), (999, 256, 96, True), (5003, 512, 512, True),
-                                         (4100, 256, 2048, False), (4357, 1024, 256, True)])
+                                         (4100, 256, 2048, False), (4357, 1024, 256, True),
+                                         (16500, 2048, 512, True), (17001, 256, 800, False)])   # T >= 16384: the 256-tile TN kernel (ragged T, K)
 def test_linear_bf16_vs_fp32_math(dev, T, N, K, bias):
     """mdl_linear_*_bf16 (hand-written bf16 MFMA Linears) against fp32 matmuls of the same bf16-representable operands.  The
     products of bf16 values are exact in fp32 and accumulation is fp32, so Y / dX differ from the reference by the output
@@ -100,7 +101,7 @@ def test_pool_bf16_vs_fp32_kernel(dev):
     assert rel_err(res["bf16"][1], res["f32"][1]) < EPS_BF16           # dE rounded once to bf16
 
 
-@pytest.mark.parametrize("T,p", [(300, 0.0), (1000, 0.25), (5, 0.25)])
+@pytest.mark.parametrize("T,p", [(300, 0.0), (1000, 0.25), (5, 0.25), (16421, 0.25)])   # 16421: the 256-tile forward / dX / dW kernels, ragged tail
 def test_gate_bf16_vs_fp32_kernel(dev, T, p):
     """bf16 MFMA gate (fwd, dX, dW through the transposed copies, column sums) against the fp32 gate kernels fed the
     same bf16-representable E and weights.  Differences: fp32 accumulation order, the bf16 rounding of the stored
