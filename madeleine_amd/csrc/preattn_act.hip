@@ -652,8 +652,8 @@ static int ln_fwd_launch(const IO* x, const float* bias, const float* gamma, con
     const ActDrop d = make_act_drop(p_drop, seed, keep);
 // (geometry of the 2048-wide kernels as macros: round 5 swept forward <4,2> / <2,4>, backward <8,1> / <2,4> and grid caps 768 / 1024 on fp32
 // and bf16 storage -- the shipped <8,1> / <4,2> / 2048 is the best or within noise everywhere, profiles/r05i_ln_2048_geometry_variants.txt;
-// the bf16 kernels (4.0 / 3.9 TB/s) are bound by their ~20 VALU issue slots per element -- two quarter-rate transcendentals of the
-// GELU, the counter hash -- not by the row geometry)
+// the bf16 kernels (then 4.0 / 3.9 TB/s) were bound by their VALU work, not by the row geometry: see act_gelu4 (polynomial GELU, round 5:
+// 2048-wide forward 4.7 TB/s, backward 4.5; the sweep repeated after that change confirms <8,1> / <4,2>, profiles/r05x_*)
 #ifndef MDL_LN_F_NV
 #define MDL_LN_F_NV 8
 #define MDL_LN_F_WPR 1
