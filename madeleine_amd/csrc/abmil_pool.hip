@@ -17,6 +17,9 @@
 
 #include "split_engine.hpp"
 
+#ifndef MDL_POOL_U
+#define MDL_POOL_U 8   // token rows in flight per thread in the forward's accumulation loop
+#endif
 #ifndef MDL_POOL_PRE
 #define MDL_POOL_PRE 1   // pool_partial_kernel: request the first rows of a chunk before its softmax statistics
 #endif
@@ -131,7 +134,7 @@ __global__ __launch_bounds__(H * 128) POOL_FWD_ATTR void pool_partial_kernel(con
     // the score load (loads return in order: the statistics then wait for vmcnt(U), not 0), they are unconditional (a branch around them
     // would make the join wait for vmcnt(0): a short tail chunk re-requests its last row for u >= nt, which meets p_s == 0 below), and
     // the phase's barriers (POOL_SYNC) wait for the LDS traffic only -- __syncthreads would drain the row loads in flight.
-    constexpr int U = 8;
+    constexpr int U = MDL_POOL_U;
     typedef PoolLd<TE> L;
     constexpr bool PRE = MDL_POOL_PRE && !IDX;
     const TE* __restrict__ Er = E + (sp.start + (IDX ? 0 : t0)) * ldE;
@@ -266,8 +269,13 @@ __global__ __launch_bounds__(H * 128) void pool_combine_kernel(const float* __re
 // One wave per token row.  Lane L, slot i in [0,2H): channels [i*256 + 4L, +4), head i/2.
 // IDX (views): d_scores == nullptr -> dE-only pass (no read of E: dE[t] += w[t,c] d_pooled[b,c,:]); both outputs accumulate.
 // LIN (see pool_partial_kernel): w = the given weight, d_weight = <E[t,c,:], d_pooled[b,c,:]> (no softmax Jacobian).
+#ifdef MDL_POOL_BWD_WPE   // A/B: occupancy target of the backward kernel (waves per SIMD)
+#define POOL_BWD_ATTR __attribute__((amdgpu_waves_per_eu(MDL_POOL_BWD_WPE, MDL_POOL_BWD_WPE)))
+#else
+#define POOL_BWD_ATTR
+#endif
 template <int H, class TE, bool IDX = false, bool LIN = false>
-__global__ __launch_bounds__(256) void pool_bwd_kernel(const TE* __restrict__ E, int64_t ldE,
+__global__ __launch_bounds__(256) POOL_BWD_ATTR void pool_bwd_kernel(const TE* __restrict__ E, int64_t ldE,
                                                        const float* __restrict__ scores,
                                                        const float* __restrict__ pooled,
                                                        const float* __restrict__ stat_m,
