@@ -532,7 +532,13 @@ def test_bench_gpus_2_without_a_launcher_prints_one_valid_line():
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
+    # the driver parses the LAST stdout line and keeps only an ~8-KB tail of stdout: compact (<= 4 KB), last, complete
+    assert r.stdout.rstrip().splitlines()[-1] == lines[0] and len(lines[0]) <= 4096, len(lines[0])
+    assert any(ln.startswith("BENCH_DETAIL {") for ln in r.stdout.splitlines())
     out = json.loads(lines[0])
+    assert {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+            "data", "config", "roofline"} <= set(out)
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(out["roofline"]) and out["roofline"]["bound"] == "hbm"
     assert out["n_gpus"] == 2 and out["config"]["ranks_seen"] == 2 and out["config"]["collective_backend"] == "gloo"
     assert out["config"]["global_batch"] == 64 and out["scaling"] == "weak" and out["value"] > 0
     assert out["config"]["grad_sync"] == "flat_all_reduce"

@@ -227,3 +227,31 @@ def test_bench_gpus_n_relaunches_itself_under_torchrun():
     assert r.returncode != 0
     assert "WORLD_SIZE" not in r.stderr, r.stderr[-2000:]
     assert r.stderr.count("bench.py needs a GPU") >= 2, r.stderr[-2000:]
+
+
+def test_bench_compact_line_fits_the_driver_record():
+    """BENCH_r05.parsed was null because bench.py printed one 22-KB line and the driver keeps an ~8-KB tail.  The
+    contract line is now built by bench.compact_line: <= 4 KB whatever the detail record holds, every contract key + roofline + cpu_baseline
+    present.  Fed with round 5's own 22-KB record (profiles/r05fin2_bench_default.json) and with a pathologically bloated one."""
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    rec = json.load(open(os.path.join(ROOT, "profiles", "r05fin2_bench_default.json")))
+    assert len(json.dumps(rec)) > 16000
+    rec["dtype_short"], rec["detail_path"] = "f32 (3-term split-fp16 MFMA products, fp32 accumulate)", "gpurun_out/bench_detail.json"
+    for bloat in (0, 400):
+        r = json.loads(json.dumps(rec))
+        for i in range(bloat):    # many more kernel families / legs than any real run has: the optional objects are shed, the contract stays
+            r["kernel_roofline"]["k%03d" % i] = {"bound": "hbm", "avg_ms": 1.0, "achieved": 1.0, "unit": "GB/s", "peak": 8000.0, "frac": 0.5}
+        r["cpu_baseline"]["sample"] = r["cpu_baseline"]["sample"] * (1 + bloat)
+        line = bench.compact_line(r)
+        assert len(line) <= bench.COMPACT_MAX == 4096 and "\n" not in line
+        out = json.loads(line)
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                  "dtype", "data", "config", "roofline", "cpu_baseline"):
+            assert k in out, k
+        assert out["config"]["workload"].startswith("c2:") and "model" not in out["config"]
+        assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(out["roofline"])
+        assert {"value", "unit", "cores", "kind", "sample"} <= set(out["cpu_baseline"])
+        assert ("kernels" in out) == (bloat == 0)
