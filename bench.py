@@ -361,6 +361,46 @@ def kernel_rooflines(prof, work, precision="float32", gemm_mode="fp32"):
     return out
 
 
+def emulated_rank_loss(D, MF, crit, largs, mods, embs, toks, labels, lab_g, noise, world):
+    """The loss ONE rank of a `world`-rank job backpropagates (distributed.calculate_losses_dp's formula), with the other ranks' share of the
+    all-gathered payload EMULATED instead of gathered -- no collective runs:
+      * slide embeddings of the global batch = [local | detached copies of the local ones + noise[m]] ([world * B_l, 1, 512] per modality);
+      * presence labels of the global batch = lab_g ([world * B_l, M], rows 0..B_l-1 = this rank's `labels`);
+      * GOT: this rank's cases only, at the GLOBAL token count n = min(k_global, 256) (loss.py:282: randperm(k) with k = the participating
+        cases of the global batch), thresholds = this rank's own extrema standing in for the gathered ones, weighted by `world`
+        (the gradient MEAN over ranks then equals the global-batch gradient).
+    loss = replicated global InfoNCE + world x local GOT sum.  tests/test_bench_path_gpu.py checks it against the oracle on the
+    concatenated global batch (8 emulated ranks x 2 cases)."""
+    from madeleine_amd.trainer import calculate_losses
+    M = len(mods)
+    dev = toks["HE"].device
+    k_g = [int(lab_g[:, s].sum()) for s in range(1, M)]
+    problems, kept = [], []
+    for s_idx, stain in enumerate(mods[1:]):
+        n = min(k_g[s_idx], 256)
+        rows = labels[:, 1 + s_idx].bool().nonzero(as_tuple=True)[0]
+        if k_g[s_idx] <= 1 or rows.numel() == 0:
+            continue
+        rows = MF.h2d(rows, dev)
+        kept.append(s_idx)
+        problems.append((toks["HE"][:, :n, :, s_idx].index_select(0, rows).float().contiguous(),
+                         toks[stain][:, :n].index_select(0, rows).float().contiguous()))
+    embs_g = {}
+    for m in mods:
+        loc = embs[m][..., 0] if m == "HE" else embs[m]                      # [B,1,512]
+        oth = loc.detach().repeat(world - 1, 1, 1) + noise[m]
+        full = torch.cat([loc, oth])
+        embs_g[m] = full.unsqueeze(3).expand(-1, -1, -1, M - 1) if m == "HE" else full
+    outs = None
+    if problems:
+        ext = D.got_local_extrema(problems, MF.HipGotImpl)      # "gathered" extrema: this rank's own stand in for the global ones
+        outs = D.got_multi(problems, MF.HipGotImpl, None, extrema=ext)     # queued before the InfoNCE section, as calculate_losses_dp does
+    loss_g, flag = calculate_losses(mods[1:], crit, None, None, embs_g, None, lab_g[:, 1:], largs)
+    if outs is None:
+        return loss_g
+    return loss_g + float(world) * largs.local_loss_weight * (outs[:, 0] + outs[:, 1]).sum()
+
+
 def secondary_rank_leg(dev, D, MF, InfoNCE, MADELEINE, world=8, steps=4, warmup=2, config="c3", all_present=False):
     """What ONE rank of an 8 x MI355X configuration (BASELINE configs[3] = 8 ranks x c3, configs[4] = 8 ranks x c5; 256-slide global
     batch, 5 stains) executes per step, on one GPU: its 32 local cases through the encoder, the replicated global InfoNCE over
@@ -373,7 +413,6 @@ def secondary_rank_leg(dev, D, MF, InfoNCE, MADELEINE, world=8, steps=4, warmup=
     absent-bag rule wsi_dataset.py:66 never firing), every stain on every case: k_global = 256 -> n = 256, the largest GOT size class,
     four problems of 32 local cases each.  config "c5": ragged bags U[1024, 16384], d = 768, stain-encoding tokens, every stain
     present (as bench.py --config c5) -> the same four n = 256 problems on top of the ragged encoder."""
-    from madeleine_amd.trainer import calculate_losses
     B, M, N, Dm, _, stain_enc = CONFIGS[config]
     ragged = N == 0
     mods = MODS5[:M]
@@ -410,22 +449,7 @@ def secondary_rank_leg(dev, D, MF, InfoNCE, MADELEINE, world=8, steps=4, warmup=
             loss.backward()
             opt.step()
             return loss
-        problems = []
-        for s_idx, stain in enumerate(mods[1:]):
-            n = min(k_g[s_idx], 256)
-            rows = MF.h2d(labels[:, 1 + s_idx].bool().nonzero(as_tuple=True)[0], dev)
-            problems.append((toks["HE"][:, :n, :, s_idx].index_select(0, rows).float().contiguous(),
-                             toks[stain][:, :n].index_select(0, rows).float().contiguous()))
-        ext = D.got_local_extrema(problems, MF.HipGotImpl)      # "gathered" extrema: this rank's own stand in for the global ones
-        embs_g = {}
-        for m in mods:
-            loc = embs[m][..., 0] if m == "HE" else embs[m]                      # [B,1,512]
-            oth = loc.detach().repeat(world - 1, 1, 1) + noise[m]
-            full = torch.cat([loc, oth])
-            embs_g[m] = full.unsqueeze(3).expand(-1, -1, -1, M - 1) if m == "HE" else full
-        outs = D.got_multi(problems, MF.HipGotImpl, None, extrema=ext)     # queued before the InfoNCE section, as calculate_losses_dp does
-        loss_g, flag = calculate_losses(mods[1:], crit, None, None, embs_g, None, lab_g[:, 1:], largs)
-        loss = loss_g + float(world) * (outs[:, 0] + outs[:, 1]).sum()
+        loss = emulated_rank_loss(D, MF, crit, largs, mods, embs, toks, labels, lab_g, noise, world)
         loss.backward()
         opt.step()
         return loss

@@ -1,0 +1,192 @@
+"""GOT at the shapes the 8-GPU configurations give ONE rank (reference madeleine/utils/loss.py:179-193,236-248,278-302):
+
+  (a) four problems x k = 32 local cases x n = 256 tokens in ONE batched launch sequence (BASELINE configs[3] with every stain present, and
+      every rank of configs[4]) -- the n in (192, 256] class of the one-pass IPOT reverse sweep (csrc/got_impl.inc, LDS-resident accumulator
+      rows) -- and a mixed batch n = 256 / 200 / 130 / 64, against the fp64 oracle: both distances and the token gradients, twice for
+      bit-reproducibility, batched == single-problem for the top size class;
+  (b) the config-5 rank shape through calculate_losses_dp: ragged bags with stain tokens -> the first 256 tokens of every bag -> k = 256,
+      n = 256, with the oracle fed the IDENTICAL token / slide embeddings (an end-to-end tolerance then separates a
+      regression of the sweep from amplified encoder rounding);
+  (c) bench.emulated_rank_loss -- the helper behind bench.py's c4 / c5 rank-emulation legs -- against the oracle evaluated on the
+      concatenated global batch (8 emulated ranks x 2 local cases).
+Test infrastructure: the oracle is the checker, the HIP path (through the C ABI) is what is checked.
+"""
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+from oracle import restatement as R
+from tests._util import MODS5, rel_err, t
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _problems(shape, tag):
+    probs, refs = [], []
+    for s, (k, n) in enumerate(shape):
+        v = t((k, n, 128), f"got:{tag}:v{s}")
+        q = t((k, n, 128), f"got:{tag}:q{s}") + 0.7 * v
+        v64, q64 = v.double().requires_grad_(), q.double().requires_grad_()
+        ref = R.got(v64, q64, subsample=None)
+        ref.backward()
+        probs.append((v, q))
+        refs.append((float(ref.detach()), v64.grad, q64.grad))
+    return probs, refs
+
+
+def _run_batched(dev, probs_cpu):
+    from madeleine_amd import distributed as DP
+    from madeleine_amd import functional as MF
+    probs = [(v.to(dev).requires_grad_(), q.to(dev).requires_grad_()) for v, q in probs_cpu]
+    ext = DP.got_local_extrema([(a.detach(), b.detach()) for a, b in probs], MF.HipGotImpl)
+    outs = DP.got_multi(probs, MF.HipGotImpl, None, extrema=ext)            # [S, 2]
+    (outs[:, 0] + outs[:, 1]).sum().backward()
+    torch.cuda.synchronize()
+    return outs.detach().clone(), [(a.grad.clone(), b.grad.clone()) for a, b in probs]
+
+
+SHAPES = {
+    # (cases this rank owns, n = min(k_global, 256)) per stain
+    "all_present_4x32x256": [(32, 256)] * 4,      # configs[3] with every stain on every case; every rank of configs[4]
+    "mixed_256_200_130_64": [(32, 256), (12, 200), (9, 130), (6, 64)],
+}
+
+
+@pytest.mark.parametrize("name", sorted(SHAPES))
+def test_got_multi_n256_class_vs_fp64_oracle(dev, name):
+    from madeleine_amd import functional as MF
+    shape = SHAPES[name]
+    probs_cpu, refs = _problems(shape, name)
+    assert MF.HipGotImpl.can_batch([(v.to(dev), q.to(dev)) for v, q in probs_cpu])   # ONE batched launch sequence, not the stream fan-out
+    o1, g1 = _run_batched(dev, probs_cpu)
+    o2, g2 = _run_batched(dev, probs_cpu)
+    assert torch.equal(o1, o2)
+    for (a1, b1), (a2, b2) in zip(g1, g2):
+        assert torch.equal(a1, a2) and torch.equal(b1, b2)
+    for s, (ref, dv, dq) in enumerate(refs):
+        got = float(o1[s].sum())
+        ev, eq = rel_err(g1[s][0], dv), rel_err(g1[s][1], dq)
+        assert abs(got - ref) < TOL * abs(ref), (s, got, ref)
+        assert ev < TOL and eq < TOL, (s, ev, eq)
+    # the same problems through the single-problem entry points: the batched launches run every problem on the kernels of the LARGEST
+    # problem's size class, so problems of that class give the same bits either way
+    top = max(n for _, n in shape)
+    for s, (v, q) in enumerate(probs_cpu):
+        vd, qd = v.to(dev).requires_grad_(), q.to(dev).requires_grad_()
+        o = MF.got(vd, qd)
+        (o[0] + o[1]).backward()
+        if shape[s][1] == top:
+            assert torch.equal(o, o1[s]) and torch.equal(vd.grad, g1[s][0]) and torch.equal(qd.grad, g1[s][1]), s
+        else:
+            assert rel_err(o, o1[s]) < 1e-5 and rel_err(vd.grad, g1[s][0]) < 1e-4 and rel_err(qd.grad, g1[s][1]) < 1e-4, s
+
+
+def test_c5_rank_shape_through_calculate_losses_dp_identical_tokens(dev):
+    """One stain, 256 participating cases, ragged bags of 256..400 patches with stain-encoding tokens (BASELINE configs[4] geometry at
+    d = 96): MADELEINE.forward_ragged keeps the first 256 tokens of every bag, calculate_losses_dp slices n = min(k, 256) = 256 of them
+    per case into ONE GOT problem of the top size class (k = 256: eight times a rank's 32 cases) and adds the global InfoNCE.  The oracle
+    receives the token and slide embeddings the HIP encoder produced (detached, fp64): loss and d loss / d embeddings are then a statement
+    about the loss kernels and the gather / scatter glue alone."""
+    from madeleine_amd import InfoNCE
+    from madeleine_amd import distributed as DP
+    from madeleine_amd import functional as MF
+    from tests.test_model_gpu import build
+    B, M, D = 256, 2, 96
+    mods = MODS5[:M]
+    model = build(mods, D, "c5rank", dev, stain_encoding=True).eval()
+    g = torch.Generator().manual_seed(5)
+    lens = torch.randint(256, 401, (B, M), generator=g)
+    bags = [[t((int(lens[b, m]), D), f"c5rank:f{b}:{m}") for m in range(M)] for b in range(B)]
+    labels = torch.ones(B, M)
+    largs = SimpleNamespace(global_loss="info-nce", symmetric_cl=True, local_loss_weight=0.5)
+    T_ = 0.1
+    embs, toks = model.forward_ragged(bags, dev)
+    assert toks[mods[1]].shape == (B, 256, 128)
+    leaves = {"e_he": embs["HE"], "e_st": embs[mods[1]], "t_he": toks["HE"], "t_st": toks[mods[1]]}
+    for v in leaves.values():
+        v.retain_grad()
+    loss, flag = DP.calculate_losses_dp(mods[1:], InfoNCE(temperature=T_), MF.HipGotImpl, embs, toks, labels[:, 1:], largs)
+    assert flag
+    loss.backward()
+    torch.cuda.synchronize()
+    ref_in = {k: v.detach().double().cpu().requires_grad_() for k, v in leaves.items()}
+    ref = R.info_nce(ref_in["e_he"][:, 0, :, 0], ref_in["e_st"][:, 0, :], T_, True) \
+        + 0.5 * R.got(ref_in["t_he"][:, :, :, 0], ref_in["t_st"], subsample=None)
+    ref.backward()
+    assert abs(float(loss.detach()) - float(ref.detach())) < 1e-4 * abs(float(ref.detach())), (float(loss.detach()), float(ref.detach()))
+    for k, v in leaves.items():
+        err = rel_err(v.grad, ref_in[k].grad)
+        assert err < 3e-4, (k, err)     # measured on MI355X: see profiles/r06_got_rank_shape_errors.txt
+    assert float(leaves["t_st"].grad.abs().sum()) > 0
+
+
+def test_bench_rank_emulation_equals_oracle_on_the_concatenated_global_batch(dev):
+    """bench.emulated_rank_loss (the c4 / c5 rank-emulation legs): 8 emulated ranks x B_l = 2 local cases, 3 stains with a mixed presence
+    pattern.  Global batch = this rank's 2 cases + 7 emulated copies: slide embeddings perturbed by the helper's noise, tokens and labels
+    tiled (so every rank's GOT share -- and the batch extrema -- equal the local ones).  The oracle's calculate_losses on that
+    concatenated 16-case batch (InfoNCE over the global rows; GOT at n = min(k_global, 256) tokens over all 16 cases, trainer.py:20-77 +
+    loss.py:278-302) must give the emulated rank's loss: global InfoNCE + 8 x the local GOT sum.  Gradients w.r.t. the local embeddings:
+    against an fp64 restatement of the same formula."""
+    import bench as BN
+    from madeleine_amd import InfoNCE
+    from madeleine_amd import distributed as DP
+    from madeleine_amd import functional as MF
+    W, Bl, M, N = 8, 2, 4, 40
+    mods = MODS5[:M]
+    labels = torch.tensor([[1., 1., 1., 0.], [1., 1., 0., 0.]])       # stain 1: both cases; stain 2: one case; stain 3: no local case
+    lab_g = labels.repeat(W, 1)
+    lab_g[5, 3] = lab_g[8, 3] = 1                                     # stain 3 lives on other ranks only: this rank owns no case of its GOT
+    k_g = [int(lab_g[:, s].sum()) for s in range(1, M)]               # [16, 8, 2]
+    e = {m: (t((Bl, 1, 512), f"emu:e:{m}")).to(dev).requires_grad_() for m in mods}
+    tk = {m: (t((Bl, N, 128), f"emu:t:{m}") + (0.7 * t((Bl, N, 128), "emu:t:HE") if m != "HE" else 0)).to(dev).requires_grad_() for m in mods}
+    embs = {m: (e[m].unsqueeze(3).expand(-1, -1, -1, M - 1) if m == "HE" else e[m]) for m in mods}
+    toks = {m: (tk[m].unsqueeze(3).expand(-1, -1, -1, M - 1) if m == "HE" else tk[m]) for m in mods}
+    noise = {m: 0.05 * t(((W - 1) * Bl, 1, 512), f"emu:n:{m}").to(dev) for m in mods}
+    T_ = 0.1
+    largs = SimpleNamespace(global_loss="info-nce", symmetric_cl=True, local_loss_weight=0.5)
+    loss = BN.emulated_rank_loss(DP, MF, InfoNCE(temperature=T_), largs, mods, embs, toks, labels, lab_g, noise, W)
+    loss.backward()
+    torch.cuda.synchronize()
+
+    # oracle, fp64, on the concatenated global batch
+    e64 = {m: e[m].detach().double().cpu().requires_grad_() for m in mods}
+    t64 = {m: tk[m].detach().double().cpu().requires_grad_() for m in mods}
+    eg, tg = {}, {}
+    for m in mods:
+        full = torch.cat([e64[m], e64[m].detach().repeat(W - 1, 1, 1) + noise[m].double().cpu()])
+        tfull = torch.cat([t64[m]] + [t64[m].detach()] * (W - 1))
+        eg[m] = full.unsqueeze(3).repeat(1, 1, 1, M - 1) if m == "HE" else full
+        tg[m] = tfull.unsqueeze(3).repeat(1, 1, 1, M - 1) if m == "HE" else tfull
+    torch.manual_seed(0)
+    ref_global, flag = R.calculate_losses(mods[1:], lambda a, b, symmetric=False: R.info_nce(a, b, T_, symmetric),
+                                          lambda a, b, subsample=None: R.got(a, b, subsample), None, eg, tg, lab_g[:, 1:], True, 0.5)
+    assert flag
+    assert abs(float(loss.detach()) - float(ref_global.detach())) < 1e-4 * abs(float(ref_global.detach())), (float(loss.detach()), float(ref_global.detach()))
+    # the same formula restated in fp64 for the gradients: global InfoNCE (other ranks' rows detached) + W x local GOT at n = k_global tokens
+    for m in mods:
+        e64[m].grad = t64[m].grad = None
+    ref = 0.0
+    for s, stain in enumerate(mods[1:]):
+        mask_g = lab_g[:, 1 + s].bool()
+        ref = ref + R.info_nce(eg["HE"][:, 0, :, s][mask_g], eg[stain][:, 0, :][mask_g], T_, True)
+        mask_l = labels[:, 1 + s].bool()
+        if int(mask_l.sum()) > 0:
+            n = min(k_g[s], 256)
+            ref = ref + W * 0.5 * R.got(t64["HE"][mask_l][:, :n], t64[stain][mask_l][:, :n], subsample=None)
+    assert abs(float(ref.detach()) - float(ref_global.detach())) < 1e-9 * abs(float(ref_global.detach()))
+    ref.backward()
+    for m in mods:
+        assert rel_err(e[m].grad, e64[m].grad) < TOL, m
+        if t64[m].grad is not None and float(t64[m].grad.norm()) > 0:
+            assert rel_err(tk[m].grad, t64[m].grad) < TOL, m
+        else:
+            assert tk[m].grad is None or float(tk[m].grad.abs().max()) == 0.0, m
