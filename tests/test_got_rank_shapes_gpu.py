@@ -11,6 +11,7 @@
       concatenated global batch (8 emulated ranks x 2 local cases).
 Test infrastructure: the oracle is the checker, the HIP path (through the C ABI) is what is checked.
 """
+import os
 from types import SimpleNamespace
 
 import pytest
@@ -75,8 +76,12 @@ def test_got_multi_n256_class_vs_fp64_oracle(dev, name):
     for s, (ref, dv, dq) in enumerate(refs):
         got = float(o1[s].sum())
         ev, eq = rel_err(g1[s][0], dv), rel_err(g1[s][1], dq)
-        assert abs(got - ref) < TOL * abs(ref), (s, got, ref)
-        assert ev < TOL and eq < TOL, (s, ev, eq)
+        if os.environ.get("MDL_TEST_VERBOSE"):
+            print("GOTERR %s problem %d (k=%d n=%d): value rel %.2e  dV rel %.2e  dQ rel %.2e" % (name, s, *shape[s], abs(got - ref) / abs(ref), ev, eq))
+        # north_star's bar is 1e-3; measured on MI355X (profiles/r06_got_rank_shape_errors.txt): values <= 2.6e-6, gradients <= 2e-7 --
+        # held at ~10x that, so a regression of the sweep shows long before the 1e-3 bar
+        assert abs(got - ref) < 3e-5 * abs(ref), (s, got, ref)
+        assert ev < 3e-6 and eq < 3e-6, (s, ev, eq)
     # the same problems through the single-problem entry points: the batched launches run every problem on the kernels of the LARGEST
     # problem's size class, so problems of that class give the same bits either way
     top = max(n for _, n in shape)
@@ -122,20 +127,24 @@ def test_c5_rank_shape_through_calculate_losses_dp_identical_tokens(dev):
     ref = R.info_nce(ref_in["e_he"][:, 0, :, 0], ref_in["e_st"][:, 0, :], T_, True) \
         + 0.5 * R.got(ref_in["t_he"][:, :, :, 0], ref_in["t_st"], subsample=None)
     ref.backward()
-    assert abs(float(loss.detach()) - float(ref.detach())) < 1e-4 * abs(float(ref.detach())), (float(loss.detach()), float(ref.detach()))
+    assert abs(float(loss.detach()) - float(ref.detach())) < 2e-5 * abs(float(ref.detach())), (float(loss.detach()), float(ref.detach()))
     for k, v in leaves.items():
         err = rel_err(v.grad, ref_in[k].grad)
-        assert err < 3e-4, (k, err)     # measured on MI355X: see profiles/r06_got_rank_shape_errors.txt
+        if os.environ.get("MDL_TEST_VERBOSE"):
+            print("GOTERR c5 rank shape (k=256 n=256, identical tokens): d loss / d %s rel %.2e; loss rel %.2e" % (
+                k, err, abs(float(loss.detach()) - float(ref.detach())) / abs(float(ref.detach()))))
+        assert err < 3e-5, (k, err)     # measured on MI355X: 3.8e-7 .. 2.4e-6 (profiles/r06_got_rank_shape_errors.txt)
     assert float(leaves["t_st"].grad.abs().sum()) > 0
 
 
 def test_bench_rank_emulation_equals_oracle_on_the_concatenated_global_batch(dev):
     """bench.emulated_rank_loss (the c4 / c5 rank-emulation legs): 8 emulated ranks x B_l = 2 local cases, 3 stains with a mixed presence
-    pattern.  Global batch = this rank's 2 cases + 7 emulated copies: slide embeddings perturbed by the helper's noise, tokens and labels
-    tiled (so every rank's GOT share -- and the batch extrema -- equal the local ones).  The oracle's calculate_losses on that
+    pattern.  (i) Global batch = this rank's 2 cases + 7 emulated copies: slide embeddings perturbed by the helper's noise, tokens and
+    labels tiled (so every rank's GOT share -- and the batch extrema -- equal the local ones).  The oracle's calculate_losses on that
     concatenated 16-case batch (InfoNCE over the global rows; GOT at n = min(k_global, 256) tokens over all 16 cases, trainer.py:20-77 +
-    loss.py:278-302) must give the emulated rank's loss: global InfoNCE + 8 x the local GOT sum.  Gradients w.r.t. the local embeddings:
-    against an fp64 restatement of the same formula."""
+    loss.py:278-302) must give the emulated rank's loss: global InfoNCE + 8 x the local GOT sum.  (ii) Labels that are NOT tiled (a stain
+    whose participating cases all live on other ranks, another whose global count differs from 8 x the local one): value and gradients
+    w.r.t. the local embeddings against an fp64 restatement of the rank's formula."""
     import bench as BN
     from madeleine_amd import InfoNCE
     from madeleine_amd import distributed as DP
@@ -143,46 +152,66 @@ def test_bench_rank_emulation_equals_oracle_on_the_concatenated_global_batch(dev
     W, Bl, M, N = 8, 2, 4, 40
     mods = MODS5[:M]
     labels = torch.tensor([[1., 1., 1., 0.], [1., 1., 0., 0.]])       # stain 1: both cases; stain 2: one case; stain 3: no local case
-    lab_g = labels.repeat(W, 1)
-    lab_g[5, 3] = lab_g[8, 3] = 1                                     # stain 3 lives on other ranks only: this rank owns no case of its GOT
-    k_g = [int(lab_g[:, s].sum()) for s in range(1, M)]               # [16, 8, 2]
-    e = {m: (t((Bl, 1, 512), f"emu:e:{m}")).to(dev).requires_grad_() for m in mods}
-    tk = {m: (t((Bl, N, 128), f"emu:t:{m}") + (0.7 * t((Bl, N, 128), "emu:t:HE") if m != "HE" else 0)).to(dev).requires_grad_() for m in mods}
-    embs = {m: (e[m].unsqueeze(3).expand(-1, -1, -1, M - 1) if m == "HE" else e[m]) for m in mods}
-    toks = {m: (tk[m].unsqueeze(3).expand(-1, -1, -1, M - 1) if m == "HE" else tk[m]) for m in mods}
-    noise = {m: 0.05 * t(((W - 1) * Bl, 1, 512), f"emu:n:{m}").to(dev) for m in mods}
     T_ = 0.1
     largs = SimpleNamespace(global_loss="info-nce", symmetric_cl=True, local_loss_weight=0.5)
-    loss = BN.emulated_rank_loss(DP, MF, InfoNCE(temperature=T_), largs, mods, embs, toks, labels, lab_g, noise, W)
-    loss.backward()
-    torch.cuda.synchronize()
+    noise = {m: 0.05 * t(((W - 1) * Bl, 1, 512), f"emu:n:{m}").to(dev) for m in mods}
+    g_loss = lambda a, b, symmetric=False: R.info_nce(a, b, T_, symmetric)     # noqa: E731
+    l_loss = lambda a, b, subsample=None: R.got(a, b, subsample)               # noqa: E731
 
-    # oracle, fp64, on the concatenated global batch
-    e64 = {m: e[m].detach().double().cpu().requires_grad_() for m in mods}
-    t64 = {m: tk[m].detach().double().cpu().requires_grad_() for m in mods}
-    eg, tg = {}, {}
-    for m in mods:
-        full = torch.cat([e64[m], e64[m].detach().repeat(W - 1, 1, 1) + noise[m].double().cpu()])
-        tfull = torch.cat([t64[m]] + [t64[m].detach()] * (W - 1))
-        eg[m] = full.unsqueeze(3).repeat(1, 1, 1, M - 1) if m == "HE" else full
-        tg[m] = tfull.unsqueeze(3).repeat(1, 1, 1, M - 1) if m == "HE" else tfull
-    torch.manual_seed(0)
-    ref_global, flag = R.calculate_losses(mods[1:], lambda a, b, symmetric=False: R.info_nce(a, b, T_, symmetric),
-                                          lambda a, b, subsample=None: R.got(a, b, subsample), None, eg, tg, lab_g[:, 1:], True, 0.5)
+    def hip(lab_g):
+        e = {m: (t((Bl, 1, 512), f"emu:e:{m}")).to(dev).requires_grad_() for m in mods}
+        tk = {m: (t((Bl, N, 128), f"emu:t:{m}") + (0.7 * t((Bl, N, 128), "emu:t:HE") if m != "HE" else 0)).to(dev).requires_grad_()
+              for m in mods}
+        embs = {m: (e[m].unsqueeze(3).expand(-1, -1, -1, M - 1) if m == "HE" else e[m]) for m in mods}
+        toks = {m: (tk[m].unsqueeze(3).expand(-1, -1, -1, M - 1) if m == "HE" else tk[m]) for m in mods}
+        loss = BN.emulated_rank_loss(DP, MF, InfoNCE(temperature=T_), largs, mods, embs, toks, labels, lab_g, noise, W)
+        loss.backward()
+        torch.cuda.synchronize()
+        return loss.detach(), e, tk
+
+    def global_batch(e, tk):
+        e64 = {m: e[m].detach().double().cpu().requires_grad_() for m in mods}
+        t64 = {m: tk[m].detach().double().cpu().requires_grad_() for m in mods}
+        eg, tg = {}, {}
+        for m in mods:
+            full = torch.cat([e64[m], e64[m].detach().repeat(W - 1, 1, 1) + noise[m].double().cpu()])
+            tfull = torch.cat([t64[m]] + [t64[m].detach()] * (W - 1))
+            eg[m] = full.unsqueeze(3).repeat(1, 1, 1, M - 1) if m == "HE" else full
+            tg[m] = tfull.unsqueeze(3).repeat(1, 1, 1, M - 1) if m == "HE" else tfull
+        return e64, t64, eg, tg
+
+    def rank_formula(lab_g, e64, t64, eg):
+        k_g = [int(lab_g[:, s].sum()) for s in range(1, M)]
+        ref = 0.0
+        for s, stain in enumerate(mods[1:]):
+            mask_g = lab_g[:, 1 + s].bool()
+            if k_g[s] <= 1:
+                continue
+            ref = ref + R.info_nce(eg["HE"][:, 0, :, s][mask_g], eg[stain][:, 0, :][mask_g], T_, True)
+            mask_l = labels[:, 1 + s].bool()
+            if int(mask_l.sum()) > 0:
+                n = min(k_g[s], 256)
+                ref = ref + W * 0.5 * R.got(t64["HE"][mask_l][:, :n], t64[stain][mask_l][:, :n], subsample=None)
+        return ref
+
+    # (i) tiled labels: the oracle on the concatenated global batch
+    lab_g = labels.repeat(W, 1)                                       # cases per stain [16, 8, 0]
+    loss, e, tk = hip(lab_g)
+    e64, t64, eg, tg = global_batch(e, tk)
+    ref_global, flag = R.calculate_losses(mods[1:], g_loss, l_loss, None, eg, tg, lab_g[:, 1:], True, 0.5)
     assert flag
-    assert abs(float(loss.detach()) - float(ref_global.detach())) < 1e-4 * abs(float(ref_global.detach())), (float(loss.detach()), float(ref_global.detach()))
-    # the same formula restated in fp64 for the gradients: global InfoNCE (other ranks' rows detached) + W x local GOT at n = k_global tokens
-    for m in mods:
-        e64[m].grad = t64[m].grad = None
-    ref = 0.0
-    for s, stain in enumerate(mods[1:]):
-        mask_g = lab_g[:, 1 + s].bool()
-        ref = ref + R.info_nce(eg["HE"][:, 0, :, s][mask_g], eg[stain][:, 0, :][mask_g], T_, True)
-        mask_l = labels[:, 1 + s].bool()
-        if int(mask_l.sum()) > 0:
-            n = min(k_g[s], 256)
-            ref = ref + W * 0.5 * R.got(t64["HE"][mask_l][:, :n], t64[stain][mask_l][:, :n], subsample=None)
+    assert abs(float(loss) - float(ref_global.detach())) < 1e-4 * abs(float(ref_global.detach())), (float(loss), float(ref_global.detach()))
+    ref = rank_formula(lab_g, e64, t64, eg)
     assert abs(float(ref.detach()) - float(ref_global.detach())) < 1e-9 * abs(float(ref_global.detach()))
+
+    # (ii) labels that differ between the ranks
+    lab_g = labels.repeat(W, 1)
+    lab_g[5, 3] = lab_g[8, 3] = lab_g[11, 3] = 1                      # stain 3: three cases, all on other ranks
+    lab_g[4, 2] = 0                                                   # stain 2: 7 cases globally, one of them here
+    loss, e, tk = hip(lab_g)
+    e64, t64, eg, tg = global_batch(e, tk)
+    ref = rank_formula(lab_g, e64, t64, eg)
+    assert abs(float(loss) - float(ref.detach())) < 1e-4 * abs(float(ref.detach())), (float(loss), float(ref.detach()))
     ref.backward()
     for m in mods:
         assert rel_err(e[m].grad, e64[m].grad) < TOL, m
