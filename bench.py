@@ -533,7 +533,8 @@ def secondary_inference_leg(dev, MF, MADELEINE, n_patches=30000, bags=20):
                                    "kernel_ms_per_call": {n: round(v[0], 4) for n, v in prof4.items()}}
     if "pool_fwd" in prof4:
         out["four_bags_per_launch"]["pool_fwd_GBs"] = round(4 * alg / (prof4["pool_fwd"][0] * 1e-3) / 1e9, 1)
-    # ... under bf16 autocast: what utils.run_inference does by default for the released checkpoint (`precision: bfloat16`, 4 bags per launch)
+    # ... under bf16 autocast (the released checkpoint's `precision: bfloat16`) with run_inference(bags_per_launch=4); its bf16 default is 1
+    # bag per launch set (reproducible across dataloader orders)
     with torch.no_grad(), torch.autocast(device_type="cuda", dtype=torch.bfloat16):
         for _ in range(2):
             model.encode_he_bags(group, dev)

@@ -17,9 +17,11 @@
  *     synchronisation.
  *   - return value: 0 on success; a positive hipError_t if a launch failed; a negative MDL_E_* code
  *     for argument validation.  Nothing throws across the boundary.
- *   - fp32 everywhere ("f32" compute; MFMA contractions use v_mfma_f32_32x32x2_f32, exact fp32) -- except the *_bf16
- *     entry points at the end of this header (the reference's `precision: bfloat16` mode: bf16 activation storage and
- *     bf16 MFMA operands, fp32 accumulation / epilogues / parameters).
+ *   - fp32 values everywhere.  Contractions come in three engines: the *_split entry points (the DEFAULT of the Python
+ *     mirror: every fp32 operand as an fp16 hi + lo image under a power-of-two scale, three v_mfma_f32_32x32x16_f16 products
+ *     per logical product, fp32 accumulation -- error below an fp32 fmaf chain), the plain entry points (exact fp32,
+ *     v_mfma_f32_32x32x2_f32; MADELEINE_GEMM=fp32) and the *_bf16 entry points at the end of this header (the reference's
+ *     `precision: bfloat16` mode: bf16 activation storage and bf16 MFMA operands, fp32 accumulation / epilogues / parameters).
  *
  * Entry points by row of SURVEY.md section 8:  A2 mdl_abmil_gate_*  |  A3 mdl_abmil_pool_*  |  A2+A3 fused backward
  * mdl_abmil_attnpool_bwd  |  L1 mdl_infonce_*  |  G0-G3 mdl_got_*  |  N1 mdl_linear_*, mdl_ln_gelu_drop_*  |  bf16 mode *_bf16.
@@ -472,7 +474,8 @@ int mdl_ln_gelu_drop_bwd_split_groups(const float* x, const float* bias, const f
  * phases of mdl_abmil_attnpool_bwd_split (bit mask, 1 .. 15): 1 = the dz pass (+ bias / wc column sums), 2 = both contractions,
  * 4 = the dX contraction alone, 8 = the dW contraction alone (dWa, dWb) -- the two contractions only read what the dz pass wrote into
  * `ws`, so a caller may queue 8 on another stream behind an event recorded after 1 while 4 and the rest of the backward proceed
- * (functional.set_dw_stream: the dW half of the backward off the critical path). */
+ * (measured null on MI355X; the Python mirror issues 3, functional.attnpool_bwd_split_raw(phases=...) issues any
+ * sequence -- tests/test_split_gpu.py holds 1, 4, 8 == 3 bit for bit). */
 int64_t mdl_abmil_gate_fwd_split_ws_bytes(int64_t T, int H);
 int mdl_abmil_gate_fwd_split(const void* E_img, int64_t e_rsb, const float* e_scale, const float* Wa, const float* ba, const float* Wb,
                              const float* bb, const float* wc, const float* bc, float* scores, float* act_a, float* act_b, int64_t T,

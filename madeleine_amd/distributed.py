@@ -94,36 +94,52 @@ class FlatGradSync:
         self.group = group
         total = sum(p.numel() for p in self.params)
         p0 = self.params[0]
-        self.flat = torch.zeros(total, dtype=p0.dtype, device=p0.device)
+        # one extra element behind the gradients: the number of ranks that found a packed parameter without a gradient (see all_reduce_mean)
+        self._buf = torch.zeros(total + 1, dtype=p0.dtype, device=p0.device)
+        self.flat = self._buf[:total]
         self.views, o = [], 0
         for p in self.params:
             self.views.append(self.flat[o:o + p.numel()].view_as(p))
             o += p.numel()
 
     def all_reduce_mean(self):
-        grads = []
-        for i, (p, v) in enumerate(zip(self.params, self.views)):
-            g = p.grad
-            if g is None:
-                raise RuntimeError("FlatGradSync: packed parameter %s has no gradient after backward -- it took no part in this step's "
-                                   "graph; exclude it when the sync is built (use_local_loss=False drops the token_projector) instead of "
-                                   "averaging a stand-in" % (self.names[i],))
-            grads.append(g)
-        src = [g for g, v in zip(grads, self.views) if g.data_ptr() != v.data_ptr()]
-        dst = [v for g, v in zip(grads, self.views) if g.data_ptr() != v.data_ptr()]
+        missing = [self.names[i] for i, p in enumerate(self.params) if p.grad is None]
+        multi = collectives_on() and dist.get_world_size(self.group) > 1
+        if missing and not multi:
+            raise RuntimeError(self._missing_message(missing))
+        # With several ranks the verdict is agreed on THROUGH the collective: a rank that misses a gradient still enters the all-reduce
+        # (its stand-ins are the buffer's previous contents, never used) with a 1 in the flag slot, and every rank raises after it --
+        # a rank-local raise in front of the collective would leave the others waiting in it until the RCCL timeout.
+        src = [p.grad for p, v in zip(self.params, self.views) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
+        dst = [v for p, v in zip(self.params, self.views) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
         if src:
             torch._foreach_copy_(dst, src)
         if collectives_on():
             W = dist.get_world_size(self.group)
-            if _host_staged(self.flat, self.group):
-                self.flat.copy_(_all_reduce_sum(self.flat, self.group) / W)
+            buf = self._buf if multi else self.flat
+            if multi:
+                self._buf[-1] = float(W if missing else 0)        # the mean over W ranks of W*[missing] = number of ranks missing
+            if _host_staged(buf, self.group):
+                buf.copy_(_all_reduce_sum(buf, self.group) / W)
             elif dist.get_backend(self.group) == "nccl":
-                dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=self.group)
+                dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.group)
             else:
-                dist.all_reduce(self.flat, group=self.group)
-                self.flat.div_(W)
+                dist.all_reduce(buf, group=self.group)
+                buf.div_(W)
+            if multi:
+                n_missing = float(self._buf[-1].item())        # one scalar read-back per step, only at world size > 1
+                if n_missing > 0.5:
+                    raise RuntimeError(self._missing_message(missing) if missing else
+                                       "FlatGradSync: %d other rank(s) found a packed parameter without a gradient after backward; "
+                                       "this step's gradient mean is void on every rank" % round(n_missing))
         for p, v in zip(self.params, self.views):
             p.grad = v
+
+    @staticmethod
+    def _missing_message(missing):
+        return ("FlatGradSync: packed parameter(s) %s have no gradient after backward -- they took no part in this step's graph; exclude "
+                "them when the sync is built (use_local_loss=False drops the token_projector) instead of averaging a stand-in"
+                % (", ".join(missing),))
 
 
 def world_size(group=None) -> int:

@@ -196,8 +196,9 @@ def gate_fwd_split_raw(Ei, Wa, ba, Wb, bb, wc, bc, p_drop, seed, keep_a, keep_b,
 
 
 def attnpool_bwd_split_raw(Ei, Wa, Wb, wc, act_a, act_b, d_scores, dE, p_drop, seed, keep_a, keep_b, scores, stat_m, stat_l, d_pooled,
-                           row_bag, N, accumulate=0, dE_absmax=None):
-    """attnpool_bwd_raw (scores None: gate_bwd_raw) on the split engine."""
+                           row_bag, N, accumulate=0, dE_absmax=None, phases=None):
+    """attnpool_bwd_raw (scores None: gate_bwd_raw) on the split engine.  `phases`: a sequence of phase masks issued one after the other
+    on the same workspace (include/madeleine_amd.h: 1 = dz pass, 2 = both contractions, 4 = dX alone, 8 = dW alone); None = one call."""
     lib = _native.lib()
     T, H = Ei.rows, Wa.shape[0]
     dev = Ei.data.device
@@ -214,7 +215,10 @@ def attnpool_bwd_split_raw(Ei, Wa, Wb, wc, act_a, act_b, d_scores, dE, p_drop, s
                                               _ptr(stat_m), _ptr(stat_l), _ptr(d_pooled), _ptr(row_bag), int(N), _ptr(dE_absmax), _ptr(ws),
                                               _stream(), phases, GRAD_TERMS)
         _native.check(rc, "mdl_abmil_attnpool_bwd_split")
-    if TIMER is not None and TIMER.wants("gate_bwd_dz"):
+    if phases is not None:
+        for ph in phases:
+            call(int(ph))
+    elif TIMER is not None and TIMER.wants("gate_bwd_dz"):
         with _timed("gate_bwd_dz", ("byte", float(T) * H * 4 * HID * 4)):
             call(1)
         with _timed("gate_bwd_gemm", ("flop", 4.0 * T * H * HID * 2 * HID)):
@@ -622,8 +626,11 @@ def _take_absmax(t):
 
 
 def _clear_absmax():
+    # Start of an encoder forward.  Also re-arms the end-of-backward callback: when a backward raises, the engine skips its final
+    # callbacks, so the flag set by _put_absmax would otherwise stay True for the life of the process.
     with _ABSMAX_LOCK:
         _ABSMAX.clear()
+        _ABSMAX_CB[0] = False
 
 
 class PreAttnBlockFn(torch.autograd.Function):

@@ -12,7 +12,7 @@ import torch
 DEVICE = torch.device("cuda" if torch.cuda.is_available() else "cpu")
 
 
-def run_inference(ssl_model, val_dataloader, config=None, torch_precision=None, bags_per_launch=4):
+def run_inference(ssl_model, val_dataloader, config=None, torch_precision=None, bags_per_launch=None):
     """Slide-embedding extraction loop (utils.py:27-66): eval mode, no gradients, full bags through `ssl_model.encode_he` under the
     configured precision; returns ({"embeds": [n,512] fp32 array, "slide_ids": [...]}, smooth rank of the embeddings).  The dataloader
     yields (feats [1,N,D], slide_ids) like the reference's SimpleDataset (wsi_dataset.py:102-124).  Forward-only use of the HIP path:
@@ -20,10 +20,16 @@ def run_inference(ssl_model, val_dataloader, config=None, torch_precision=None, 
     Organisation (same embeddings, bit for bit, as one encode_he call per bag): up to `bags_per_launch` bags go through ONE launch set
     (MADELEINE.encode_he_bags: packed tokens + cu_seqlens; bags of at most 256 patches go alone, they take the small-M kernels), and
     the embeddings stay on the device until the loop ends -- the reference's per-bag `.cpu()` is a device synchronisation per slide,
-    which leaves the GPU idle while the host prepares the next bag."""
+    which leaves the GPU idle while the host prepares the next bag.
+    `bags_per_launch` = None: 4 in fp32, where packing is bit-identical to one bag per call, and 1 under bf16 / fp16 autocast, where the
+    Linear and gate kernels pick their tile from the packed row count: a slide's embedding then depends (at the bf16 rounding level,
+    < 1e-2 relative) on which bags it is packed with, so extraction would not be reproducible across dataloader orders.  Pass
+    bags_per_launch > 1 explicitly to trade that for throughput (2.2k instead of ~1k bags/s on 30,000-patch bags)."""
     ssl_model.eval()
     precision = torch_precision if torch_precision is not None else set_model_precision(config.precision)
     reduced = precision in (torch.bfloat16, torch.float16)      # for fp32 / fp64 torch disables autocast (SURVEY.md section 5)
+    if bags_per_launch is None:
+        bags_per_launch = 1 if reduced else 4
     batched = bags_per_launch > 1 and hasattr(ssl_model, "encode_he_bags")
     outs, slide_ids, pending = [], [], []
 

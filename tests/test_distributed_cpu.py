@@ -208,3 +208,42 @@ def test_got_parts_matches_got():
     ex = R.got_extrema(v, q)
     c = R.got_parts(v[:2], q[:2], ex) + R.got_parts(v[2:], q[2:], ex)
     assert abs(float(c.sum()) - float(a)) < 1e-5 * abs(float(a))
+
+
+def _missing_grad_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from madeleine_amd import distributed as DP
+        a = torch.nn.Parameter(torch.ones(3))
+        b = torch.nn.Parameter(torch.ones(2))
+        sync = DP.FlatGradSync([("a", a), ("b", b)])
+        a.grad = torch.full((3,), float(rank + 1))
+        b.grad = torch.full((2,), 2.0 * (rank + 1))
+        sync.all_reduce_mean()                       # a complete step: the mean, and the flag slot stays out of the gradients
+        ok = bool(torch.allclose(a.grad, torch.full((3,), 1.5)) and torch.allclose(b.grad, torch.full((2,), 3.0)))
+        a.grad = torch.ones(3)
+        b.grad = None if rank == 1 else torch.ones(2)      # only rank 1 misses a gradient
+        try:
+            sync.all_reduce_mean()
+            raised = ""
+        except RuntimeError as e:
+            raised = str(e)
+        dist.barrier()                                # nobody is stuck inside a collective
+        ret["r%d" % rank] = (ok, raised)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_flat_grad_sync_missing_gradient_raises_on_every_rank():
+    """A packed parameter without a gradient on ONE rank: every rank raises in the same step, after the collective (a rank-local raise
+    in front of it would leave the peers inside the all-reduce until the backend's timeout)."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_missing_grad_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    ok0, msg0 = ret["r0"]
+    ok1, msg1 = ret["r1"]
+    assert ok0 and ok1
+    assert "other rank" in msg0, msg0
+    assert "no gradient" in msg1 and "b" in msg1, msg1

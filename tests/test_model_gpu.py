@@ -480,6 +480,9 @@ def test_inference_full_bag_vs_oracle_and_run_inference(dev):
     # the reference's bf16 extraction (extract_slide_embeddings.py:49 passes torch_precision): same loop under autocast
     res16, _ = run_inference(model, loader[1:], torch_precision=torch.bfloat16)
     assert rel_err(res16["embeds"], res["embeds"][1:]) < 3e-2
+    # ... whose default packs nothing under autocast: an embedding does not depend on the bags around it (order-reproducible extraction)
+    rev16, _ = run_inference(model, many[::-1], torch_precision=torch.bfloat16)
+    assert np.array_equal(rev16["embeds"][::-1], o16["embeds"])
     # extract_slide_level_embeddings (utils.py:68-90): one pickle per validation dataset
     import pickle
     import tempfile

@@ -322,3 +322,34 @@ def test_embedder_image_only_matches_fp32_tokens(dev):
             assert float((a - b).abs().max()) < 1e-6 * top
         else:
             assert rel_err(a, b) < 1e-4
+
+
+def test_gate_backward_phase_masks_compose(dev):
+    """mdl_abmil_attnpool_bwd_split's phase bit mask (include/madeleine_amd.h): the dz pass (1), then the dX contraction alone (4), then
+    the dW contraction alone (8) on the same workspace produce the bits of the one-call form (3 = dz + both contractions); and a
+    CU-masked HIP stream can be created and released through the ABI (mdl_stream_create_cu_mask / mdl_stream_destroy)."""
+    import ctypes
+    from madeleine_amd import _native
+    from madeleine_amd import functional as MF
+    H, T = 2, 700
+    E = t((T, H * 512), "ph:E").to(dev)
+    Wa, Wb = (t((H, 512, 512), "ph:Wa") * 0.05).to(dev), (t((H, 512, 512), "ph:Wb") * 0.05).to(dev)
+    ba, bb = (t((H, 512), "ph:ba") * 0.1).to(dev), (t((H, 512), "ph:bb") * 0.1).to(dev)
+    wc, bc = (t((H, 512), "ph:wc") * 0.1).to(dev), (t((H,), "ph:bc") * 0.1).to(dev)
+    ds = t((T, H), "ph:ds").to(dev)
+    Ei = MF.split_image(E)
+    _s, a, b = MF.gate_fwd_split_raw(Ei, Wa, ba, Wb, bb, wc, bc, 0.25, 1234, None, None, True)
+    outs = []
+    for phases in (None, (3,), (1, 4, 8), (1, 8, 4)):
+        dE = torch.zeros_like(E)
+        g = MF.attnpool_bwd_split_raw(Ei, Wa, Wb, wc, a, b, ds, dE, 0.25, 1234, None, None, None, None, None, None, None, 0, phases=phases)
+        outs.append((dE,) + tuple(g))
+    for o in outs[1:]:
+        for x, y in zip(outs[0], o):
+            assert torch.equal(x, y)
+    assert float(outs[0][0].abs().max()) > 0 and float(outs[0][1].abs().max()) > 0
+    lib = _native.lib()
+    words = (ctypes.c_uint32 * 8)(*([0xFFFFFFFF] * 8))
+    stream = ctypes.c_void_p()
+    assert lib.mdl_stream_create_cu_mask(8, words, ctypes.byref(stream)) == 0 and stream.value
+    assert lib.mdl_stream_destroy(stream) == 0
