@@ -561,7 +561,8 @@ def compact_line(out):
     c["dtype"] = out["dtype_short"]
     cfg = out["config"]
     c["config"] = {k: cfg[k] for k in ("workload", "global_batch", "parallelism", "collective_backend", "ranks_seen", "grad_sync", "gemm_mode",
-                                       "device_allocs_in_timed_region", "final_loss") if k in cfg}
+                                       "device_allocs_in_timed_region", "final_loss", "grad_sync_ms", "grad_sync_share_of_step",
+                                       "host_numa_pin", "local_cases_per_stain") if k in cfg}
     if "roofline" in out:
         r = out["roofline"]
         c["roofline"] = {k: r[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch",
@@ -633,6 +634,10 @@ def main():
     ap.add_argument("--skip-absent", action="store_true",
                     help="SURVEY 8(f) N4: encode the all-zero bag of an absent stain once instead of once per case (c3/c4 "
                          "mask stains with ACROBAT's presence rates; no effect on c2).  Off by default: the reference encodes them all")
+    ap.add_argument("--slides", type=int, default=None,
+                    help="slides per rank instead of the configuration's (32): a REDUCED workload, named as such in config.workload -- for "
+                         "debug runs of many gloo ranks on one GPU (tests); never the metric")
+    ap.add_argument("--label-seed", type=int, default=77, help="seed of the ACROBAT stain-presence masks (rank r draws with seed + r)")
     a = ap.parse_args()
 
     if a.gpus > 1 and "RANK" not in os.environ:
@@ -662,8 +667,12 @@ def main():
     n_dev = torch.cuda.device_count()
     dev = torch.device("cuda", local_rank % n_dev)   # (several ranks per GPU only in gloo debug runs)
     torch.cuda.set_device(dev)
+    numa = D.pin_to_gpu_numa(dev.index) if world > 1 else None   # one process per GPU: host threads next to the GPU's PCIe root
 
     B, M, N, Dm, use_got, stain_enc = CONFIGS[a.config]
+    reduced = a.slides is not None and a.slides != B
+    if a.slides is not None:
+        B = a.slides
     mods = MODS5[:M]
     torch.manual_seed(42)
     model = MADELEINE(make_cfg(M, Dm), stain_encoding=stain_enc).to(dev)
@@ -699,7 +708,7 @@ def main():
     labels = torch.ones(B, M)
     if M > 2 and not ragged:  # ACROBAT stain presence rates; absent stain -> all-zero bag (wsi_dataset.py:66)
         rates = torch.tensor([1.0, 0.46, 0.73, 0.73, 0.73][:M])
-        labels = (torch.rand(B, M, generator=torch.Generator().manual_seed(77 + rank)) < rates).float()
+        labels = (torch.rand(B, M, generator=torch.Generator().manual_seed(a.label_seed + rank)) < rates).float()
         labels[:, 0] = 1
         feats = feats * labels.to(dev)[:, :, None, None]
     data = {"bags": bags, "modality_labels": labels} if ragged else {"feats": feats, "modality_labels": labels}
@@ -734,9 +743,18 @@ def main():
                                                labels_global_withoutHE=pending.wait(), use_local_loss=use_got)
         loss.backward()
         if gsync is not None:
-            gsync.all_reduce_mean()
+            if MF.TIMER is not None:       # profiled pass only: the packed copy + the one all-reduce between events on the launch stream
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                gsync.all_reduce_mean()
+                e1.record()
+                gsync_events.append((e0, e1))
+            else:
+                gsync.all_reduce_mean()
         opt.step()
         return loss
+
+    gsync_events = []
 
     def fence():
         if dist_on:
@@ -910,7 +928,7 @@ def main():
             "data": ("synthetic (HOST-resident randn bags through the pinned double-buffered H2D stager, PCIe-inclusive)"
                      if host_iter is not None else
                      "synthetic (device-resident randn bags, random-init weights, manual_seed 42)"),
-            "config": {"workload": f"{a.config}: {B} slides/GPU x {M} stains x {'ragged U[1024,16384] (mean ' + str(N) + ')' if ragged else N} patches x {Dm}-d, "
+            "config": {"workload": f"{'REDUCED (--slides), not the metric: ' if reduced else ''}{a.config}: {B} slides/GPU x {M} stains x {'ragged U[1024,16384] (mean ' + str(N) + ')' if ragged else N} patches x {Dm}-d, "
                                    f"ABMIL pool + global InfoNCE{' + local GOT' if use_got else ''}, "
                                    f"{'eval (dropout off)' if a.eval_mode else 'train mode (dropout on)'}, AdamW"
                                    f"{', absent-stain zero bags encoded once (N4)' if a.skip_absent else ''}",
@@ -922,6 +940,15 @@ def main():
                        "host_label_exchange": ("gloo" if hgroup is not None else ("device" if dist_on else "none")),
                        "grad_sync": ("none" if not dist_on else ("ddp" if gsync is None else "flat_all_reduce"))},
         }
+        if gsync_events:
+            torch.cuda.synchronize()
+            gms = sorted(e0.elapsed_time(e1) for e0, e1 in gsync_events)
+            out["config"]["grad_sync_ms"] = round(gms[len(gms) // 2], 4)      # median over the profiled pass's steps
+            out["config"]["grad_sync_share_of_step"] = round(gms[len(gms) // 2] / ms_per_step, 5)
+        if numa is not None:
+            out["config"]["host_numa_pin"] = numa
+        if use_got and M > 2 and not ragged:
+            out["config"]["local_cases_per_stain"] = [int(v) for v in labels[:, 1:].sum(0)]
         if "pool_fwd" in prof:
             ms, n = prof["pool_fwd"]
             esz = 4 if a.precision == "float32" else 2

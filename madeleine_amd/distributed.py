@@ -53,6 +53,41 @@ def init_from_env(backend: Optional[str] = None):
     return rank, world, local_rank
 
 
+def _parse_cpulist(text: str):
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def pin_to_gpu_numa(device_index: int, sysfs: str = "/sys"):
+    """Restricts this process's host threads to the cores of the NUMA node its GPU hangs off (one process per GPU: the launch thread,
+    the pinned-memory stager and the gloo side channel then stay next to the GPU's PCIe root instead of wandering across sockets).
+    The node comes from <sysfs>/bus/pci/devices/<domain:bus:device.function>/numa_node, its cores from
+    <sysfs>/devices/system/node/node<k>/cpulist; the new mask is the intersection with the current affinity mask.  Returns
+    {"numa_node": k, "cpus": n} or None when the topology is not exposed (containers without sysfs, numa_node = -1, an empty
+    intersection) -- nothing is changed then.  MADELEINE_NO_NUMA_PIN=1 disables it."""
+    if os.environ.get("MADELEINE_NO_NUMA_PIN") or not hasattr(os, "sched_setaffinity"):
+        return None
+    try:
+        props = torch.cuda.get_device_properties(device_index)
+        bdf = "%04x:%02x:%02x.0" % (props.pci_domain_id, props.pci_bus_id, props.pci_device_id)
+        node = int(open(os.path.join(sysfs, "bus/pci/devices", bdf, "numa_node")).read())
+        if node < 0:
+            return None
+        cpus = _parse_cpulist(open(os.path.join(sysfs, "devices/system/node/node%d/cpulist" % node)).read())
+        cpus &= set(os.sched_getaffinity(0))
+        if not cpus:
+            return None
+        os.sched_setaffinity(0, cpus)
+        return {"numa_node": node, "cpus": len(cpus)}
+    except (OSError, ValueError, AttributeError, RuntimeError, AssertionError):
+        return None
+
+
 def wrap_ddp(model, device, use_local_loss: bool = True, bucket_cap_mb: int = 8):
     """The model under DistributedDataParallel as the data-parallel step uses it: 20 MB of fp32 gradients in 8-MB buckets (their
     all-reduce starts while the pre_attn backward is still running; the default single 25-MB bucket would only fire after the last
@@ -72,8 +107,9 @@ def wrap_ddp(model, device, use_local_loss: bool = True, bucket_cap_mb: int = 8)
 
 class FlatGradSync:
     """Gradient mean over the ranks WITHOUT the DistributedDataParallel wrapper: after backward() the parameter gradients (20 MB fp32,
-    ~30 tensors) are packed into ONE flat buffer by one multi-tensor copy, all-reduced by ONE RCCL call (stream-ordered: the host does not
-    wait) and handed to the optimizer as views of that buffer.  On MI355X the all-reduce of 20 MB over xGMI is ~0.3-0.5 ms against a
+    ~30 tensors) are packed into ONE flat buffer by one multi-tensor copy, all-reduced by ONE RCCL call (stream-ordered; at world size > 1
+    the host then reads ONE scalar back -- the ranks' agreement that nobody missed a gradient, see all_reduce_mean) and handed to the
+    optimizer as views of that buffer.  On MI355X the all-reduce of 20 MB over xGMI is ~0.3-0.5 ms against a
     24-60 ms step, so hiding it behind the backward (what DDP's buckets and per-parameter hooks are for) buys < 2 %, while the wrapper's
     per-step bookkeeping measured +5 ms on this step (tools/exp_ddp.py).  Same result as DDP's mean (reference semantics:
     nn.DataParallel's summed replica gradients of a global-batch-mean loss, setup_components.py:185-187).

@@ -542,3 +542,41 @@ def test_bench_gpus_2_without_a_launcher_prints_one_valid_line():
     assert out["n_gpus"] == 2 and out["config"]["ranks_seen"] == 2 and out["config"]["collective_backend"] == "gloo"
     assert out["config"]["global_batch"] == 64 and out["scaling"] == "weak" and out["value"] > 0
     assert out["config"]["grad_sync"] == "flat_all_reduce"
+
+
+def test_bench_gpus_8_config3_gloo_ranks_with_empty_stain_shards():
+    """the command the first 8-GPU run will use -- `python bench.py --gpus 8 --config c3` -- as 8 gloo ranks sharing
+    the one GPU (4 slides per rank through --slides so that eight working sets fit beside each other; on a node the same command runs
+    RCCL, one rank per GPU, 32 slides each).  The ACROBAT presence masks are drawn with a seed under which rank 0 holds ZERO cases of a
+    participating stain (an empty GOT problem that still joins the [S,6] all-reduce) -- rank 0 prints the compact line with
+    ranks_seen = 8 and a finite loss (setup_components.py:185-187; trainer.py:25-28,71-75)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import torch
+    seed = None
+    rates = torch.tensor([1.0, 0.46, 0.73, 0.73, 0.73])
+    for cand in range(1, 400):                                    # same draw as bench.py: rank r uses manual_seed(label_seed + r)
+        per_rank = [(torch.rand(4, 5, generator=torch.Generator().manual_seed(cand + r)) < rates).float()[:, 1:].sum(0) for r in range(8)]
+        tot = torch.stack(per_rank).sum(0)
+        if float(per_rank[0].min()) == 0 and float(tot.min()) >= 2 and any(float(p.min()) == 0 for p in per_rank[1:]):
+            seed = cand
+            break
+    assert seed is not None
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["MADELEINE_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--config", "c3", "--slides", "4", "--label-seed", str(seed),
+                        "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extra-legs", "--no-pmc", "--no-bf16-leg"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and r.stdout.rstrip().splitlines()[-1] == lines[0] and len(lines[0]) <= 4096, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    cfg = out["config"]
+    assert out["n_gpus"] == 8 and cfg["ranks_seen"] == 8 and cfg["collective_backend"] == "gloo" and cfg["global_batch"] == 32
+    assert cfg["workload"].startswith("REDUCED") and "local GOT" in cfg["workload"] and cfg["grad_sync"] == "flat_all_reduce"
+    assert min(cfg["local_cases_per_stain"]) == 0                  # rank 0's shard has no case of some stain
+    assert cfg["grad_sync_ms"] > 0 and 0 < cfg["grad_sync_share_of_step"] < 1
+    assert out["value"] > 0 and out["scaling"] == "weak" and abs(cfg["final_loss"]) < 1e6 and cfg["final_loss"] == cfg["final_loss"]

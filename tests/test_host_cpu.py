@@ -255,3 +255,14 @@ def test_bench_compact_line_fits_the_driver_record():
         assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(out["roofline"])
         assert {"value", "unit", "cores", "kind", "sample"} <= set(out["cpu_baseline"])
         assert ("kernels" in out) == (bloat == 0)
+
+
+def test_numa_pin_helper_is_harmless_without_topology():
+    """distributed.pin_to_gpu_numa: cpulist parsing, and no change of the affinity mask when the GPU / sysfs topology is unavailable."""
+    import os
+    from madeleine_amd import distributed as DP
+    assert DP._parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+    assert DP._parse_cpulist("") == set()
+    before = os.sched_getaffinity(0)
+    assert DP.pin_to_gpu_numa(0, sysfs="/nonexistent") is None
+    assert os.sched_getaffinity(0) == before

@@ -36,4 +36,21 @@ run got_pmc_sq 40 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_IN
 run got_pmc_fetch 40 --pmc FETCH_SIZE TCC_HIT_sum --kernel-trace -d /tmp/prof_got_pmc_fetch -- python $R/tools/bench_got.py
 run got_pmc_write 40 --pmc WRITE_SIZE --kernel-trace -d /tmp/prof_got_pmc_write -- python $R/tools/bench_got.py
 fi
+if [ $WHAT = split ]; then
+# Counters of the split-engine matrix-core kernels at config-2 geometry (tools/prof_split.py: gate fwd / dz / dX / dW, Linear 512 -> 2048
+# fwd / dX / dW), one --pmc pass per counter group; tools/pmc_mfma_busy.py turns the databases into per-kernel MFMA-busy fractions
+PS="python $R/tools/prof_split.py --iters 2"
+pmc() {  # name, counters...
+    local name=$1; shift
+    rm -rf /tmp/prof_$name
+    rocprofv3 --pmc "$@" --kernel-trace -d /tmp/prof_$name -- $PS > /tmp/prof_$name.log 2>&1
+    { echo "# $TAG $name: rocprofv3 --pmc $* --kernel-trace -- $PS" | sed "s#$R/##g"; python $R/tools/rocpd_summary.py /tmp/prof_$name/*/*.db 60; } > $OUT/${TAG}_$name.txt 2>&1
+}
+pmc split_pmc_mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES
+pmc split_pmc_insts SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU
+pmc split_pmc_wait SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT
+pmc split_pmc_tcc TCC_HIT_sum TCC_MISS_sum TCC_EA_RDREQ_sum TCC_EA_WRREQ_sum
+python $R/tools/pmc_mfma_busy.py $OUT/${TAG}_split_mfma_busy.json /tmp/prof_split_pmc_*/*/*.db > $OUT/${TAG}_split_mfma_busy.txt 2>&1
+rm -rf /tmp/prof_split_pmc_*
+fi
 ls -la $OUT
