@@ -30,7 +30,10 @@ def run(L, v, q, reps=2):
         rc = L.mdl_got_bwd(v.data_ptr(), q.data_ptr(), go.data_ptr(), dv.data_ptr(), dq.data_ptr(), k, n, d, ws.data_ptr(), st); assert rc == 0, rc
         e[2].record(); torch.cuda.synchronize()
         best = (min(best[0], e[0].elapsed_time(e[1])), min(best[1], e[1].elapsed_time(e[2])))
-    return out.clone(), dv.clone(), dq.clone(), best
+    # exchange time-out flag of the split sweeps (got_impl.inc: ws[g_gen + 1]; the global region ends with g_gen[4])
+    nf = (ws.numel() - 64) // 4
+    err = float(ws[:nf * 4].view(torch.float32)[nf - 3]) if nf >= 4 else 0.0
+    return out.clone(), dv.clone(), dq.clone(), best, err
 
 
 def rel(a, b):
@@ -49,8 +52,8 @@ if __name__ == "__main__":
         q = torch.randn(k, n, 128, device=dev, generator=g) + 0.7 * v
         ref = None
         for name, L in libs:
-            o, dv, dq, t = run(L, v, q, reps=3)
+            o, dv, dq, t, err = run(L, v, q, reps=3)
             if ref is None:
                 ref = (o, dv, dq)
             print(f"k={k:3d} n={n:3d} {name:<24} wd {float(o[0]):.6f} gw {float(o[1]):.6f}  dV rel {rel(dv, ref[1]):.2e} dQ rel {rel(dq, ref[2]):.2e}   "
-                  f"{t[0]:7.3f} + {t[1]:7.3f} ms", flush=True)
+                  f"{t[0]:7.3f} + {t[1]:7.3f} ms" + (f"  EXCHANGE TIME-OUT FLAG {err}" if err != 0.0 and name.startswith("libmadeleine") else ""), flush=True)
