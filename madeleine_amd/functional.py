@@ -1351,6 +1351,14 @@ def got_extrema(V, Q):
     return mm
 
 
+def got_exchange_timeouts(ws) -> float:
+    """Diagnostic of the split IPOT sweeps (csrc/got_impl.inc, Xch): non-zero when a workgroup gave up waiting for its partner's column
+    sums in the last pass on this workspace (that pass's numbers are void).  The workspace's global region ends with
+    {generation, time-out flag, 0, 0}; mdl_got_ws_bytes adds 64 bytes of padding behind it.  Synchronises."""
+    nf = (ws.numel() * ws.element_size() - 64) // 4
+    return float(ws.view(torch.uint8)[:nf * 4].view(torch.float32)[nf - 3])
+
+
 def got(V, Q, minmax_in=None, reduce_dminmax=None, return_extrema=False):
     out, mm = GOTFn.apply(V, Q, minmax_in, reduce_dminmax)
     return (out, mm) if return_extrema else out

@@ -219,3 +219,43 @@ def test_bench_rank_emulation_equals_oracle_on_the_concatenated_global_batch(dev
             assert rel_err(tk[m].grad, t64[m].grad) < TOL, m
         else:
             assert tk[m].grad is None or float(tk[m].grad.abs().max()) == 0.0, m
+
+
+def test_split_sweeps_equal_one_workgroup_sweeps_and_do_not_depend_on_timing(dev):
+    """Round 6: the IPOT sweeps of the n <= 192 / 256 classes run as TWO workgroups per case and branch that exchange their column sums
+    once per iteration (csrc/got_impl.inc, Xch).  (i) Same numbers as the one-workgroup sweeps (MADELEINE_GOT_NOSPLIT=1) up to the
+    re-association of the column sums; (ii) bit-identical from run to run while another stream keeps the memory system and the compute
+    units busy (the exchange is value-deterministic: a stale or torn granule would change bits); (iii) no exchange timed out."""
+    from madeleine_amd import functional as MF
+    for name, shape in (("4x32x256", [(32, 256)] * 4), ("3x20x180", [(20, 180)] * 3)):
+        probs_cpu, _ = _problems(shape, "split:" + name)
+        o1, g1 = _run_batched(dev, probs_cpu)
+        os.environ["MADELEINE_GOT_NOSPLIT"] = "1"
+        try:
+            o0, g0 = _run_batched(dev, probs_cpu)
+        finally:
+            del os.environ["MADELEINE_GOT_NOSPLIT"]
+        assert rel_err(o1, o0) < 1e-6, (name, rel_err(o1, o0))
+        for (a1, b1), (a0, b0) in zip(g1, g0):
+            assert rel_err(a1, a0) < 2e-6 and rel_err(b1, b0) < 2e-6, (name, rel_err(a1, a0), rel_err(b1, b0))
+        assert not torch.equal(o1, o0) or not all(torch.equal(a1, a0) for (a1, _), (a0, _) in zip(g1, g0))   # the switch did switch paths
+        # (ii) under load from a second stream: 1-GiB copies that occupy compute units and HBM while the sweeps exchange
+        src = torch.empty(256 * 2 ** 20, device=dev)
+        dst = torch.empty_like(src)
+        side = torch.cuda.Stream()
+        for rep in range(4):
+            with torch.cuda.stream(side):
+                for _ in range(12):
+                    dst.copy_(src)
+            o2, g2 = _run_batched(dev, probs_cpu)
+            side.synchronize()
+            assert torch.equal(o2, o1), (name, rep)
+            for (a2, b2), (a1, b1) in zip(g2, g1):
+                assert torch.equal(a2, a1) and torch.equal(b2, b1), (name, rep)
+    # (iii) the time-out flag of a workspace after a forward and a backward pass at k = 32, n = 256
+    v, q = _problems([(32, 256)], "split:flag")[0][0]
+    v, q = v.to(dev), q.to(dev)
+    out, state = MF.HipGotImpl.forward(v, q, MF.got_extrema(v, q))
+    assert MF.got_exchange_timeouts(state[2]) == 0.0
+    MF.HipGotImpl.backward_begin(state, torch.ones(2, device=dev))
+    assert MF.got_exchange_timeouts(state[2]) == 0.0 and torch.isfinite(out).all()
