@@ -56,7 +56,7 @@ const char* mdl_version(void);
 /* ABI revision of this header: bumped whenever an entry point's argument list changes.  A binding compares
  * mdl_abi_version() with the MDL_ABI_VERSION it was written against BEFORE calling anything else, so that a stale
  * shared object fails loudly instead of being called with shifted arguments. */
-#define MDL_ABI_VERSION 22
+#define MDL_ABI_VERSION 23
 int mdl_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -270,6 +270,11 @@ int mdl_linear_bwd(const float* X, int64_t ldx, const float* W, const float* dY,
  * ws: mdl_got_ws_bytes(k,n,d) bytes: cost matrices + the per-iteration plans T_t and scaling vectors that
  * the reverse sweep replays (the same tensors the reference's autograd tape holds).  The backward calls
  * must receive the forward's workspace untouched.
+ * ABI 23: for 128 < n <= 256 and 2 * (cases of the launch) <= compute units of the device, every IPOT sweep runs as TWO workgroups per
+ * case and branch (row halves) that exchange their column sums once per iteration through 8-byte {value, tag} granules in the workspace
+ * (device-scope stores / polls; csrc/got_impl.inc, Xch); MADELEINE_GOT_NOSPLIT=1 keeps the one-workgroup sweeps.  Same results up to the
+ * association of the column sums; bit-reproducible.  The workspace's global region ends with four floats {pass generation (uint32 bits),
+ * exchange time-out flag (0 = none; non-zero voids the pass), 0, 0}, followed by the 64 bytes of padding mdl_got_ws_bytes adds.
  */
 int64_t mdl_got_ws_bytes(int k, int n, int d);
 int mdl_got_fwd(const float* V, const float* Q, float* out, float* minmax_out, const float* minmax_in,
