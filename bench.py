@@ -361,6 +361,35 @@ def kernel_rooflines(prof, work, precision="float32", gemm_mode="fp32"):
     return out
 
 
+def committed_mfma_busy():
+    """Matrix-core occupancy of the split-engine kernel families from the COMMITTED counter passes (profiles/*_split_mfma_busy.json,
+    written by tools/collect_profiles.sh <tag> split + tools/pmc_mfma_busy.py: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x
+    GRBM_GUI_ACTIVE), separate --pmc passes over tools/prof_split.py at config-2 geometry).  Counters cannot be collected inside a timed
+    run; the figure sits beside `frac` with its provenance.  Returns {family: {...}} (empty when no file is committed)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_split_mfma_busy.json")))
+    if not files:
+        return {}
+    try:
+        d = json.load(open(files[-1]))
+    except (OSError, ValueError):
+        return {}
+    src = os.path.relpath(files[-1], ROOT)
+
+    def pick(*needles):
+        ks = [v for k, v in d.items() if all(n in k for n in needles) and v.get("mfma_busy")]
+        if not ks:
+            return None
+        w = [(v["avg_us_under_pmc"] or 0) * (v["dispatches"] or 0) for v in ks]
+        tot = sum(w) or 1.0
+        return {"mfma_busy": round(sum(v["mfma_busy"] * wi for v, wi in zip(ks, w)) / tot, 4),
+                "effective_clock_GHz_under_pmc": round(sum((v.get("effective_clock_GHz") or 0) * wi for v, wi in zip(ks, w)) / tot, 3),
+                "source": src}
+    fams = {"gate_fwd": pick("gate_fwd_kernel"), "gate_bwd_gemm": pick("sp_gate_d"), "linear_fwd": pick("sp_nt_kernel"),
+            "linear_bwd": pick("sp_", "n_kernel")}
+    return {k: v for k, v in fams.items() if v}
+
+
 def emulated_rank_loss(D, MF, crit, largs, mods, embs, toks, labels, lab_g, noise, world):
     """The loss ONE rank of a `world`-rank job backpropagates (distributed.calculate_losses_dp's formula), with the other ranks' share of the
     all-gathered payload EMULATED instead of gathered -- no collective runs:
@@ -573,7 +602,9 @@ def compact_line(out):
         c["cpu_baseline"]["sample"] = str(c["cpu_baseline"].get("sample"))[:200]
     kr = out.get("kernel_roofline", {})
     if kr:   # [ms per call, fraction of the 8 TB/s HBM or dense-MFMA peak]
-        c["kernels"] = {k: [round(v["avg_ms"], 3), round(v["frac"], 3)] for k, v in kr.items()}
+        # (+ MFMA-busy fraction of the kernel's cycles from the committed counter passes, for the matrix-core families)
+        c["kernels"] = {k: [round(v["avg_ms"], 3), round(v["frac"], 3)] + ([round(v["mfma_busy"], 3)] if "mfma_busy" in v else [])
+                        for k, v in kr.items()}
     if "roofline_mfma" in out:
         m = out["roofline_mfma"]
         c["roofline_mfma"] = {k: m[k] for k in ("bound", "achieved", "peak", "unit", "frac", "frac_of_sustained_peak_random_operands") if k in m}
@@ -1021,6 +1052,10 @@ def main():
         if power is not None:
             out["power_clock"] = power
         out["kernel_roofline"] = kernel_rooflines(prof, work, a.precision, MF.gemm_mode())
+        if a.precision == "float32" and MF.gemm_mode() == "split":
+            for fam, busy in committed_mfma_busy().items():
+                if fam in out["kernel_roofline"]:
+                    out["kernel_roofline"][fam].update(busy)
         out["config"]["gemm_mode"] = MF.gemm_mode() if a.precision == "float32" else "bf16"
         if host_leg is not None:
             out["host_input_mode"] = host_leg
