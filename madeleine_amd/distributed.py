@@ -49,6 +49,10 @@ def init_from_env(backend: Optional[str] = None):
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
+        if torch.cuda.is_available() and world > torch.cuda.device_count():
+            # debug runs with several ranks on one GPU: the processes' launches share the compute units, so the residency bound the split
+            # IPOT sweeps rely on (csrc/got_impl.inc, Xch) does not hold -- keep the one-workgroup sweeps
+            os.environ.setdefault("MADELEINE_GOT_NOSPLIT", "1")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local_rank
 
@@ -392,6 +396,11 @@ class _fan_out:
             # the side lanes depend on what the current stream held BEFORE the fan-out, not on lane 0's own launches
             self.start = torch.cuda.Event()
             self.start.record(self.main)
+            # The split IPOT sweeps (two workgroups per case that wait for each other, csrc/got_impl.inc) size every launch so that all of
+            # its workgroups can be resident together; several chains launched side by side on different streams void that bound: keep the
+            # one-workgroup sweeps for launches issued inside a fan-out (the launcher reads the variable at every launch).
+            self.nosplit_was = os.environ.get("MADELEINE_GOT_NOSPLIT")
+            os.environ["MADELEINE_GOT_NOSPLIT"] = "1"
         return self._lane
 
     def _lane(self, i):
@@ -405,6 +414,10 @@ class _fan_out:
 
     def __exit__(self, *exc):
         if self.on:
+            if self.nosplit_was is None:
+                os.environ.pop("MADELEINE_GOT_NOSPLIT", None)
+            else:
+                os.environ["MADELEINE_GOT_NOSPLIT"] = self.nosplit_was
             for i in self.used:
                 self.main.wait_stream(self.streams[i])
         return False
