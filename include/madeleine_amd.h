@@ -56,7 +56,7 @@ const char* mdl_version(void);
 /* ABI revision of this header: bumped whenever an entry point's argument list changes.  A binding compares
  * mdl_abi_version() with the MDL_ABI_VERSION it was written against BEFORE calling anything else, so that a stale
  * shared object fails loudly instead of being called with shifted arguments. */
-#define MDL_ABI_VERSION 23
+#define MDL_ABI_VERSION 24
 int mdl_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -327,6 +327,26 @@ int mdl_ln_gelu_drop_fwd_bf16(const uint16_t* x, const float* bias, const float*
 int mdl_ln_gelu_drop_bwd_bf16(const uint16_t* x, const float* bias, const float* gamma, const float* beta, const float* mean,
                               const float* rstd, const uint16_t* dy, uint16_t* dx, float* dgamma, float* dbeta, float* dbias,
                               int64_t rows, int W, float p_drop, uint64_t seed, const uint8_t* keep, void* ws, void* stream);
+/* Grouped LayerNorm-GELU-Dropout (ABI 24) for the engines whose GEMM epilogue adds no bias (exact fp32: no suffix; bf16): rows
+ * [cu_groups[g], cu_groups[g + 1]) of group g (int64 [G + 1] on the device, G <= 2048, rows of a group contiguous) take the bias row
+ * group_bias[g][W] -- the preceding Linear's bias + the bag's stain-encoding row times the encoding columns of the first weight
+ * (Model.py:125-132, :351: [x | e_g] W^T = x Wx^T + e_g We^T), so the [T, D + 32] concatenation never exists.  The backward returns
+ * dgroup_bias [G][W] = per-group column sums of dx (merged in a fixed order).  W in {256, 512, 1024}.
+ * ws of the backward: mdl_ln_gelu_drop_bwd_groups_ws_bytes(rows, W, G). */
+int mdl_ln_gelu_drop_fwd_groups(const float* x, const float* group_bias, const float* gamma, const float* beta, float* y, float* mean,
+                                float* rstd, int64_t rows, int W, float eps, float p_drop, uint64_t seed, const uint8_t* keep,
+                                const int64_t* cu_groups, int G, void* stream);
+int mdl_ln_gelu_drop_fwd_groups_bf16(const uint16_t* x, const float* group_bias, const float* gamma, const float* beta, uint16_t* y,
+                                     float* mean, float* rstd, int64_t rows, int W, float eps, float p_drop, uint64_t seed,
+                                     const uint8_t* keep, const int64_t* cu_groups, int G, void* stream);
+int mdl_ln_gelu_drop_bwd_groups(const float* x, const float* group_bias, const float* gamma, const float* beta, const float* mean,
+                                const float* rstd, const float* dy, float* dx, float* dgamma, float* dbeta, float* dgroup_bias,
+                                int64_t rows, int W, float p_drop, uint64_t seed, const uint8_t* keep, const int64_t* cu_groups, int G,
+                                void* ws, void* stream);
+int mdl_ln_gelu_drop_bwd_groups_bf16(const uint16_t* x, const float* group_bias, const float* gamma, const float* beta,
+                                     const float* mean, const float* rstd, const uint16_t* dy, uint16_t* dx, float* dgamma,
+                                     float* dbeta, float* dgroup_bias, int64_t rows, int W, float p_drop, uint64_t seed,
+                                     const uint8_t* keep, const int64_t* cu_groups, int G, void* ws, void* stream);
 int mdl_abmil_pool_fwd_bf16(const uint16_t* E, int64_t ldE, const float* scores, float* pooled, float* stat_m,
                             float* stat_l, int64_t n_bags, int64_t N, const int64_t* cu_seqlens, int64_t max_len, int H,
                             void* ws, void* stream);

@@ -13,7 +13,7 @@ from . import _build
 
 _LOCK = threading.Lock()
 _LIB = None
-ABI_VERSION = 23   # == MDL_ABI_VERSION of include/madeleine_amd.h this file's SIGNATURES were written against
+ABI_VERSION = 24   # == MDL_ABI_VERSION of include/madeleine_amd.h this file's SIGNATURES were written against
 
 c_f = ctypes.c_void_p  # float* (device)
 c_p = ctypes.c_void_p
@@ -70,6 +70,12 @@ SIGNATURES = {
     "mdl_ln_gelu_drop_fwd_bf16": (i32, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, i64, i32, f32, f32, u64, c_p, c_p]),
     "mdl_ln_gelu_drop_bwd_bf16": (i32, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i64, i32, f32, u64, c_p, c_p,
                                         c_p]),
+    "mdl_ln_gelu_drop_fwd_groups": (i32, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, i64, i32, f32, f32, u64, c_p, c_p, i32, c_p]),
+    "mdl_ln_gelu_drop_fwd_groups_bf16": (i32, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, i64, i32, f32, f32, u64, c_p, c_p, i32, c_p]),
+    "mdl_ln_gelu_drop_bwd_groups": (i32, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i64, i32, f32, u64, c_p, c_p, i32,
+                                          c_p, c_p]),
+    "mdl_ln_gelu_drop_bwd_groups_bf16": (i32, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i64, i32, f32, u64, c_p, c_p, i32,
+                                               c_p, c_p]),
     "mdl_abmil_pool_fwd_bf16": (i32, [c_f, i64, c_f, c_f, c_f, c_f, i64, i64, c_p, i64, i32, c_p, c_p]),
     "mdl_abmil_pool_bwd_bf16": (i32, [c_f, i64, c_f, c_f, c_f, c_f, c_f, c_f, i32, c_f, i32, i64, i64, c_p, i64, i32, c_p]),
     "mdl_abmil_wpool_fwd": (i32, [c_f, i64, c_f, c_f, c_f, c_f, i64, i64, c_p, i64, i32, c_p, c_p]),

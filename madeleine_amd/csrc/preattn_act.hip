@@ -299,10 +299,19 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_fwd_kernel(const IO* _
                                                                      ActDrop drop, char* __restrict__ img = nullptr,
                                                                      const float* __restrict__ img_sc = nullptr,
                                                                      const float* __restrict__ row_mul = nullptr,
-                                                                     float* __restrict__ rstd_max = nullptr) {
+                                                                     float* __restrict__ rstd_max = nullptr,
+                                                                     const int64_t* __restrict__ cu = nullptr, int bias_gstride = 0) {
     // rstd_max (split variant): raised to max_r rstd[r] * row_mul[r] -- the factor of the backward's dx-image bound, taken here where the
     // statistics are computed instead of by a pass over rstd in every backward (one atomic per wave)
+    // cu (grouped forward, round 6): rows [cu[g], cu[g + 1]) of group g = blockIdx.y, whose bias row is bias + g * bias_gstride -- the
+    // stain-encoding columns of the first Linear folded into a per-bag bias (Model.py:125-132, :351) for the engines whose GEMM epilogue
+    // does not add it (bf16, exact fp32)
     constexpr int W = NV * 256 * WPR, RPB = 4 / WPR;
+    const int64_t row_lo = cu ? cu[blockIdx.y] : 0;
+    if (cu) {
+        rows = cu[blockIdx.y + 1];
+        if (bias) bias += (int64_t)blockIdx.y * bias_gstride;
+    }
     __shared__ float red[1][4][2];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, slot = wv / WPR, seg = wv % WPR;
     typedef ColMap<IO, NV> CM;
@@ -322,7 +331,7 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_fwd_kernel(const IO* _
     // because a plain 1 read : 1 write float4 stream gains 15-25 % from it (tools/micro/hbm_rate.hip: 4.6-5.0 -> 5.8-6.1 TB/s at 8-16
     // workgroups per CU); in these kernels it is a null -- forward 0.436 / 0.441 vs 0.437 / 0.427 ms, backward 0.657 / 0.659 vs 0.637 /
     // 0.653 ms in a same-box A/B (profiles/r05d_contig_rows_and_dw_stream_ab.txt): they are not at the streaming ceiling the order moves.
-    const ActRange rg = act_range(0, rows, RPB);
+    const ActRange rg = act_range(row_lo, rows, RPB);
     {
         const int64_t r = rg.base0 + slot;
         if (rg.base0 < rg.base1 && r < rows) row_load<IO, NV>(x + r * W + cb, lane, vn);
@@ -398,11 +407,13 @@ __global__ __launch_bounds__(ACT_BLOCK) void ln_gelu_drop_bwd_kernel(const IO* _
                                                                      char* __restrict__ img = nullptr,
                                                                      const float* __restrict__ img_sc = nullptr,
                                                                      const float* __restrict__ row_mul = nullptr,
-                                                                     const int64_t* __restrict__ cu = nullptr) {
+                                                                     const int64_t* __restrict__ cu = nullptr, int bias_gstride = 0) {
     // cu (grouped backward, round 5): rows [cu[g], cu[g + 1]) of group g = blockIdx.y are this workgroup's; its partial column sums
     // (slot blockIdx.y * gridDim.x + blockIdx.x) then belong to ONE group: the dbias third of them is the gradient of that group's bias row
+    // bias_gstride != 0 (round 6): x does NOT hold the group's bias row yet (bf16 / exact-fp32 engines): it is bias + g * bias_gstride
     constexpr int W = NV * 256 * WPR, RPB = 4 / WPR;
     const int64_t row_lo = cu ? cu[blockIdx.y] : 0, rows = cu ? cu[blockIdx.y + 1] : rows_all;
+    if (cu && bias) bias += (int64_t)blockIdx.y * bias_gstride;
     __shared__ float red[1][4][2];
     __shared__ float csum[WPR < 4 ? 3 * W : 1];  // WPR < 4: several waves own the same columns -> merged through LDS
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, slot = wv / WPR, seg = wv % WPR;
@@ -641,10 +652,39 @@ extern "C" int64_t mdl_ln_gelu_drop_bwd_ws_bytes(int64_t rows, int W) {
         default: return MDL_E_UNSUPPORTED;                                           \
     }
 
+__global__ __launch_bounds__(256) void ln_group_bias_kernel(const float* __restrict__ part, float* __restrict__ dgb, int nbx, int W) {
+    const int g = blockIdx.x;
+    for (int c = threadIdx.x; c < W; c += 256) {
+        float v = 0.f;
+        for (int b = 0; b < nbx; ++b) v += part[((int64_t)g * nbx + b) * 3 * W + 2 * W + c];
+        dgb[(int64_t)g * W + c] = v;
+    }
+}
+static inline int ln_group_nbx(int64_t rows, int W, int G) {   // workgroups per group: G * nbx <= 2048 partial slots
+    int nbx = 2048 / (G > 0 ? G : 1);
+    const int64_t per = (rows / (G > 0 ? G : 1) + act_rpb(W) - 1) / act_rpb(W);   // no more than an average group has row blocks
+    if (nbx > per) nbx = (int)per;
+    return nbx < 1 ? 1 : nbx;
+}
+
 template <class IO>
 static int ln_fwd_launch(const IO* x, const float* bias, const float* gamma, const float* beta, IO* y, float* mean, float* rstd, int64_t rows, int W,
-                         float eps, float p_drop, uint64_t seed, const uint8_t* keep, void* stream) {
+                         float eps, float p_drop, uint64_t seed, const uint8_t* keep, void* stream, const int64_t* cu_groups = nullptr,
+                         int G = 0) {
     if (!x || !gamma || !beta || !y || !mean || !rstd || rows < 0) return MDL_E_ARG;
+    if (cu_groups && (G < 1 || G > 2048 || !bias)) return MDL_E_ARG;
+    if (cu_groups && rows > 0) {   // grouped: nbx workgroups per group, the group's bias row (never the one-wave-per-row 2048-wide geometry)
+        if (!(p_drop >= 0.f && p_drop < 1.f) || !(eps > 0.f)) return MDL_E_ARG;
+        if (!host_aligned16(x) || !host_aligned16(y) || !host_aligned16(gamma) || !host_aligned16(beta) || !host_aligned16(bias)) return MDL_E_ALIGN;
+        const ActDrop dg = make_act_drop(p_drop, seed, keep);
+        const dim3 grid(ln_group_nbx(rows, W, G), G);
+        MDL_DISPATCH_W(W, {
+            hipLaunchKernelGGL((ln_gelu_drop_fwd_kernel<NV, WPR, IO, 0, -1>), grid, dim3(ACT_BLOCK), 0, (hipStream_t)stream, x, bias, gamma, beta, y,
+                               mean, rstd, rows, eps, dg, (char*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, cu_groups, W);
+            MDL_LAUNCH_CHECK();
+        });
+        return MDL_OK;
+    }
     if (!(p_drop >= 0.f && p_drop < 1.f) || !(eps > 0.f)) return MDL_E_ARG;
     if (!host_aligned16(x) || !host_aligned16(y) || !host_aligned16(gamma) || !host_aligned16(beta) || !host_aligned16(bias))
         return MDL_E_ALIGN;
@@ -693,8 +733,30 @@ static int ln_fwd_launch(const IO* x, const float* bias, const float* gamma, con
 template <class IO>
 static int ln_bwd_launch(const IO* x, const float* bias, const float* gamma, const float* beta, const float* mean, const float* rstd,
                          const IO* dy, IO* dx, float* dgamma, float* dbeta, float* dbias, int64_t rows, int W, float p_drop, uint64_t seed,
-                         const uint8_t* keep, void* ws, void* stream) {
+                         const uint8_t* keep, void* ws, void* stream, const int64_t* cu_groups = nullptr, int G = 0,
+                         float* dgroup_bias = nullptr) {
     if (!x || !gamma || !beta || !mean || !rstd || !dy || !dx || !dgamma || !dbeta || !ws || rows < 0) return MDL_E_ARG;
+    if (cu_groups) {   // grouped: per-group bias rows in, per-group bias gradients out (dbias = their sum over the groups)
+        if (G < 1 || G > 2048 || !bias || !dgroup_bias) return MDL_E_ARG;
+        if (!(p_drop >= 0.f && p_drop < 1.f)) return MDL_E_ARG;
+        if (!host_aligned16(x) || !host_aligned16(dy) || !host_aligned16(dx) || !host_aligned16(gamma) || !host_aligned16(beta) ||
+            !host_aligned16(bias))
+            return MDL_E_ALIGN;
+        hipStream_t sg = (hipStream_t)stream;
+        const ActDrop dd = make_act_drop(p_drop, seed, keep);
+        const int nbx = ln_group_nbx(rows, W, G);
+        const dim3 grid(nbx, G);
+        MDL_DISPATCH_W(W, {
+            hipLaunchKernelGGL((ln_gelu_drop_bwd_kernel<NV, WPR, IO, false, -1>), grid, dim3(ACT_BLOCK), 0, sg, x, bias, gamma, beta, mean, rstd, dy, dx,
+                               (float*)ws, rows, dd, (char*)nullptr, (const float*)nullptr, (const float*)nullptr, cu_groups, W);
+            MDL_LAUNCH_CHECK();
+        });
+        hipLaunchKernelGGL(ln_reduce_kernel, dim3((3 * W + 31) / 32), dim3(256), 0, sg, (const float*)ws, dgamma, dbeta, dbias, nbx * G, W);
+        MDL_LAUNCH_CHECK();
+        hipLaunchKernelGGL(ln_group_bias_kernel, dim3(G), dim3(256), 0, sg, (const float*)ws, dgroup_bias, nbx, W);
+        MDL_LAUNCH_CHECK();
+        return MDL_OK;
+    }
     if (!(p_drop >= 0.f && p_drop < 1.f)) return MDL_E_ARG;
     if (!host_aligned16(x) || !host_aligned16(dy) || !host_aligned16(dx) || !host_aligned16(gamma) || !host_aligned16(beta) ||
         !host_aligned16(bias))
@@ -769,6 +831,44 @@ extern "C" int mdl_ln_gelu_drop_bwd_bf16(const uint16_t* x, const float* bias, c
                                  dbias, rows, W, p_drop, seed, keep, ws, stream);
 }
 
+/* Grouped forms for the engines whose GEMM epilogue adds no bias (exact fp32, bf16): rows [cu_groups[g], cu_groups[g + 1]) of group g take
+ * the bias row group_bias[g][W] (the bias of the preceding Linear + the bag's stain-encoding row times the encoding columns of the weight,
+ * Model.py:125-132, :351: [x | e_g] W^T = x Wx^T + e_g We^T); the backward returns dgroup_bias [G][W] (per-group column sums of dx, merged
+ * in a fixed order).  ws of the backward: mdl_ln_gelu_drop_bwd_groups_ws_bytes(rows, W, G).  W <= 1024 (the first block is 512 wide). */
+extern "C" int mdl_ln_gelu_drop_fwd_groups(const float* x, const float* group_bias, const float* gamma, const float* beta, float* y, float* mean,
+                                           float* rstd, int64_t rows, int W, float eps, float p_drop, uint64_t seed, const uint8_t* keep,
+                                           const int64_t* cu_groups, int G, void* stream) {
+    if (!cu_groups) return MDL_E_ARG;
+    if (W > 1024) return MDL_E_UNSUPPORTED;
+    return ln_fwd_launch<float>(x, group_bias, gamma, beta, y, mean, rstd, rows, W, eps, p_drop, seed, keep, stream, cu_groups, G);
+}
+extern "C" int mdl_ln_gelu_drop_fwd_groups_bf16(const uint16_t* x, const float* group_bias, const float* gamma, const float* beta, uint16_t* y,
+                                                float* mean, float* rstd, int64_t rows, int W, float eps, float p_drop, uint64_t seed,
+                                                const uint8_t* keep, const int64_t* cu_groups, int G, void* stream) {
+    if (!cu_groups) return MDL_E_ARG;
+    if (W > 1024) return MDL_E_UNSUPPORTED;
+    return ln_fwd_launch<bf16_t>((const bf16_t*)x, group_bias, gamma, beta, (bf16_t*)y, mean, rstd, rows, W, eps, p_drop, seed, keep, stream,
+                                 cu_groups, G);
+}
+extern "C" int mdl_ln_gelu_drop_bwd_groups(const float* x, const float* group_bias, const float* gamma, const float* beta, const float* mean,
+                                           const float* rstd, const float* dy, float* dx, float* dgamma, float* dbeta, float* dgroup_bias,
+                                           int64_t rows, int W, float p_drop, uint64_t seed, const uint8_t* keep, const int64_t* cu_groups, int G,
+                                           void* ws, void* stream) {
+    if (!cu_groups) return MDL_E_ARG;
+    if (W > 1024) return MDL_E_UNSUPPORTED;
+    return ln_bwd_launch<float>(x, group_bias, gamma, beta, mean, rstd, dy, dx, dgamma, dbeta, (float*)nullptr, rows, W, p_drop, seed, keep, ws,
+                                stream, cu_groups, G, dgroup_bias);
+}
+extern "C" int mdl_ln_gelu_drop_bwd_groups_bf16(const uint16_t* x, const float* group_bias, const float* gamma, const float* beta,
+                                                const float* mean, const float* rstd, const uint16_t* dy, uint16_t* dx, float* dgamma,
+                                                float* dbeta, float* dgroup_bias, int64_t rows, int W, float p_drop, uint64_t seed,
+                                                const uint8_t* keep, const int64_t* cu_groups, int G, void* ws, void* stream) {
+    if (!cu_groups) return MDL_E_ARG;
+    if (W > 1024) return MDL_E_UNSUPPORTED;
+    return ln_bwd_launch<bf16_t>((const bf16_t*)x, group_bias, gamma, beta, mean, rstd, (const bf16_t*)dy, (bf16_t*)dx, dgamma, dbeta,
+                                 (float*)nullptr, rows, W, p_drop, seed, keep, ws, stream, cu_groups, G, dgroup_bias);
+}
+
 /* mdl_ln_gelu_drop_fwd whose output is written as a SPLIT IMAGE (rows of 4 W bytes at img; scale[2] = {scale, bound} from the
  * parameters: |y| <= (max|gamma| sqrt(W-1) + max|beta|) / (1-p)) -- and, when y != NULL, as fp32 as well. */
 extern "C" int mdl_ln_gelu_drop_fwd_split(const float* x, const float* bias, const float* gamma, const float* beta, float* y, void* img,
@@ -813,21 +913,6 @@ extern "C" int mdl_ln_gelu_drop_fwd_split(const float* x, const float* bias, con
  * float holding max |dy| (e.g. from the epilogue of the kernel that produced dy), or NULL: computed here by one pass over dy.
  * ws: mdl_ln_gelu_drop_bwd_ws_bytes(rows, W) + 64 bytes. */
 // gradient of the group bias rows: dgb[g][c] = sum over the nbx partial slots of group g of their dbias third
-__global__ __launch_bounds__(256) void ln_group_bias_kernel(const float* __restrict__ part, float* __restrict__ dgb, int nbx, int W) {
-    const int g = blockIdx.x;
-    for (int c = threadIdx.x; c < W; c += 256) {
-        float v = 0.f;
-        for (int b = 0; b < nbx; ++b) v += part[((int64_t)g * nbx + b) * 3 * W + 2 * W + c];
-        dgb[(int64_t)g * W + c] = v;
-    }
-}
-static inline int ln_group_nbx(int64_t rows, int W, int G) {   // workgroups per group: G * nbx <= 2048 partial slots
-    int nbx = 2048 / (G > 0 ? G : 1);
-    const int64_t per = (rows / (G > 0 ? G : 1) + act_rpb(W) - 1) / act_rpb(W);   // no more than an average group has row blocks
-    if (nbx > per) nbx = (int)per;
-    return nbx < 1 ? 1 : nbx;
-}
-
 static int ln_bwd_split_impl(const float* x, const float* bias, const float* gamma, const float* beta, const float* mean,
                              const float* rstd, const float* dy, const float* dy_absmax, void* dx_img, float* dx_scale,
                              float* dgamma, float* dbeta, float* dbias, int64_t rows, int W, float p_drop, uint64_t seed,

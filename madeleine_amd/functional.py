@@ -1147,6 +1147,61 @@ class LNGeluDropFn(torch.autograd.Function):
         return dx, dg, db, None, None, None, None, dbias
 
 
+class LNGeluDropGroupsFn(torch.autograd.Function):
+    """LNGeluDropFn with one bias row per GROUP of rows (rows [cu_groups[g], cu_groups[g + 1]) take group_bias[g]): the first block of
+    the pre-attention MLP when the stain encoding is folded out of its Linear (Model.py:125-132, :351) on the bf16 / exact-fp32 engines --
+    the split engine adds the row in its GEMM epilogue instead (PreAttnBlockFn).  The backward returns the per-group sums of dx."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, p_drop, seed, keep, group_bias, cu_groups):
+        _require_act(x, "x")
+        _require(gamma, "gamma")
+        _require(beta, "beta")
+        _require(group_bias, "group_bias")
+        _require(cu_groups, "cu_groups", torch.int64)
+        lib = _native.lib()
+        W = x.shape[-1]
+        rows, G = x.numel() // W, group_bias.shape[0]
+        if group_bias.shape != (G, W) or cu_groups.numel() != G + 1:
+            raise ValueError("group_bias must be [G, W] with cu_groups [G + 1]")
+        y = torch.empty_like(x)
+        mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        with _timed("ln_gelu_drop_fwd", ("byte", 2.0 * x.numel() * x.element_size())):
+            rc = getattr(lib, "mdl_ln_gelu_drop_fwd_groups" + _sfx(x))(_ptr(x), _ptr(group_bias), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean),
+                                                                     _ptr(rstd), rows, W, float(eps), float(p_drop), int(seed), _ptr(keep),
+                                                                     _ptr(cu_groups), G, _stream())
+        if rc == -3:
+            raise NotImplementedError("grouped LayerNorm-GELU-Dropout supports widths 256/512/1024 (got %d)" % W)
+        _native.check(rc, "mdl_ln_gelu_drop_fwd_groups")
+        ctx.save_for_backward(x, gamma, beta, mean, rstd, group_bias, cu_groups)
+        ctx.cfg = (float(p_drop), int(seed), keep)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, mean, rstd, group_bias, cu_groups = ctx.saved_tensors
+        p_drop, seed, keep = ctx.cfg
+        lib = _native.lib()
+        W = x.shape[-1]
+        rows, G = x.numel() // W, group_bias.shape[0]
+        dy = dy.to(x.dtype).contiguous()
+        dx = torch.empty_like(x)
+        dg, db, dgb = torch.empty_like(gamma), torch.empty_like(beta), torch.empty_like(group_bias)
+        ws = _ws(lib.mdl_ln_gelu_drop_bwd_groups_ws_bytes(rows, W, G), x.device)
+        with _timed("ln_gelu_drop_bwd", ("byte", 3.0 * x.numel() * x.element_size())):
+            rc = getattr(lib, "mdl_ln_gelu_drop_bwd_groups" + _sfx(x))(_ptr(x), _ptr(group_bias), _ptr(gamma), _ptr(beta), _ptr(mean),
+                                                                     _ptr(rstd), _ptr(dy), _ptr(dx), _ptr(dg), _ptr(db), _ptr(dgb), rows, W,
+                                                                     p_drop, seed, _ptr(keep), _ptr(cu_groups), G, _ptr(ws), _stream())
+        _native.check(rc, "mdl_ln_gelu_drop_bwd_groups")
+        return dx, dg, db, None, None, None, None, dgb, None
+
+
+def ln_gelu_drop_groups(x, gamma, beta, eps, p_drop, seed, keep, group_bias, cu_groups):
+    return LNGeluDropGroupsFn.apply(x.contiguous(), gamma.contiguous(), beta.contiguous(), eps, p_drop, seed, keep,
+                                    group_bias.float().contiguous(), cu_groups)
+
+
 def ln_gelu_drop(x, gamma, beta, eps=1e-5, p_drop=0.0, seed=0, keep=None, bias=None):
     return LNGeluDropFn.apply(x.contiguous(), gamma.contiguous(), beta.contiguous(), eps, p_drop, seed, keep,
                               None if bias is None else bias.contiguous())

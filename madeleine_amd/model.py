@@ -171,7 +171,8 @@ class ABMILEmbedder(nn.Module):
         # stain = (e [G, 32], row_group int32 [T], cu_groups int64 [G + 1]): MADELEINE's stain encoding concatenates ONE 32-vector per bag to
         # every patch feature in front of the first Linear (Model.py:125-132, :351).  [x | e_g] W^T = x Wx^T + e_g We^T: on the split engine the
         # concat never exists -- the bag's row e_g We^T ([G, 512], a small HIP Linear with autograd) enters the first product as a per-group
-        # bias (mdl_split_gemm_nt_group_bias) and its gradient comes back from the grouped LayerNorm backward.  The other engines concatenate.
+        # bias (mdl_split_gemm_nt_group_bias) and its gradient comes back from the grouped LayerNorm backward.  The other engines (bf16, exact
+        # fp32) add the row in a grouped LayerNorm-GELU-Dropout pass (round 6); only more than 2048 bags per call still concatenate.
         group_bias = None
         if stain is not None:
             e_rows, row_group, cu_groups = stain
@@ -187,6 +188,27 @@ class ABMILEmbedder(nn.Module):
                 img, sc, E = self._block_split(img, sc, 2, perm, want_fp32=keep_fp32)
                 E = (E if keep_fp32 else img).view(*bags.shape[:-1], img.shape[-1])
                 return (E, (img, sc)) if return_image else E
+            Wfull = pa[0].weight
+            if cu_groups is not None and Wfull.shape[0] in (256, 512, 1024) and e_rows.shape[0] <= 2048:
+                # bf16 / exact-fp32 engines (round 6): the same fold with the bag's row as a per-group bias of the fused
+                # LayerNorm-GELU-Dropout pass (functional.LNGeluDropGroupsFn) -- their GEMM epilogues add no bias
+                with torch.autocast(device_type="cuda", enabled=False):
+                    gb = MF.linear(e_rows.float(), Wfull[:, d_feat:].contiguous()) + pa[0].bias          # [G, 512]
+                    Wx = Wfull[:, :d_feat]
+                    xin = x_flat
+                    if d_feat % 32:
+                        padc = 32 - d_feat % 32
+                        xin, Wx = F.pad(xin, (0, padc)), F.pad(Wx, (0, padc))
+                    xin = xin.to(torch.bfloat16) if bf16_mode() else xin.float()
+                    p, seed, keep = self._drop_cfg(0, None)
+                    if keep is not None:
+                        keep = keep.reshape(-1, keep.shape[-1])
+                    x = MF.ln_gelu_drop_groups(MF.linear(xin, Wx.contiguous()), pa[1].weight, pa[1].bias, pa[1].eps, p, seed, keep, gb,
+                                               cu_groups)
+                    x = self._act(MF.linear(x, pa[4].weight), pa[5], 1, None, pa[4].bias)
+                    E = self._act(MF.linear(x, self.permuted(pa[8].weight, 0)), pa[9], 2, perm, pa[8].bias)
+                E = E.view(*bags.shape[:-1], E.shape[-1])
+                return (E, None) if return_image else E
             enc = e_rows.index_select(0, row_group.long()).view(*bags.shape[:-1], e_rows.shape[1])
             bags = torch.cat([bags, enc.to(bags.dtype)], dim=-1)
         # Any patch_embedding_dim (Model.py:351 is a plain nn.Linear): the kernels contract over 32-column blocks, so an input width that

@@ -316,3 +316,41 @@ def test_short_training_run_autocast_tracks_fp32(dev):
     dev_rel = [abs(x - y) / abs(y) for x, y in zip(b, f)]
     print("\\nbf16 vs fp32 loss, max relative deviation: first 10 steps %.3e, all 40 steps %.3e" % (max(dev_rel[:10]), max(dev_rel)))
     assert max(dev_rel[:10]) < 2e-2 and max(dev_rel) < 0.15
+
+
+def test_stain_encoding_under_autocast_takes_the_grouped_pass(dev):
+    """Round 6: with stain encodings (the reference's scripts/launch_pretrain_withStainEncodings.sh runs bf16 + stain tokens) the bf16 engine
+    no longer concatenates a [T, D + 32] copy of the bags: the bag's encoding row enters the first block as a per-group bias of the fused
+    LayerNorm-GELU-Dropout pass (functional.LNGeluDropGroupsFn).  Dense train branch (the `r // B` quirk) and eval branch against the fp32
+    path of the same model, embedding.weight gradient included."""
+    from madeleine_amd import functional as MF
+    from tests.test_model_gpu import build
+    B, M, N, D = 3, 3, 300, 96
+    mods = MODS5[:M]
+    model = build(mods, D, "wse16", dev, stain_encoding=True).eval()
+    feats = t((B, M, N, D), "se16:feats")
+    calls = []
+    orig = MF.ln_gelu_drop_groups
+    MF.ln_gelu_drop_groups = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        def run(bf16):
+            model.zero_grad()
+            with torch.autocast(device_type="cuda", dtype=BF, enabled=bf16):
+                embs, toks = model({"feats": feats}, device=dev, train=True)
+            loss = sum((embs[k].float() ** 2).sum() for k in mods) + sum((toks[k].float() ** 2).sum() for k in mods)
+            loss.backward()
+            return {k: embs[k].detach().float() for k in mods}, model.embedding.weight.grad.detach().clone()
+        e32, g32 = run(False)
+        assert not calls                      # fp32 values: the split engine folds the row into its GEMM epilogue
+        e16, g16 = run(True)
+        assert len(calls) == 1
+        with torch.no_grad(), torch.autocast(device_type="cuda", dtype=BF):
+            ev16 = model({"feats": feats[:1, 2:3]}, device=dev, train=False, custom_stain_idx=2)[mods[2]].float()
+        with torch.no_grad():
+            ev32 = model({"feats": feats[:1, 2:3]}, device=dev, train=False, custom_stain_idx=2)[mods[2]]
+    finally:
+        MF.ln_gelu_drop_groups = orig
+    for k in mods:
+        assert rel_err(e16[k], e32[k]) < 3e-2, (k, rel_err(e16[k], e32[k]))
+    assert rel_err(ev16, ev32) < 3e-2
+    assert rel_err(g16, g32) < 6e-2 and float(g32.abs().max()) > 0, rel_err(g16, g32)

@@ -556,6 +556,50 @@ def test_ln_gelu_drop_vs_torch(dev, W, rows, mode):
         assert rel_err(lbd.grad, lb.grad) < 1e-4
 
 
+@pytest.mark.parametrize("W,dtype", [(512, torch.float32), (512, torch.bfloat16), (256, torch.float32), (1024, torch.bfloat16)])
+def test_ln_gelu_drop_groups_vs_torch(dev, W, dtype):
+    """Round 6: the grouped LayerNorm-GELU-Dropout pass of the bf16 / exact-fp32 engines -- one bias row per GROUP of rows (the stain
+    encoding folded out of the first Linear: Model.py:125-132, :351; [x | e_g] W^T = x Wx^T + e_g We^T) -- against torch in fp64 on the same
+    (storage-rounded) input: output, dx, dgamma, dbeta and the per-group bias gradients; ragged groups incl. an empty one and one of a single
+    row; injected keep mask and the in-kernel RNG (same seed -> same bits, group launch or not)."""
+    import torch.nn.functional as F
+    from madeleine_amd import functional as MF
+    from oracle import recipe
+    lens = [37, 0, 1, 300, 5, 129]
+    G, rows = len(lens), sum(lens)
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int64)
+    x = (t((rows, W), f"lng:x{W}") * 3 + 0.5).to(dtype)
+    g = (1 + 0.2 * t((W,), f"lng:g{W}")).requires_grad_()
+    b = (0.3 * t((W,), f"lng:b{W}")).requires_grad_()
+    gb = (0.7 * t((G, W), f"lng:gb{W}")).requires_grad_()
+    dy = t((rows, W), f"lng:dy{W}").to(dtype)
+    keep = torch.from_numpy(recipe.bernoulli((rows, W), f"lng:k{W}", 0.9))
+    x64 = x.double().requires_grad_()
+    row_group = torch.repeat_interleave(torch.arange(G), torch.tensor(lens))
+    ref = F.gelu(F.layer_norm(x64 + gb.double()[row_group], (W,), g.double(), b.double(), 1e-5)) * keep / 0.9
+    ref.backward(dy.double())
+    xd = x.to(dev).requires_grad_()
+    gd, bd, gbd = (v.detach().to(dev).requires_grad_() for v in (g, b, gb))
+    out = MF.ln_gelu_drop_groups(xd, gd, bd, 1e-5, 0.1, 0, keep.to(torch.uint8).to(dev), gbd, cu.to(dev))
+    out.backward(dy.to(dev))
+    lo = dtype == torch.bfloat16
+    tol_o, tol_g = (6e-3, 1e-2) if lo else (1e-5, 1e-4)      # bf16: the storage grid of y / dx (2^-9 relative per element)
+    assert rel_err(out.float(), ref.float()) < tol_o
+    assert rel_err(xd.grad.float(), x64.grad.float()) < tol_g
+    assert rel_err(gd.grad, g.grad) < tol_g and rel_err(bd.grad, b.grad) < tol_g
+    assert rel_err(gbd.grad, gb.grad) < tol_g
+    assert float(gbd.grad[1].abs().max()) == 0.0                     # the empty group
+    # the same numbers as the un-grouped kernel given the gathered bias rows added beforehand (fp32 storage: exact same arithmetic)
+    if not lo:
+        x2 = (x.to(dev) + gb.detach().to(dev)[row_group.to(dev)]).requires_grad_()
+        o2 = MF.ln_gelu_drop(x2, gd.detach(), bd.detach(), 1e-5, 0.1, 0, keep.to(torch.uint8).to(dev))
+        assert rel_err(out, o2) < 1e-6
+    # in-kernel RNG: row-indexed counters, so the group launch draws the mask of the plain launch
+    o_r = MF.ln_gelu_drop_groups(xd.detach(), gd.detach(), bd.detach(), 1e-5, 0.1, 1234, None, torch.zeros(G, W, device=dev), cu.to(dev))
+    o_p = MF.ln_gelu_drop(xd.detach(), gd.detach(), bd.detach(), 1e-5, 0.1, 1234)
+    assert torch.equal(o_r, o_p)
+
+
 def test_ln_gelu_drop_rng_is_consistent(dev):
     """in-kernel RNG: keep rate ~0.9, same seed -> same output, backward zeros exactly where forward dropped."""
     from madeleine_amd import functional as MF

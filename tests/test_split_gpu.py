@@ -118,6 +118,7 @@ def test_parity_suite_in_fp32_gemm_mode(dev):
     MF.set_gemm_mode("fp32")
     try:
         TM.test_encoder_eval_and_grads(dev)
+        TM.test_stain_encoding_quirk(dev)          # round 6: the stain fold through the grouped LayerNorm pass of this engine
         TB.test_gate_split_path_vs_oracle(dev, 0.25)
         TB.test_full_step_dp_w1_matches_reference_golden(dev)
         TM.test_forward_ragged_unequal_backward_vs_oracle(dev, False)
