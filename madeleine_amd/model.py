@@ -21,6 +21,8 @@ from collections import OrderedDict
 from typing import Dict, Optional, Union
 
 import numpy as np
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -189,9 +191,11 @@ class ABMILEmbedder(nn.Module):
                 E = (E if keep_fp32 else img).view(*bags.shape[:-1], img.shape[-1])
                 return (E, (img, sc)) if return_image else E
             Wfull = pa[0].weight
-            if cu_groups is not None and Wfull.shape[0] in (256, 512, 1024) and e_rows.shape[0] <= 2048:
+            if cu_groups is not None and Wfull.shape[0] in (256, 512, 1024) and e_rows.shape[0] <= 2048 \
+                    and not os.environ.get("MADELEINE_STAIN_CONCAT"):      # (A/B switch: the round-5 concatenation)
                 # bf16 / exact-fp32 engines (round 6): the same fold with the bag's row as a per-group bias of the fused
                 # LayerNorm-GELU-Dropout pass (functional.LNGeluDropGroupsFn) -- their GEMM epilogues add no bias
+                lowp = bf16_mode()          # (read before autocast is switched off for the kernels' own dtype handling)
                 with torch.autocast(device_type="cuda", enabled=False):
                     gb = MF.linear(e_rows.float(), Wfull[:, d_feat:].contiguous()) + pa[0].bias          # [G, 512]
                     Wx = Wfull[:, :d_feat]
@@ -199,7 +203,7 @@ class ABMILEmbedder(nn.Module):
                     if d_feat % 32:
                         padc = 32 - d_feat % 32
                         xin, Wx = F.pad(xin, (0, padc)), F.pad(Wx, (0, padc))
-                    xin = xin.to(torch.bfloat16) if bf16_mode() else xin.float()
+                    xin = xin.to(torch.bfloat16) if lowp else xin.float()
                     p, seed, keep = self._drop_cfg(0, None)
                     if keep is not None:
                         keep = keep.reshape(-1, keep.shape[-1])

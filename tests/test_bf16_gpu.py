@@ -331,7 +331,7 @@ def test_stain_encoding_under_autocast_takes_the_grouped_pass(dev):
     feats = t((B, M, N, D), "se16:feats")
     calls = []
     orig = MF.ln_gelu_drop_groups
-    MF.ln_gelu_drop_groups = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    MF.ln_gelu_drop_groups = lambda *a, **k: (calls.append(a[0].dtype), orig(*a, **k))[1]
     try:
         def run(bf16):
             model.zero_grad()
@@ -343,7 +343,7 @@ def test_stain_encoding_under_autocast_takes_the_grouped_pass(dev):
         e32, g32 = run(False)
         assert not calls                      # fp32 values: the split engine folds the row into its GEMM epilogue
         e16, g16 = run(True)
-        assert len(calls) == 1
+        assert calls == [BF]                  # ... on bf16 storage: the bf16 engine, not a detour through fp32
         with torch.no_grad(), torch.autocast(device_type="cuda", dtype=BF):
             ev16 = model({"feats": feats[:1, 2:3]}, device=dev, train=False, custom_stain_idx=2)[mods[2]].float()
         with torch.no_grad():
