@@ -678,11 +678,18 @@ static int ln_fwd_launch(const IO* x, const float* bias, const float* gamma, con
         if (!host_aligned16(x) || !host_aligned16(y) || !host_aligned16(gamma) || !host_aligned16(beta) || !host_aligned16(bias)) return MDL_E_ALIGN;
         const ActDrop dg = make_act_drop(p_drop, seed, keep);
         const dim3 grid(ln_group_nbx(rows, W, G), G);
+#define MDL_LN_FWD_G(DMV)                                                                                                                    \
+    hipLaunchKernelGGL((ln_gelu_drop_fwd_kernel<NV, WPR, IO, 0, DMV>), grid, dim3(ACT_BLOCK), 0, (hipStream_t)stream, x, bias, gamma, beta, y, mean, \
+                       rstd, rows, eps, dg, (char*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, cu_groups, W)
+        const int dmg = ln_dm<IO>(dg);   // (dropout mode fixed at compile time where the un-grouped launch does so)
         MDL_DISPATCH_W(W, {
-            hipLaunchKernelGGL((ln_gelu_drop_fwd_kernel<NV, WPR, IO, 0, -1>), grid, dim3(ACT_BLOCK), 0, (hipStream_t)stream, x, bias, gamma, beta, y,
-                               mean, rstd, rows, eps, dg, (char*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, cu_groups, W);
+            if (dmg < 0) MDL_LN_FWD_G(-1);
+            else if (dmg == 0) MDL_LN_FWD_G(0);
+            else if (dmg == 1) MDL_LN_FWD_G(1);
+            else MDL_LN_FWD_G(2);
             MDL_LAUNCH_CHECK();
         });
+#undef MDL_LN_FWD_G
         return MDL_OK;
     }
     if (!(p_drop >= 0.f && p_drop < 1.f) || !(eps > 0.f)) return MDL_E_ARG;
@@ -746,11 +753,18 @@ static int ln_bwd_launch(const IO* x, const float* bias, const float* gamma, con
         const ActDrop dd = make_act_drop(p_drop, seed, keep);
         const int nbx = ln_group_nbx(rows, W, G);
         const dim3 grid(nbx, G);
+#define MDL_LN_BWD_G(DMV)                                                                                                                    \
+    hipLaunchKernelGGL((ln_gelu_drop_bwd_kernel<NV, WPR, IO, false, DMV>), grid, dim3(ACT_BLOCK), 0, sg, x, bias, gamma, beta, mean, rstd, dy, dx, \
+                       (float*)ws, rows, dd, (char*)nullptr, (const float*)nullptr, (const float*)nullptr, cu_groups, W)
+        const int dmg = ln_dm<IO>(dd);
         MDL_DISPATCH_W(W, {
-            hipLaunchKernelGGL((ln_gelu_drop_bwd_kernel<NV, WPR, IO, false, -1>), grid, dim3(ACT_BLOCK), 0, sg, x, bias, gamma, beta, mean, rstd, dy, dx,
-                               (float*)ws, rows, dd, (char*)nullptr, (const float*)nullptr, (const float*)nullptr, cu_groups, W);
+            if (dmg < 0) MDL_LN_BWD_G(-1);
+            else if (dmg == 0) MDL_LN_BWD_G(0);
+            else if (dmg == 1) MDL_LN_BWD_G(1);
+            else MDL_LN_BWD_G(2);
             MDL_LAUNCH_CHECK();
         });
+#undef MDL_LN_BWD_G
         hipLaunchKernelGGL(ln_reduce_kernel, dim3((3 * W + 31) / 32), dim3(256), 0, sg, (const float*)ws, dgamma, dbeta, dbias, nbx * G, W);
         MDL_LAUNCH_CHECK();
         hipLaunchKernelGGL(ln_group_bias_kernel, dim3(G), dim3(256), 0, sg, (const float*)ws, dgroup_bias, nbx, W);
