@@ -430,7 +430,7 @@ def emulated_rank_loss(D, MF, crit, largs, mods, embs, toks, labels, lab_g, nois
     return loss_g + float(world) * largs.local_loss_weight * (outs[:, 0] + outs[:, 1]).sum()
 
 
-def secondary_rank_leg(dev, D, MF, InfoNCE, MADELEINE, world=8, steps=4, warmup=2, config="c3", all_present=False):
+def secondary_rank_leg(dev, D, MF, InfoNCE, MADELEINE, world=8, steps=4, warmup=2, config="c3", all_present=False, bf16=False):
     """What ONE rank of an 8 x MI355X configuration (BASELINE configs[3] = 8 ranks x c3, configs[4] = 8 ranks x c5; 256-slide global
     batch, 5 stains) executes per step, on one GPU: its 32 local cases through the encoder, the replicated global InfoNCE over
     k_global <= 256 cases, and its share of GOT with the GLOBAL token count n = min(k_global, 256) (loss.py:282: indices are
@@ -472,13 +472,12 @@ def secondary_rank_leg(dev, D, MF, InfoNCE, MADELEINE, world=8, steps=4, warmup=
 
     def rank_step(local_only=False):
         opt.zero_grad(set_to_none=True)
-        embs, toks = model(data, device=dev)
-        if local_only:   # the single-rank step of the same configuration (the weak-scaling reference: world size 1, n = k_local)
-            loss, _ = D.calculate_losses_dp(mods[1:], crit, MF.HipGotImpl, embs, toks, labels[:, 1:], largs)
-            loss.backward()
-            opt.step()
-            return loss
-        loss = emulated_rank_loss(D, MF, crit, largs, mods, embs, toks, labels, lab_g, noise, world)
+        with torch.autocast(device_type="cuda", dtype=torch.bfloat16, enabled=bf16):   # bf16: trainer.py:101-103 under `precision: bfloat16`
+            embs, toks = model(data, device=dev)
+            if local_only:   # the single-rank step of the same configuration (the weak-scaling reference: world size 1, n = k_local)
+                loss, _ = D.calculate_losses_dp(mods[1:], crit, MF.HipGotImpl, embs, toks, labels[:, 1:], largs)
+            else:
+                loss = emulated_rank_loss(D, MF, crit, largs, mods, embs, toks, labels, lab_g, noise, world)
         loss.backward()
         opt.step()
         return loss
@@ -486,7 +485,8 @@ def secondary_rank_leg(dev, D, MF, InfoNCE, MADELEINE, world=8, steps=4, warmup=
     el, loss, prof, _work, psteps = measure_leg(MF, rank_step, steps, warmup)
     got_ms = sum(prof[k][0] * prof[k][1] / psteps for k in ("got_fwd", "got_bwd", "got_bwd_finish") if k in prof)
     out = {"ms_per_step": round(1e3 * el / steps, 3), "steps": steps, "emulated_world": world,
-           "workload": f"one rank of {world} x {config}{' (all stains present)' if all_present and not ragged else ''}: {B} local slides x {M} stains x "
+           "workload": f"one rank of {world} x {config}{' (all stains present)' if all_present and not ragged else ''}"
+                       f"{' under torch.autocast(bfloat16)' if bf16 else ''}: {B} local slides x {M} stains x "
                        f"{shape}; global batch {world * B} emulated: cases per stain {k_g} -> GOT token count n = min(k_global, 256) = "
                        f"{[min(k, 256) for k in k_g]}, replicated InfoNCE over k_global rows; no collective",
            "final_loss": float(loss.detach()), "got_ms_per_step_sum_over_stains": round(got_ms, 3),
@@ -609,7 +609,8 @@ def compact_line(out):
         m = out["roofline_mfma"]
         c["roofline_mfma"] = {k: m[k] for k in ("bound", "achieved", "peak", "unit", "frac", "frac_of_sustained_peak_random_operands") if k in m}
     sec = {}
-    for name in ("bf16_mode", "c3_mode", "c4_rank_emulation", "c4_rank_emulation_all_present", "c5_rank_emulation", "host_input_mode"):
+    for name in ("bf16_mode", "c3_mode", "c4_rank_emulation", "c4_rank_emulation_all_present", "c5_rank_emulation", "c5_rank_emulation_bf16",
+                 "host_input_mode"):
         if name in out and "ms_per_step" in out[name]:
             sec[name] = out[name]["ms_per_step"]
     if sec:
@@ -913,7 +914,7 @@ def main():
                 step()
             fence()
         power = ps.summary(skip_s=1.0)
-    c3_leg = infer_leg = c4_leg = c3ap_leg = c4ap_leg = c5_leg = c3skip_leg = None
+    c3_leg = infer_leg = c4_leg = c3ap_leg = c4ap_leg = c5_leg = c5b_leg = c3skip_leg = None
     if a.config == "c2" and a.precision == "float32" and world == 1 and not a.no_extra_legs and host_iter is None:
         # free the c2 working set first (the c3 step keeps ~60 GiB live)
         feats = data = None
@@ -934,6 +935,9 @@ def main():
         c4ap_leg = secondary_rank_leg(dev, D, MF, InfoNCE, MADELEINE, all_present=True)
         torch.cuda.empty_cache()
         c5_leg = secondary_rank_leg(dev, D, MF, InfoNCE, MADELEINE, config="c5", steps=3)
+        torch.cuda.empty_cache()
+        # ... and in the precision the reference runs that recipe in (scripts/launch_pretrain_withStainEncodings.sh: bf16 + stain tokens)
+        c5b_leg = secondary_rank_leg(dev, D, MF, InfoNCE, MADELEINE, config="c5", steps=3, bf16=True)
         torch.cuda.empty_cache()
 
     tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -1079,6 +1083,8 @@ def main():
             out["c4_rank_emulation_all_present"] = c4ap_leg
         if c5_leg is not None:
             out["c5_rank_emulation"] = c5_leg
+        if c5b_leg is not None:
+            out["c5_rank_emulation_bf16"] = c5b_leg
         if world == 1 and not a.no_cpu_baseline:
             try:
                 nb = min(a.cpu_sample, B)
