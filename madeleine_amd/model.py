@@ -289,10 +289,18 @@ class ABMILEmbedder(nn.Module):
         [T,P] with tok_proj = (W, bias), see pool_headmajor)."""
         for h in self.attn:
             h._check_geometry()
-        if self.attn[0].activation != 'softmax':
-            raise NotImplementedError("ragged bags are supported for activation='softmax' (the reference's scripts)")
         wa, ba, wb, bb, wc, bc = self.gate_params_stacked()
         p, seed, ka, kb = self._gate_dropout((E_hm.shape[0], 1))
+        act = self.attn[0].activation
+        if act != 'softmax':
+            # relu / leaky_relu / sigmoid attention (abmil.py:56-61) on ragged bags: element-wise weights, no normalisation over the patch
+            # axis -- raw scores from the gate kernel, the activation in torch, un-normalised weighted pooling over cu_seqlens
+            # (mdl_abmil_wpool_*), as the dense path does (forward_headmajor_from_tokens)
+            if self.image_only(E_hm, e_img) or tok_proj is not None:
+                raise ValueError("activation=%r pools the token embeddings themselves: call embed_tokens_headmajor(want_fp32=True) and project "
+                                 "the tokens separately" % act)
+            scores = MF.gate_scores(E_hm, wa, ba, wb, bb, wc, bc, p, seed, ka, kb)          # [T, H]
+            return MF.weighted_pool(E_hm, activate(scores, act), cu_seqlens, max_len), scores
         return MF.attn_pool(E_hm, wa, ba, wb, bb, wc, bc, p, seed, ka, kb, cu_seqlens, max_len, e_img=e_img, tok_proj=tok_proj,
                             e_only_image=self.image_only(E_hm, e_img))
 
@@ -524,7 +532,8 @@ class MADELEINE(nn.Module):
         # Split GEMM mode: the token projection is part of the pooling node (every token, on the image of E) and the head tokens are
         # gathered from ITS output -- gathering rows of E instead makes autograd fill a zero [T, 2048] tensor and add it to the node's dE
         # (3 x 11 GB of traffic per config-5 step), and E need not exist in fp32 at all.
-        fuse_tok = (not bf16_mode()) and MF.split_linear_supported(x.shape[0], tp[0].shape[0], tp[0].shape[1])
+        fuse_tok = (not bf16_mode()) and MF.split_linear_supported(x.shape[0], tp[0].shape[0], tp[0].shape[1]) \
+            and emb.attn[0].activation == 'softmax'      # (the other activations pool fp32 tokens through the weighted-pooling kernels)
         E, e_img = emb.embed_tokens_headmajor(x, return_image=True, want_fp32=not fuse_tok, stain=stain)   # [T, H*512]
         if fuse_tok and e_img is not None:
             pooled, _, tok_all = emb.pool_headmajor_ragged(E, cu_d, max(lens), e_img=e_img, tok_proj=tp)
