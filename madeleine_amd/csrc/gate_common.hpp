@@ -171,10 +171,26 @@ static inline DropCfg make_drop(float p, uint64_t seed, const uint8_t* ka, const
 // i.e. a last round that is 2/3 idle; 3072 or 768 tiles are exact.  Splits stay >= 1024 tokens and <= 192.
 // `slots`: resident workgroups of the kernel on the chip: 768 for the 156-VGPR fp32 TN kernels, 512 for the bf16 TN kernels (200-216
 // VGPRs: two per CU) -- with 768 assumed the bf16 Linear dW launched 768 tiles on 512 slots (1.5 rounds).
+// Round 6: MADELEINE_SPLIT_TOKENS (default MDL_SPLIT_TOKENS) = tokens per split to aim for once the chip is filled: every split writes
+// one fp32 slab of the whole gradient that a reduction kernel re-reads (config 2, gate dW: 64 splits = 537 MB written + read, 127 us of
+// reduction alone), so beyond one full round of workgroups more splits only add traffic.  The count falls from the 4096-token base
+// towards T / quantum but never below the `slots / tiles_per_split` that give every CU a workgroup.  Same-box A/B at config 2
+// (profiles/r06e_split_tokens_ab.txt): 4096 -> 32768 tokens: gate dX + dW 5.91 -> 5.72 ms (fp32 values), 2.30 -> 2.08 ms (bf16); step
+// 22.20 -> 21.93-22.05 ms, bf16 10.41-10.49 -> 10.19-10.23 ms.  MADELEINE_SPLIT_TOKENS=4096 restores the round-5 counts.
+#ifndef MDL_SPLIT_TOKENS
+#define MDL_SPLIT_TOKENS 32768
+#endif
 static inline int splits_for(int64_t T, int tiles_per_split, int64_t slots = 768) {
+    static const int64_t quantum = getenv("MADELEINE_SPLIT_TOKENS") ? atoll(getenv("MADELEINE_SPLIT_TOKENS")) : MDL_SPLIT_TOKENS;
     int64_t s = (T + 4095) / 4096;
     if (s < 1) s = 1;
     if (s > 64) s = 64;
+    if (quantum > 4096) {
+        const int64_t fill = (slots + tiles_per_split - 1) / tiles_per_split, sq = (T + quantum - 1) / quantum;
+        const int64_t lo = s < fill ? s : fill;
+        s = sq > lo ? sq : lo;
+        if (s > 64) s = 64;
+    }
     if (s * tiles_per_split >= slots / 2) {
         const int64_t rounds = (s * tiles_per_split + slots - 1) / slots;
         const int64_t want = (rounds * slots + tiles_per_split - 1) / tiles_per_split;

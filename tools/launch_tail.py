@@ -41,16 +41,34 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stac
     torch.cuda.synchronize()
 small = collections.Counter()
 dur = collections.Counter()
+names = collections.defaultdict(collections.Counter)
+
+
+def ancestors(ev):
+    out = []
+    p = ev.cpu_parent
+    while p is not None:
+        out.append(p.name)
+        p = p.cpu_parent
+    return out
+
+
 for ev in prof.events():
     if ev.device_type != torch.autograd.DeviceType.CPU or not ev.kernels:
         continue
     ks = [k for k in ev.kernels if k.duration < 20]
     if not ks:
         continue
-    frame = next((f for f in ev.stack if ("madeleine_amd/" in f or "bench" in f or "tools/" in f) and "_native" not in f), "(no python frame: autograd engine)")
+    frame = next((f for f in ev.stack if ("madeleine_amd/" in f or "bench" in f or "tools/" in f) and "_native" not in f), None)
+    if frame is None:   # autograd engine thread: name the backward node (or the outermost op) instead
+        anc = ancestors(ev)
+        node = next((a for a in anc if a.startswith("autograd::engine::evaluate_function")), anc[-1] if anc else "(top level)")
+        frame = node.replace("autograd::engine::evaluate_function: ", "bwd node ")
     key = (ev.name, frame.split("/root/repo/")[-1] if "/root/repo/" in frame else frame[-90:])
     small[key] += len(ks)
     dur[key] += sum(k.duration for k in ks)
+    for k in ks:
+        names[key][k.name[:60]] += 1
 print("launches < 20 us in ONE config-2 step: %d, %.1f us" % (sum(small.values()), sum(dur.values())))
 for key, n in small.most_common(80):
-    print("%3d  %7.1f us  %-28s %s" % (n, dur[key], key[0], key[1]))
+    print("%3d  %7.1f us  %-28s %s   [%s]" % (n, dur[key], key[0], key[1], ", ".join("%s x%d" % kv for kv in names[key].most_common(4))))
