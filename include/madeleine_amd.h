@@ -275,6 +275,9 @@ int mdl_linear_bwd(const float* X, int64_t ldx, const float* W, const float* dY,
  * (device-scope stores / polls; csrc/got_impl.inc, Xch); MADELEINE_GOT_NOSPLIT=1 keeps the one-workgroup sweeps.  Same results up to the
  * association of the column sums; bit-reproducible.  The workspace's global region ends with four floats {pass generation (uint32 bits),
  * exchange time-out flag (0 = none; non-zero voids the pass), 0, 0}, followed by the 64 bytes of padding mdl_got_ws_bytes adds.
+ * A voided pass says so in its results: out[0..1] of the forward and dV / dQ of the backward are NaN when the flag is up (a sweep waited
+ * ~1 s for a partner workgroup that never became resident -- the device was shared with work the launch did not know about, e.g. a
+ * second training process; run those with MADELEINE_GOT_NOSPLIT=1).  The flag is cleared by the extrema kernel of every forward.
  */
 int64_t mdl_got_ws_bytes(int k, int n, int d);
 int mdl_got_fwd(const float* V, const float* Q, float* out, float* minmax_out, const float* minmax_in,

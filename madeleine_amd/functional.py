@@ -1408,10 +1408,18 @@ def got_extrema(V, Q):
 
 def got_exchange_timeouts(ws) -> float:
     """Diagnostic of the split IPOT sweeps (csrc/got_impl.inc, Xch): non-zero when a workgroup gave up waiting for its partner's column
-    sums in the last pass on this workspace (that pass's numbers are void).  The workspace's global region ends with
+    sums in the last pass on this workspace.  That pass's numbers are void and say so themselves: the distances of a forward and the
+    token gradients of a backward on a flagged workspace come back NaN (got_sum_kernel / got_cost_bwd_kernel) -- the flag is for
+    diagnosis, nothing has to poll it.  The workspace's global region ends with
     {generation, time-out flag, 0, 0}; mdl_got_ws_bytes adds 64 bytes of padding behind it.  Synchronises."""
     nf = (ws.numel() * ws.element_size() - 64) // 4
     return float(ws.view(torch.uint8)[:nf * 4].view(torch.float32)[nf - 3])
+
+
+def _got_set_exchange_timeout(ws, value: float = 1.0) -> None:
+    """Test hook: writes the workspace's time-out flag (what a split sweep does when it gives up on its partner)."""
+    nf = (ws.numel() * ws.element_size() - 64) // 4
+    ws.view(torch.uint8)[:nf * 4].view(torch.float32)[nf - 3] = value
 
 
 def got(V, Q, minmax_in=None, reduce_dminmax=None, return_extrema=False):

@@ -259,3 +259,27 @@ def test_split_sweeps_equal_one_workgroup_sweeps_and_do_not_depend_on_timing(dev
     assert MF.got_exchange_timeouts(state[2]) == 0.0
     MF.HipGotImpl.backward_begin(state, torch.ones(2, device=dev))
     assert MF.got_exchange_timeouts(state[2]) == 0.0 and torch.isfinite(out).all()
+
+
+@pytest.mark.parametrize("k,n", [(6, 256), (5, 150), (4, 100), (3, 40), (2, 300)])
+def test_void_pass_comes_back_as_nan_not_as_numbers(dev, k, n):
+    """A split sweep that gives up on its partner (csrc/got_impl.inc, Xch: e.g. two processes sharing the GPU, each assuming it owns every
+    compute unit) raises the workspace's time-out flag.  Nothing polls that flag in a training loop, so the pass itself must say it is
+    void: with the flag raised the backward returns NaN token gradients (and a forward NaN distances: got_sum_kernel reads the same
+    word).  Every size class defines the flag (cleared by the extrema kernel), so regular passes stay finite in all of them."""
+    from madeleine_amd import functional as MF
+    v = t((k, n, 128), "void:v%d:%d" % (k, n))
+    q = (t((k, n, 128), "void:q%d:%d" % (k, n)) + 0.7 * v).to(dev)
+    v = v.to(dev)
+    out, state = MF.HipGotImpl.forward(v, q, MF.got_extrema(v, q))
+    assert torch.isfinite(out).all() and MF.got_exchange_timeouts(state[2]) == 0.0
+    dmm = MF.HipGotImpl.backward_begin(state, torch.ones(2, device=dev))
+    dV, dQ = MF.HipGotImpl.backward_finish(state, dmm)
+    assert torch.isfinite(dV).all() and torch.isfinite(dQ).all() and float(dV.abs().sum()) > 0
+    # the same backward on a workspace whose flag is up
+    out2, state2 = MF.HipGotImpl.forward(v, q, MF.got_extrema(v, q))
+    assert torch.equal(out2, out)
+    MF._got_set_exchange_timeout(state2[2])
+    dmm2 = MF.HipGotImpl.backward_begin(state2, torch.ones(2, device=dev))
+    dV2, dQ2 = MF.HipGotImpl.backward_finish(state2, dmm2)
+    assert torch.isnan(dV2).all() and torch.isnan(dQ2).all()
