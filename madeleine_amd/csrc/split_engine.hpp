@@ -48,10 +48,16 @@ constexpr int SP_PW = 32 / SP_WAVES;        // LDS-DMA pieces (1 KiB) per wave, 
 constexpr int SP_NP = 2 * SP_PW;            // pieces per wave and chunk = MFMAs of one set = 4 SPNCT
 constexpr int SP_WCOLS = 32 * SPNCT;        // columns per wave
 typedef f32x16 SpAcc[4][SPNCT];
-struct __attribute__((aligned(16))) SmemSP {
-    char A[2][SP_STAGE];
+// NA = stages of the A ring.  2: the symmetric two-stage ring (128 KiB).  3 (round 6, NT products): the A operand -- the one that
+// streams from HBM -- three deep, B (a weight: L2 / MALL resident) two deep = 160 KiB, the whole LDS: a block of A is requested TWO chunks
+// before its first read instead of one (see sp_nt_mainloop).
+template <int NA>
+struct __attribute__((aligned(16))) SmemSPn {
+    char A[NA][SP_STAGE];
     char B[2][SP_STAGE];
 };
+typedef SmemSPn<2> SmemSP;
+typedef SmemSPn<3> SmemSP3;
 
 // a wave-uniform pointer the compiler can keep in SGPRs (saddr operand of the LDS-DMA)
 __device__ __forceinline__ const char* sp_uniform(const char* p) {
@@ -89,9 +95,16 @@ __device__ __forceinline__ void sp_nt_slot(int wave, int i, int lane, int& row, 
 // per chunk instead of six.  For gradient products whose B operand is a weight (dX = dY W); never the default.
 // chunk0_in_flight: the caller already issued this wave's pieces of block 0 into stage 0 (a persistent workgroup requests the next
 // tile's first block before the epilogue of the current one and keeps its epilogue staging inside stage 1: sp_stage1_tile).
-template <int TERMS = 3, class Dma>
-__device__ __forceinline__ void sp_nt_mainloop(SmemSP& sm, SpAcc& acc, int nblk, int wm, int wn, int lane, Dma&& dma,
+// NA = 3 (SmemSP3): counters at config 2 (profiles/r06_split_mfma_busy.json) show the waves of the two-stage loop 37 % of their cycles in
+// s_waitcnt with LDS waits at 2.6 %: the vmcnt(0) in front of the chunk barrier, i.e. the LDS-DMA of the NEXT block, requested one chunk
+// (~2.4 us) earlier, has not landed for the slowest of the workgroup's 4096 16-B requests.  With three A stages block ch + 3 goes into the
+// stage chunk ch just freed and is awaited at the end of chunk ch + 2 -- two chunks of flight time.  The wait becomes vmcnt(SP_PW): this
+// wave's B pieces of block ch + 1 (requested FIRST at the end of chunk ch - 1) and the older A pieces of block ch + 1 must have landed,
+// its SP_PW newest requests (A of block ch + 2) may still be in flight.
+template <int TERMS = 3, int NA = 2, class Dma>
+__device__ __forceinline__ void sp_nt_mainloop(SmemSPn<NA>& sm, SpAcc& acc, int nblk, int wm, int wn, int lane, Dma&& dma,
                                                bool chunk0_in_flight = false) {
+    static_assert(NA == 2 || NA == 3, "A ring of two or three stages");
     const int l32 = lane & 31, kh = lane >> 5;
     uint32_t offA[4], offB[SPNCT];
 #pragma unroll
@@ -133,40 +146,62 @@ __device__ __forceinline__ void sp_nt_mainloop(SmemSP& sm, SpAcc& acc, int nblk,
     __syncthreads();
     {
         const int f = nblk > 1 ? 1 : 0;
+        if constexpr (NA == 2) {
 #pragma unroll
-        for (int p = 0; p < SP_NP; ++p) dma(1, f, p);
+            for (int p = 0; p < SP_NP; ++p) dma(1, f, p);
+        } else {   // B of block 1 first, then A of blocks 1 and 2: the counted wait of chunk 0 leaves the newest SP_PW requests in flight
+            const int f2 = nblk > 2 ? 2 : nblk - 1;
+#pragma unroll
+            for (int p = SP_PW; p < SP_NP; ++p) dma(1, f, p);
+#pragma unroll
+            for (int p = 0; p < SP_PW; ++p) dma(1, f, p);
+#pragma unroll
+            for (int p = 0; p < SP_PW; ++p) dma(2, f2, p);
+        }
     }
     ldA(a0, 0, 0);
     ldB(b0, 0, 0);
+    int sa = 0;   // A stage of chunk ch (ch % NA)
     for (int ch = 0; ch < nblk; ++ch) {
-        const int st = ch & 1;
+        const int st = ch & 1;   // B stage
+        const int san = (sa + 1 == NA) ? 0 : sa + 1;
         // ks: 0 = hi k 0-15, 1 = hi k 16-31, 2 = lo k 0-15, 3 = lo k 16-31;  a0 = A hi s0, b0 = B hi s0 on entry
         if constexpr (TERMS == 3) {
             SP_SET(a0, b0, ldB(b1, st, 2))                   // hi hi, s0   | B lo s0
-            SP_SET(a0, b1, ldA(a1, st, 2))                   // hi lo, s0   | A lo s0
-            SP_SET(a1, b0, ldA(a2, st, 1); ldB(b2, st, 1))   // lo hi, s0   | A hi s1, B hi s1
+            SP_SET(a0, b1, ldA(a1, sa, 2))                   // hi lo, s0   | A lo s0
+            SP_SET(a1, b0, ldA(a2, sa, 1); ldB(b2, st, 1))   // lo hi, s0   | A hi s1, B hi s1
             SP_SET(a2, b2, ldB(b1, st, 3))                   // hi hi, s1   | B lo s1
-            SP_SET(a2, b1, ldA(a1, st, 3))                   // hi lo, s1   | A lo s1
+            SP_SET(a2, b1, ldA(a1, sa, 3))                   // hi lo, s1   | A lo s1
         } else {
-            SP_SET(a0, b0, ldA(a1, st, 2))                   // hi hi, s0   | A lo s0
-            SP_SET(a1, b0, ldA(a2, st, 1); ldB(b2, st, 1))   // lo hi, s0   | A hi s1, B hi s1
-            SP_SET(a2, b2, ldA(a1, st, 3))                   // hi hi, s1   | A lo s1
+            SP_SET(a0, b0, ldA(a1, sa, 2))                   // hi hi, s0   | A lo s0
+            SP_SET(a1, b0, ldA(a2, sa, 1); ldB(b2, st, 1))   // lo hi, s0   | A hi s1, B hi s1
+            SP_SET(a2, b2, ldA(a1, sa, 3))                   // hi hi, s1   | A lo s1
         }
-        // last set of the chunk: every read of stage st has been requested -> barrier, then the next chunk's first fragments and
-        // the DMA of block ch + 2 between this set's MFMAs (the last two iterations re-fetch the last block: branch-free body)
-        SP_DMA_WAIT();
+        // last set of the chunk: every read of this chunk's stages has been requested -> barrier, then the next chunk's first fragments
+        // and the DMA of block ch + 2 (NA = 3: B of block ch + 2, then A of block ch + 3) between this set's MFMAs into the stages just
+        // freed (the last iterations re-fetch the last block: branch-free body)
+        if constexpr (NA == 2) SP_DMA_WAIT();
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SP_PW) : "memory");
         __syncthreads();
-        ldA(a0, st ^ 1, 0);
+        ldA(a0, san, 0);
         ldB(b0, st ^ 1, 0);
         SP_SB();
         const int f = (ch + 2 < nblk) ? ch + 2 : nblk - 1;
+        const int fa = (NA == 2) ? f : ((ch + 3 < nblk) ? ch + 3 : nblk - 1);
 #pragma unroll
         for (int m = 0; m < SP_NP; ++m) {
             mma1(a1, b2, m);                             // lo hi, s1
             SP_SB();
-            dma(st, f, m);
+            if constexpr (NA == 2) {
+                dma(st, f, m);
+            } else {
+                const int piece = (m + SP_PW) % SP_NP;   // B pieces first
+                if (piece < SP_PW) dma(sa, fa, piece);
+                else dma(st, f, piece);
+            }
             SP_SB();
         }
+        sa = san;
     }
     SP_DMA_WAIT();
     __syncthreads();   // staging memory is free for the epilogue
@@ -175,7 +210,8 @@ __device__ __forceinline__ void sp_nt_mainloop(SmemSP& sm, SpAcc& acc, int nblk,
 
 // the wave's [32][64]-float epilogue staging tile inside STAGE 1 of the ring (waves 0 .. SP_WAVES/2 - 1: A[1], the rest: B[1]), for
 // persistent workgroups whose stage 0 already receives the next tile's first block during the epilogue
-__device__ __forceinline__ float* sp_stage1_tile(SmemSP& sm, int wave) {
+template <int NA>
+__device__ __forceinline__ float* sp_stage1_tile(SmemSPn<NA>& sm, int wave) {
     static_assert(SP_WAVES / 2 * 8192 <= SP_STAGE, "staging tiles of half the waves fit one operand stage");
     return reinterpret_cast<float*>(wave < SP_WAVES / 2 ? &sm.A[1][wave * 8192] : &sm.B[1][(wave - SP_WAVES / 2) * 8192]);
 }
