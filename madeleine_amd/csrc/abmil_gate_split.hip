@@ -77,15 +77,19 @@ __global__ void sp_bound_scale_kernel(const float* __restrict__ in, float mult, 
 #define MDL_GATE_SP_PMODE 0
 #endif
 constexpr int GATE_PT = 4;
-template <int DM, bool SAVE, int PMODE>
+// NA = 3 (round 6; one tile per workgroup only): sp_nt_mainloop3 on SmemSP3 -- the LDS-DMA pieces spread over the chunk; the epilogue's
+// transposes then use A[0] / A[1] and the row sums B[0] of the drained ring (160 KiB leave no room for a separate array).
+template <int DM, bool SAVE, int PMODE, int NA = 2>
 __global__ __launch_bounds__(SP_THREADS) void sp_gate_fwd_kernel(const char* __restrict__ Ei, int64_t e_rsb, const float* __restrict__ e_sc,
                                                           const char* __restrict__ WK, const float* __restrict__ w_sc,
                                                           const float* __restrict__ ba, const float* __restrict__ bb,
                                                           const float* __restrict__ wc, float* __restrict__ part,
                                                           float* __restrict__ act_a, float* __restrict__ act_b, int64_t T, int H,
                                                           int n_ttiles, DropCfg drop) {
-    __shared__ SmemSP sm;
-    __shared__ float sred_s[SP_WN * SPM];   // [SP_WN][256 rows]
+    static_assert(NA == 2 || PMODE == 0, "the three-stage ring serves one tile per workgroup");
+    __shared__ SmemSPn<NA> sm;
+    __shared__ float sred_own[NA == 2 ? SP_WN * SPM : 1];   // [SP_WN][256 rows]
+    float* sred_s = NA == 2 ? sred_own : reinterpret_cast<float*>(&sm.B[0][0]);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / SP_WN, wn = wave % SP_WN;
@@ -120,7 +124,7 @@ __global__ __launch_bounds__(SP_THREADS) void sp_gate_fwd_kernel(const char* __r
     };
     const float inv = 1.f / (e_sc[0] * w_sc[0]);
     const int l32 = lane & 31;
-    float* tile = sp_stage1_tile(sm, wave);
+    float* tile = NA == 2 ? sp_stage1_tile(sm, wave) : reinterpret_cast<float*>(&sm.A[wave / (SP_WAVES / 2)][(wave % (SP_WAVES / 2)) * 8192]);
     float* sred = sred_s + wn * SPM + wm * 128;
     const int g8 = lane & 7, r8 = lane >> 3;
 
@@ -135,11 +139,13 @@ __global__ __launch_bounds__(SP_THREADS) void sp_gate_fwd_kernel(const char* __r
     a_offsets(t0, voA);
     SpAcc acc;
     sp_zero(acc);
-    sp_nt_mainloop(sm, acc, HID / 32, wm, wn, lane, [&](int st, int f, int piece) {
+    auto dma = [&](int st, int f, int piece) {
         const int i = piece % SP_PW;
         if (piece < SP_PW) glds16_s(voA[i], sp_uniform(baseA + (int64_t)f * 128), lds_addr_of(&sm.A[st][(wave * SP_PW + i) * 1024]));
         else glds16_s(voB[i], sp_uniform(baseB + (int64_t)f * 128), lds_addr_of(&sm.B[st][(wave * SP_PW + i) * 1024]));
-    }, k > 0);
+    };
+    if constexpr (NA == 3) sp_nt_mainloop3(sm, acc, HID / 32, wm, wn, lane, dma);
+    else sp_nt_mainloop(sm, acc, HID / 32, wm, wn, lane, dma, k > 0);
     if (k + 1 < n_k && tt_of(k + 1) < n_ttiles) {   // the next tile's first block travels during this epilogue
         const int64_t t0n = (int64_t)tt_of(k + 1) * SPM;
         const char* baseAn = Ei + t0n * e_rsb + (int64_t)c * (HID * 4);
@@ -297,12 +303,13 @@ __global__ __launch_bounds__(64 * MDL_MAX_HEADS) void sp_gate_dz_kernel(const fl
 // ================================================================================================
 // backward, stage 2: dE[t, c, n0 + n] (+)= sum_j dz[t, c, j] WN[c][n0 + n][j]  (+ pooling term), K = 1024
 // ================================================================================================
-template <int TERMS>
+template <int TERMS, int NA = 2>   // NA = 3: sp_nt_mainloop3 on SmemSP3 (the epilogue works in the first 128 KiB of the drained ring)
 __global__ __launch_bounds__(SP_THREADS) void sp_gate_dx_kernel(const char* __restrict__ dzi, const float* __restrict__ dz_sc,
                                                          const char* __restrict__ WN, const float* __restrict__ w_sc,
                                                          float* __restrict__ dE, int64_t ldE, int accumulate, int64_t T, int H,
                                                          PoolTerm pt, float* __restrict__ absmax_out) {
-    __shared__ SmemSP sm;
+    __shared__ SmemSPn<NA> sm3;
+    SmemSP& sm = reinterpret_cast<SmemSP&>(sm3);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / SP_WN, wn = wave % SP_WN;
@@ -337,11 +344,13 @@ __global__ __launch_bounds__(SP_THREADS) void sp_gate_dx_kernel(const char* __re
     }
     SpAcc acc;
     sp_zero(acc);
-    sp_nt_mainloop<TERMS>(sm, acc, 1024 / 32, wm, wn, lane, [&](int st, int f, int piece) {
+    auto dma = [&](int st, int f, int piece) {
         const int i = piece % SP_PW;
-        if (piece < SP_PW) glds16_s(voA[i], sp_uniform(baseA + (int64_t)f * 128), lds_addr_of(&sm.A[st][(wave * SP_PW + i) * 1024]));
-        else glds16_s(voB[i], sp_uniform(baseB + (int64_t)f * 128), lds_addr_of(&sm.B[st][(wave * SP_PW + i) * 1024]));
-    });
+        if (piece < SP_PW) glds16_s(voA[i], sp_uniform(baseA + (int64_t)f * 128), lds_addr_of(&sm3.A[st][(wave * SP_PW + i) * 1024]));
+        else glds16_s(voB[i], sp_uniform(baseB + (int64_t)f * 128), lds_addr_of(&sm3.B[st][(wave * SP_PW + i) * 1024]));
+    };
+    if constexpr (NA == 3) sp_nt_mainloop3<TERMS>(sm3, acc, 1024 / 32, wm, wn, lane, dma);
+    else sp_nt_mainloop<TERMS>(sm3, acc, 1024 / 32, wm, wn, lane, dma);
     const float inv = 1.f / (dz_sc[0] * w_sc[0]);
     float amax = 0.f;
     char* ob = reinterpret_cast<char*>(dE + t0 * ldE + (int64_t)c * HID + n0);
@@ -513,6 +522,7 @@ extern "C" int mdl_abmil_gate_fwd_split(const void* E_img, int64_t e_rsb, const 
     if (pmode == 1 && !gate_persist_pays(grid, 0.96)) pmode = 0;
     if (pmode == 2 && !gate_persist_pays(grid, 0.96, GATE_PT)) pmode = 0;
     const int64_t pgrid = pmode == 1 ? grid / GATE_JT : pmode == 2 ? 8 * ((per_share + GATE_PT - 1) / GATE_PT) * GATE_JT : grid;
+    const bool na3 = sp_nt_stages() == 3;   // sp_nt_mainloop3 (MADELEINE_SP_NT_STAGES, split_engine.hpp)
 #define MDL_GATE_FWD_SP1(DM, SAVE, PM)                                                                                                 \
     hipLaunchKernelGGL((sp_gate_fwd_kernel<DM, SAVE, PM>), dim3((unsigned)pgrid), dim3(SP_THREADS), 0, s, (const char*)E_img, e_rsb,   \
                        e_scale, (const char*)WK, (const float*)sc, ba, bb, wc, part, act_a, act_b, T, H, (int)n_tt, d)
@@ -520,6 +530,9 @@ extern "C" int mdl_abmil_gate_fwd_split(const void* E_img, int64_t e_rsb, const 
     do {                                                                                                                              \
         if (pmode == 1) MDL_GATE_FWD_SP1(DM, SAVE, 1);                                                                                \
         else if (pmode == 2) MDL_GATE_FWD_SP1(DM, SAVE, 2);                                                                           \
+        else if (na3) hipLaunchKernelGGL((sp_gate_fwd_kernel<DM, SAVE, 0, 3>), dim3((unsigned)pgrid), dim3(SP_THREADS), 0, s,             \
+                                         (const char*)E_img, e_rsb, e_scale, (const char*)WK, (const float*)sc, ba, bb, wc, part, act_a,  \
+                                         act_b, T, H, (int)n_tt, d);                                                                  \
         else MDL_GATE_FWD_SP1(DM, SAVE, 0);                                                                                           \
     } while (0)
     if (act_a) {
@@ -618,7 +631,8 @@ extern "C" int mdl_abmil_attnpool_bwd_split(const void* E_img, int64_t e_rsb, co
         const int64_t n_tt = (T + SPM - 1) / SPM;
         const int64_t grid = xcd_head_grid(n_tt, 2, H);
         if (grid > 0x7fffffff) return MDL_E_UNSUPPORTED;
-        hipLaunchKernelGGL(terms == 2 ? sp_gate_dx_kernel<2> : sp_gate_dx_kernel<3>, dim3((unsigned)grid), dim3(SP_THREADS), 0, s, (const char*)dzi, (const float*)(sc + 4),
+        const bool na3 = sp_nt_stages() == 3;
+        hipLaunchKernelGGL(terms == 2 ? (na3 ? sp_gate_dx_kernel<2, 3> : sp_gate_dx_kernel<2, 2>) : (na3 ? sp_gate_dx_kernel<3, 3> : sp_gate_dx_kernel<3, 2>), dim3((unsigned)grid), dim3(SP_THREADS), 0, s, (const char*)dzi, (const float*)(sc + 4),
                            (const char*)WN, (const float*)sc, dE, ldE, accumulate, T, H, pt, dE_absmax);
         MDL_LAUNCH_CHECK();
     }

@@ -48,9 +48,8 @@ constexpr int SP_PW = 32 / SP_WAVES;        // LDS-DMA pieces (1 KiB) per wave, 
 constexpr int SP_NP = 2 * SP_PW;            // pieces per wave and chunk = MFMAs of one set = 4 SPNCT
 constexpr int SP_WCOLS = 32 * SPNCT;        // columns per wave
 typedef f32x16 SpAcc[4][SPNCT];
-// NA = stages of the A ring.  2: the symmetric two-stage ring (128 KiB).  3 (round 6, NT products): the A operand -- the one that
-// streams from HBM -- three deep, B (a weight: L2 / MALL resident) two deep = 160 KiB, the whole LDS: a block of A is requested TWO chunks
-// before its first read instead of one (see sp_nt_mainloop).
+// NA = stages of the A ring.  2: the symmetric two-stage ring (128 KiB).  3 (round 6, NT products, sp_nt_mainloop3): A three deep, B two
+// deep = 160 KiB, the whole LDS.
 template <int NA>
 struct __attribute__((aligned(16))) SmemSPn {
     char A[NA][SP_STAGE];
@@ -58,6 +57,14 @@ struct __attribute__((aligned(16))) SmemSPn {
 };
 typedef SmemSPn<2> SmemSP;
 typedef SmemSPn<3> SmemSP3;
+// which NT main loop the launchers pick: MADELEINE_SP_NT_STAGES = 2 | 3 (A/B switch), default MDL_SP_NT_STAGES
+#ifndef MDL_SP_NT_STAGES
+#define MDL_SP_NT_STAGES 3
+#endif
+static inline int sp_nt_stages() {
+    static const int v = getenv("MADELEINE_SP_NT_STAGES") ? atoi(getenv("MADELEINE_SP_NT_STAGES")) : MDL_SP_NT_STAGES;
+    return v == 2 ? 2 : 3;
+}
 
 // a wave-uniform pointer the compiler can keep in SGPRs (saddr operand of the LDS-DMA)
 __device__ __forceinline__ const char* sp_uniform(const char* p) {
@@ -95,16 +102,9 @@ __device__ __forceinline__ void sp_nt_slot(int wave, int i, int lane, int& row, 
 // per chunk instead of six.  For gradient products whose B operand is a weight (dX = dY W); never the default.
 // chunk0_in_flight: the caller already issued this wave's pieces of block 0 into stage 0 (a persistent workgroup requests the next
 // tile's first block before the epilogue of the current one and keeps its epilogue staging inside stage 1: sp_stage1_tile).
-// NA = 3 (SmemSP3): counters at config 2 (profiles/r06_split_mfma_busy.json) show the waves of the two-stage loop 37 % of their cycles in
-// s_waitcnt with LDS waits at 2.6 %: the vmcnt(0) in front of the chunk barrier, i.e. the LDS-DMA of the NEXT block, requested one chunk
-// (~2.4 us) earlier, has not landed for the slowest of the workgroup's 4096 16-B requests.  With three A stages block ch + 3 goes into the
-// stage chunk ch just freed and is awaited at the end of chunk ch + 2 -- two chunks of flight time.  The wait becomes vmcnt(SP_PW): this
-// wave's B pieces of block ch + 1 (requested FIRST at the end of chunk ch - 1) and the older A pieces of block ch + 1 must have landed,
-// its SP_PW newest requests (A of block ch + 2) may still be in flight.
-template <int TERMS = 3, int NA = 2, class Dma>
-__device__ __forceinline__ void sp_nt_mainloop(SmemSPn<NA>& sm, SpAcc& acc, int nblk, int wm, int wn, int lane, Dma&& dma,
+template <int TERMS = 3, class Dma>
+__device__ __forceinline__ void sp_nt_mainloop(SmemSP& sm, SpAcc& acc, int nblk, int wm, int wn, int lane, Dma&& dma,
                                                bool chunk0_in_flight = false) {
-    static_assert(NA == 2 || NA == 3, "A ring of two or three stages");
     const int l32 = lane & 31, kh = lane >> 5;
     uint32_t offA[4], offB[SPNCT];
 #pragma unroll
@@ -146,66 +146,147 @@ __device__ __forceinline__ void sp_nt_mainloop(SmemSPn<NA>& sm, SpAcc& acc, int 
     __syncthreads();
     {
         const int f = nblk > 1 ? 1 : 0;
-        if constexpr (NA == 2) {
 #pragma unroll
-            for (int p = 0; p < SP_NP; ++p) dma(1, f, p);
-        } else {   // B of block 1 first, then A of blocks 1 and 2: the counted wait of chunk 0 leaves the newest SP_PW requests in flight
-            const int f2 = nblk > 2 ? 2 : nblk - 1;
-#pragma unroll
-            for (int p = SP_PW; p < SP_NP; ++p) dma(1, f, p);
-#pragma unroll
-            for (int p = 0; p < SP_PW; ++p) dma(1, f, p);
-#pragma unroll
-            for (int p = 0; p < SP_PW; ++p) dma(2, f2, p);
-        }
+        for (int p = 0; p < SP_NP; ++p) dma(1, f, p);
     }
     ldA(a0, 0, 0);
     ldB(b0, 0, 0);
-    int sa = 0;   // A stage of chunk ch (ch % NA)
     for (int ch = 0; ch < nblk; ++ch) {
-        const int st = ch & 1;   // B stage
-        const int san = (sa + 1 == NA) ? 0 : sa + 1;
+        const int st = ch & 1;
         // ks: 0 = hi k 0-15, 1 = hi k 16-31, 2 = lo k 0-15, 3 = lo k 16-31;  a0 = A hi s0, b0 = B hi s0 on entry
         if constexpr (TERMS == 3) {
             SP_SET(a0, b0, ldB(b1, st, 2))                   // hi hi, s0   | B lo s0
-            SP_SET(a0, b1, ldA(a1, sa, 2))                   // hi lo, s0   | A lo s0
-            SP_SET(a1, b0, ldA(a2, sa, 1); ldB(b2, st, 1))   // lo hi, s0   | A hi s1, B hi s1
+            SP_SET(a0, b1, ldA(a1, st, 2))                   // hi lo, s0   | A lo s0
+            SP_SET(a1, b0, ldA(a2, st, 1); ldB(b2, st, 1))   // lo hi, s0   | A hi s1, B hi s1
             SP_SET(a2, b2, ldB(b1, st, 3))                   // hi hi, s1   | B lo s1
-            SP_SET(a2, b1, ldA(a1, sa, 3))                   // hi lo, s1   | A lo s1
+            SP_SET(a2, b1, ldA(a1, st, 3))                   // hi lo, s1   | A lo s1
         } else {
-            SP_SET(a0, b0, ldA(a1, sa, 2))                   // hi hi, s0   | A lo s0
-            SP_SET(a1, b0, ldA(a2, sa, 1); ldB(b2, st, 1))   // lo hi, s0   | A hi s1, B hi s1
-            SP_SET(a2, b2, ldA(a1, sa, 3))                   // hi hi, s1   | A lo s1
+            SP_SET(a0, b0, ldA(a1, st, 2))                   // hi hi, s0   | A lo s0
+            SP_SET(a1, b0, ldA(a2, st, 1); ldB(b2, st, 1))   // lo hi, s0   | A hi s1, B hi s1
+            SP_SET(a2, b2, ldA(a1, st, 3))                   // hi hi, s1   | A lo s1
         }
-        // last set of the chunk: every read of this chunk's stages has been requested -> barrier, then the next chunk's first fragments
-        // and the DMA of block ch + 2 (NA = 3: B of block ch + 2, then A of block ch + 3) between this set's MFMAs into the stages just
-        // freed (the last iterations re-fetch the last block: branch-free body)
-        if constexpr (NA == 2) SP_DMA_WAIT();
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SP_PW) : "memory");
+        // last set of the chunk: every read of stage st has been requested -> barrier, then the next chunk's first fragments and
+        // the DMA of block ch + 2 between this set's MFMAs (the last two iterations re-fetch the last block: branch-free body)
+        SP_DMA_WAIT();
         __syncthreads();
-        ldA(a0, san, 0);
+        ldA(a0, st ^ 1, 0);
         ldB(b0, st ^ 1, 0);
         SP_SB();
         const int f = (ch + 2 < nblk) ? ch + 2 : nblk - 1;
-        const int fa = (NA == 2) ? f : ((ch + 3 < nblk) ? ch + 3 : nblk - 1);
 #pragma unroll
         for (int m = 0; m < SP_NP; ++m) {
             mma1(a1, b2, m);                             // lo hi, s1
             SP_SB();
-            if constexpr (NA == 2) {
-                dma(st, f, m);
-            } else {
-                const int piece = (m + SP_PW) % SP_NP;   // B pieces first
-                if (piece < SP_PW) dma(sa, fa, piece);
-                else dma(st, f, piece);
-            }
+            dma(st, f, m);
             SP_SB();
         }
-        sa = san;
     }
     SP_DMA_WAIT();
     __syncthreads();   // staging memory is free for the epilogue
 #undef SP_SET
+}
+
+// The same loop on SmemSP3 (round 6, an experiment kept behind MADELEINE_SP_NT_STAGES=3): A ring three stages deep, and the LDS-DMA pieces
+// SPREAD over the chunk instead of issued together behind the chunk barrier.  In the two-stage loop all eight pieces of block ch + 2 are
+// issued inside the last MFMA set of chunk ch -- the only place where a stage is free -- and an LDS-DMA piece costs 100-185 issue cycles in
+// a phase that already carries eight of them (MI355X_MICROARCH.md price list; the NODMA probe of round 4: +19 %).  With a third A stage a
+// free stage exists during the whole chunk: iteration ch issues B of block ch + 1 (into the B stage freed by chunk ch - 1) behind MFMAs
+// 2 and 4 of its first two sets and A of block ch + 2 (into the A stage freed by chunk ch - 1) in sets 3 .. 5.  Wait at the chunk end:
+// vmcnt(SP_PW) -- everything but this iteration's A pieces has landed (B of ch + 1 was issued before them, A of ch + 1 an iteration ago).
+template <int TERMS = 3, class Dma>
+__device__ __forceinline__ void sp_nt_mainloop3(SmemSP3& sm, SpAcc& acc, int nblk, int wm, int wn, int lane, Dma&& dma) {
+    static_assert(SP_PW == 4, "piece placement below is written for four pieces per wave and operand");
+    const int l32 = lane & 31, kh = lane >> 5;
+    uint32_t offA[4], offB[SPNCT];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+        const int r = wm * 128 + rt * 32 + l32;
+        offA[rt] = r * 128 + ((kh ^ ((r >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int ct = 0; ct < SPNCT; ++ct) {
+        const int r = wn * SP_WCOLS + ct * 32 + l32;
+        offB[ct] = r * 128 + ((kh ^ ((r >> 1) & 7)) << 4);
+    }
+    auto ldA = [&](u32x4 (&fa)[4], int st, int ks) {
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) fa[rt] = *reinterpret_cast<const u32x4*>(&sm.A[st][offA[rt] ^ (ks << 5)]);
+    };
+    auto ldB = [&](u32x4 (&fb)[SPNCT], int st, int ks) {
+#pragma unroll
+        for (int ct = 0; ct < SPNCT; ++ct) fb[ct] = *reinterpret_cast<const u32x4*>(&sm.B[st][offB[ct] ^ (ks << 5)]);
+    };
+    auto mma1 = [&](const u32x4 (&fa)[4], const u32x4 (&fb)[SPNCT], int m) {
+        const int rt = m / SPNCT, ct = m % SPNCT;
+        acc[rt][ct] = sp_mfma(fa[rt], fb[ct], acc[rt][ct]);
+    };
+    // one MFMA set with the fragment loads of the next set behind its first MFMA and DMA pieces behind its third and fifth
+#define SP_SETD(FA, FB, LOADS, D1, D2)                                          \
+    mma1(FA, FB, 0);                                                            \
+    SP_SB();                                                                    \
+    LOADS;                                                                      \
+    SP_SB();                                                                    \
+    mma1(FA, FB, 1);                                                            \
+    mma1(FA, FB, 2);                                                            \
+    SP_SB();                                                                    \
+    D1;                                                                         \
+    SP_SB();                                                                    \
+    mma1(FA, FB, 3);                                                            \
+    mma1(FA, FB, 4);                                                            \
+    SP_SB();                                                                    \
+    D2;                                                                         \
+    SP_SB();                                                                    \
+    _Pragma("unroll") for (int m = 5; m < SP_NP; ++m) mma1(FA, FB, m);          \
+    SP_SB();
+    if (nblk <= 0) return;
+    u32x4 a0[4], a1[4], a2[4], b0[SPNCT], b1[SPNCT], b2[SPNCT];
+#pragma unroll
+    for (int p = 0; p < SP_NP; ++p) dma(0, 0, p);
+    SP_DMA_WAIT();
+    __syncthreads();
+    {
+        const int f = nblk > 1 ? 1 : 0;
+#pragma unroll
+        for (int p = 0; p < SP_PW; ++p) dma(1, f, p);   // A of block 1 (B of block 1 follows inside iteration 0)
+    }
+    ldA(a0, 0, 0);
+    ldB(b0, 0, 0);
+    int sa = 0;   // A stage of chunk ch = ch % 3
+    for (int ch = 0; ch < nblk; ++ch) {
+        const int st = ch & 1;                               // B stage of chunk ch
+        const int san = (sa == 2) ? 0 : sa + 1;             // A stage of chunk ch + 1 (in flight since the previous iteration)
+        const int saf = (san == 2) ? 0 : san + 1;           // A stage freed by chunk ch - 1: receives block ch + 2
+        const int fb = (ch + 1 < nblk) ? ch + 1 : nblk - 1, fa = (ch + 2 < nblk) ? ch + 2 : nblk - 1;
+#define SP_DB(i) dma(st ^ 1, fb, SP_PW + (i))
+#define SP_DA(i) dma(saf, fa, (i))
+        if constexpr (TERMS == 3) {
+            SP_SETD(a0, b0, ldB(b1, st, 2), SP_DB(0), SP_DB(1))                    // hi hi, s0   | B lo s0
+            SP_SETD(a0, b1, ldA(a1, sa, 2), SP_DB(2), SP_DB(3))                    // hi lo, s0   | A lo s0
+            SP_SETD(a1, b0, ldA(a2, sa, 1); ldB(b2, st, 1), SP_DA(0), SP_DA(1))    // lo hi, s0   | A hi s1, B hi s1
+            SP_SETD(a2, b2, ldB(b1, st, 3), SP_DA(2), (void)0)                     // hi hi, s1   | B lo s1
+            SP_SETD(a2, b1, ldA(a1, sa, 3), SP_DA(3), (void)0)                     // hi lo, s1   | A lo s1
+        } else {
+            SP_SETD(a0, b0, ldA(a1, sa, 2), SP_DB(0); SP_DB(1), SP_DB(2); SP_DB(3))              // hi hi, s0   | A lo s0
+            SP_SETD(a1, b0, ldA(a2, sa, 1); ldB(b2, st, 1), SP_DA(0), SP_DA(1))                  // lo hi, s0   | A hi s1, B hi s1
+            SP_SETD(a2, b2, ldA(a1, sa, 3), SP_DA(2), SP_DA(3))                                  // hi hi, s1   | A lo s1
+        }
+#undef SP_DB
+#undef SP_DA
+        // every read of this chunk's stages has been requested; B of block ch + 1 and A of block ch + 1 have landed once at most this
+        // iteration's SP_PW A pieces are outstanding -> barrier, the next chunk's first fragments, the last MFMA set
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SP_PW) : "memory");
+        __syncthreads();
+        ldA(a0, san, 0);
+        ldB(b0, st ^ 1, 0);
+        SP_SB();
+#pragma unroll
+        for (int m = 0; m < SP_NP; ++m) mma1(a1, b2, m);   // lo hi, s1
+        SP_SB();
+        sa = san;
+    }
+    SP_DMA_WAIT();
+    __syncthreads();   // staging memory is free for the epilogue
+#undef SP_SETD
 }
 
 // the wave's [32][64]-float epilogue staging tile inside STAGE 1 of the ring (waves 0 .. SP_WAVES/2 - 1: A[1], the rest: B[1]), for

@@ -214,9 +214,6 @@ __global__ __launch_bounds__(256) void sp_tile_absmax_kernel(const float* __rest
 }
 
 // ---- NT -------------------------------------------------------------------------------------------------------------------------------
-#ifndef MDL_SP_NT_STAGES
-#define MDL_SP_NT_STAGES 2
-#endif
 // C[m][n] (+)= inv * sum_k A[m][k] B[n][k] (+ bias[n]);  rows m >= M / n >= N re-read the last valid row (discarded).
 template <int TERMS, int NA>
 __global__ __launch_bounds__(SP_THREADS) void sp_nt_kernel(const char* __restrict__ A, int64_t a_rsb, const float* __restrict__ a_sc,
@@ -228,7 +225,7 @@ __global__ __launch_bounds__(SP_THREADS) void sp_nt_kernel(const char* __restric
                                                     const int32_t* __restrict__ row_group = nullptr) {
     // group_bias [G][N] + row_group [M] (round 5): C[m][:] += group_bias[row_group[m]][:] -- a bias row per GROUP of rows (MADELEINE's
     // stain-encoding columns of the first Linear as a per-bag bias: [x | e_g] W^T = x Wx^T + e_g We^T, Model.py:132, :351)
-    // NA: stages of the A ring (split_engine.hpp, SmemSPn): 3 = the streamed operand two chunks ahead (160 KiB of LDS)
+    // NA: stages of the A ring (split_engine.hpp, SmemSPn): 3 = sp_nt_mainloop3 (LDS-DMA pieces spread over the chunk, 160 KiB of LDS)
     __shared__ SmemSPn<NA> sm3;
     SmemSP& sm = reinterpret_cast<SmemSP&>(sm3);   // (epilogue staging: the first 128 KiB, whatever the ring depth)
     const int tid = threadIdx.x, lane = tid & 63;
@@ -256,11 +253,13 @@ __global__ __launch_bounds__(SP_THREADS) void sp_nt_kernel(const char* __restric
     }
     SpAcc acc;
     sp_zero(acc);
-    sp_nt_mainloop<TERMS, NA>(sm3, acc, nblk, wm, wn, lane, [&](int st, int f, int piece) {
+    auto dma = [&](int st, int f, int piece) {
         const int i = piece % SP_PW;
         if (piece < SP_PW) glds16_s(voA[i], sp_uniform(baseA + (int64_t)f * 128), lds_addr_of(&sm3.A[st][(wave * SP_PW + i) * 1024]));
         else glds16_s(voB[i], sp_uniform(baseB + (int64_t)f * 128), lds_addr_of(&sm3.B[st][(wave * SP_PW + i) * 1024]));
-    });
+    };
+    if constexpr (NA == 3) sp_nt_mainloop3<TERMS>(sm3, acc, nblk, wm, wn, lane, dma);
+    else sp_nt_mainloop<TERMS>(sm3, acc, nblk, wm, wn, lane, dma);
     const float inv = 1.f / (a_sc[0] * b_sc[0]);
     float amax = 0.f;
     char* cb = reinterpret_cast<char*>(C + m0 * ldc + n0);
@@ -539,9 +538,7 @@ static int sp_gemm_nt_impl(const void* A, int64_t a_rsb, const float* a_scale, c
     }
     const int64_t tiles = ((M + SPM - 1) / SPM) * ((N + SPN - 1) / SPN);
     if (tiles > 0x7fffffff || a_rsb * SPM > 0x7fffffff || b_rsb * SPN > 0x7fffffff) return MDL_E_UNSUPPORTED;
-    // MADELEINE_SP_NT_STAGES = 2 | 3: depth of the A ring (A/B switch; default MDL_SP_NT_STAGES)
-    static const int na_env = getenv("MADELEINE_SP_NT_STAGES") ? atoi(getenv("MADELEINE_SP_NT_STAGES")) : MDL_SP_NT_STAGES;
-    const bool na3 = na_env == 3;
+    const bool na3 = sp_nt_stages() == 3;   // sp_nt_mainloop3 (split_engine.hpp)
     hipLaunchKernelGGL(terms == 2 ? (na3 ? sp_nt_kernel<2, 3> : sp_nt_kernel<2, 2>) : (na3 ? sp_nt_kernel<3, 3> : sp_nt_kernel<3, 2>),
                        dim3((unsigned)tiles), dim3(SP_THREADS), 0, (hipStream_t)stream,
                        (const char*)A, a_rsb, a_scale, (const char*)B, b_rsb, b_scale, C, ldc, M, N, K / 32, (int)tiles, bias, accumulate,
