@@ -387,12 +387,13 @@ __global__ __launch_bounds__(SP_THREADS) void sp_gate_dx_kernel(const char* __re
 // ================================================================================================
 // backward, stage 3: slabW[sp][c][k' 512][1024: a | b] = sum_{t in split} E[t, c, k'] dz[t, c, n]      (TN over tokens)
 // ================================================================================================
-template <int TERMS>
+template <int TERMS, int NA = 2>   // NA = 3: sp_tn_mainloop3 on SmemSP3
 __global__ __launch_bounds__(SP_THREADS) void sp_gate_dw_kernel(const char* __restrict__ Ei, int64_t e_rsb, const float* __restrict__ e_sc,
                                                          const char* __restrict__ dzi, const float* __restrict__ dz_sc,
                                                          float* __restrict__ slabW, int64_t T, int H, int64_t tok_per_split,
                                                          int n_splits) {
-    __shared__ SmemSP sm;
+    __shared__ SmemSPn<NA> sm3;
+    SmemSP& sm = reinterpret_cast<SmemSP&>(sm3);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / SP_WN, wn = wave % SP_WN;
@@ -418,17 +419,19 @@ __global__ __launch_bounds__(SP_THREADS) void sp_gate_dw_kernel(const char* __re
     const char* baseB = dzi + (ts * H + c) * (int64_t)4096;
     SpAcc acc;
     sp_zero(acc);
-    sp_tn_mainloop<TERMS>(sm, acc, nch, wm, wn, lane, [&](int st, int64_t f, int piece) {
+    auto dma = [&](int st, int64_t f, int piece) {
         const int q = piece % SP_PW;
         if (piece < SP_PW) {   // E rows past T - 1 re-read row T - 1: their dz rows are the zero pad
             uint32_t tk = tokq[q];
             const int64_t left = T - 1 - (ts + f * SPK);
             if (left < SPK) tk = tk < (uint32_t)left ? tk : (uint32_t)left;
-            glds16_s(tk * (uint32_t)e_rsb + coA[q], sp_uniform(baseA + f * SPK * e_rsb), lds_addr_of(&sm.A[st][(wave * SP_PW + q) * 1024]));
+            glds16_s(tk * (uint32_t)e_rsb + coA[q], sp_uniform(baseA + f * SPK * e_rsb), lds_addr_of(&sm3.A[st][(wave * SP_PW + q) * 1024]));
         } else {
-            glds16_s(tokq[q] * rowB + coB[q], sp_uniform(baseB + f * SPK * (int64_t)rowB), lds_addr_of(&sm.B[st][(wave * SP_PW + q) * 1024]));
+            glds16_s(tokq[q] * rowB + coB[q], sp_uniform(baseB + f * SPK * (int64_t)rowB), lds_addr_of(&sm3.B[st][(wave * SP_PW + q) * 1024]));
         }
-    });
+    };
+    if constexpr (NA == 3) sp_tn_mainloop3<TERMS>(sm3, acc, nch, wm, wn, lane, dma);
+    else sp_tn_mainloop<TERMS>(sm3, acc, nch, wm, wn, lane, dma);
     const float inv = 1.f / (e_sc[0] * dz_sc[0]);
     float* so = slabW + (((int64_t)sp * H + c) * HID + i0) * 1024 + n0;
     auto emit = [&](int row, int col, const f32x4& v) { *reinterpret_cast<f32x4*>(so + (int64_t)row * 1024 + col) = v * inv; };
@@ -637,7 +640,8 @@ extern "C" int mdl_abmil_attnpool_bwd_split(const void* E_img, int64_t e_rsb, co
         MDL_LAUNCH_CHECK();
     }
     if (do_dw) {
-        hipLaunchKernelGGL(terms == 2 ? sp_gate_dw_kernel<2> : sp_gate_dw_kernel<3>, dim3((unsigned)xcd_head_grid(L.S, 8, H)), dim3(SP_THREADS), 0, s, (const char*)E_img, e_rsb, e_scale,
+        const bool tn3 = sp_tn_stages() == 3;
+        hipLaunchKernelGGL(terms == 2 ? (tn3 ? sp_gate_dw_kernel<2, 3> : sp_gate_dw_kernel<2, 2>) : (tn3 ? sp_gate_dw_kernel<3, 3> : sp_gate_dw_kernel<3, 2>), dim3((unsigned)xcd_head_grid(L.S, 8, H)), dim3(SP_THREADS), 0, s, (const char*)E_img, e_rsb, e_scale,
                            (const char*)dzi, (const float*)(sc + 4), slabW, T, H, L.tps, L.S);
         MDL_LAUNCH_CHECK();
         const int rc = gate_launch_reduce_w(slabW, dWa, dWb, H, L.S, s);

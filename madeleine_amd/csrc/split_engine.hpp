@@ -61,6 +61,14 @@ typedef SmemSPn<3> SmemSP3;
 #ifndef MDL_SP_NT_STAGES
 #define MDL_SP_NT_STAGES 3
 #endif
+// the TN (dW) loops: MADELEINE_SP_TN_STAGES = 2 | 3 (sp_tn_mainloop3), default MDL_SP_TN_STAGES
+#ifndef MDL_SP_TN_STAGES
+#define MDL_SP_TN_STAGES 3
+#endif
+static inline int sp_tn_stages() {
+    static const int v = getenv("MADELEINE_SP_TN_STAGES") ? atoi(getenv("MADELEINE_SP_TN_STAGES")) : MDL_SP_TN_STAGES;
+    return v == 3 ? 3 : 2;
+}
 static inline int sp_nt_stages() {
     static const int v = getenv("MADELEINE_SP_NT_STAGES") ? atoi(getenv("MADELEINE_SP_NT_STAGES")) : MDL_SP_NT_STAGES;
     return v == 2 ? 2 : 3;
@@ -555,6 +563,105 @@ __device__ __forceinline__ void sp_tn_mainloop(SmemSP& sm, SpAcc& acc, int64_t n
     SP_DMA_WAIT();
     __syncthreads();
 #undef SP_TSET
+}
+
+// The TN loop on SmemSP3 (round 6): both operands of a dW product stream from HBM, so only A gets the third stage and the
+// spread -- iteration ch issues A of chunk ch + 2 (into the A stage freed by chunk ch - 1) one piece per set behind MFMA 2 of its first
+// four sets; B of chunk ch + 2 still goes into the stage chunk ch frees, inside the last set (four pieces instead of eight there).  Wait at
+// the chunk end: vmcnt(SP_PW) -- B of chunk ch + 1 (issued in the previous last set) and A of chunk ch + 1 (an iteration ago) have landed.
+template <int TERMS = 3, class Dma>
+__device__ __forceinline__ void sp_tn_mainloop3(SmemSP3& sm, SpAcc& acc, int64_t nch, int wm, int wn, int lane, Dma&& dma) {
+    static_assert(SP_PW == 4, "piece placement below is written for four pieces per wave and operand");
+    const int g = lane >> 4, r = lane & 15;
+    const int kb = (g >> 1) * 8 + (r >> 2);
+    uint32_t a_0[4], b_0[SPNCT];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+        a_0[rt] = lds_addr_of(&sm.A[0][0]) + kb * 512 + (((wm * 128 + rt * 32 + (g & 1) * 16 + (r & 3) * 4) * 2) ^ ((kb & 3) << 6));
+#pragma unroll
+    for (int ct = 0; ct < SPNCT; ++ct)
+        b_0[ct] = lds_addr_of(&sm.B[0][0]) + kb * 512 + (((wn * SP_WCOLS + ct * 32 + (g & 1) * 16 + (r & 3) * 4) * 2) ^ ((kb & 3) << 6));
+    if (nch <= 0) return;
+#pragma unroll
+    for (int p = 0; p < SP_NP; ++p) dma(0, (int64_t)0, p);
+    SP_DMA_WAIT();
+    __syncthreads();
+    {
+        const int64_t f = nch > 1 ? 1 : 0;
+#pragma unroll
+        for (int p = 0; p < SP_NP; ++p) dma(1, f, p);   // A and B of chunk 1 (A of chunk 2 follows inside iteration 0)
+    }
+    SpFragA a0, a1, a2;
+    SpFragB b0, b1, b2;
+    sp_tn_ldA<0>(a0, a_0);
+    sp_tn_ldB<0>(b0, b_0);
+    SP_LGKM_WAIT();
+    SP_SB();
+#define SP_TSETD(FA, FB, LOADS, D1)                                              \
+    sp_tn_mma(acc, FA, FB, 0);                                                  \
+    SP_SB();                                                                    \
+    LOADS;                                                                      \
+    SP_SB();                                                                    \
+    sp_tn_mma(acc, FA, FB, 1);                                                  \
+    sp_tn_mma(acc, FA, FB, 2);                                                  \
+    SP_SB();                                                                    \
+    D1;                                                                         \
+    SP_SB();                                                                    \
+    _Pragma("unroll") for (int m = 3; m < SP_NP; ++m) sp_tn_mma(acc, FA, FB, m); \
+    SP_SB();                                                                    \
+    SP_LGKM_WAIT();                                                             \
+    SP_SB();
+    int sa = 0;
+    for (int64_t ch = 0; ch < nch; ++ch) {
+        const int st = (int)(ch & 1);
+        const int san = (sa == 2) ? 0 : sa + 1, saf = (san == 2) ? 0 : san + 1;
+        uint32_t aA[4], aB[SPNCT], nA[4], nB[SPNCT];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+            aA[rt] = a_0[rt] + sa * SP_STAGE;
+            nA[rt] = a_0[rt] + san * SP_STAGE;
+        }
+#pragma unroll
+        for (int ct = 0; ct < SPNCT; ++ct) {
+            aB[ct] = b_0[ct] + st * SP_STAGE;
+            nB[ct] = b_0[ct] + (st ^ 1) * SP_STAGE;
+        }
+        const int64_t fa = (ch + 2 < nch) ? ch + 2 : nch - 1;
+#define SP_DA(i) dma(saf, fa, (i))
+        if constexpr (TERMS == 3) {
+            SP_TSETD(a0, b0, sp_tn_ldB<2>(b1, aB), SP_DA(0))                          // hi hi, s0 | B lo s0
+            SP_TSETD(a0, b1, sp_tn_ldA<2>(a1, aA), SP_DA(1))                          // hi lo, s0 | A lo s0
+            SP_TSETD(a1, b0, sp_tn_ldA<1>(a2, aA); sp_tn_ldB<1>(b2, aB), SP_DA(2))    // lo hi, s0 | A hi s1, B hi s1
+            SP_TSETD(a2, b2, sp_tn_ldB<3>(b1, aB), SP_DA(3))                          // hi hi, s1 | B lo s1
+            SP_TSETD(a2, b1, sp_tn_ldA<3>(a1, aA), (void)0)                           // hi lo, s1 | A lo s1
+        } else {
+            SP_TSETD(a0, b0, sp_tn_ldB<2>(b1, aB), SP_DA(0); SP_DA(1))                          // hi hi, s0 | B lo s0
+            SP_TSETD(a0, b1, sp_tn_ldA<1>(a2, aA); sp_tn_ldB<1>(b2, aB), SP_DA(2); SP_DA(3))    // hi lo, s0 | A hi s1, B hi s1
+            SP_TSETD(a2, b2, sp_tn_ldB<3>(b1, aB), (void)0)                                     // hi hi, s1 | B lo s1
+        }
+#undef SP_DA
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SP_PW) : "memory");
+        SP_SB();
+        __syncthreads();
+        sp_tn_ldA<0>(a0, nA);
+        sp_tn_ldB<0>(b0, nB);
+        SP_SB();
+        const int64_t fb = (ch + 2 < nch) ? ch + 2 : nch - 1;
+#pragma unroll
+        for (int m = 0; m < SP_NP; ++m) {
+            if constexpr (TERMS == 3) sp_tn_mma(acc, a1, b2, m);       // lo hi, s1
+            else sp_tn_mma(acc, a2, b1, m);                            // hi lo, s1
+            SP_SB();
+            if (m >= SP_NP - SP_PW) dma(st, fb, m);                    // the four B pieces (pieces SP_PW .. SP_NP - 1) behind the last MFMAs
+            SP_SB();
+        }
+        SP_LGKM_WAIT();
+        SP_SB();
+        sa = san;
+    }
+    SP_DMA_WAIT();
+    __syncthreads();
+#undef SP_TSETD
 }
 
 // ---- epilogue through LDS ---------------------------------------------------------------------------------------------------------

@@ -360,13 +360,14 @@ __global__ __launch_bounds__(256) void sp_chunk_list_kernel(const float* __restr
 // ---- TN -------------------------------------------------------------------------------------------------------------------------------
 // slab[sp][m][n] = inv * sum_{t in split sp} A[t][m] B[t][n].  A rows t >= T re-read row T - 1; the B image must continue with >= 32
 // all-zero rows after row T - 1 (their products vanish).  Columns >= Mi / >= N fetch column 0 (discarded).
-template <int TERMS>
+template <int TERMS, int NA = 2>   // NA = 3: sp_tn_mainloop3 on SmemSP3
 __global__ __launch_bounds__(SP_THREADS) void sp_tn_kernel(const char* __restrict__ A, int64_t a_rsb, const float* __restrict__ a_sc, int Mi,
                                                     const char* __restrict__ B, int64_t b_rsb, const float* __restrict__ b_sc, int N,
                                                     float* __restrict__ slab, int64_t T, int64_t tok_per_split, int n_tiles,
                                                     const int32_t* __restrict__ chunk_list, const int32_t* __restrict__ chunk_count,
                                                     int list_stride) {
-    __shared__ SmemSP sm;
+    __shared__ SmemSPn<NA> sm3;
+    SmemSP& sm = reinterpret_cast<SmemSP&>(sm3);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / SP_WN, wn = wave % SP_WN;
@@ -395,18 +396,20 @@ __global__ __launch_bounds__(SP_THREADS) void sp_tn_kernel(const char* __restric
     const char* baseB = B + ts * b_rsb;
     SpAcc acc;
     sp_zero(acc);
-    sp_tn_mainloop<TERMS>(sm, acc, nch, wm, wn, lane, [&](int st, int64_t fl, int piece) {
+    auto dma = [&](int st, int64_t fl, int piece) {
         const int q = piece % SP_PW;
         const int64_t f = clist ? (int64_t)clist[fl] : fl;
         if (piece < SP_PW) {
             uint32_t tk = tokq[q];
             const int64_t left = T - 1 - (ts + f * SPK);   // >= 0
             if (left < SPK) tk = tk < (uint32_t)left ? tk : (uint32_t)left;   // uniform branch: only the chunk at the end of A
-            glds16_s(tk * (uint32_t)a_rsb + coA[q], sp_uniform(baseA + f * SPK * a_rsb), lds_addr_of(&sm.A[st][(wave * SP_PW + q) * 1024]));
+            glds16_s(tk * (uint32_t)a_rsb + coA[q], sp_uniform(baseA + f * SPK * a_rsb), lds_addr_of(&sm3.A[st][(wave * SP_PW + q) * 1024]));
         } else {
-            glds16_s(tokq[q] * (uint32_t)b_rsb + coB[q], sp_uniform(baseB + f * SPK * b_rsb), lds_addr_of(&sm.B[st][(wave * SP_PW + q) * 1024]));
+            glds16_s(tokq[q] * (uint32_t)b_rsb + coB[q], sp_uniform(baseB + f * SPK * b_rsb), lds_addr_of(&sm3.B[st][(wave * SP_PW + q) * 1024]));
         }
-    });
+    };
+    if constexpr (NA == 3) sp_tn_mainloop3<TERMS>(sm3, acc, nch, wm, wn, lane, dma);
+    else sp_tn_mainloop<TERMS>(sm3, acc, nch, wm, wn, lane, dma);
     const float inv = 1.f / (a_sc[0] * b_sc[0]);
     float* so = slab + (int64_t)sp * Mi * N + (int64_t)i0 * N + n0;
     const int cols_valid = N - n0;
@@ -593,7 +596,8 @@ extern "C" int mdl_split_gemm_tn(const void* A, int64_t a_rsb, const float* a_sc
         hipLaunchKernelGGL(sp_chunk_list_kernel, dim3(S), dim3(256), 0, s, b_chunk_max, T, tps, list, count, stride);
         MDL_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(terms == 2 ? sp_tn_kernel<2> : sp_tn_kernel<3>, dim3(tiles), dim3(SP_THREADS), 0, s, (const char*)A, a_rsb, a_scale, Mi, (const char*)B, b_rsb, b_scale, N,
+    const bool tn3 = sp_tn_stages() == 3;
+    hipLaunchKernelGGL(terms == 2 ? (tn3 ? sp_tn_kernel<2, 3> : sp_tn_kernel<2, 2>) : (tn3 ? sp_tn_kernel<3, 3> : sp_tn_kernel<3, 2>), dim3(tiles), dim3(SP_THREADS), 0, s, (const char*)A, a_rsb, a_scale, Mi, (const char*)B, b_rsb, b_scale, N,
                        (float*)ws, T, tps, tiles, (const int32_t*)list, (const int32_t*)count, stride);
     MDL_LAUNCH_CHECK();
     return lin_launch_reduce((const float*)ws, out, Mi, N, S, s);
