@@ -13,6 +13,7 @@
 // Operands reach LDS by LDS-DMA (global_load_lds_dwordx4) into the same XOR-swizzled 64-B row image the fp32 kernels
 // use (16-B chunk kq of row r is stored at slot kq ^ ((r >> 2) & 3)), read back with conflict-free ds_read_b128.
 #include <cstdlib>
+#include <type_traits>
 
 #include "tile_engine_bf16.hpp"
 
@@ -397,10 +398,12 @@ __global__ __launch_bounds__(256, 2) void gate_dx_bf16_kernel(const bf16_t* __re
 // dX on the 256 x 256 x 64 tile (tile_engine_bf16.hpp: the long contraction K = 1024 is where that tile wins): same products and
 // epilogue as gate_dx_bf16_kernel, 256 token rows x 256 of the head's 512 input channels per workgroup of 8 waves.
 // ------------------------------------------------------------------------------------------------
+template <int NA>   // NA = 3: nt256_mainloop3 on SmemQ3
 __global__ __launch_bounds__(512) void gate_dx256_bf16_kernel(const bf16_t* __restrict__ dz, const bf16_t* __restrict__ WN,
                                                               bf16_t* __restrict__ dE, int64_t ldE, int accumulate, int64_t T, int H,
                                                               PoolTerm pt) {
-    __shared__ SmemQ sm;
+    __shared__ typename std::conditional<NA == 3, SmemQ3, SmemQ>::type sm3;
+    SmemQ& sm = reinterpret_cast<SmemQ&>(sm3);   // (epilogue staging: the first 128 KiB of the drained ring)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
@@ -425,8 +428,8 @@ __global__ __launch_bounds__(512) void gate_dx256_bf16_kernel(const bf16_t* __re
     }
     auto dma = [&](int st, int64_t f, int piece) {
         const int i = piece & 3;
-        if (piece < 4) glds16_s(voA[i], baseA + f * (QK * 2), lds_addr_of(&sm.A[st][(wave * 4 + i) * 1024]));
-        else glds16_s(voB[i], baseB + f * (QK * 2), lds_addr_of(&sm.B[st][(wave * 4 + i) * 1024]));
+        if (piece < 4) glds16_s(voA[i], baseA + f * (QK * 2), lds_addr_of(&sm3.A[st][(wave * 4 + i) * 1024]));
+        else glds16_s(voB[i], baseB + f * (QK * 2), lds_addr_of(&sm3.B[st][(wave * 4 + i) * 1024]));
     };
     // fused A3 term: softmax weight and d_pooled row of every tile row, once per row (see sp_gate_dx_kernel)
     float row_w = 0.f;
@@ -437,7 +440,8 @@ __global__ __launch_bounds__(512) void gate_dx256_bf16_kernel(const bf16_t* __re
         row_off = (bag * H + c) * HID;
     }
     f32x16 acc[4][2];
-    nt256_mainloop(sm, acc, 1024 / QK, wm, wn, lane, dma);
+    if constexpr (NA == 3) nt256_mainloop3(sm3, acc, 1024 / QK, wm, wn, lane, dma);
+    else nt256_mainloop(sm3, acc, 1024 / QK, wm, wn, lane, dma);
 
     float* rw_s = reinterpret_cast<float*>(&sm) + 8 * (32 * 64);   // behind the eight waves' transpose areas
     int* ro_s = reinterpret_cast<int*>(rw_s + QM);
@@ -548,10 +552,11 @@ static inline int64_t up16(int64_t b) { return (b + 15) & ~(int64_t)15; }
 
 // dW on the 256 x 256 tile (round 5; tn256_mainloop, 64-token chunks): tile = 256 of the head's 512 E columns x 256 of its 1024 dz columns,
 // 8 tiles per head and split.  E rows past T - 1 re-read row T - 1: their dz rows are the zero pad (TQK rows).
+template <int NA>   // NA = 3: tn256_mainloop3 on SmemQ3
 __global__ __launch_bounds__(512) void gate_dw256_bf16_kernel(const bf16_t* __restrict__ E, int64_t ldE, const bf16_t* __restrict__ dz,
                                                               float* __restrict__ slabW, int64_t T, int H, int64_t tok_per_split,
                                                               int n_splits) {
-    __shared__ SmemQ sm;
+    __shared__ typename std::conditional<NA == 3, SmemQ3, SmemQ>::type sm;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
@@ -587,7 +592,8 @@ __global__ __launch_bounds__(512) void gate_dw256_bf16_kernel(const bf16_t* __re
         }
     };
     f32x16 acc[4][2];
-    tn256_mainloop(sm, acc, nch, wm, wn, lane, dma);
+    if constexpr (NA == 3) tn256_mainloop3(sm, acc, nch, wm, wn, lane, dma);
+    else tn256_mainloop(sm, acc, nch, wm, wn, lane, dma);
 
     // slabW [split][head][k' 512][1024: a-cols 0..511 | b-cols 512..1023]
     float* __restrict__ so = slabW + (((int64_t)sp * H + c) * HID) * 1024;
@@ -768,8 +774,12 @@ static int gate_bwd_bf16_impl(const uint16_t* E, int64_t ldE, const float* Wa, c
                 const int64_t n_tt = (T + QM - 1) / QM;
                 const int64_t grid = xcd_head_grid(n_tt, 2, H);
                 if (grid > 0x7fffffff) return MDL_E_UNSUPPORTED;
-                hipLaunchKernelGGL(gate_dx256_bf16_kernel, dim3((unsigned)grid), dim3(512), 0, s, (const bf16_t*)dz, (const bf16_t*)WN,
-                                   (bf16_t*)dE, ldE, accumulate, T, H, pt);
+                if (bf16_stages() == 3)
+                    hipLaunchKernelGGL(gate_dx256_bf16_kernel<3>, dim3((unsigned)grid), dim3(512), 0, s, (const bf16_t*)dz, (const bf16_t*)WN,
+                                       (bf16_t*)dE, ldE, accumulate, T, H, pt);
+                else
+                    hipLaunchKernelGGL(gate_dx256_bf16_kernel<2>, dim3((unsigned)grid), dim3(512), 0, s, (const bf16_t*)dz, (const bf16_t*)WN,
+                                       (bf16_t*)dE, ldE, accumulate, T, H, pt);
             } else {
                 const int64_t n_tt = (T + BBM - 1) / BBM;
                 const int64_t grid = xcd_head_grid(n_tt, 2, H);
@@ -779,8 +789,11 @@ static int gate_bwd_bf16_impl(const uint16_t* E, int64_t ldE, const float* Wa, c
             }
             MDL_LAUNCH_CHECK();
         }
-        if (gate_dw_use_q(T))
-            hipLaunchKernelGGL(gate_dw256_bf16_kernel, dim3((unsigned)xcd_head_grid(L.S, 8, H)), dim3(512), 0, s, (const bf16_t*)E, ldE,
+        if (gate_dw_use_q(T) && bf16_stages() == 3)
+            hipLaunchKernelGGL(gate_dw256_bf16_kernel<3>, dim3((unsigned)xcd_head_grid(L.S, 8, H)), dim3(512), 0, s, (const bf16_t*)E, ldE,
+                               (const bf16_t*)dz, slabW, T, H, L.tps, L.S);
+        else if (gate_dw_use_q(T))
+            hipLaunchKernelGGL(gate_dw256_bf16_kernel<2>, dim3((unsigned)xcd_head_grid(L.S, 8, H)), dim3(512), 0, s, (const bf16_t*)E, ldE,
                                (const bf16_t*)dz, slabW, T, H, L.tps, L.S);
         else
         hipLaunchKernelGGL(gate_dw_bf16_kernel, dim3((unsigned)xcd_head_grid(L.S, 16, H)), dim3(256), 0, s, (const bf16_t*)E, ldE,

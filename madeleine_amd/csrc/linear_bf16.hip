@@ -9,6 +9,8 @@
 // Geometry: N % 128 == 0 (forward: 128 x 256 tile when N % 256 == 0, else 128 x 128), K % 32 == 0 (ragged last 256-column tile of dX /
 // dW: clamped operand fetches, masked stores);
 // leading dimensions multiples of 8 elements, 16-B aligned bases.  T is free (row tails are clamped / zero-filled).
+#include <type_traits>
+
 #include "tile_engine_bf16.hpp"
 
 namespace mdl {
@@ -112,11 +114,13 @@ __global__ __launch_bounds__(256, 2) void linb_nt_kernel(const bf16_t* __restric
 // Round 5: PER > 1 = persistent workgroup over PER consecutive column tiles of one row tile (n_ct % PER == 0): the next tile's first
 // chunk (same A rows, next 256 weight rows) is requested before the epilogue of the current one, which then stages through stage 1
 // only (see gate_fwd256_bf16_kernel).  With the prologue hidden the tile also serves contractions of 512 (linb_use_q).
-template <int PER>
+template <int PER, int NA = 2>   // NA = 3 (PER = 1 only): nt256_mainloop3 on SmemQ3
 __global__ __launch_bounds__(512) void linb_nt256_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B,
                                                          const float* __restrict__ bias, bf16_t* __restrict__ C, int64_t ldc,
                                                          int64_t T, int Kc, int n_ct, int n_tiles) {
-    __shared__ SmemQ sm;
+    static_assert(NA == 2 || PER == 1, "the three-stage ring serves one tile per workgroup");
+    __shared__ typename std::conditional<NA == 3, SmemQ3, SmemQ>::type sm3;
+    SmemQ& sm = reinterpret_cast<SmemQ&>(sm3);   // (epilogue staging / persistent prefetch: the two-stage view)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;   // rows wm*128 + rt*32 (rt < 4), columns wn*64 + ct*32 (ct < 2)
@@ -141,11 +145,12 @@ __global__ __launch_bounds__(512) void linb_nt256_kernel(const bf16_t* __restric
         const char* baseB = reinterpret_cast<const char*>(B + (int64_t)n0 * Kc);
         auto dma = [&](int st, int64_t f, int piece) {   // piece 0..7: 0-3 = A row blocks, 4-7 = B row blocks
             const int i = piece & 3;
-            if (piece < 4) glds16_s(voA[i], uniform_ptr(baseA + f * (QK * 2)), lds_addr_of(&sm.A[st][(wave * 4 + i) * 1024]));
-            else glds16_s(voB[i], uniform_ptr(baseB + f * (QK * 2)), lds_addr_of(&sm.B[st][(wave * 4 + i) * 1024]));
+            if (piece < 4) glds16_s(voA[i], uniform_ptr(baseA + f * (QK * 2)), lds_addr_of(&sm3.A[st][(wave * 4 + i) * 1024]));
+            else glds16_s(voB[i], uniform_ptr(baseB + f * (QK * 2)), lds_addr_of(&sm3.B[st][(wave * 4 + i) * 1024]));
         };
         f32x16 acc[4][2];
-        nt256_mainloop(sm, acc, Kc / QK, wm, wn, lane, dma, k > 0);
+        if constexpr (NA == 3) nt256_mainloop3(sm3, acc, Kc / QK, wm, wn, lane, dma);
+        else nt256_mainloop(sm3, acc, Kc / QK, wm, wn, lane, dma, k > 0);
         if (k + 1 < PER) {   // the next column tile's first chunk travels during this epilogue
             const char* baseBn = baseB + (int64_t)QN * Kc * 2;
 #pragma unroll
@@ -178,7 +183,8 @@ static inline void linb_launch_nt256(hipStream_t s, const bf16_t* A, int64_t lda
     const int per = (persist && Kc < 1024 && n_ct % 4 == 0) ? 4 : 1;
     const dim3 grid((unsigned)(tiles / per));
     if (per == 4) hipLaunchKernelGGL(linb_nt256_kernel<4>, grid, dim3(512), 0, s, A, lda, B, bias, C, ldc, T, Kc, n_ct, (int)tiles);
-    else hipLaunchKernelGGL(linb_nt256_kernel<1>, grid, dim3(512), 0, s, A, lda, B, bias, C, ldc, T, Kc, n_ct, (int)tiles);
+    else if (bf16_lin_stages() == 3 || bf16_lin_stages() == 31) hipLaunchKernelGGL((linb_nt256_kernel<1, 3>), grid, dim3(512), 0, s, A, lda, B, bias, C, ldc, T, Kc, n_ct, (int)tiles);
+    else hipLaunchKernelGGL((linb_nt256_kernel<1, 2>), grid, dim3(512), 0, s, A, lda, B, bias, C, ldc, T, Kc, n_ct, (int)tiles);
 }
 
 // ---- TN product: slab[sp][n0 + m][k0 + n] = sum_{t in split sp} dY[t][n0 + m] X[t][k0 + n] --------------
@@ -306,10 +312,11 @@ constexpr int LINB_COLSUM_BLOCKS = 1024;
 
 // ---- TN product on the 256 x 256 tile (round 5): tn256_mainloop, 64-token chunks; N % 256 == 0 (rows of the slab = dY columns), ragged K
 // tail as above.  Token rows past T: dY reads the zero row (per-lane address form, last chunk only), X re-reads row T - 1.
+template <int NA>   // NA = 3: tn256_mainloop3 on SmemQ3
 __global__ __launch_bounds__(512) void linb_tn256_kernel(const bf16_t* __restrict__ dY, int64_t lddy, const bf16_t* __restrict__ X,
                                                          int64_t ldx, const bf16_t* __restrict__ zrow, float* __restrict__ slab,
                                                          int64_t T, int N, int K, int64_t tok_per_split, int n_splits, int n_tiles) {
-    __shared__ SmemQ sm;
+    __shared__ typename std::conditional<NA == 3, SmemQ3, SmemQ>::type sm;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
@@ -352,7 +359,8 @@ __global__ __launch_bounds__(512) void linb_tn256_kernel(const bf16_t* __restric
         }
     };
     f32x16 acc[4][2];
-    tn256_mainloop(sm, acc, nch, wm, wn, lane, dma);
+    if constexpr (NA == 3) tn256_mainloop3(sm, acc, nch, wm, wn, lane, dma);
+    else tn256_mainloop(sm, acc, nch, wm, wn, lane, dma);
 
     float* __restrict__ so = slab + (int64_t)sp * N * K;
     const int l32 = lane & 31;
@@ -510,8 +518,11 @@ extern "C" int mdl_linear_bwd_bf16(const uint16_t* X, int64_t ldx, const float* 
         const bool q = linb_tn_use_q(T, (int)N);
         const int64_t tiles = (int64_t)L.S * (N / (q ? 256 : 128)) * ((K + 255) / 256);
         if (tiles > 0x7fffffff) return MDL_E_UNSUPPORTED;
-        if (q)
-            hipLaunchKernelGGL(linb_tn256_kernel, dim3((unsigned)tiles), dim3(512), 0, s, (const bf16_t*)dY, lddy, (const bf16_t*)X, ldx,
+        if (q && (bf16_lin_stages() == 3 || bf16_lin_stages() == 32))
+            hipLaunchKernelGGL(linb_tn256_kernel<3>, dim3((unsigned)tiles), dim3(512), 0, s, (const bf16_t*)dY, lddy, (const bf16_t*)X, ldx,
+                               (const bf16_t*)zrow, slab, T, (int)N, (int)K, L.tps, L.S, (int)tiles);
+        else if (q)
+            hipLaunchKernelGGL(linb_tn256_kernel<2>, dim3((unsigned)tiles), dim3(512), 0, s, (const bf16_t*)dY, lddy, (const bf16_t*)X, ldx,
                                (const bf16_t*)zrow, slab, T, (int)N, (int)K, L.tps, L.S, (int)tiles);
         else
         hipLaunchKernelGGL(linb_tn_kernel, dim3((unsigned)tiles), dim3(256), 0, s, (const bf16_t*)dY, lddy, (const bf16_t*)X, ldx,

@@ -57,6 +57,13 @@ struct __attribute__((aligned(16))) SmemSPn {
 };
 typedef SmemSPn<2> SmemSP;
 typedef SmemSPn<3> SmemSP3;
+// which pieces the three-stage loops spread (A/B through tools/ab: -DMDL_SP_NT_BSPREAD=0 / -DMDL_SP_TN_BSPREAD=1)
+#ifndef MDL_SP_NT_BSPREAD
+#define MDL_SP_NT_BSPREAD 1   // NT: the B operand is a weight (L2 / MALL resident): its pieces inside the chunk too
+#endif
+#ifndef MDL_SP_TN_BSPREAD
+#define MDL_SP_TN_BSPREAD 0   // TN: both operands stream from HBM: B keeps the full chunk of flight time
+#endif
 // which NT main loop the launchers pick: MADELEINE_SP_NT_STAGES = 2 | 3 (A/B switch), default MDL_SP_NT_STAGES
 #ifndef MDL_SP_NT_STAGES
 #define MDL_SP_NT_STAGES 3
@@ -201,7 +208,9 @@ __device__ __forceinline__ void sp_nt_mainloop(SmemSP& sm, SpAcc& acc, int nblk,
 // free stage exists during the whole chunk: iteration ch issues B of block ch + 1 (into the B stage freed by chunk ch - 1) behind MFMAs
 // 2 and 4 of its first two sets and A of block ch + 2 (into the A stage freed by chunk ch - 1) in sets 3 .. 5.  Wait at the chunk end:
 // vmcnt(SP_PW) -- everything but this iteration's A pieces has landed (B of ch + 1 was issued before them, A of ch + 1 an iteration ago).
-template <int TERMS = 3, class Dma>
+// BSPREAD = false: only the A pieces are spread (one per set, sets 1 .. 4); B of block ch + 2 keeps the slot behind the chunk barrier (the
+// placement of sp_tn_mainloop3).
+template <int TERMS = 3, bool BSPREAD = (MDL_SP_NT_BSPREAD != 0), class Dma>
 __device__ __forceinline__ void sp_nt_mainloop3(SmemSP3& sm, SpAcc& acc, int nblk, int wm, int wn, int lane, Dma&& dma) {
     static_assert(SP_PW == 4, "piece placement below is written for four pieces per wave and operand");
     const int l32 = lane & 31, kh = lane >> 5;
@@ -255,7 +264,7 @@ __device__ __forceinline__ void sp_nt_mainloop3(SmemSP3& sm, SpAcc& acc, int nbl
     {
         const int f = nblk > 1 ? 1 : 0;
 #pragma unroll
-        for (int p = 0; p < SP_PW; ++p) dma(1, f, p);   // A of block 1 (B of block 1 follows inside iteration 0)
+        for (int p = 0; p < (BSPREAD ? SP_PW : SP_NP); ++p) dma(1, f, p);   // A of block 1 (BSPREAD: B of block 1 follows inside iteration 0)
     }
     ldA(a0, 0, 0);
     ldB(b0, 0, 0);
@@ -267,7 +276,17 @@ __device__ __forceinline__ void sp_nt_mainloop3(SmemSP3& sm, SpAcc& acc, int nbl
         const int fb = (ch + 1 < nblk) ? ch + 1 : nblk - 1, fa = (ch + 2 < nblk) ? ch + 2 : nblk - 1;
 #define SP_DB(i) dma(st ^ 1, fb, SP_PW + (i))
 #define SP_DA(i) dma(saf, fa, (i))
-        if constexpr (TERMS == 3) {
+        if constexpr (!BSPREAD && TERMS == 3) {
+            SP_SETD(a0, b0, ldB(b1, st, 2), SP_DA(0), (void)0)
+            SP_SETD(a0, b1, ldA(a1, sa, 2), SP_DA(1), (void)0)
+            SP_SETD(a1, b0, ldA(a2, sa, 1); ldB(b2, st, 1), SP_DA(2), (void)0)
+            SP_SETD(a2, b2, ldB(b1, st, 3), SP_DA(3), (void)0)
+            SP_SETD(a2, b1, ldA(a1, sa, 3), (void)0, (void)0)
+        } else if constexpr (!BSPREAD) {
+            SP_SETD(a0, b0, ldA(a1, sa, 2), SP_DA(0), SP_DA(1))
+            SP_SETD(a1, b0, ldA(a2, sa, 1); ldB(b2, st, 1), SP_DA(2), SP_DA(3))
+            SP_SETD(a2, b2, ldA(a1, sa, 3), (void)0, (void)0)
+        } else if constexpr (TERMS == 3) {
             SP_SETD(a0, b0, ldB(b1, st, 2), SP_DB(0), SP_DB(1))                    // hi hi, s0   | B lo s0
             SP_SETD(a0, b1, ldA(a1, sa, 2), SP_DB(2), SP_DB(3))                    // hi lo, s0   | A lo s0
             SP_SETD(a1, b0, ldA(a2, sa, 1); ldB(b2, st, 1), SP_DA(0), SP_DA(1))    // lo hi, s0   | A hi s1, B hi s1
@@ -288,7 +307,14 @@ __device__ __forceinline__ void sp_nt_mainloop3(SmemSP3& sm, SpAcc& acc, int nbl
         ldB(b0, st ^ 1, 0);
         SP_SB();
 #pragma unroll
-        for (int m = 0; m < SP_NP; ++m) mma1(a1, b2, m);   // lo hi, s1
+        for (int m = 0; m < SP_NP; ++m) {
+            mma1(a1, b2, m);   // lo hi, s1
+            if constexpr (!BSPREAD) {
+                SP_SB();
+                if (m >= SP_NP - SP_PW) dma(st, fa, m);   // B of block ch + 2 into the stage this chunk frees
+                SP_SB();
+            }
+        }
         SP_SB();
         sa = san;
     }
@@ -569,7 +595,7 @@ __device__ __forceinline__ void sp_tn_mainloop(SmemSP& sm, SpAcc& acc, int64_t n
 // spread -- iteration ch issues A of chunk ch + 2 (into the A stage freed by chunk ch - 1) one piece per set behind MFMA 2 of its first
 // four sets; B of chunk ch + 2 still goes into the stage chunk ch frees, inside the last set (four pieces instead of eight there).  Wait at
 // the chunk end: vmcnt(SP_PW) -- B of chunk ch + 1 (issued in the previous last set) and A of chunk ch + 1 (an iteration ago) have landed.
-template <int TERMS = 3, class Dma>
+template <int TERMS = 3, bool BSPREAD = (MDL_SP_TN_BSPREAD != 0), class Dma>   // BSPREAD = true: B too is issued inside the chunk (the placement of sp_nt_mainloop3)
 __device__ __forceinline__ void sp_tn_mainloop3(SmemSP3& sm, SpAcc& acc, int64_t nch, int wm, int wn, int lane, Dma&& dma) {
     static_assert(SP_PW == 4, "piece placement below is written for four pieces per wave and operand");
     const int g = lane >> 4, r = lane & 15;
@@ -589,7 +615,7 @@ __device__ __forceinline__ void sp_tn_mainloop3(SmemSP3& sm, SpAcc& acc, int64_t
     {
         const int64_t f = nch > 1 ? 1 : 0;
 #pragma unroll
-        for (int p = 0; p < SP_NP; ++p) dma(1, f, p);   // A and B of chunk 1 (A of chunk 2 follows inside iteration 0)
+        for (int p = 0; p < (BSPREAD ? SP_PW : SP_NP); ++p) dma(1, f, p);   // A (and B) of chunk 1 (A of chunk 2 follows inside iteration 0)
     }
     SpFragA a0, a1, a2;
     SpFragB b0, b1, b2;
@@ -597,7 +623,7 @@ __device__ __forceinline__ void sp_tn_mainloop3(SmemSP3& sm, SpAcc& acc, int64_t
     sp_tn_ldB<0>(b0, b_0);
     SP_LGKM_WAIT();
     SP_SB();
-#define SP_TSETD(FA, FB, LOADS, D1)                                              \
+#define SP_TSETD2(FA, FB, LOADS, D1, D2)                                         \
     sp_tn_mma(acc, FA, FB, 0);                                                  \
     SP_SB();                                                                    \
     LOADS;                                                                      \
@@ -607,10 +633,16 @@ __device__ __forceinline__ void sp_tn_mainloop3(SmemSP3& sm, SpAcc& acc, int64_t
     SP_SB();                                                                    \
     D1;                                                                         \
     SP_SB();                                                                    \
-    _Pragma("unroll") for (int m = 3; m < SP_NP; ++m) sp_tn_mma(acc, FA, FB, m); \
+    sp_tn_mma(acc, FA, FB, 3);                                                  \
+    sp_tn_mma(acc, FA, FB, 4);                                                  \
+    SP_SB();                                                                    \
+    D2;                                                                         \
+    SP_SB();                                                                    \
+    _Pragma("unroll") for (int m = 5; m < SP_NP; ++m) sp_tn_mma(acc, FA, FB, m); \
     SP_SB();                                                                    \
     SP_LGKM_WAIT();                                                             \
     SP_SB();
+#define SP_TSETD(FA, FB, LOADS, D1) SP_TSETD2(FA, FB, LOADS, D1, (void)0)
     int sa = 0;
     for (int64_t ch = 0; ch < nch; ++ch) {
         const int st = (int)(ch & 1);
@@ -627,8 +659,20 @@ __device__ __forceinline__ void sp_tn_mainloop3(SmemSP3& sm, SpAcc& acc, int64_t
             nB[ct] = b_0[ct] + (st ^ 1) * SP_STAGE;
         }
         const int64_t fa = (ch + 2 < nch) ? ch + 2 : nch - 1;
+        const int64_t fb1 = (ch + 1 < nch) ? ch + 1 : nch - 1;
 #define SP_DA(i) dma(saf, fa, (i))
-        if constexpr (TERMS == 3) {
+#define SP_DB(i) dma(st ^ 1, fb1, SP_PW + (i))
+        if constexpr (BSPREAD && TERMS == 3) {
+            SP_TSETD2(a0, b0, sp_tn_ldB<2>(b1, aB), SP_DB(0), SP_DB(1))
+            SP_TSETD2(a0, b1, sp_tn_ldA<2>(a1, aA), SP_DB(2), SP_DB(3))
+            SP_TSETD2(a1, b0, sp_tn_ldA<1>(a2, aA); sp_tn_ldB<1>(b2, aB), SP_DA(0), SP_DA(1))
+            SP_TSETD2(a2, b2, sp_tn_ldB<3>(b1, aB), SP_DA(2), (void)0)
+            SP_TSETD2(a2, b1, sp_tn_ldA<3>(a1, aA), SP_DA(3), (void)0)
+        } else if constexpr (BSPREAD) {
+            SP_TSETD2(a0, b0, sp_tn_ldB<2>(b1, aB), SP_DB(0); SP_DB(1), SP_DB(2); SP_DB(3))
+            SP_TSETD2(a0, b1, sp_tn_ldA<1>(a2, aA); sp_tn_ldB<1>(b2, aB), SP_DA(0), SP_DA(1))
+            SP_TSETD2(a2, b2, sp_tn_ldB<3>(b1, aB), SP_DA(2), SP_DA(3))
+        } else if constexpr (TERMS == 3) {
             SP_TSETD(a0, b0, sp_tn_ldB<2>(b1, aB), SP_DA(0))                          // hi hi, s0 | B lo s0
             SP_TSETD(a0, b1, sp_tn_ldA<2>(a1, aA), SP_DA(1))                          // hi lo, s0 | A lo s0
             SP_TSETD(a1, b0, sp_tn_ldA<1>(a2, aA); sp_tn_ldB<1>(b2, aB), SP_DA(2))    // lo hi, s0 | A hi s1, B hi s1
@@ -640,6 +684,7 @@ __device__ __forceinline__ void sp_tn_mainloop3(SmemSP3& sm, SpAcc& acc, int64_t
             SP_TSETD(a2, b2, sp_tn_ldB<3>(b1, aB), (void)0)                                     // hi hi, s1 | B lo s1
         }
 #undef SP_DA
+#undef SP_DB
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SP_PW) : "memory");
         SP_SB();
         __syncthreads();
@@ -652,7 +697,9 @@ __device__ __forceinline__ void sp_tn_mainloop3(SmemSP3& sm, SpAcc& acc, int64_t
             if constexpr (TERMS == 3) sp_tn_mma(acc, a1, b2, m);       // lo hi, s1
             else sp_tn_mma(acc, a2, b1, m);                            // hi lo, s1
             SP_SB();
-            if (m >= SP_NP - SP_PW) dma(st, fb, m);                    // the four B pieces (pieces SP_PW .. SP_NP - 1) behind the last MFMAs
+            if constexpr (!BSPREAD) {
+                if (m >= SP_NP - SP_PW) dma(st, fb, m);                // the four B pieces (pieces SP_PW .. SP_NP - 1) behind the last MFMAs
+            }
             SP_SB();
         }
         SP_LGKM_WAIT();
@@ -662,6 +709,7 @@ __device__ __forceinline__ void sp_tn_mainloop3(SmemSP3& sm, SpAcc& acc, int64_t
     SP_DMA_WAIT();
     __syncthreads();
 #undef SP_TSETD
+#undef SP_TSETD2
 }
 
 // ---- epilogue through LDS ---------------------------------------------------------------------------------------------------------

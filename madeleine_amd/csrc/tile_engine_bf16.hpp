@@ -4,6 +4,7 @@
 //   NT: C[m][n] = sum_k A[m][k] B[n][k]  both operands K-contiguous rows; LDS image = XOR-swizzled 64-B rows, ds_read_b128.
 //   TN: C[m][n] = sum_k A[k][m] B[k][n]  both operands K-major; fragments gathered by ds_read_b64_tr_b16.
 #pragma once
+#include <cstdlib>
 #include "gate_common.hpp"
 
 namespace mdl {
@@ -170,6 +171,28 @@ struct __attribute__((aligned(16))) SmemQ {
     char A[2][Q_STAGE];
     char B[2][Q_STAGE];
 };
+// Round 6: A ring three stages deep = 160 KiB, the LDS-DMA pieces of a chunk spread over its k-steps instead of issued
+// together behind the chunk barrier (nt256_mainloop3 / tn256_mainloop3; the one-tile-per-workgroup kernels).  MADELEINE_BF16_STAGES = 2 | 3.
+struct __attribute__((aligned(16))) SmemQ3 {
+    char A[3][Q_STAGE];
+    char B[2][Q_STAGE];
+};
+#ifndef MDL_BF16_STAGES
+#define MDL_BF16_STAGES 3
+#endif
+// the Linears' 256-tile kernels separately (MADELEINE_BF16_LIN_STAGES = 2 | 3 | 31 (NT only) | 32 (TN only)): measured at config 2
+// (profiles/r06r_*, r06s_*) the gate's dX / dW gain 5 %; of the Linears the dX (NT) gains 1 %, the dW (TN) loses 4 % -- default 31
+#ifndef MDL_BF16_LIN_STAGES
+#define MDL_BF16_LIN_STAGES 31
+#endif
+static inline int bf16_lin_stages() {
+    static const int v = getenv("MADELEINE_BF16_LIN_STAGES") ? atoi(getenv("MADELEINE_BF16_LIN_STAGES")) : MDL_BF16_LIN_STAGES;
+    return v;
+}
+static inline int bf16_stages() {
+    static const int v = getenv("MADELEINE_BF16_STAGES") ? atoi(getenv("MADELEINE_BF16_STAGES")) : MDL_BF16_STAGES;
+    return v == 2 ? 2 : 3;
+}
 // LDS-DMA piece i (0..3) of wave w for either operand: 8 rows x 128 B; this lane fetches global 16-B chunk c of row `row` (tile-relative)
 // and the DMA deposits it at LDS slot (wave*4 + i)*1024 + lane*16 = row*128 + (c ^ ((row >> 1) & 7))*16.
 __device__ __forceinline__ void nt256_slot(int wave, int i, int lane, int& row, int& c) {
@@ -253,6 +276,100 @@ __device__ __forceinline__ void nt256_mainloop(SmemQ& sm, f32x16 (&acc)[4][2], i
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped re-fetches of the tail
     __syncthreads();                                    // staging memory is free for the epilogue
 #undef NT256_KSTEP
+#undef NT256_SB
+}
+// The same loop on SmemQ3: iteration ch issues B of chunk ch + 1 (into the B stage chunk ch - 1 freed; B is a weight image: L2 / MALL
+// resident) and A of chunk ch + 2 (into the A stage chunk ch - 1 freed) behind MFMAs 1, 3 and 5 of its first three k-steps -- B first --
+// and waits with vmcnt(4): everything but this iteration's A pieces has landed.  No chunk0_in_flight form (one tile per workgroup).
+template <class Dma>
+__device__ __forceinline__ void nt256_mainloop3(SmemQ3& sm, f32x16 (&acc)[4][2], int64_t nch, int wm, int wn, int lane, Dma&& dma) {
+    const int l32 = lane & 31, kh = lane >> 5;
+    uint32_t offA[4], offB[2];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+        const int r = wm * 128 + rt * 32 + l32;
+        offA[rt] = r * 128 + ((kh ^ ((r >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        const int r = wn * 64 + ct * 32 + l32;
+        offB[ct] = r * 128 + ((kh ^ ((r >> 1) & 7)) << 4);
+    }
+    bf16x8 fa0[4], fb0[2], fa1[4], fb1[2];
+    auto ld = [&](bf16x8 (&fa)[4], bf16x8 (&fb)[2], int sa, int sb, int ks) {
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) fa[rt] = *reinterpret_cast<const bf16x8*>(&sm.A[sa][offA[rt] ^ (ks << 5)]);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) fb[ct] = *reinterpret_cast<const bf16x8*>(&sm.B[sb][offB[ct] ^ (ks << 5)]);
+    };
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    auto mma1 = [&](const bf16x8 (&fa)[4], const bf16x8 (&fb)[2], int m) {
+        const int rt = m >> 1, ct = m & 1;
+        acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[rt], fb[ct], acc[rt][ct], 0, 0, 0);
+    };
+#define NT256_SB() __builtin_amdgcn_sched_barrier(0)
+#define NT256_KSTEPD(FA, FB, LOADS, D1, D2, D3)                                 \
+    mma1(FA, FB, 0);                                                            \
+    NT256_SB();                                                                 \
+    LOADS;                                                                      \
+    NT256_SB();                                                                 \
+    mma1(FA, FB, 1);                                                            \
+    NT256_SB();                                                                 \
+    D1;                                                                         \
+    NT256_SB();                                                                 \
+    mma1(FA, FB, 2);                                                            \
+    mma1(FA, FB, 3);                                                            \
+    NT256_SB();                                                                 \
+    D2;                                                                         \
+    NT256_SB();                                                                 \
+    mma1(FA, FB, 4);                                                            \
+    mma1(FA, FB, 5);                                                            \
+    NT256_SB();                                                                 \
+    D3;                                                                         \
+    NT256_SB();                                                                 \
+    mma1(FA, FB, 6);                                                            \
+    mma1(FA, FB, 7);                                                            \
+    NT256_SB();
+    if (nch <= 0) return;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) dma(0, (int64_t)0, p);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    {
+        const int64_t f = nch > 1 ? 1 : 0;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) dma(1, f, p);   // A of chunk 1 (B of chunk 1 follows inside iteration 0)
+    }
+    ld(fa0, fb0, 0, 0, 0);
+    int sa = 0;
+    for (int64_t ch = 0; ch < nch; ++ch) {
+        const int st = (int)(ch & 1);
+        const int san = (sa == 2) ? 0 : sa + 1, saf = (san == 2) ? 0 : san + 1;
+        const int64_t fb = (ch + 1 < nch) ? ch + 1 : nch - 1, fa = (ch + 2 < nch) ? ch + 2 : nch - 1;
+#define NT256_DB(i) dma(st ^ 1, fb, 4 + (i))
+#define NT256_DA(i) dma(saf, fa, (i))
+        NT256_KSTEPD(fa0, fb0, ld(fa1, fb1, sa, st, 1), NT256_DB(0), NT256_DB(1), NT256_DB(2))
+        NT256_KSTEPD(fa1, fb1, ld(fa0, fb0, sa, st, 2), NT256_DB(3), NT256_DA(0), NT256_DA(1))
+        NT256_KSTEPD(fa0, fb0, ld(fa1, fb1, sa, st, 3), NT256_DA(2), NT256_DA(3), (void)0)
+#undef NT256_DB
+#undef NT256_DA
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __syncthreads();
+        ld(fa0, fb0, san, st ^ 1, 0);
+        NT256_SB();
+#pragma unroll
+        for (int m = 0; m < 8; ++m) mma1(fa1, fb1, m);
+        NT256_SB();
+        sa = san;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped re-fetches of the tail
+    __syncthreads();                                    // staging memory is free for the epilogue
+#undef NT256_KSTEPD
 #undef NT256_SB
 }
 // epilogue of the 256-tile: the wave's 128 x 64 sub-tile through its private 32 x 64 LDS transpose tile, as two 64-row halves of
@@ -510,6 +627,107 @@ __device__ __forceinline__ void tn256_mainloop(SmemQ& sm, f32x16 (&acc)[4][2], i
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped re-fetches of the tail
     __syncthreads();
 #undef TQ_SET
+#undef TQ_LGKM
+#undef TQ_SB
+}
+
+// The TN loop on SmemQ3: both operands stream from HBM -- A of chunk ch + 2 is spread over the first three k-steps of
+// iteration ch (into the A stage chunk ch - 1 freed), B of chunk ch + 2 keeps the slot behind the chunk barrier (four pieces instead of eight
+// there); wait vmcnt(4).
+template <class Dma>
+__device__ __forceinline__ void tn256_mainloop3(SmemQ3& sm, f32x16 (&acc)[4][2], int64_t nch, int wm, int wn, int lane, Dma&& dma) {
+    const int g = lane >> 4, r = lane & 15;
+    const int kb = (g >> 1) * 8 + (r >> 2);
+    uint32_t a_0[4], b_0[2];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+        a_0[rt] = lds_addr_of(&sm.A[0][0]) + kb * 512 + (((wm * 128 + rt * 32 + (g & 1) * 16 + (r & 3) * 4) * 2) ^ ((kb & 3) << 6));
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+        b_0[ct] = lds_addr_of(&sm.B[0][0]) + kb * 512 + (((wn * 64 + ct * 32 + (g & 1) * 16 + (r & 3) * 4) * 2) ^ ((kb & 3) << 6));
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    if (nch <= 0) return;
+#define TQ_SB() __builtin_amdgcn_sched_barrier(0)
+#define TQ_LGKM() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#pragma unroll
+    for (int p = 0; p < 8; ++p) dma(0, (int64_t)0, p);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    {
+        const int64_t f = nch > 1 ? 1 : 0;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) dma(1, f, p);   // A and B of chunk 1 (A of chunk 2 follows inside iteration 0)
+    }
+    Tn256Frag f0, f1;
+    tn256_load<0>(f0, a_0, b_0);
+    TQ_LGKM();
+    TQ_SB();
+#define TQ_SETD(F, LOADS, D1, D2)                                       \
+    tn256_mma(acc, F, 0);                                               \
+    TQ_SB();                                                            \
+    LOADS;                                                              \
+    TQ_SB();                                                            \
+    tn256_mma(acc, F, 1);                                               \
+    tn256_mma(acc, F, 2);                                               \
+    TQ_SB();                                                            \
+    D1;                                                                 \
+    TQ_SB();                                                            \
+    tn256_mma(acc, F, 3);                                               \
+    tn256_mma(acc, F, 4);                                               \
+    tn256_mma(acc, F, 5);                                               \
+    TQ_SB();                                                            \
+    D2;                                                                 \
+    TQ_SB();                                                            \
+    tn256_mma(acc, F, 6);                                               \
+    tn256_mma(acc, F, 7);                                               \
+    TQ_SB();                                                            \
+    TQ_LGKM();                                                          \
+    TQ_SB();
+    int sa = 0;
+    for (int64_t ch = 0; ch < nch; ++ch) {
+        const int st = (int)(ch & 1);
+        const int san = (sa == 2) ? 0 : sa + 1, saf = (san == 2) ? 0 : san + 1;
+        uint32_t aA[4], aB[2], nA[4], nB[2];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+            aA[rt] = a_0[rt] + sa * Q_STAGE;
+            nA[rt] = a_0[rt] + san * Q_STAGE;
+        }
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            aB[ct] = b_0[ct] + st * Q_STAGE;
+            nB[ct] = b_0[ct] + (st ^ 1) * Q_STAGE;
+        }
+        const int64_t fa = (ch + 2 < nch) ? ch + 2 : nch - 1;
+#define TQ_DA(i) dma(saf, fa, (i))
+        TQ_SETD(f0, tn256_load<1>(f1, aA, aB), TQ_DA(0), TQ_DA(1))
+        TQ_SETD(f1, tn256_load<2>(f0, aA, aB), TQ_DA(2), (void)0)
+        TQ_SETD(f0, tn256_load<3>(f1, aA, aB), TQ_DA(3), (void)0)
+#undef TQ_DA
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        TQ_SB();
+        __syncthreads();
+        tn256_load<0>(f0, nA, nB);
+        TQ_SB();
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            tn256_mma(acc, f1, m);
+            TQ_SB();
+            if (m >= 4) dma(st, fa, m);   // B of chunk ch + 2 into the stage this chunk frees
+            TQ_SB();
+        }
+        TQ_LGKM();
+        TQ_SB();
+        sa = san;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped re-fetches of the tail
+    __syncthreads();
+#undef TQ_SETD
 #undef TQ_LGKM
 #undef TQ_SB
 }
