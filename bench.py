@@ -262,6 +262,7 @@ def measure_leg(MF, stepf, steps, warmup=2, prof_steps=3):
     torch.cuda.synchronize()
     MF.TIMER = None
     dev = torch.cuda.current_device()
+    stable = []
     for _attempt in range(8):
         # steady state only: a leg that follows torch.cuda.empty_cache() can still be growing its pools, and a hipMalloc right after tens
         # of GiB were freed waits for the driver to scrub them (seen: 2-6x the step time in one of four processes; round 6: the ragged
@@ -274,7 +275,14 @@ def measure_leg(MF, stepf, steps, warmup=2, prof_steps=3):
         el = time.perf_counter() - t0
         measure_leg.last_allocs = torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - a0
         if measure_leg.last_allocs == 0:
-            break
+            # a second allocation-free pass, the faster of the two reported: single steps of the ragged legs come out 20-35 ms long now
+            # and then (66 / 73 / 88 ms for the same c5 bf16 step in back-to-back passes, tools/debug/dbg_c5_bf16_leg.py) -- host-side
+            # (pinned staging blocks still in flight -> a fresh hipHostMalloc), not a property of the kernels
+            stable.append(el)
+            if len(stable) == 2:
+                break
+    if stable:
+        el = min(stable)
     MF.TIMER = MF.KernelTimer()
     try:
         for _ in range(prof_steps):
