@@ -19,9 +19,11 @@
 //   NT  C[m][n] = sum_k A[m][k] B[n][k]   rows of both images are K-contiguous          (forward products, dX)
 //   TN  C[m][n] = sum_t A[t][m] B[t][n]   rows of both images are the contraction index  (dW; fragments by ds_read_b64_tr_b16)
 // Tile: 256 x 256 per workgroup (8 waves as 2 x 4, 128 x 64 = 4 x 2 MFMA tiles per wave, 128 accumulators; see SPNCT), one chunk =
-// one 32-k block of both operands = 2 x 32 KiB by LDS-DMA, two stages (128 KiB, one workgroup per CU), 48 MFMAs per wave and chunk, the in-wave
-// software pipeline of the other engines (fragments of the next MFMA set requested behind the first MFMA of the current one, one
-// barrier per chunk before its last set, the next-but-one chunk's DMA between that set's MFMAs).
+// one 32-k block of both operands = 2 x 32 KiB by LDS-DMA, 48 MFMAs per wave and chunk, the in-wave software pipeline of the other engines
+// (fragments of the next MFMA set requested behind the first MFMA of the current one, one barrier per chunk before its last set).  Two
+// loop families: the two-stage ring (128 KiB; the next-but-one chunk's eight DMA pieces between the MFMAs of the last set) and, since
+// round 6 the default of every one-tile-per-workgroup kernel, the three-stage A ring (160 KiB) with the DMA pieces spread over the chunk
+// (sp_nt_mainloop3 / sp_tn_mainloop3).
 #pragma once
 #include "gate_common.hpp"
 
