@@ -276,6 +276,9 @@ __global__ __launch_bounds__(SP_THREADS) void sp_nt_kernel(const char* __restric
         *o = r;
         amax = fmaxf(fmaxf(amax, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));
     };
+    // (Round 6: storing straight from the MFMA accumulator layout -- one dword store of a wave = two whole 128-B lines, no LDS transpose --
+    // measured SLOWER: 262144 x 2048 x 512 1.62 -> 1.84 ms, profiles/r06zb_*: the epilogue is bound by store issue, and 128 dword stores
+    // per wave cost more than 32 dwordx4 ones.)
     if (m0 + SPM <= M) sp_epilogue_rows<true>(acc, sm, wave, wm, wn, lane, SPM, emit);
     else sp_epilogue_rows<false>(acc, sm, wave, wm, wn, lane, (int)(M - m0), emit);
     if (absmax_out) sp_block_absmax(absmax_out, amax, reinterpret_cast<float*>(&sm.B[1][0]));   // (B stages: outside the epilogue's transpose areas)
