@@ -273,7 +273,7 @@ __global__ __launch_bounds__(SP_THREADS) void sp_nt_kernel(const char* __restric
         if (group_bias) r += *reinterpret_cast<const f32x4*>(group_bias + (int64_t)row_group[m0 + row] * N + n0 + col);
         f32x4* o = reinterpret_cast<f32x4*>(cb + (int64_t)row * ldc4 + (uint32_t)col * 4u);
         if (accumulate) r += *o;
-        *o = r;
+        *o = r;   // (nontemporal stores here: null, 21.60-21.62 vs 21.63-21.64 ms, profiles/r06zc_*)
         amax = fmaxf(fmaxf(amax, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));
     };
     // (Round 6: storing straight from the MFMA accumulator layout -- one dword store of a wave = two whole 128-B lines, no LDS transpose --
