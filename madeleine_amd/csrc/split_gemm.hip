@@ -214,6 +214,9 @@ __global__ __launch_bounds__(256) void sp_tile_absmax_kernel(const float* __rest
 }
 
 // ---- NT -------------------------------------------------------------------------------------------------------------------------------
+#ifdef MDL_SP_PROBE   // tools/ab variant only: s_memtime stamps of every workgroup of the last sp_nt launch (entry | loop start | loop end | exit | hw id)
+__device__ unsigned long long sp_probe_buf[8192 * 5];
+#endif
 // C[m][n] (+)= inv * sum_k A[m][k] B[n][k] (+ bias[n]);  rows m >= M / n >= N re-read the last valid row (discarded).
 template <int TERMS, int NA>
 __global__ __launch_bounds__(SP_THREADS) void sp_nt_kernel(const char* __restrict__ A, int64_t a_rsb, const float* __restrict__ a_sc,
@@ -228,6 +231,9 @@ __global__ __launch_bounds__(SP_THREADS) void sp_nt_kernel(const char* __restric
     // NA: stages of the A ring (split_engine.hpp, SmemSPn): 3 = sp_nt_mainloop3 (LDS-DMA pieces spread over the chunk, 160 KiB of LDS)
     __shared__ SmemSPn<NA> sm3;
     SmemSP& sm = reinterpret_cast<SmemSP&>(sm3);   // (epilogue staging: the first 128 KiB, whatever the ring depth)
+#ifdef MDL_SP_PROBE
+    const unsigned long long pt0 = __builtin_amdgcn_s_memtime();
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / SP_WN, wn = wave % SP_WN;
@@ -258,8 +264,14 @@ __global__ __launch_bounds__(SP_THREADS) void sp_nt_kernel(const char* __restric
         if (piece < SP_PW) glds16_s(voA[i], sp_uniform(baseA + (int64_t)f * 128), lds_addr_of(&sm3.A[st][(wave * SP_PW + i) * 1024]));
         else glds16_s(voB[i], sp_uniform(baseB + (int64_t)f * 128), lds_addr_of(&sm3.B[st][(wave * SP_PW + i) * 1024]));
     };
+#ifdef MDL_SP_PROBE
+    const unsigned long long pt1 = __builtin_amdgcn_s_memtime();
+#endif
     if constexpr (NA == 3) sp_nt_mainloop3<TERMS>(sm3, acc, nblk, wm, wn, lane, dma);
     else sp_nt_mainloop<TERMS>(sm3, acc, nblk, wm, wn, lane, dma);
+#ifdef MDL_SP_PROBE
+    const unsigned long long pt2 = __builtin_amdgcn_s_memtime();
+#endif
     const float inv = 1.f / (a_sc[0] * b_sc[0]);
     float amax = 0.f;
     char* cb = reinterpret_cast<char*>(C + m0 * ldc + n0);
@@ -282,7 +294,22 @@ __global__ __launch_bounds__(SP_THREADS) void sp_nt_kernel(const char* __restric
     if (m0 + SPM <= M) sp_epilogue_rows<true>(acc, sm, wave, wm, wn, lane, SPM, emit);
     else sp_epilogue_rows<false>(acc, sm, wave, wm, wn, lane, (int)(M - m0), emit);
     if (absmax_out) sp_block_absmax(absmax_out, amax, reinterpret_cast<float*>(&sm.B[1][0]));   // (B stages: outside the epilogue's transpose areas)
+#ifdef MDL_SP_PROBE
+    if (tid == 0 && blockIdx.x < 8192) {
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned long long* o = sp_probe_buf + (size_t)blockIdx.x * 5;
+        o[0] = pt0; o[1] = pt1; o[2] = pt2; o[3] = __builtin_amdgcn_s_memtime(); o[4] = ((unsigned long long)xcc << 32) | hw;
+    }
+#endif
 }
+#ifdef MDL_SP_PROBE
+extern "C" int mdl_debug_sp_probe_read(unsigned long long* host_out, int n_wg) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(mdl::sp_probe_buf), (size_t)n_wg * 5 * sizeof(unsigned long long));
+}
+#endif
 
 // The same product on the tall tile (512 rows x 128 columns per workgroup) for N <= 128: no row gate (callers with a row gate have wide
 // outputs), everything else as sp_nt_kernel.
